@@ -1,0 +1,119 @@
+/* mcevidence_hip.h -- C ABI of libmcevidence_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the k-nearest-neighbour evidence hot path of
+ * yabebalFantaye/MCEvidence.  The reference has no FFI of its own: the seam is
+ * the Python call into scikit-learn plus ~25 lines of NumPy
+ * (reference MCEvidence.py:1093-1131).  Each entry point below names the
+ * reference lines it replaces.  The Python binding a maintainer would add is
+ * shown in INTEGRATION.md (ctypes; mcevidence_amd/_capi.py is that binding).
+ *
+ * Conventions
+ *   - plain C types only; every matrix is C-contiguous (row-major) fp64.
+ *   - *_f64      : pointers are HOST pointers to caller-owned buffers; the
+ *                  library owns every device allocation it makes and frees it
+ *                  before returning; nothing is retained after return.
+ *   - *_f64_dev  : pointers are DEVICE pointers on the current HIP device
+ *                  (e.g. torch tensors' data_ptr()); work is enqueued on
+ *                  `stream` (a hipStream_t passed as void*, NULL = default
+ *                  stream) and NOT synchronised; `ws` is caller-provided
+ *                  scratch of at least mce_*_workspace_bytes().
+ *   - return 0 on success, a negative MCE_ERR_* otherwise; mce_last_error()
+ *     returns a thread-local message for the last failure on this thread.
+ *   - one caller thread per device; calls are re-entrant across devices.
+ *
+ * Neighbour semantics (all entry points): Euclidean distance, the K smallest
+ * per query in ascending order, ties broken by smaller reference index --
+ * what `NearestNeighbors(...).kneighbors()` returns at MCEvidence.py:1104.
+ */
+#ifndef MCEVIDENCE_HIP_H
+#define MCEVIDENCE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCE_ABI_VERSION 1
+
+#define MCE_OK 0
+#define MCE_ERR_INVALID (-1)   /* bad argument (NULL, d<1, K<1, ...)        -> ValueError  */
+#define MCE_ERR_K_RANGE (-2)   /* K larger than usable reference rows / MCE_MAX_K -> ValueError */
+#define MCE_ERR_HIP (-3)       /* HIP runtime failure                        -> RuntimeError */
+#define MCE_ERR_NO_DEVICE (-4) /* no gfx950 device visible                   -> RuntimeError */
+#define MCE_ERR_WORKSPACE (-5) /* caller workspace too small                 -> ValueError  */
+#define MCE_ERR_DIM_RANGE (-6) /* d larger than MCE_MAX_DIM                  -> ValueError  */
+
+#define MCE_MAX_K 32    /* neighbours per query the MFMA kernel keeps in registers */
+#define MCE_MAX_DIM 63  /* dimensions (d+1 is padded to a multiple of 4, <= 64)     */
+
+/* self_mode: how the query set relates to the reference set.
+ *   MCE_SELF_NONE    Y is a different set (cross evidence, MCEvidence.py:1093-1096, k0=0)
+ *   MCE_SELF_INCLUDE Y row (self_offset+q) IS query q; it is reported with distance
+ *                    exactly 0 in column 0 (what the auto path sees, MCEvidence.py:1099-1104)
+ *   MCE_SELF_EXCLUDE same relation, but that row is skipped: the K columns are true
+ *                    neighbours (equivalent to dropping column 0, `k0=1`, :1099)
+ * self_offset is the reference row of query 0; query shards of one chain pass
+ * their first global row (multi-GPU query sharding). */
+#define MCE_SELF_NONE 0
+#define MCE_SELF_INCLUDE 1
+#define MCE_SELF_EXCLUDE 2
+
+int mce_abi_version(void);
+int mce_device_count(void);
+const char *mce_last_error(void);
+
+/* ---- host-pointer entry points (the literal drop-in) ------------------- */
+
+/* Replaces NearestNeighbors(n_neighbors=K,...).fit(Y).kneighbors(X)
+ * (MCEvidence.py:1093-1104).  dist[nq*K] ascending per row; idx[nq*K] int64 or NULL. */
+int mce_knn_f64(const double *X, int64_t nq, const double *Y, int64_t nr, int32_t d, int32_t K,
+                int32_t self_mode, int64_t self_offset, double *dist, int64_t *idx, int32_t device);
+
+/* Replaces the volume loop + np.dot (MCEvidence.py:1107-1117):
+ * dotp[k] = sum_j pi^(d/2) dist[j*ld+k]^d / Gamma(1+d/2) / w[j] * exp(fs[j]),  k in [k0,kmax).
+ * Entries dotp[0..k0) are set to 0. */
+int mce_dotp_f64(const double *dist, int64_t nq, int32_t ld, int32_t k0, int32_t kmax, int32_t d,
+                 const double *w, const double *fs, double *dotp, int32_t device);
+
+/* Fused path: search + reduction without returning the distances
+ * (MCEvidence.py:1093-1117 in one call).  k0 = 1 -> auto evidence (Y must be the
+ * set X was cut from; self excluded by index), k0 = 0 -> cross evidence.
+ * dotp[kmax] as above.  dist_out (optional, may be NULL) receives the
+ * [nq, kmax-k0] neighbour distances that entered the sum (columns k0..kmax-1 of
+ * the reference's DkNN).  The query rows are split evenly over `ndev` devices
+ * (devices[i] = HIP ordinal; NULL/0 -> device 0 only); partial sums are added on
+ * the host in device order. */
+int mce_knn_dotp_f64(const double *X, int64_t nq, const double *Y, int64_t nr, int32_t d, int32_t kmax,
+                     int32_t k0, int64_t self_offset, const double *w, const double *fs, double *dotp,
+                     double *dist_out, const int32_t *devices, int32_t ndev);
+
+/* ---- device-pointer entry points (resident data, caller's stream) ------ */
+
+size_t mce_knn_workspace_bytes(int64_t nq, int64_t nr, int32_t d, int32_t K);
+
+int mce_knn_f64_dev(const double *dX, int64_t nq, const double *dY, int64_t nr, int32_t d, int32_t K,
+                    int32_t self_mode, int64_t self_offset, double *d_dist, int64_t *d_idx, void *ws,
+                    size_t ws_bytes, void *stream);
+
+size_t mce_dotp_workspace_bytes(int64_t nq, int32_t kmax);
+
+int mce_dotp_f64_dev(const double *d_dist, int64_t nq, int32_t ld, int32_t k0, int32_t kmax, int32_t d,
+                     const double *d_w, const double *d_fs, double *d_dotp, void *ws, size_t ws_bytes,
+                     void *stream);
+
+/* Fused search + reduction on resident data; d_dotp[kmax] device, d_dist_out optional.
+ * workspace: mce_knn_workspace_bytes(nq, nr, d, kmax-k0) + mce_dotp_workspace_bytes(nq, kmax). */
+int mce_knn_dotp_f64_dev(const double *dX, int64_t nq, const double *dY, int64_t nr, int32_t d, int32_t kmax,
+                         int32_t k0, int64_t self_offset, const double *d_w, const double *d_fs,
+                         double *d_dotp, double *d_dist_out, void *ws, size_t ws_bytes, void *stream);
+
+/* Name of the dominant kernel last launched by this thread and its launch
+ * geometry (for bench.py / profiles): "knn_mfma_f64<KS=7,KCAP=12>" etc. */
+const char *mce_last_kernel(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCEVIDENCE_HIP_H */

@@ -1,0 +1,196 @@
+"""ctypes binding of ``libmcevidence_hip.so`` (C ABI: ``include/mcevidence_hip.h``).
+
+This is the only place the package touches native code.  There is no CPU
+fallback: if the shared library is missing, or no MI355X is visible when a
+compute entry point is called, an exception is raised.
+
+Error mapping follows what the replaced scikit-learn call would raise
+(``/root/reference/MCEvidence.py:1093-1104``): argument problems ->
+``ValueError`` (sklearn raises ValueError for ``n_neighbors > n_samples_fit``),
+runtime/device problems -> ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcevidence_hip.so")
+
+MCE_OK = 0
+MCE_ERR_INVALID = -1
+MCE_ERR_K_RANGE = -2
+MCE_ERR_HIP = -3
+MCE_ERR_NO_DEVICE = -4
+MCE_ERR_WORKSPACE = -5
+MCE_ERR_DIM_RANGE = -6
+MCE_MAX_K = 32
+MCE_MAX_DIM = 63
+SELF_NONE, SELF_INCLUDE, SELF_EXCLUDE = 0, 1, 2
+
+#: every symbol include/mcevidence_hip.h declares: name -> (restype, argtypes)
+_c = ctypes
+_P = _c.c_void_p
+SIGNATURES = {
+    "mce_abi_version": (_c.c_int, []),
+    "mce_device_count": (_c.c_int, []),
+    "mce_last_error": (_c.c_char_p, []),
+    "mce_last_kernel": (_c.c_char_p, []),
+    "mce_knn_f64": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _c.c_int32]),
+    "mce_dotp_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_int32]),
+    "mce_knn_dotp_f64": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _P, _P, _P, _c.c_int32]),
+    "mce_knn_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32]),
+    "mce_dotp_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int32]),
+    "mce_knn_f64_dev": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _P, _c.c_size_t, _P]),
+    "mce_dotp_f64_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _c.c_size_t, _P]),
+    "mce_knn_dotp_f64_dev": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "mcevidence_amd: %s not found -- build it with `make -C mcevidence_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.mce_abi_version() != 1:
+            raise RuntimeError("mcevidence_amd: ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().mce_last_error().decode("utf-8", "replace")
+
+
+def last_kernel():
+    return load().mce_last_kernel().decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc == MCE_OK:
+        return
+    msg = last_error()
+    if rc in (MCE_ERR_INVALID, MCE_ERR_K_RANGE, MCE_ERR_WORKSPACE, MCE_ERR_DIM_RANGE):
+        raise ValueError(msg)
+    raise RuntimeError("mcevidence_amd HIP backend: " + msg)
+
+
+def device_count():
+    return int(load().mce_device_count())
+
+
+def require_device():
+    n = device_count()
+    if n < 1:
+        raise RuntimeError("mcevidence_amd: no HIP device visible (this package has no CPU fallback)")
+    return n
+
+
+def _f64(a, name):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if not np.all(np.isfinite(a)):
+        raise ValueError("%s contains NaN or infinity" % name)   # sklearn's check_array does the same
+    return a
+
+
+# ---------------------------------------------------------------------------
+# host-pointer wrappers (NumPy in, NumPy out)
+# ---------------------------------------------------------------------------
+def knn(X, Y, K, self_mode=SELF_NONE, self_offset=0, return_index=True, device=0):
+    """K nearest reference rows (Euclidean) for every query row.  Returns
+    (dist[nq,K] ascending, idx[nq,K] int64 or None)."""
+    lib = load()
+    X = _f64(X, "X")
+    Y = _f64(Y, "Y")
+    if X.ndim != 2 or Y.ndim != 2 or X.shape[1] != Y.shape[1]:
+        raise ValueError("X and Y must be 2-D with the same number of columns, got %r and %r" % (X.shape, Y.shape))
+    nq, d = X.shape
+    nr = Y.shape[0]
+    K = int(K)
+    dist = np.empty((nq, K), dtype=np.float64)
+    idx = np.empty((nq, K), dtype=np.int64) if return_index else None
+    check(lib.mce_knn_f64(X.ctypes.data, nq, Y.ctypes.data, nr, d, K, int(self_mode), int(self_offset),
+                          dist.ctypes.data, idx.ctypes.data if idx is not None else None, int(device)))
+    return dist, idx
+
+
+def dotp(dist, w, fs, d, k0, kmax, device=0):
+    """sum_j V_d(dist[j,k]) / w[j] * exp(fs[j]) for k in [k0,kmax) (entries < k0 are 0)."""
+    lib = load()
+    dist = _f64_allow_inf(dist)
+    w = _f64(w, "weight")
+    fs = _f64(fs, "fs")
+    if dist.ndim != 2 or w.shape != (dist.shape[0],) or fs.shape != w.shape:
+        raise ValueError("shape mismatch: dist %r, w %r, fs %r" % (dist.shape, w.shape, fs.shape))
+    out = np.zeros(int(kmax), dtype=np.float64)
+    check(lib.mce_dotp_f64(dist.ctypes.data, dist.shape[0], dist.shape[1], int(k0), int(kmax), int(d),
+                           w.ctypes.data, fs.ctypes.data, out.ctypes.data, int(device)))
+    return out
+
+
+def _f64_allow_inf(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def knn_dotp(X, Y, w, fs, kmax, k0, self_offset=0, return_dist=False, devices=None):
+    """Fused search + reduction.  Returns dotp[kmax] (and dist[nq,kmax-k0] if asked)."""
+    lib = load()
+    X = _f64(X, "X")
+    Y = X if Y is None else _f64(Y, "Y")
+    w = _f64(w, "weight")
+    fs = _f64(fs, "fs")
+    if X.ndim != 2 or Y.ndim != 2 or X.shape[1] != Y.shape[1]:
+        raise ValueError("X and Y must be 2-D with the same number of columns")
+    nq, d = X.shape
+    if w.shape != (nq,) or fs.shape != (nq,):
+        raise ValueError("weight and fs must have one entry per query row")
+    out = np.zeros(int(kmax), dtype=np.float64)
+    dist = np.empty((nq, int(kmax) - int(k0)), dtype=np.float64) if return_dist else None
+    if devices is None:
+        devs, ndev = None, 0
+    else:
+        arr = (ctypes.c_int32 * len(devices))(*[int(x) for x in devices])
+        devs, ndev = ctypes.cast(arr, ctypes.c_void_p), len(devices)
+    check(lib.mce_knn_dotp_f64(X.ctypes.data, nq, Y.ctypes.data, Y.shape[0], d, int(kmax), int(k0), int(self_offset),
+                               w.ctypes.data, fs.ctypes.data, out.ctypes.data,
+                               dist.ctypes.data if dist is not None else None, devs, ndev))
+    return (out, dist) if return_dist else out
+
+
+# ---------------------------------------------------------------------------
+# device-pointer wrappers (raw addresses: torch tensors' data_ptr(), stream handle)
+# ---------------------------------------------------------------------------
+def knn_workspace_bytes(nq, nr, d, K):
+    n = int(load().mce_knn_workspace_bytes(int(nq), int(nr), int(d), int(K)))
+    if n == 0:
+        raise ValueError(last_error())
+    return n
+
+
+def dotp_workspace_bytes(nq, kmax):
+    return int(load().mce_dotp_workspace_bytes(int(nq), int(kmax)))
+
+
+def knn_dev(dX, nq, dY, nr, d, K, self_mode, self_offset, d_dist, d_idx, ws, ws_bytes, stream=0):
+    check(load().mce_knn_f64_dev(dX, nq, dY, nr, d, K, self_mode, self_offset, d_dist, d_idx or None, ws, ws_bytes, stream or None))
+
+
+def dotp_dev(d_dist, nq, ld, k0, kmax, d, d_w, d_fs, d_dotp, ws, ws_bytes, stream=0):
+    check(load().mce_dotp_f64_dev(d_dist, nq, ld, k0, kmax, d, d_w, d_fs, d_dotp, ws, ws_bytes, stream or None))
+
+
+def knn_dotp_dev(dX, nq, dY, nr, d, kmax, k0, self_offset, d_w, d_fs, d_dotp, d_dist_out, ws, ws_bytes, stream=0):
+    check(load().mce_knn_dotp_f64_dev(dX, nq, dY, nr, d, kmax, k0, self_offset, d_w, d_fs, d_dotp, d_dist_out or None,
+                                      ws, ws_bytes, stream or None))

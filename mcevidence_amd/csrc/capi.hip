@@ -1,0 +1,434 @@
+// capi.hip -- the C ABI of libmcevidence_hip.so (see include/mcevidence_hip.h).
+//
+// Host-side planning, workspace carving, kernel dispatch and the host-pointer
+// convenience wrappers.  No torch, no Python: plain HIP runtime calls.
+#include "../../include/mcevidence_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "knn_dispatch.hpp"
+#include "knn_mfma.hpp"
+#include "pack_refs.hpp"
+#include "reduce_kernels.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local char g_last_kernel[256] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define MCE_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(MCE_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int kAssumedCUs = 256;   // MI355X; only steers the reference-split heuristic
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Plan {
+    const mce::KnnVariant* v = nullptr;
+    int KS = 0, KCAP = 0, QT = 0, CT = 0;
+    int64_t nchunk = 0;      // reference chunks (CT tiles of 16 rows)
+    int64_t nrow_pad = 0;    // padded reference rows
+    int nqblk = 0;
+    int64_t nq_pad = 0;
+    int rsplit = 1;
+    int L = 4;
+    size_t off_yf = 0, off_pd = 0, off_pi = 0, total = 0;
+};
+
+const mce::KnnVariant* variant_for(int KS, int kcap_idx)
+{
+    switch (kcap_idx) {
+        case 0: return &mce::g_knn_kcap4[KS - 1];
+        case 1: return &mce::g_knn_kcap8[KS - 1];
+        case 2: return &mce::g_knn_kcap12[KS - 1];
+        case 3: return &mce::g_knn_kcap16[KS - 1];
+        case 4: return &mce::g_knn_kcap24[KS - 1];
+        default: return &mce::g_knn_kcap32[KS - 1];
+    }
+}
+
+// Validates (nq, nr, d, K, self_mode) and lays out the workspace.  Pure function of its
+// arguments so mce_knn_workspace_bytes() and the launcher always agree.
+int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, Plan& p)
+{
+    if (nq < 0 || nr < 1 || d < 1 || K < 1) return fail(MCE_ERR_INVALID, "invalid sizes nq=%lld nr=%lld d=%d K=%d", (long long)nq, (long long)nr, d, K);
+    if (self_mode < 0 || self_mode > 2) return fail(MCE_ERR_INVALID, "invalid self_mode %d", self_mode);
+    if (d > MCE_MAX_DIM) return fail(MCE_ERR_DIM_RANGE, "d=%d exceeds MCE_MAX_DIM=%d", d, MCE_MAX_DIM);
+    if (K > MCE_MAX_K) return fail(MCE_ERR_K_RANGE, "K=%d exceeds MCE_MAX_K=%d", K, MCE_MAX_K);
+    const int64_t usable = (self_mode == MCE_SELF_EXCLUDE) ? nr - 1 : nr;
+    if (K > usable)   // sklearn raises ValueError("Expected n_neighbors <= n_samples_fit")
+        return fail(MCE_ERR_K_RANGE, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", K, (long long)usable);
+    if (nr >= (int64_t)1 << 31) return fail(MCE_ERR_INVALID, "nr=%lld exceeds 2^31-1 reference rows", (long long)nr);
+
+    p.KS = (d + 1 + 3) / 4;
+    int ki = 0;
+    while (ki < mce::kNumKcap - 1 && mce::kKcapList[ki] < K) ++ki;
+    p.KCAP = mce::kKcapList[ki];
+    p.v = variant_for(p.KS, ki);
+    p.QT = p.v->qt;
+    p.CT = p.v->ct;
+    const int qpb = mce::queries_per_block(p.QT);
+    p.nqblk = (int)std::max<int64_t>(1, (nq + qpb - 1) / qpb);
+    p.nq_pad = (int64_t)p.nqblk * qpb;
+    const int64_t rows_per_chunk = (int64_t)p.CT * 16;
+    p.nchunk = (nr + rows_per_chunk - 1) / rows_per_chunk;
+    p.nrow_pad = p.nchunk * rows_per_chunk;
+
+    // reference split: fill the chip and trim the last partial round of workgroups
+    // (one 512-thread workgroup per CU).  cost(r) ~ ceil(nqblk*r / CUs) / r.
+    int best_r = 1;
+    double best_c = 1e300;
+    const int rmax = (int)std::min<int64_t>(mce::kMaxLists / mce::kLaneLists, p.nchunk);
+    for (int r = 1; r <= rmax; ++r) {
+        const double rounds = std::ceil((double)p.nqblk * r / kAssumedCUs);
+        const double c = rounds / r;
+        if (c < best_c * 0.99) { best_c = c; best_r = r; }   // need >1% gain to take a bigger split
+    }
+    p.rsplit = best_r;
+    p.L = p.rsplit * mce::kLaneLists;
+
+    size_t off = 0;
+    p.off_yf = off;
+    off = align_up(off + (size_t)p.nrow_pad * (size_t)(4 * p.KS) * sizeof(double), 256);
+    p.off_pd = off;
+    off = align_up(off + (size_t)p.L * p.KCAP * (size_t)p.nq_pad * sizeof(double), 256);
+    p.off_pi = off;
+    off = align_up(off + (size_t)p.L * p.KCAP * (size_t)p.nq_pad * sizeof(int), 256);
+    p.total = off;
+    return MCE_OK;
+}
+
+size_t dotp_ws_bytes(int64_t nq, int32_t kmax)
+{
+    const int64_t nb = (nq + mce::kRedThreads - 1) / mce::kRedThreads;
+    return align_up((size_t)std::max<int64_t>(nb, 1) * (size_t)kmax * sizeof(double), 256);
+}
+
+double ln_unit_ball(int d) { return 0.5 * d * std::log(M_PI) - std::lgamma(1.0 + 0.5 * d); }
+
+// pack + search; leaves the lane/split lists in the workspace
+int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, int64_t nr, int32_t d,
+               int32_t self_mode, int64_t self_offset, char* ws, hipStream_t st)
+{
+    double* yf = reinterpret_cast<double*>(ws + p.off_yf);
+    double* pd = reinterpret_cast<double*>(ws + p.off_pd);
+    int* pi = reinterpret_cast<int*>(ws + p.off_pi);
+    {
+        const int threads = 256;
+        const unsigned blocks = (unsigned)((p.nrow_pad + threads - 1) / threads);
+        hipLaunchKernelGGL(mce::pack_refs_kernel, dim3(blocks), dim3(threads), 0, st, dY, nr, (int)d, p.KS, p.nrow_pad, yf);
+        MCE_HIP(hipGetLastError());
+    }
+    mce::KnnArgs a;
+    a.Yf = yf;
+    a.nchunk_total = p.nchunk;
+    a.rsplit = p.rsplit;
+    a.X = dX;
+    a.nq = nq;
+    a.D = d;
+    a.nq_pad = p.nq_pad;
+    a.nqblk = p.nqblk;
+    a.self_exclude = (self_mode == MCE_SELF_EXCLUDE) ? 1 : 0;
+    a.self_offset = self_offset;
+    a.part_d = pd;
+    a.part_i = pi;
+    MCE_HIP(p.v->launch(a, st));
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d", p.v->name,
+             p.nqblk * p.rsplit, mce::kThreads, p.v->lds_bytes, p.QT, p.CT, p.rsplit);
+    return MCE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mce_abi_version(void) { return MCE_ABI_VERSION; }
+
+const char* mce_last_error(void) { return g_err; }
+
+const char* mce_last_kernel(void) { return g_last_kernel; }
+
+int mce_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+size_t mce_knn_workspace_bytes(int64_t nq, int64_t nr, int32_t d, int32_t K)
+{
+    Plan p;
+    if (make_plan(nq, nr, d, K, MCE_SELF_NONE, p) != MCE_OK) return 0;
+    return p.total;
+}
+
+size_t mce_dotp_workspace_bytes(int64_t nq, int32_t kmax) { return dotp_ws_bytes(nq, kmax); }
+
+int mce_knn_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t nr, int32_t d, int32_t K,
+                    int32_t self_mode, int64_t self_offset, double* d_dist, int64_t* d_idx, void* ws,
+                    size_t ws_bytes, void* stream)
+{
+    if (!dX || !dY || !d_dist || !ws) return fail(MCE_ERR_INVALID, "null pointer argument");
+    Plan p;
+    int rc = make_plan(nq, nr, d, K, self_mode, p);
+    if (rc != MCE_OK) return rc;
+    if (ws_bytes < p.total) return fail(MCE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, p.total);
+    if (nq == 0) return MCE_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = run_search(p, dX, nq, dY, nr, d, self_mode, self_offset, static_cast<char*>(ws), st);
+    if (rc != MCE_OK) return rc;
+    const unsigned blocks = (unsigned)((nq + mce::kRedThreads - 1) / mce::kRedThreads);
+    hipLaunchKernelGGL((mce::merge_lists_kernel<true, false>), dim3(blocks), dim3(mce::kRedThreads), 0, st,
+                       reinterpret_cast<const double*>(static_cast<char*>(ws) + p.off_pd),
+                       reinterpret_cast<const int*>(static_cast<char*>(ws) + p.off_pi), p.L, p.KCAP, nq, p.nq_pad, dX,
+                       (int)d, (int)K, (int)self_mode, self_offset, d_dist, d_idx, (int)K, 0, 0,
+                       (const double*)nullptr, (const double*)nullptr, 0.0, (double*)nullptr);
+    MCE_HIP(hipGetLastError());
+    return MCE_OK;
+}
+
+int mce_dotp_f64_dev(const double* d_dist, int64_t nq, int32_t ld, int32_t k0, int32_t kmax, int32_t d,
+                     const double* d_w, const double* d_fs, double* d_dotp, void* ws, size_t ws_bytes,
+                     void* stream)
+{
+    if (!d_dist || !d_w || !d_fs || !d_dotp || !ws) return fail(MCE_ERR_INVALID, "null pointer argument");
+    if (nq < 1 || d < 1 || k0 < 0 || kmax < 1 || k0 > kmax || kmax > ld)
+        return fail(MCE_ERR_INVALID, "invalid sizes nq=%lld ld=%d k0=%d kmax=%d d=%d", (long long)nq, ld, k0, kmax, d);
+    if (ws_bytes < dotp_ws_bytes(nq, kmax)) return fail(MCE_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const unsigned blocks = (unsigned)((nq + mce::kRedThreads - 1) / mce::kRedThreads);
+    double* partial = static_cast<double*>(ws);
+    hipLaunchKernelGGL(mce::dotp_partial_kernel, dim3(blocks), dim3(mce::kRedThreads), 0, st, d_dist, nq, (int)ld,
+                       (int)k0, (int)kmax, (int)d, ln_unit_ball(d), d_w, d_fs, partial);
+    MCE_HIP(hipGetLastError());
+    hipLaunchKernelGGL(mce::dotp_final_kernel, dim3((unsigned)kmax), dim3(mce::kRedThreads), 0, st, partial,
+                       (int64_t)blocks, (int)k0, (int)kmax, d_dotp);
+    MCE_HIP(hipGetLastError());
+    return MCE_OK;
+}
+
+int mce_knn_dotp_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t nr, int32_t d, int32_t kmax,
+                         int32_t k0, int64_t self_offset, const double* d_w, const double* d_fs,
+                         double* d_dotp, double* d_dist_out, void* ws, size_t ws_bytes, void* stream)
+{
+    if (!dX || !dY || !d_w || !d_fs || !d_dotp || !ws) return fail(MCE_ERR_INVALID, "null pointer argument");
+    if (k0 != 0 && k0 != 1) return fail(MCE_ERR_INVALID, "k0 must be 0 (cross) or 1 (auto), got %d", k0);
+    if (kmax <= k0) return fail(MCE_ERR_INVALID, "kmax=%d must exceed k0=%d", kmax, k0);
+    if (nq < 1) return fail(MCE_ERR_INVALID, "nq must be >= 1");
+    const int K = kmax - k0;
+    const int self_mode = k0 == 1 ? MCE_SELF_EXCLUDE : MCE_SELF_NONE;
+    Plan p;
+    int rc = make_plan(nq, nr, d, K, self_mode, p);
+    if (rc != MCE_OK) return rc;
+    const size_t need = p.total + dotp_ws_bytes(nq, kmax);
+    if (ws_bytes < need) return fail(MCE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* wsc = static_cast<char*>(ws);
+    rc = run_search(p, dX, nq, dY, nr, d, self_mode, self_offset, wsc, st);
+    if (rc != MCE_OK) return rc;
+    double* partial = reinterpret_cast<double*>(wsc + p.total);
+    const unsigned blocks = (unsigned)((nq + mce::kRedThreads - 1) / mce::kRedThreads);
+    const double* pd = reinterpret_cast<const double*>(wsc + p.off_pd);
+    const int* pi = reinterpret_cast<const int*>(wsc + p.off_pi);
+    if (d_dist_out) {
+        hipLaunchKernelGGL((mce::merge_lists_kernel<true, true>), dim3(blocks), dim3(mce::kRedThreads), 0, st, pd, pi,
+                           p.L, p.KCAP, nq, p.nq_pad, dX, (int)d, K, self_mode, self_offset, d_dist_out,
+                           (int64_t*)nullptr, K, (int)k0, (int)kmax, d_w, d_fs, ln_unit_ball(d), partial);
+    } else {
+        hipLaunchKernelGGL((mce::merge_lists_kernel<false, true>), dim3(blocks), dim3(mce::kRedThreads), 0, st, pd, pi,
+                           p.L, p.KCAP, nq, p.nq_pad, dX, (int)d, K, self_mode, self_offset, (double*)nullptr,
+                           (int64_t*)nullptr, K, (int)k0, (int)kmax, d_w, d_fs, ln_unit_ball(d), partial);
+    }
+    MCE_HIP(hipGetLastError());
+    hipLaunchKernelGGL(mce::dotp_final_kernel, dim3((unsigned)kmax), dim3(mce::kRedThreads), 0, st, partial,
+                       (int64_t)blocks, (int)k0, (int)kmax, d_dotp);
+    MCE_HIP(hipGetLastError());
+    return MCE_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// host-pointer wrappers
+// ---------------------------------------------------------------------------
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+int select_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return fail(MCE_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(MCE_ERR_INVALID, "device %d out of range (have %d)", device, n);
+    MCE_HIP(hipSetDevice(device));
+    return MCE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mce_knn_f64(const double* X, int64_t nq, const double* Y, int64_t nr, int32_t d, int32_t K,
+                int32_t self_mode, int64_t self_offset, double* dist, int64_t* idx, int32_t device)
+{
+    if (!X || !Y || !dist) return fail(MCE_ERR_INVALID, "null pointer argument");
+    Plan p;
+    int rc = make_plan(nq, nr, d, K, self_mode, p);
+    if (rc != MCE_OK) return rc;
+    if (nq == 0) return MCE_OK;
+    rc = select_device(device);
+    if (rc != MCE_OK) return rc;
+    DevBuf dX, dY, dD, dI, ws;
+    MCE_HIP(dX.alloc((size_t)nq * d * sizeof(double)));
+    MCE_HIP(dY.alloc((size_t)nr * d * sizeof(double)));
+    MCE_HIP(dD.alloc((size_t)nq * K * sizeof(double)));
+    if (idx) MCE_HIP(dI.alloc((size_t)nq * K * sizeof(int64_t)));
+    MCE_HIP(ws.alloc(p.total));
+    MCE_HIP(hipMemcpy(dX.p, X, (size_t)nq * d * sizeof(double), hipMemcpyHostToDevice));
+    MCE_HIP(hipMemcpy(dY.p, Y, (size_t)nr * d * sizeof(double), hipMemcpyHostToDevice));
+    rc = mce_knn_f64_dev(dX.as<double>(), nq, dY.as<double>(), nr, d, K, self_mode, self_offset, dD.as<double>(),
+                         idx ? dI.as<int64_t>() : nullptr, ws.p, p.total, nullptr);
+    if (rc != MCE_OK) return rc;
+    MCE_HIP(hipDeviceSynchronize());
+    MCE_HIP(hipMemcpy(dist, dD.p, (size_t)nq * K * sizeof(double), hipMemcpyDeviceToHost));
+    if (idx) MCE_HIP(hipMemcpy(idx, dI.p, (size_t)nq * K * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return MCE_OK;
+}
+
+int mce_dotp_f64(const double* dist, int64_t nq, int32_t ld, int32_t k0, int32_t kmax, int32_t d,
+                 const double* w, const double* fs, double* dotp, int32_t device)
+{
+    if (!dist || !w || !fs || !dotp) return fail(MCE_ERR_INVALID, "null pointer argument");
+    if (nq < 1 || d < 1 || k0 < 0 || kmax < 1 || k0 > kmax || kmax > ld)
+        return fail(MCE_ERR_INVALID, "invalid sizes nq=%lld ld=%d k0=%d kmax=%d d=%d", (long long)nq, ld, k0, kmax, d);
+    int rc = select_device(device);
+    if (rc != MCE_OK) return rc;
+    DevBuf dD, dW, dF, dO, ws;
+    const size_t wsb = dotp_ws_bytes(nq, kmax);
+    MCE_HIP(dD.alloc((size_t)nq * ld * sizeof(double)));
+    MCE_HIP(dW.alloc((size_t)nq * sizeof(double)));
+    MCE_HIP(dF.alloc((size_t)nq * sizeof(double)));
+    MCE_HIP(dO.alloc((size_t)kmax * sizeof(double)));
+    MCE_HIP(ws.alloc(wsb));
+    MCE_HIP(hipMemcpy(dD.p, dist, (size_t)nq * ld * sizeof(double), hipMemcpyHostToDevice));
+    MCE_HIP(hipMemcpy(dW.p, w, (size_t)nq * sizeof(double), hipMemcpyHostToDevice));
+    MCE_HIP(hipMemcpy(dF.p, fs, (size_t)nq * sizeof(double), hipMemcpyHostToDevice));
+    rc = mce_dotp_f64_dev(dD.as<double>(), nq, ld, k0, kmax, d, dW.as<double>(), dF.as<double>(), dO.as<double>(), ws.p, wsb, nullptr);
+    if (rc != MCE_OK) return rc;
+    MCE_HIP(hipDeviceSynchronize());
+    MCE_HIP(hipMemcpy(dotp, dO.p, (size_t)kmax * sizeof(double), hipMemcpyDeviceToHost));
+    return MCE_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// one device's share of the fused path: queries [q_lo, q_hi)
+int fused_on_device(int device, const double* X, int64_t q_lo, int64_t q_hi, const double* Y, int64_t nr, int32_t d,
+                    int32_t kmax, int32_t k0, int64_t self_offset, const double* w, const double* fs,
+                    double* dotp_part, double* dist_out)
+{
+    const int64_t nq = q_hi - q_lo;
+    const int K = kmax - k0;
+    int rc = select_device(device);
+    if (rc != MCE_OK) return rc;
+    Plan p;
+    rc = make_plan(nq, nr, d, K, k0 == 1 ? MCE_SELF_EXCLUDE : MCE_SELF_NONE, p);
+    if (rc != MCE_OK) return rc;
+    const size_t wsb = p.total + dotp_ws_bytes(nq, kmax);
+    DevBuf dX, dY, dW, dF, dO, dD, ws;
+    MCE_HIP(dX.alloc((size_t)nq * d * sizeof(double)));
+    MCE_HIP(dY.alloc((size_t)nr * d * sizeof(double)));
+    MCE_HIP(dW.alloc((size_t)nq * sizeof(double)));
+    MCE_HIP(dF.alloc((size_t)nq * sizeof(double)));
+    MCE_HIP(dO.alloc((size_t)kmax * sizeof(double)));
+    if (dist_out) MCE_HIP(dD.alloc((size_t)nq * K * sizeof(double)));
+    MCE_HIP(ws.alloc(wsb));
+    MCE_HIP(hipMemcpy(dX.p, X + q_lo * (int64_t)d, (size_t)nq * d * sizeof(double), hipMemcpyHostToDevice));
+    MCE_HIP(hipMemcpy(dY.p, Y, (size_t)nr * d * sizeof(double), hipMemcpyHostToDevice));
+    MCE_HIP(hipMemcpy(dW.p, w + q_lo, (size_t)nq * sizeof(double), hipMemcpyHostToDevice));
+    MCE_HIP(hipMemcpy(dF.p, fs + q_lo, (size_t)nq * sizeof(double), hipMemcpyHostToDevice));
+    rc = mce_knn_dotp_f64_dev(dX.as<double>(), nq, dY.as<double>(), nr, d, kmax, k0, self_offset + q_lo,
+                              dW.as<double>(), dF.as<double>(), dO.as<double>(), dist_out ? dD.as<double>() : nullptr,
+                              ws.p, wsb, nullptr);
+    if (rc != MCE_OK) return rc;
+    MCE_HIP(hipDeviceSynchronize());
+    MCE_HIP(hipMemcpy(dotp_part, dO.p, (size_t)kmax * sizeof(double), hipMemcpyDeviceToHost));
+    if (dist_out) MCE_HIP(hipMemcpy(dist_out + q_lo * (int64_t)K, dD.p, (size_t)nq * K * sizeof(double), hipMemcpyDeviceToHost));
+    return MCE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mce_knn_dotp_f64(const double* X, int64_t nq, const double* Y, int64_t nr, int32_t d, int32_t kmax,
+                     int32_t k0, int64_t self_offset, const double* w, const double* fs, double* dotp,
+                     double* dist_out, const int32_t* devices, int32_t ndev)
+{
+    if (!X || !Y || !w || !fs || !dotp) return fail(MCE_ERR_INVALID, "null pointer argument");
+    if (k0 != 0 && k0 != 1) return fail(MCE_ERR_INVALID, "k0 must be 0 (cross) or 1 (auto), got %d", k0);
+    if (kmax <= k0 || nq < 1) return fail(MCE_ERR_INVALID, "invalid kmax=%d k0=%d nq=%lld", kmax, k0, (long long)nq);
+    {   // validate before touching any device
+        Plan p;
+        int rc = make_plan(nq, nr, d, kmax - k0, k0 == 1 ? MCE_SELF_EXCLUDE : MCE_SELF_NONE, p);
+        if (rc != MCE_OK) return rc;
+    }
+    std::vector<int> devs;
+    if (!devices || ndev <= 0) devs.push_back(0);
+    else devs.assign(devices, devices + ndev);
+    const int n = (int)std::min<int64_t>((int64_t)devs.size(), nq);
+    std::vector<std::vector<double>> parts(n, std::vector<double>(kmax, 0.0));
+    std::vector<int> rcs(n, MCE_OK);
+    std::vector<std::string> errs(n);
+    auto work = [&](int i) {
+        const int64_t lo = nq * i / n, hi = nq * (i + 1) / n;
+        rcs[i] = fused_on_device(devs[i], X, lo, hi, Y, nr, d, kmax, k0, self_offset, w, fs, parts[i].data(), dist_out);
+        if (rcs[i] != MCE_OK) errs[i] = g_err;   // g_err is thread-local
+    };
+    if (n == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < n; ++i) th.emplace_back(work, i);
+        for (auto& t : th) t.join();
+    }
+    for (int i = 0; i < n; ++i)
+        if (rcs[i] != MCE_OK) return fail(rcs[i], "device %d: %s", devs[i], errs[i].c_str());
+    for (int k = 0; k < kmax; ++k) {   // fixed device order -> reproducible
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += parts[i][k];
+        dotp[k] = s;
+    }
+    return MCE_OK;
+}
+
+}  // extern "C"

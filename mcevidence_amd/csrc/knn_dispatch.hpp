@@ -1,0 +1,46 @@
+// knn_dispatch.hpp -- host-side table of the knn_mfma_kernel<KS,KCAP,QT> instantiations.
+// One translation unit per list capacity KCAP (knn_inst.hip compiled with -DMCE_KCAP=n)
+// so the 96 variants build in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mce {
+
+struct KnnArgs {
+    const double* Yf;       // packed references [nchunk_total*CT][KS][64]
+    int64_t nchunk_total;
+    int rsplit;
+    const double* X;        // queries [nq, D]
+    int64_t nq;
+    int D;
+    int64_t nq_pad;
+    int nqblk;
+    int self_exclude;
+    int64_t self_offset;
+    double* part_d;         // [rsplit*4][KCAP][nq_pad]
+    int* part_i;
+};
+
+typedef hipError_t (*knn_launch_fn)(const KnnArgs&, hipStream_t);
+
+struct KnnVariant {
+    knn_launch_fn launch;
+    int ks, kcap, qt, ct;
+    size_t lds_bytes;
+    const char* name;
+};
+
+constexpr int kMaxKS = 16;
+constexpr int kNumKcap = 6;
+constexpr int kKcapList[kNumKcap] = {4, 8, 12, 16, 24, 32};
+
+// defined in knn_inst.hip (one per KCAP): variants for KS = 1..16 (index KS-1)
+extern const KnnVariant g_knn_kcap4[kMaxKS];
+extern const KnnVariant g_knn_kcap8[kMaxKS];
+extern const KnnVariant g_knn_kcap12[kMaxKS];
+extern const KnnVariant g_knn_kcap16[kMaxKS];
+extern const KnnVariant g_knn_kcap24[kMaxKS];
+extern const KnnVariant g_knn_kcap32[kMaxKS];
+
+}  // namespace mce

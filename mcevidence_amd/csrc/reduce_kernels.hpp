@@ -1,0 +1,167 @@
+// reduce_kernels.hpp -- list merge, distance finalisation and the volume/weight
+// reduction of the evidence estimator (reference MCEvidence.py:1107-1117).
+//
+//   dotp[k] = sum_j  pi^(D/2) r_jk^D / Gamma(1+D/2) / w_j * exp(fs_j)
+//           = sum_j  exp( lnC_D + (D/2) ln r_jk^2 - ln w_j + fs_j )          (log domain)
+//
+// Deterministic: per-workgroup partial sums in a fixed tree, then one fixed-order
+// pass over the partials (no floating-point atomics), so results are run-to-run
+// reproducible and independent of dispatch order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mce {
+
+constexpr int kRedThreads = 256;
+constexpr int kMaxK = 32;        // == MCE_MAX_K
+constexpr int kMaxLists = 64;    // 4 lane-lists x rsplit <= 16
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// sum over the workgroup; result valid in thread 0.  `red` = kRedThreads/64 doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double* red)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < kRedThreads / 64; ++i) s += red[i];
+    }
+    return s;
+}
+
+// ---------------------------------------------------------------------------
+// merge_lists: one thread per query merges its L sorted lane/split lists
+// (keys in s-space, s = d^2 - |x|^2) into the K best, converts to Euclidean
+// distance and optionally feeds the evidence reduction.
+//   part_d/part_i : [L][KCAP][nq_pad]
+//   self_mode 1 (include): the entry whose reference row is self_offset+q is
+//                          forced to distance 0 and sorts first.
+// ---------------------------------------------------------------------------
+template <bool WRITE_DIST, bool FUSE_DOTP>
+__global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
+    const double* __restrict__ part_d, const int* __restrict__ part_i, int L, int KCAP,
+    int64_t nq, int64_t nq_pad, const double* __restrict__ X, int D, int K,
+    int self_mode, int64_t self_offset,
+    double* __restrict__ dist, int64_t* __restrict__ idx, int ld_out,
+    int k0, int kmax, const double* __restrict__ w, const double* __restrict__ fs, double lnc,
+    double* __restrict__ partial)
+{
+    __shared__ double red[kRedThreads / 64];
+    const int64_t q = (int64_t)blockIdx.x * kRedThreads + threadIdx.x;
+    const bool live = q < nq;
+    const double INF = __builtin_huge_val();
+
+    double term[kMaxK];
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k) term[k] = 0.0;
+
+    if (live) {
+        double xn = 0.0;
+        const double* x = X + q * (int64_t)D;
+        for (int i = 0; i < D; ++i) { const double t = x[i]; xn = fma(t, t, xn); }
+        const int selfj = (self_mode == 1) ? (int)(self_offset + q) : -1;
+        double base = 0.0;
+        if (FUSE_DOTP) base = lnc - log(w[q]) + fs[q];
+
+        unsigned char head[kMaxLists];
+        for (int l = 0; l < L; ++l) head[l] = 0;
+
+        for (int k = 0; k < K; ++k) {
+            double bv = INF;
+            int bi = 0x7fffffff, bl = -1;
+            bool bself = false;
+            for (int l = 0; l < L; ++l) {
+                const int h = head[l];
+                if (h >= KCAP) continue;
+                const int64_t o = ((int64_t)l * KCAP + h) * nq_pad + q;
+                const int i = part_i[o];
+                if (i < 0) continue;                       // list exhausted
+                double v = part_d[o];
+                const bool isself = (i == selfj);
+                if (isself) v = -INF;
+                if (v < bv || (v == bv && i < bi)) { bv = v; bi = i; bl = l; bself = isself; }
+            }
+            double d2 = INF;
+            int64_t oi = -1;
+            if (bl >= 0) {
+                head[bl]++;
+                d2 = bself ? 0.0 : fmax(bv + xn, 0.0);
+                oi = bi;
+            }
+            if (WRITE_DIST) {
+                dist[q * (int64_t)ld_out + k] = sqrt(d2);
+                if (idx) idx[q * (int64_t)ld_out + k] = oi;
+            }
+            if (FUSE_DOTP) {
+                // column k of the K = kmax-k0 true neighbours <-> reference column k0+k
+                const double t = exp(base + 0.5 * (double)D * log(d2));
+#pragma unroll
+                for (int kk = 0; kk < kMaxK; ++kk)
+                    if (kk == k) term[kk] = t;
+            }
+        }
+    }
+
+    if (FUSE_DOTP) {
+        const int ncol = kmax - k0;
+#pragma unroll
+        for (int kk = 0; kk < kMaxK; ++kk) {
+            if (kk < ncol) {
+                const double s = block_sum(term[kk], red);
+                if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * kmax + k0 + kk] = s;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// dotp from an explicit distance matrix (the unfused path, MCEvidence.py:1107-1117)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kRedThreads) void dotp_partial_kernel(
+    const double* __restrict__ dist, int64_t nq, int ld, int k0, int kmax, int D, double lnc,
+    const double* __restrict__ w, const double* __restrict__ fs, double* __restrict__ partial)
+{
+    __shared__ double red[kRedThreads / 64];
+    const int64_t q = (int64_t)blockIdx.x * kRedThreads + threadIdx.x;
+    const bool live = q < nq;
+    double base = 0.0;
+    if (live) base = lnc - log(w[q]) + fs[q];
+    for (int k = k0; k < kmax; ++k) {
+        double t = 0.0;
+        if (live) {
+            const double r = dist[q * (int64_t)ld + k];
+            t = exp(base + (double)D * log(r));
+        }
+        const double s = block_sum(t, red);
+        if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * kmax + k] = s;
+    }
+}
+
+// final pass: block k sums partial[:, k] in a fixed order.
+__global__ __launch_bounds__(kRedThreads) void dotp_final_kernel(
+    const double* __restrict__ partial, int64_t nblocks, int k0, int kmax, double* __restrict__ dotp)
+{
+    __shared__ double red[kRedThreads / 64];
+    const int k = blockIdx.x;
+    if (k < k0) {
+        if (threadIdx.x == 0) dotp[k] = 0.0;
+        return;
+    }
+    double acc = 0.0;
+    for (int64_t b = threadIdx.x; b < nblocks; b += kRedThreads) acc += partial[b * kmax + k];
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) dotp[k] = s;
+}
+
+}  // namespace mce
