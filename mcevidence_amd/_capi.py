@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -59,6 +60,15 @@ def load():
             raise RuntimeError(
                 "mcevidence_amd: %s not found -- build it with `make -C mcevidence_amd/csrc` "
                 "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+        # PyTorch-ROCm wheels bundle their own HIP/HSA runtime (torch/lib/libamdhip64.so, same
+        # soname as /opt/rocm's).  Two HSA runtimes in one process cannot both own the GPU, so
+        # when torch is installed let it load its runtime FIRST; our library then binds to the
+        # already-loaded libamdhip64.so.7.  torch is plumbing here, never a compute fallback.
+        if "torch" not in sys.modules and os.environ.get("MCE_SKIP_TORCH_PRELOAD", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:  # torch absent: plain ROCm runtime from /opt/rocm
+                pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

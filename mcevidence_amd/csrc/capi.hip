@@ -100,14 +100,14 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     // (one 512-thread workgroup per CU).  cost(r) ~ ceil(nqblk*r / CUs) / r.
     int best_r = 1;
     double best_c = 1e300;
-    const int rmax = (int)std::min<int64_t>(mce::kMaxLists / mce::kLaneLists, p.nchunk);
+    const int rmax = (int)std::min<int64_t>(mce::kMaxLists, p.nchunk);
     for (int r = 1; r <= rmax; ++r) {
         const double rounds = std::ceil((double)p.nqblk * r / kAssumedCUs);
         const double c = rounds / r;
         if (c < best_c * 0.99) { best_c = c; best_r = r; }   // need >1% gain to take a bigger split
     }
     p.rsplit = best_r;
-    p.L = p.rsplit * mce::kLaneLists;
+    p.L = p.rsplit;
 
     size_t off = 0;
     p.off_yf = off;
@@ -129,7 +129,7 @@ size_t dotp_ws_bytes(int64_t nq, int32_t kmax)
 double ln_unit_ball(int d) { return 0.5 * d * std::log(M_PI) - std::lgamma(1.0 + 0.5 * d); }
 
 // pack + search; leaves the lane/split lists in the workspace
-int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, int64_t nr, int32_t d,
+int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, int64_t nr, int32_t d, int32_t K,
                int32_t self_mode, int64_t self_offset, char* ws, hipStream_t st)
 {
     double* yf = reinterpret_cast<double*>(ws + p.off_yf);
@@ -152,6 +152,7 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
     a.nqblk = p.nqblk;
     a.self_exclude = (self_mode == MCE_SELF_EXCLUDE) ? 1 : 0;
     a.self_offset = self_offset;
+    a.ksel = K;
     a.part_d = pd;
     a.part_i = pi;
     MCE_HIP(p.v->launch(a, st));
@@ -197,7 +198,7 @@ int mce_knn_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t nr, 
     if (ws_bytes < p.total) return fail(MCE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, p.total);
     if (nq == 0) return MCE_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    rc = run_search(p, dX, nq, dY, nr, d, self_mode, self_offset, static_cast<char*>(ws), st);
+    rc = run_search(p, dX, nq, dY, nr, d, K, self_mode, self_offset, static_cast<char*>(ws), st);
     if (rc != MCE_OK) return rc;
     const unsigned blocks = (unsigned)((nq + mce::kRedThreads - 1) / mce::kRedThreads);
     hipLaunchKernelGGL((mce::merge_lists_kernel<true, false>), dim3(blocks), dim3(mce::kRedThreads), 0, st,
@@ -246,7 +247,7 @@ int mce_knn_dotp_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t
     if (ws_bytes < need) return fail(MCE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* wsc = static_cast<char*>(ws);
-    rc = run_search(p, dX, nq, dY, nr, d, self_mode, self_offset, wsc, st);
+    rc = run_search(p, dX, nq, dY, nr, d, K, self_mode, self_offset, wsc, st);
     if (rc != MCE_OK) return rc;
     double* partial = reinterpret_cast<double*>(wsc + p.total);
     const unsigned blocks = (unsigned)((nq + mce::kRedThreads - 1) / mce::kRedThreads);

@@ -18,6 +18,7 @@ struct KnnArgs {
     int nqblk;
     int self_exclude;
     int64_t self_offset;
+    int ksel;               // neighbours actually wanted (<= KCAP)
     double* part_d;         // [rsplit*4][KCAP][nq_pad]
     int* part_i;
 };

@@ -12,13 +12,10 @@ namespace mce {
 template <int KS, int KCAP>
 hipError_t launch_variant(const KnnArgs& a, hipStream_t st)
 {
-    constexpr int QT = pick_qt(KS, KCAP);
-    constexpr int CT = chunk_tiles(KS);
-    constexpr int CHUNK_VEC = CT * KS * 32;
-    constexpr int VPT = (CHUNK_VEC + kThreads - 1) / kThreads;
-    constexpr size_t LDS = (size_t)2 * VPT * kThreads * 16;
+    constexpr size_t LDS = lds_bytes(KS, KCAP);
+    static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;   // benign race: idempotent
-    auto kern = knn_mfma_kernel<KS, KCAP, QT>;
+    auto kern = knn_mfma_kernel<KS, KCAP>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) return e;
@@ -26,15 +23,14 @@ hipError_t launch_variant(const KnnArgs& a, hipStream_t st)
     }
     const dim3 grid((unsigned)(a.nqblk * a.rsplit));
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), LDS, st, a.Yf, a.nchunk_total, a.rsplit, a.X, a.nq, a.D,
-                       a.nq_pad, a.nqblk, a.self_exclude, a.self_offset, a.part_d, a.part_i);
+                       a.nq_pad, a.nqblk, a.self_exclude, a.self_offset, a.ksel, a.part_d, a.part_i);
     return hipGetLastError();
 }
 
 #define MCE_STR2(x) #x
 #define MCE_STR(x) MCE_STR2(x)
 #define MCE_VARIANT(KS)                                                                                  \
-    {&launch_variant<KS, MCE_KCAP>, KS, MCE_KCAP, pick_qt(KS, MCE_KCAP), chunk_tiles(KS),                \
-     (size_t)2 * ((chunk_tiles(KS) * KS * 32 + kThreads - 1) / kThreads) * kThreads * 16,                \
+    {&launch_variant<KS, MCE_KCAP>, KS, MCE_KCAP, kQT, chunk_tiles(KS, MCE_KCAP), lds_bytes(KS, MCE_KCAP),  \
      "knn_mfma_kernel<KS=" #KS ",KCAP=" MCE_STR(MCE_KCAP) ">"}
 
 #define MCE_CAT2(a, b) a##b
@@ -49,7 +45,7 @@ extern const KnnVariant MCE_CAT(g_knn_kcap, MCE_KCAP)[kMaxKS] = {
 };
 #else
 // device pass: force the kernel instantiations
-#define MCE_INST(KS) template __global__ void knn_mfma_kernel<KS, MCE_KCAP, pick_qt(KS, MCE_KCAP)>(const double*, int64_t, int, const double*, int64_t, int, int64_t, int, int, int64_t, double*, int*);
+#define MCE_INST(KS) template __global__ void knn_mfma_kernel<KS, MCE_KCAP>(const double*, int64_t, int, const double*, int64_t, int, int64_t, int, int, int64_t, int, double*, int*);
 MCE_INST(1) MCE_INST(2) MCE_INST(3) MCE_INST(4) MCE_INST(5) MCE_INST(6) MCE_INST(7) MCE_INST(8)
 MCE_INST(9) MCE_INST(10) MCE_INST(11) MCE_INST(12) MCE_INST(13) MCE_INST(14) MCE_INST(15) MCE_INST(16)
 #endif

@@ -15,7 +15,7 @@ namespace mce {
 
 constexpr int kRedThreads = 256;
 constexpr int kMaxK = 32;        // == MCE_MAX_K
-constexpr int kMaxLists = 64;    // 4 lane-lists x rsplit <= 16
+constexpr int kMaxLists = 16;    // reference splits merged per query
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -41,8 +41,8 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 }
 
 // ---------------------------------------------------------------------------
-// merge_lists: one thread per query merges its L sorted lane/split lists
-// (keys in s-space, s = d^2 - |x|^2) into the K best, converts to Euclidean
+// merge_lists: one thread per query merges its L sorted per-split lists
+// (keys = squared distances) into the K best, converts to Euclidean
 // distance and optionally feeds the evidence reduction.
 //   part_d/part_i : [L][KCAP][nq_pad]
 //   self_mode 1 (include): the entry whose reference row is self_offset+q is
@@ -67,9 +67,6 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
     for (int k = 0; k < kMaxK; ++k) term[k] = 0.0;
 
     if (live) {
-        double xn = 0.0;
-        const double* x = X + q * (int64_t)D;
-        for (int i = 0; i < D; ++i) { const double t = x[i]; xn = fma(t, t, xn); }
         const int selfj = (self_mode == 1) ? (int)(self_offset + q) : -1;
         double base = 0.0;
         if (FUSE_DOTP) base = lnc - log(w[q]) + fs[q];
@@ -96,7 +93,7 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
             int64_t oi = -1;
             if (bl >= 0) {
                 head[bl]++;
-                d2 = bself ? 0.0 : fmax(bv + xn, 0.0);
+                d2 = bself ? 0.0 : fmax(bv, 0.0);
                 oi = bi;
             }
             if (WRITE_DIST) {
