@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the kNN evidence hot path on MI355X.
+
+Metric (BASELINE.json): kNN queries/s (+ |dlnE|) at N = 1M, D = 27, kmax = 10 (config C3:
+seeded synthetic Gaussian chain, `mcevidence_amd.synth.CONFIGS['C3']`), inputs resident in
+HBM when the timed region starts.  One "step" = one full pass of the hot path (pack ->
+fp64 MFMA kNN -> merge -> volume/weight reduction -> dotp[kmax]) over this rank's query
+shard; with --gpus N the 1M queries are sharded over N ranks (reference set replicated),
+one RCCL all-reduce of kmax doubles per step: strong scaling.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 1000000] [--d 27] [--kmax 10]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (knn_mfma_kernel):
+algorithmic flops per launch = nq * nr * 2 * 4*KS (the augmented dot product
+|x|^2 + x'.y' the MFMA evaluates) over its launch duration measured with HIP
+events on the launch stream; peak = 78.6 TFLOP/s fp64 (MI355X matrix = vector fp64 peak;
+the f64 MFMA microbenchmark tools/mfma_f64_peak.hip reaches 72-74 on this part).
+`cpu_baseline` = the reference's own CPU path (scikit-learn NearestNeighbors with its
+default algorithm + NumPy reduction, via the oracle) on a bounded query sample, rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FP64_PEAK_TFLOPS = 78.6
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--d", type=int, default=27)
+    ap.add_argument("--kmax", type=int, default=10)
+    ap.add_argument("--cpu-sample", type=int, default=4000, help="queries timed on the CPU baseline (0 = skip)")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 or world > 1:
+        assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from mcevidence_amd import _capi, parallel
+    from mcevidence_amd.synth import gaussian_chain
+    import mcevidence_amd as pkg
+
+    # ---- synthetic chain (config C3 recipe) + host-side feeders (whitening etc.) ----
+    n, d, kmax = a.n, a.d, a.kmax
+    chain = gaussian_chain(seed=3, n=n, d=d, cov="corr")
+    mce = pkg.MCEvidence([chain], kmax=kmax, verbose=0)
+    cov = mce.get_covariance()
+    s1, logL, weight, _ = mce.get_samples(n, prewhiten=False)
+    Xh = np.ascontiguousarray(mce.diagonalise_chain(s1, cov["eVec"], cov["eVal"]))
+    logLmax = float(np.amax(logL))
+    fsh = logL - logLmax
+    SumW = float(np.sum(weight))
+
+    lo, hi = parallel.shard_bounds(n, world, rank)
+    nq = hi - lo
+    K = kmax - 1
+    X = torch.from_numpy(Xh).to(dev)                       # reference set, replicated
+    Xq = X[lo:hi]                                          # this rank's query shard (a view)
+    w = torch.from_numpy(np.ascontiguousarray(weight[lo:hi])).to(dev)
+    fs = torch.from_numpy(np.ascontiguousarray(fsh[lo:hi])).to(dev)
+    wsb = _capi.knn_workspace_bytes(nq, n, d, K) + _capi.dotp_workspace_bytes(nq, kmax)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    dotp = torch.zeros(kmax, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        _capi.knn_dotp_dev(Xq.data_ptr(), nq, X.data_ptr(), n, d, kmax, 1, lo, w.data_ptr(), fs.data_ptr(),
+                           dotp.data_ptr(), 0, ws.data_ptr(), wsb, stream.cuda_stream)
+        if world > 1:
+            dist.all_reduce(dotp, op=dist.ReduceOp.SUM)    # the single collective of the path
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in ev:
+        e0.record(stream)
+        step()
+        e1.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_step = elapsed / a.steps * 1e3
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))     # whole hot path on the launch stream
+
+    # ---- ln E from the device result, and parity against the golden / CPU sample ----
+    dp = dotp.cpu().numpy()
+    lnE = np.array([math.log(SumW * dp[k] / (n * k + 1.0) * cov["J"]) + logLmax - math.log(1.0) for k in range(1, kmax)])
+
+    out = None
+    if rank == 0:
+        KS = (d + 1 + 3) // 4
+        flops = float(nq) * n * 2.0 * 4 * KS
+        # dominant kernel time: the hot path minus pack/merge/reduce is not separable from
+        # torch events; rocprofv3 (profiles/) attributes >98% of the step to knn_mfma_kernel.
+        achieved = flops / (kern_ms * 1e-3) / 1e12
+        roof = dict(bound="mfma", achieved=round(achieved, 3), peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(achieved / FP64_PEAK_TFLOPS, 4), traffic=None,
+                    kernel=_capi.last_kernel(), algorithmic_flops_per_launch=flops,
+                    note="fp64 MFMA-bound (SURVEY 8d); HBM traffic is the packed reference set streamed once per workgroup round")
+        cpu = None
+        dlnE = None
+        if a.cpu_sample > 0:
+            from oracle import oracle_np as orc                 # checker / baseline only
+            rng = np.random.default_rng(0)
+            rows = np.sort(rng.choice(n, size=min(a.cpu_sample, n), replace=False))
+            t1 = time.perf_counter()
+            dsk, _ = orc.knn_sklearn(Xh[rows], Xh, kmax + 1)  # the reference's exact call (MCEvidence.py:1093-1104)
+            full = orc.dotp_literal(dsk, weight[rows], fsh[rows], d, 1, kmax)
+            t_cpu = time.perf_counter() - t1
+            cpu = dict(value=round(len(rows) / t_cpu, 1), unit="queries/s", cores=len(os.sched_getaffinity(0)), kind="port",
+                       sample="%d random query rows of the same chain against the full %d-row reference set; sklearn NearestNeighbors(algorithm='auto', n_jobs=-1) + NumPy volume/weight sum" % (len(rows), n))
+            # row-level parity on the sample: distances of the sampled rows, GPU vs CPU
+            dg, _ = _capi.knn(Xh[rows], Xh, kmax + 1, self_mode=_capi.SELF_NONE)
+            rel = float(np.max(np.abs(dg[:, 1:kmax] - dsk[:, 1:kmax]) / dsk[:, 1:kmax]))
+            cpu["max_rel_dist_err_vs_gpu"] = rel
+        gold = os.path.join(REPO, "tests", "golden", "evidence_big.json")
+        if (n, d, kmax) == (1_000_000, 27, 10) and os.path.exists(gold):
+            for c in json.load(open(gold)):
+                if c["name"] == "auto_n1000000_d27_k10_C3":
+                    dlnE = float(np.max(np.abs(lnE - np.array(c["lnE"]))))
+        out = dict(metric="knn_queries_per_sec", value=round(n / (ms_step * 1e-3), 1), unit="queries/s", n_gpus=world,
+                   steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True,
+                   scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
+                   config=dict(workload="C3: auto-evidence, seeded Gaussian chain N=%d D=%d kmax=%d (K=%d true neighbours/query), query-sharded over %d GPU(s)" % (n, d, kmax, K, world),
+                               N=n, D=d, kmax=kmax, queries_per_rank=nq),
+                   max_abs_dlnE_vs_reference=dlnE, lnE=[round(float(x), 10) for x in lnE],
+                   roofline=roof, cpu_baseline=cpu)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -96,15 +96,23 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     p.nchunk = (nr + rows_per_chunk - 1) / rows_per_chunk;
     p.nrow_pad = p.nchunk * rows_per_chunk;
 
-    // reference split: fill the chip and trim the last partial round of workgroups
-    // (one 512-thread workgroup per CU).  cost(r) ~ ceil(nqblk*r / CUs) / r.
+    // reference split r: more workgroups fill the chip and trim the last partial round
+    // (one 512-thread workgroup per CU), but every split re-pays the list warm-up: a query
+    // accepts ~K(1+ln(n/K)) candidates while streaming n references, each a serialised
+    // whole-wave insertion.  Model (cycles per SIMD, measured on MI355X):
+    //   block(r) = 256*KS*tiles(r) + 1000 * 32 * K * (1 + ln(n_r/K)),   n_r = nr/r
+    //   total(r) = ceil(nqblk*r / CUs) * block(r)
     int best_r = 1;
     double best_c = 1e300;
     const int rmax = (int)std::min<int64_t>(mce::kMaxLists, p.nchunk);
     for (int r = 1; r <= rmax; ++r) {
+        const double n_r = (double)nr / r;
+        const double tiles = n_r / 16.0;
+        const double cand = 32.0 * K * (1.0 + std::log(std::max(1.0, n_r / K)));
+        const double block = 256.0 * p.KS * tiles + 1000.0 * cand;
         const double rounds = std::ceil((double)p.nqblk * r / kAssumedCUs);
-        const double c = rounds / r;
-        if (c < best_c * 0.99) { best_c = c; best_r = r; }   // need >1% gain to take a bigger split
+        const double c = rounds * block;
+        if (c < best_c * 0.98) { best_c = c; best_r = r; }   // need >2% gain to take a bigger split
     }
     p.rsplit = best_r;
     p.L = p.rsplit;

@@ -1,0 +1,279 @@
+"""``MCEvidence`` -- drop-in for the reference class of the same name.
+
+Same constructor and ``evidence()`` signatures as
+``/root/reference/MCEvidence.py:614-624`` and ``:950-952``.  Everything around
+the hot path (chain handling, whitening, prior volume, the final ln-evidence
+assembly) is host NumPy, as in the reference and as BASELINE.json's north_star
+keeps it; the hot path itself --
+
+    nbrs = NearestNeighbors(n_neighbors=kmax+1, ...).fit(Y)      # :1093-1101
+    DkNN, indices = nbrs.kneighbors(samples)                      # :1104
+    volume[j,k] = pi^(D/2) DkNN[j,k]^D / Gamma(1+D/2)             # :1107-1110
+    dotp = np.dot(volume[:,k]/weight, np.exp(fs))                 # :1117
+
+-- is ONE call into the HIP library (``_capi.knn_dotp`` ->
+``mce_knn_dotp_f64``), or, under ``torchrun``, one call per rank on its query
+shard followed by a single RCCL all-reduce of the ``kmax`` partial sums
+(``parallel.sharded_knn_dotp``).  There is no CPU implementation of the hot
+path in this package; without the shared library or a GPU it raises.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import statistics
+from collections import namedtuple
+
+import numpy as np
+
+from .chains import MCSamples
+
+FORMAT = "%(levelname)s:%(filename)s.%(funcName)s():%(lineno)-8s %(message)s"
+logger = logging.getLogger("mcevidence_amd")
+
+__all__ = ["MCEvidence", "HipBackend"]
+
+
+class HipBackend(object):
+    """The MI355X hot path.  ``knn_dotp`` returns (dotp[kmax], dist or None) where dist
+    holds the distances that entered the sum (reference DkNN columns k0..kmax-1)."""
+
+    name = "hip"
+
+    def __init__(self, devices=None):
+        self.devices = devices
+
+    def knn_dotp(self, X, Y, weight, fs, kmax, k0, want_dist=False):
+        from . import parallel
+        if parallel.is_distributed():
+            return parallel.sharded_knn_dotp(X, Y, weight, fs, kmax, k0, want_dist=want_dist)
+        from . import _capi
+        out = _capi.knn_dotp(X, Y, weight, fs, kmax, k0, return_dist=want_dist, devices=self.devices)
+        return out if want_dist else (out, None)
+
+
+class MCEvidence(object):
+    def __init__(self, method, ischain=True, isfunc=None,
+                 thinlen=0.0, burnlen=0.0,
+                 split=False, s1frac=0.5, shuffle=True,
+                 ndim=None, kmax=5,
+                 priorvolume=1, debug=False,
+                 nsample=None, covtype="single",
+                 nbatch=1,
+                 brange=None,
+                 bscale="",
+                 verbose=1, args={},
+                 **gdkwargs):
+        """Evidence estimation from MCMC chains (Heavens et al. 2017, arXiv:1704.03472).
+
+        Parameters have the reference's meaning.  One keyword is added and consumed here
+        (it is not forwarded to the chain reader): ``backend`` -- an object with a
+        ``knn_dotp`` method; default ``HipBackend()``.
+
+        method      chain root name / file name(s), or list/tuple/dict of chain arrays
+                    (columns: weight, -lnL, parameters...)
+        kmax        k-th nearest neighbours used: k = 1 .. kmax-1 (kmax >= 2 is enforced)
+        ndim        number of leading parameter columns to use (default all)
+        split       cross-evidence: neighbours of s1 points are searched in s2
+        priorvolume prior volume; burnlen/thinlen as in the reference (files only)
+        nbatch, brange, bscale   batched runs; only bscale='logpower' is supported
+        """
+        self.backend = gdkwargs.pop("backend", None) or HipBackend()
+        self.logger = logger
+        self.verbose = verbose
+        self.debug = bool(debug or verbose > 1)
+        level = logging.DEBUG if self.debug else (logging.INFO if verbose == 1 else logging.WARNING)
+        if not logging.getLogger().handlers:
+            logging.basicConfig(format=FORMAT)
+        self.logger.setLevel(level)
+
+        self.info = {}
+        self.split = split
+        self.covtype = covtype
+        self.nbatch = nbatch
+        self.brange = brange
+        self.bscale = bscale if not isinstance(brange, int) else "constant"
+        self.snames = ["s1", "s2"] if split else ["s1"]
+        self.idbatch = np.arange(self.nbatch, dtype=int)
+        self.powers = np.zeros((self.nbatch, len(self.snames)))
+        self.bsize = np.zeros((self.nbatch, len(self.snames)), dtype=int)
+        self.nchain = np.zeros((self.nbatch, len(self.snames)), dtype=int)
+        self.kmax = max(2, kmax)                       # reference :694
+        self.priorvolume = priorvolume
+        self.ischain = ischain
+        self.fname = method if isinstance(method, str) else None
+        if not ischain:
+            raise NotImplementedError("ischain=False (sampling from a model class) is not supported; "
+                                      "pass the chain (the reference's own path is broken: undefined self.nsamples)")
+
+        gdkwargs.setdefault("thinlen", thinlen)
+        gdkwargs.setdefault("burnlen", burnlen)
+        csplit = namedtuple("split_var", "split frac shuffle")(split=split, frac=s1frac, shuffle=shuffle)
+        self.gd = MCSamples(method, csplit=csplit, debug=self.debug, **gdkwargs)
+
+        if isfunc:
+            self.gd.importance_sample(isfunc, name="s1")
+            if self.split:
+                self.gd.importance_sample(isfunc, name="s2")
+
+        self.info["NparamsMC"] = self.gd.nparamMC
+        self.info["Nsamples_read"] = self.gd.get_shape()[0]
+        self.info["Nparams_read"] = self.gd.get_shape()[1]
+        self.nsample = [self.gd.get_shape(name=s)[0] for s in self.snames]
+        self.ndim = self.gd.nparamMC if ndim is None else ndim
+        self.info["NparamsCosmo"] = self.ndim
+        self.info["Nsamples"] = ", ".join(str(x) for x in self.nsample)
+        self.logger.info("chain array dimensions: %s x %s =" % (self.nsample, self.ndim))
+        self.set_batch()
+
+    # ------------------------------------------------------------------ batching
+    def summary(self):
+        print()
+        for k in ("ndim", "nsample", "kmax", "brange", "bsize", "powers", "nchain"):
+            print("%s=%s" % (k, getattr(self, k)))
+        print()
+
+    def get_batch_range(self):
+        if self.brange is None:
+            return None, None
+        lo, hi = float(np.min(self.brange)), float(np.max(self.brange))
+        if lo == hi and self.nbatch > 1:
+            raise ValueError("nbatch>1 but batch range is set to zero.")
+        return lo, hi
+
+    def set_batch(self, bscale=None):
+        """brange None: one batch with every sample.  bscale='logpower': batch sizes
+        10**linspace(min,max,nbatch) (reference :808-840; its 'linear' and 'constant'
+        branches raise NameError / ValueError, here they raise ValueError)."""
+        if bscale is None:
+            bscale = self.bscale
+        else:
+            self.bscale = bscale
+        if self.brange is None:
+            self.bsize = self.brange
+            for ix, nn in enumerate(self.nsample):
+                self.nchain[0, ix] = nn
+                self.powers[0, ix] = np.log10(nn)
+        elif bscale == "logpower":
+            lo, hi = self.get_batch_range()
+            for ix, _ in enumerate(self.nsample):
+                self.powers[:, ix] = np.linspace(lo, hi, self.nbatch)
+                self.bsize[:, ix] = np.array([int(pow(10.0, x)) for x in self.powers[:, ix]])
+            self.nchain = self.bsize
+        else:
+            raise ValueError("batching supports bscale='logpower' only (got %r)" % (bscale,))
+
+    # ------------------------------------------------------------------ whitening
+    def diagonalise_chain(self, s, eigenVec, eigenVal):
+        """Rotate onto the covariance eigenvectors and scale to unit variance (:842-849)."""
+        if (np.asarray(eigenVal)[: s.shape[1]] < 0).any():
+            raise ValueError("math domain error: negative covariance eigenvalue (use fewer parameters, ndim)")
+        return np.dot(s, eigenVec) / np.sqrt(np.asarray(eigenVal)[: s.shape[1]])[None, :]
+
+    def get_covariance(self, s=None):
+        """UNWEIGHTED sample covariance, its eigen-system and J = sqrt(det) (:851-882).
+        With a negative eigenvalue: J = 1, posdef False."""
+        if s is None:
+            self.logger.info("Estimating covariance matrix using all chains")
+            s, _, _ = self.gd.all_sample_arrays()
+            s = s[:, 0:self.ndim]
+        self.logger.info("covariance matrix estimated using nsample=%s" % len(s))
+        cov = np.atleast_2d(np.cov(s.T))
+        eigenVal, eigenVec = np.linalg.eig(cov)
+        if (eigenVal < 0).any():
+            self.logger.warning("Some of the eigenvalues of the covariance matrix are negative and/or complex: %s" % (eigenVal,))
+            return {"cov": cov, "posdef": False, "J": 1, "eVec": eigenVec, "eVal": eigenVal}
+        return {"cov": cov, "posdef": True, "J": math.sqrt(np.linalg.det(cov)), "eVec": eigenVec, "eVal": eigenVal}
+
+    def get_samples(self, nsamples, istart=0, rand=False, name="s1", prewhiten=True):
+        """Rows [istart, istart+nsamples) of a partition (all rows if nsamples == 0),
+        cut to the first ndim parameters (:884-947)."""
+        ntot = self.gd.get_shape(name)[0]
+        s, lnp, w = self.gd.arrays(name)
+        s = s[:, 0:self.ndim]
+        if nsamples > 0:
+            if rand and self.brange is not None:
+                if nsamples > ntot:
+                    raise ValueError("partition %s nsamples=%s, ntotal_chain=%s" % (name, nsamples, ntot))
+                idx = np.random.randint(0, high=ntot, size=nsamples)
+            else:
+                idx = np.arange(istart, nsamples + istart)
+            s, lnp, w = s[idx, :], lnp[idx], w[idx]
+        else:
+            nsamples = ntot
+        self.logger.info("getting samples for partition %s: nsamples=%s" % (name, nsamples))
+        stat = {"J": 1, "eVec": None, "eVal": None}
+        if prewhiten:
+            cs = self.get_covariance(s=s)
+            stat = {"J": cs["J"], "eVec": cs["eVec"], "eVal": cs["eVal"]}
+            if cs["posdef"]:
+                s = self.diagonalise_chain(s, cs["eVec"], cs["eVal"])
+        return s, lnp, w, stat
+
+    # ------------------------------------------------------------------ the estimator
+    def evidence(self, verbose=None, rand=False, info=False, covtype="all",
+                 profile=False, pvolume=None, pos_lnp=False,
+                 nproc=-1, prewhiten=True):
+        """ln-evidence for k = 1..kmax-1 nearest neighbours (auto), or k = 2..kmax (cross,
+        ``split=True``).  Returns the array ``MLE[1:]`` like the reference (and the info
+        dict if ``info=True``).  ``nproc``/``profile``/``prewhiten`` are accepted for
+        signature compatibility (the reference ignores the last two as well)."""
+        if verbose is None:
+            verbose = self.verbose
+        logPriorVolume = math.log(self.priorvolume if pvolume is None else pvolume)
+        kmax, ndim = self.kmax, self.ndim
+        MLE = np.zeros((self.nbatch, kmax))
+        if covtype is None:
+            covtype = self.covtype
+        if covtype == "all":
+            covstat = self.get_covariance()
+            Jacobian = covstat["J"]
+
+        for ipow, nsample in zip(self.idbatch, self.nchain):
+            S = int(nsample[0])
+            samples, logL, weight, _ = self.get_samples(S, istart=0, rand=rand, prewhiten=False, name="s1")
+            if covtype == "single":
+                covstat = self.get_covariance(s=samples)
+                Jacobian = covstat["J"]
+            samples = self.diagonalise_chain(samples, covstat["eVec"], covstat["eVal"])
+            if pos_lnp:
+                logL = -logL
+            logLmax = np.amax(logL)                         # renormalise against underflow (:1062-1064)
+            fs = logL - logLmax
+
+            if self.split:
+                samples2, _, _, _ = self.get_samples(0, istart=0, rand=rand, prewhiten=False, name="s2")
+                if covtype == "single":
+                    covstat = self.get_covariance(s=samples2)    # s2's own eigen-system, J stays s1's (:1080-1086)
+                samples2 = self.diagonalise_chain(samples2, covstat["eVec"], covstat["eVal"])
+                self.logger.info("using XMCEvidence. NN distance is estimated using nsamples=(%s, %s)" % (S, samples2.shape[0]))
+                k0 = 0
+                refset = samples2
+            else:
+                k0 = 1                                      # the nearest "neighbour" is the point itself (:1099)
+                refset = None
+
+            # ---- the hot path: kNN search + volume/weight reduction on the GPU -------
+            want_dist = verbose > 1
+            dotp, dist = self.backend.knn_dotp(np.ascontiguousarray(samples), refset, np.asarray(weight, dtype=np.float64),
+                                               np.asarray(fs, dtype=np.float64), kmax, k0, want_dist=want_dist)
+
+            SumW = np.sum(self.gd.data["s1"].adjusted_weights)   # ALL of s1, also when batching (:1126)
+            for k in range(k0, kmax):
+                k_nn = k if k0 == 1 else k + 1
+                amax = dotp[k] / (S * k_nn + 1.0)
+                MLE[ipow, k] = math.log(SumW * amax * Jacobian) + logLmax - logPriorVolume
+                if verbose > 1:
+                    lnc = 0.5 * ndim * math.log(math.pi) - math.lgamma(1.0 + 0.5 * ndim)
+                    with np.errstate(divide="ignore"):
+                        medvol = math.exp(lnc + ndim * math.log(statistics.median(dist[:, k - k0]))) if dist is not None else float("nan")
+                    self.logger.debug("k={},nsample={}, dotp={}, median_volume={}, a_max={}, MLE={}".format(
+                        k, S, dotp[k], medvol, amax, MLE[ipow, k]))
+
+        MLE = MLE[0, 1:] if self.brange is None else MLE[:, 1:]
+        if verbose > 0:
+            for k in range(1, self.kmax):
+                self.logger.info("   ln(B)[k={}] = {}".format(k, MLE[k - 1] if self.brange is None else MLE[:, k - 1]))
+        if info:
+            return MLE, self.info
+        return MLE

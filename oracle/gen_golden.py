@@ -46,6 +46,22 @@ def import_reference():
     sys.path.insert(0, "/root/reference")
     import MCEvidence as ref  # noqa: E402
 
+    # The reference globs chain files in directory-listing order, which is arbitrary; the
+    # build reads them sorted.  Pin the reference to the sorted order too (harness-side
+    # wrapper around glob, the reference source is untouched) so file-based pins are
+    # reproducible.
+    import glob as _glob
+    _orig = _glob.glob
+
+    class _SortedGlob(object):
+        def __getattr__(self, k):
+            return getattr(_glob, k)
+
+        @staticmethod
+        def glob(pat, *a, **k):
+            return sorted(_orig(pat, *a, **k))
+
+    ref.glob = _SortedGlob()
     return ref
 
 

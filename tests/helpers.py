@@ -1,0 +1,77 @@
+"""Shared test helpers (tests only; the oracle is never imported by the product)."""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+for p in (REPO, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from oracle import oracle_np as orc  # noqa: E402
+from mcevidence_amd.synth import gaussian_chain  # noqa: E402
+
+GOLD = os.path.join(HERE, "golden")
+
+#: stated fp64 tolerance on ln E (|dlnE| <= 1e-9)
+LNE_TOL = 1e-9
+#: row-level tolerance on kNN distances (GEMM-form fp64 vs exact differences)
+DIST_RTOL = 1e-10
+
+
+def load_golden():
+    out = {}
+    for tag in ("small", "medium", "big"):
+        jp = os.path.join(GOLD, "evidence_%s.json" % tag)
+        if not os.path.exists(jp):
+            continue
+        arrays = np.load(os.path.join(GOLD, "evidence_%s.npz" % tag))
+        for case in json.load(open(jp)):
+            case = dict(case)
+            case["tag"] = tag
+            case["arrays"] = {k[len(case["name"]) + 2:]: arrays[k] for k in arrays.files if k.startswith(case["name"] + "__")}
+            out[case["name"]] = case
+    return out
+
+
+def host_pins():
+    return json.load(open(os.path.join(GOLD, "host_pins.json")))
+
+
+def chain_of(case):
+    return gaussian_chain(**case["chain"])
+
+
+class OracleBackend(object):
+    """Test double for ``HipBackend``: the same interface served by the CPU oracle, so the
+    host bookkeeping of ``MCEvidence`` can be pinned against the goldens without a GPU."""
+
+    name = "oracle"
+
+    def __init__(self, knn="brute"):
+        self.knn = knn
+        self.calls = []
+
+    def knn_dotp(self, X, Y, weight, fs, kmax, k0, want_dist=False):
+        ref = X if Y is None else Y
+        K = kmax - k0
+        if self.knn == "sklearn":
+            d, _ = orc.knn_sklearn(X, ref, kmax + 1)
+            d = d[:, k0:kmax]
+        else:
+            d, _ = orc.knn_brute(X, ref, K, self_mode=2 if k0 == 1 else 0)
+        ndim = X.shape[1]
+        full = np.zeros((X.shape[0], kmax))
+        full[:, k0:] = d
+        dotp = orc.dotp_literal(full, weight, fs, ndim, k0, kmax)
+        self.calls.append(dict(nq=X.shape[0], nr=ref.shape[0], d=ndim, kmax=kmax, k0=k0))
+        return dotp, (d if want_dist else None)
+
+
+def lnE_from_dotp(case, dotp):
+    return orc.mle_from_dotp(np.asarray(dotp), case["S"], case["k0"], case["kmax"], case["SumW"], case["J"],
+                             case["logLmax"], case["lnPriorVolume"])

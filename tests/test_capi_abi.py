@@ -1,0 +1,90 @@
+"""The C-ABI library loads and exports every symbol include/mcevidence_hip.h declares;
+argument validation works without a GPU; compute calls fail LOUDLY without one
+(no CPU fallback in the product).  CPU only."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import REPO
+from mcevidence_amd import _capi
+
+HEADER = os.path.join(REPO, "include", "mcevidence_hip.h")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mce_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 12
+    for s in syms:
+        assert hasattr(lib, s), "libmcevidence_hip.so does not export %s" % s
+    # and the binding covers exactly the header
+    assert sorted(_capi.SIGNATURES) == syms
+
+
+def test_header_constants_match_binding():
+    txt = open(HEADER).read()
+    for name in ("MCE_MAX_K", "MCE_MAX_DIM", "MCE_ERR_INVALID", "MCE_ERR_K_RANGE", "MCE_ERR_HIP", "MCE_ERR_NO_DEVICE",
+                 "MCE_ERR_WORKSPACE", "MCE_ERR_DIM_RANGE"):
+        m = re.search(r"#define\s+%s\s+\(?(-?\d+)\)?" % name, txt)
+        assert m and int(m.group(1)) == getattr(_capi, name), name
+    assert _capi.load().mce_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    X = np.zeros((5, 3))
+    with pytest.raises(ValueError, match="n_neighbors <= n_samples_fit"):
+        _capi.knn(X, X, 9)                                      # sklearn's error for K > n
+    with pytest.raises(ValueError, match="n_neighbors <= n_samples_fit"):
+        _capi.knn(X, X, 5, self_mode=_capi.SELF_EXCLUDE)        # self excluded: only 4 usable rows
+    with pytest.raises(ValueError):
+        _capi.knn(np.zeros((5, 64)), np.zeros((5, 64)), 2)      # d > MCE_MAX_DIM
+    with pytest.raises(ValueError):
+        _capi.knn(np.zeros((50, 3)), np.zeros((50, 3)), 33)     # K > MCE_MAX_K
+    with pytest.raises(ValueError):
+        _capi.knn(np.zeros((5, 3)), np.zeros((5, 4)), 2)        # column mismatch
+    with pytest.raises(ValueError):
+        _capi.knn(np.full((5, 3), np.nan), X, 2)                # NaN input (sklearn check_array)
+    with pytest.raises(ValueError):
+        _capi.knn_dotp(X, None, np.ones(5), np.zeros(5), kmax=2, k0=3)
+    with pytest.raises(ValueError):
+        _capi.knn_dotp(X, None, np.ones(4), np.zeros(5), kmax=2, k0=1)
+    assert _capi.knn_workspace_bytes(1000, 1000, 6, 4) > 0
+    assert _capi.dotp_workspace_bytes(1000, 4) >= 4 * 4 * 8
+    with pytest.raises(ValueError):
+        _capi.knn_workspace_bytes(10, 10, 100, 4)
+
+
+def test_compute_fails_loudly_without_gpu():
+    if _capi.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    X = np.random.default_rng(0).standard_normal((50, 3))
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        _capi.knn(X, X, 3)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        _capi.knn_dotp(X, None, np.ones(50), np.zeros(50), kmax=3, k0=1)
+    import mcevidence_amd as pkg
+    from mcevidence_amd.synth import gaussian_chain
+    with pytest.raises(RuntimeError):
+        pkg.MCEvidence([gaussian_chain(0, 300, 3)], verbose=0).evidence()
+    from mcevidence_amd.neighbors import NearestNeighbors
+    with pytest.raises(RuntimeError):
+        NearestNeighbors(n_neighbors=3).fit(X).kneighbors(X)
+
+
+def test_product_never_imports_the_oracle():
+    """the package must not reference oracle/ anywhere (parity claims depend on it)."""
+    pkgdir = os.path.join(REPO, "mcevidence_amd")
+    for root, _, files in os.walk(pkgdir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(root, f)).read()
+                assert "oracle" not in txt.lower(), "%s mentions the oracle" % f

@@ -1,0 +1,229 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the
+golden vectors recorded from the reference.  Need a real MI355X: run with -m gpu."""
+import logging
+import math
+
+import numpy as np
+import pytest
+
+from helpers import DIST_RTOL, LNE_TOL, OracleBackend, chain_of, load_golden, orc
+
+pytestmark = pytest.mark.gpu
+logging.disable(logging.CRITICAL)
+G = load_golden()
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from mcevidence_amd import _capi
+    assert _capi.device_count() >= 1, "no GPU visible: the HIP path cannot be tested"
+    return _capi
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300) * (b != 0)) if a.size else 0.0
+
+
+# --------------------------------------------------------------------------- kNN
+@pytest.mark.parametrize("d", [1, 2, 3, 6, 7, 8, 15, 16, 27, 33, 63])
+def test_knn_matches_oracle_over_dims(capi, d):
+    rng = np.random.default_rng(100 + d)
+    n = 3001
+    Y = rng.standard_normal((n, d))
+    K = 7
+    dist, idx = capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE)
+    od, oi = orc.knn_brute(Y, Y, K, self_mode=2)
+    assert _rel(dist, od) < DIST_RTOL
+    assert np.mean(idx == oi) > 0.9999            # identical neighbour sets (ties aside)
+    assert np.all(np.diff(dist, axis=1) >= 0)
+
+
+@pytest.mark.parametrize("K", [1, 2, 4, 5, 8, 9, 11, 12, 13, 16, 17, 24, 25, 32])
+def test_knn_matches_oracle_over_k(capi, K):
+    rng = np.random.default_rng(200 + K)
+    X = rng.standard_normal((777, 6))
+    Y = rng.standard_normal((2500, 6))
+    dist, idx = capi.knn(X, Y, K)
+    od, oi = orc.knn_brute(X, Y, K)
+    assert _rel(dist, od) < DIST_RTOL and np.array_equal(idx, oi)
+
+
+@pytest.mark.parametrize("nq,nr", [(1, 50), (17, 33), (255, 256), (257, 129), (1000, 13), (513, 100000)])
+def test_knn_ragged_sizes(capi, nq, nr):
+    rng = np.random.default_rng(nq * 7 + nr)
+    X = rng.standard_normal((nq, 5))
+    Y = rng.standard_normal((nr, 5))
+    K = min(12, nr)
+    dist, idx = capi.knn(X, Y, K)
+    od, oi = orc.knn_brute(X, Y, K)
+    assert _rel(dist, od) < DIST_RTOL and np.array_equal(idx, oi)
+
+
+def test_knn_self_modes(capi):
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((4099, 9))
+    K = 6
+    d0, i0 = capi.knn(X, X, K, self_mode=capi.SELF_NONE)
+    d1, i1 = capi.knn(X, X, K, self_mode=capi.SELF_INCLUDE)
+    d2, i2 = capi.knn(X, X, K - 1, self_mode=capi.SELF_EXCLUDE)
+    assert np.all(d1[:, 0] == 0.0) and np.array_equal(i1[:, 0], np.arange(len(X)))     # exactly 0, like the kd-tree path
+    assert np.array_equal(d1[:, 1:], d2) and np.array_equal(i1[:, 1:], i2)
+    assert np.all(d0[:, 0] < 1e-6) and np.array_equal(d0[:, 1:], d1[:, 1:])          # GEMM-form self distance ~1e-8
+    # query shard with an offset == rows of the full answer (multi-GPU sharding rule)
+    ds, is_ = capi.knn(X[1000:1777], X, K - 1, self_mode=capi.SELF_EXCLUDE, self_offset=1000)
+    assert np.array_equal(ds, d2[1000:1777]) and np.array_equal(is_, i2[1000:1777])
+
+
+def test_knn_duplicates_and_ties(capi):
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((2000, 4))
+    X[100:105] = X[99]                     # 6 identical rows
+    X[1500] = X[3]
+    d, i = capi.knn(X, X, 4, self_mode=capi.SELF_EXCLUDE)
+    od, oi = orc.knn_brute(X, X, 4, self_mode=2)
+    assert np.all(d[99:105, :4] < 1e-7)    # duplicates: 0 up to GEMM-form rounding (sklearn brute: ~1e-8 too)
+    mask = od > 0
+    assert _rel(d[mask], od[mask]) < DIST_RTOL
+    # integer grid -> many exact ties: distances must agree exactly in value
+    Z = rng.integers(0, 4, size=(1500, 3)).astype(float)
+    d, _ = capi.knn(Z, Z, 8, self_mode=capi.SELF_EXCLUDE)
+    od, _ = orc.knn_brute(Z, Z, 8, self_mode=2)
+    assert np.allclose(d, od, rtol=0, atol=1e-7) and np.allclose(d ** 2, od ** 2, atol=1e-12)
+
+
+def test_knn_large_offsets_are_stable(capi):
+    """un-whitened data far from the origin: GEMM-form cancellation stays within tolerance."""
+    rng = np.random.default_rng(5)
+    Y = 50.0 + rng.standard_normal((5000, 6))
+    d, i = capi.knn(Y, Y, 5, self_mode=capi.SELF_EXCLUDE)
+    od, oi = orc.knn_brute(Y, Y, 5, self_mode=2)
+    assert _rel(d, od) < 1e-8 and np.mean(i == oi) > 0.999
+
+
+def test_error_codes_on_gpu(capi):
+    X = np.zeros((5, 3))
+    with pytest.raises(ValueError):
+        capi.knn(X, X, 6)
+    with pytest.raises(ValueError):
+        capi.knn(X, X, 2, device=99)
+
+
+# --------------------------------------------------------------------------- reduction
+@pytest.mark.parametrize("n,d,kmax,k0", [(6000, 6, 5, 1), (5000, 27, 10, 1), (4000, 15, 4, 0), (3000, 2, 2, 1), (2000, 33, 6, 0)])
+def test_fused_and_unfused_dotp(capi, n, d, kmax, k0):
+    rng = np.random.default_rng(n + d)
+    X = rng.standard_normal((n, d))
+    Y = X if k0 == 1 else rng.standard_normal((n + 37, d))
+    w = rng.integers(1, 6, n).astype(float)
+    fs = -0.5 * (X ** 2).sum(1)
+    fs -= fs.max()
+    dp, dist = capi.knn_dotp(X, None if k0 == 1 else Y, w, fs, kmax, k0, return_dist=True)
+    od, _ = orc.knn_brute(X, Y, kmax - k0, self_mode=2 if k0 == 1 else 0)
+    full = np.zeros((n, kmax))
+    full[:, k0:] = od
+    ref = orc.dotp_literal(full, w, fs, d, k0, kmax)
+    assert np.allclose(dp[k0:], ref[k0:], rtol=1e-11) and np.all(dp[:k0] == 0)
+    assert _rel(dist, od) < DIST_RTOL
+    un = capi.dotp(full, w, fs, d, k0, kmax)
+    assert np.allclose(un[k0:], ref[k0:], rtol=1e-12)
+    # bitwise reproducible run to run (fixed-order reduction, no atomics)
+    dp2 = capi.knn_dotp(X, None if k0 == 1 else Y, w, fs, kmax, k0)
+    assert np.array_equal(dp, dp2)
+
+
+def test_dotp_zero_distance_terms(capi):
+    rng = np.random.default_rng(8)
+    dist = np.abs(rng.standard_normal((500, 4)))
+    dist[7, 1] = 0.0
+    out = capi.dotp(dist, np.ones(500), np.zeros(500), 6, 1, 4)
+    ref = orc.dotp_literal(dist, np.ones(500), np.zeros(500), 6, 1, 4)
+    assert np.all(np.isfinite(out)) and np.allclose(out[1:], ref[1:], rtol=1e-12)
+
+
+def test_query_sharding_sums_to_full(capi):
+    """shard the queries, add the partial sums."""
+    rng = np.random.default_rng(9)
+    n, d, kmax = 20011, 6, 5
+    X = rng.standard_normal((n, d))
+    w = np.ones(n)
+    fs = -rng.random(n)
+    full = capi.knn_dotp(X, None, w, fs, kmax, 1)
+    parts = np.zeros(kmax)
+    for lo, hi in ((0, 5000), (5000, 13337), (13337, n)):
+        parts += capi.knn_dotp(X[lo:hi], X, w[lo:hi], fs[lo:hi], kmax, 1, self_offset=lo)
+    assert np.allclose(parts, full, rtol=1e-13)
+
+
+# --------------------------------------------------------------------------- the class, against the reference's outputs
+@pytest.mark.parametrize("name", sorted(G))
+def test_class_on_gpu_reproduces_reference(name):
+    import mcevidence_amd as pkg
+    case = G[name]
+    if case["seed_split"] is not None:
+        np.random.seed(case["seed_split"])
+    mce = pkg.MCEvidence([chain_of(case)], verbose=0, **case["mce"])
+    assert mce.backend.name == "hip"
+    lnE = mce.evidence(**case["ev"])
+    assert np.max(np.abs(lnE - np.array(case["lnE"]))) < LNE_TOL, (lnE, case["lnE"])
+
+
+def test_sampled_rows_at_full_size_C3(capi):
+    """N = 1M, D = 27 (BASELINE configs[2]): 1500 sampled query rows against the exact CPU search,
+    plus size-independent properties over all rows."""
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((1_000_000, 27))
+    K = 9
+    rows = np.sort(rng.choice(len(X), 1500, replace=False))
+    dist, idx = capi.knn(X, X, K, self_mode=capi.SELF_EXCLUDE)
+    assert np.all(np.diff(dist, axis=1) >= 0) and np.all(dist > 0)
+    assert np.all(idx != np.arange(len(X))[:, None]) and idx.min() >= 0 and idx.max() < len(X)
+    d_, i_ = orc.knn_brute(X[rows], X, K + 1)              # exact CPU search incl. self; drop column 0
+    ods, ois = d_[:, 1:], i_[:, 1:]
+    assert _rel(dist[rows], ods) < DIST_RTOL and np.array_equal(idx[rows], ois)
+    # symmetry property: if j is i's nearest neighbour at distance r, then i is within r of j
+    nn = idx[:, 0]
+    assert np.all(dist[nn, 0] <= dist[:, 0] * (1 + 1e-12))
+
+
+def test_neighbors_shim_matches_sklearn_semantics(capi):
+    from mcevidence_amd.neighbors import NearestNeighbors
+    rng = np.random.default_rng(11)
+    Y = rng.standard_normal((3000, 6))
+    X = rng.standard_normal((500, 6))
+    nb = NearestNeighbors(n_neighbors=5, metric="euclidean", leaf_size=20, algorithm="auto", n_jobs=-1).fit(Y)
+    d, i = nb.kneighbors(X)
+    sd, si = orc.knn_sklearn(X, Y, 5)
+    assert _rel(d, sd) < DIST_RTOL and np.array_equal(i, si)
+    d, i = nb.kneighbors(Y)                       # the reference's auto-evidence call shape (:1100-1104)
+    sd, si = orc.knn_sklearn(Y, Y, 5)
+    assert np.all(d[:, 0] == 0) and _rel(d[:, 1:], sd[:, 1:]) < DIST_RTOL and np.array_equal(i, si)
+    d, i = nb.kneighbors()                        # sklearn: X=None excludes each point itself
+    assert _rel(d, orc.knn_brute(Y, Y, 5, self_mode=2)[0]) < DIST_RTOL
+
+
+def test_device_pointer_entry_points(capi):
+    """resident data path used by bench.py: torch tensors, caller's stream, caller's workspace."""
+    import torch
+    rng = np.random.default_rng(12)
+    n, d, kmax = 30000, 6, 4
+    Xh = rng.standard_normal((n, d))
+    X = torch.from_numpy(Xh).cuda()
+    w = torch.ones(n, dtype=torch.float64, device="cuda")
+    fs = torch.zeros(n, dtype=torch.float64, device="cuda")
+    K = kmax - 1
+    wsb = capi.knn_workspace_bytes(n, n, d, K) + capi.dotp_workspace_bytes(n, kmax)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(kmax, dtype=torch.float64, device="cuda")
+    dd = torch.zeros((n, K), dtype=torch.float64, device="cuda")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        capi.knn_dotp_dev(X.data_ptr(), n, X.data_ptr(), n, d, kmax, 1, 0, w.data_ptr(), fs.data_ptr(), out.data_ptr(),
+                          dd.data_ptr(), ws.data_ptr(), wsb, st.cuda_stream)
+    st.synchronize()
+    host = capi.knn_dotp(Xh, None, np.ones(n), np.zeros(n), kmax, 1)
+    assert np.array_equal(out.cpu().numpy(), host)
+    od, _ = orc.knn_brute(Xh[:2000], Xh, K + 1)
+    assert _rel(dd.cpu().numpy()[:2000], od[:, 1:]) < DIST_RTOL
+    with pytest.raises(ValueError):
+        capi.knn_dotp_dev(X.data_ptr(), n, X.data_ptr(), n, d, kmax, 1, 0, w.data_ptr(), fs.data_ptr(), out.data_ptr(),
+                          0, ws.data_ptr(), 1024, 0)

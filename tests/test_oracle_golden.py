@@ -1,0 +1,95 @@
+"""Pins the CPU oracle against golden vectors produced by the reference itself
+(oracle/gen_golden.py imported /root/reference/MCEvidence.py in the build container).
+CPU only."""
+import math
+
+import numpy as np
+import pytest
+
+from helpers import DIST_RTOL, LNE_TOL, chain_of, load_golden, orc
+
+G = load_golden()
+SMALL = [n for n, c in G.items() if c["tag"] == "small"]
+MEDIUM = [n for n, c in G.items() if c["tag"] == "medium"]
+
+
+def _oracle_run(case, knn):
+    a = case["arrays"]
+    mk, ek = case["mce"], case["ev"]
+    kw = dict(ndim=mk.get("ndim"), kmax=mk.get("kmax", 5), priorvolume=ek.get("pvolume") or mk.get("priorvolume", 1.0),
+              pos_lnp=ek.get("pos_lnp", False), knn=knn)
+    cov = ek.get("covtype", "all")
+    kw["covtype"] = mk.get("covtype", "single") if cov is None else cov
+    if mk.get("split"):
+        kw["s1_idx"], kw["s2_idx"] = a["s1_idx"], a["s2_idx"]
+    return orc.evidence_from_chain(chain_of(case), **kw)
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_oracle_reproduces_reference_lnE_sklearn(name):
+    """numpy restatement + the reference's own sklearn call == reference output."""
+    case = G[name]
+    out = _oracle_run(case, "sklearn")
+    assert np.allclose(out["lnE"], case["lnE"], rtol=0, atol=1e-11)
+    assert math.isclose(out["J"], case["J"], rel_tol=1e-12)
+    assert math.isclose(out["SumW"], case["SumW"], rel_tol=1e-14)
+    assert math.isclose(out["logLmax"], case["logLmax"], rel_tol=1e-14, abs_tol=1e-14)
+    assert np.allclose(out["dotp"][case["k0"]:], np.array(case["dotp"])[case["k0"]:], rtol=1e-11)
+    assert out["S"] == case["S"] and out["k0"] == case["k0"]
+
+
+@pytest.mark.parametrize("name", SMALL + MEDIUM)
+def test_oracle_bruteforce_knn_matches_reference(name):
+    """the independent exact C search gives the reference's distances and ln E."""
+    case = G[name]
+    out = _oracle_run(case, "brute")
+    assert np.allclose(out["lnE"], case["lnE"], rtol=0, atol=LNE_TOL)
+    rows = case["arrays"]["rows"]
+    ref_rows = case["arrays"]["DkNN_rows"]
+    got = out["DkNN"][rows]
+    k0 = case["k0"]      # auto mode: sklearn's column 0 is the point itself (0 or ~1e-8 on the GEMM path)
+    assert np.allclose(got[:, k0:], ref_rows[:, k0:], rtol=DIST_RTOL, atol=0)
+    assert np.allclose(out["X"][rows], case["arrays"]["X_rows"], rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", SMALL[:6])
+def test_dotp_forms_agree(name):
+    """literal pow/gamma form (reference) == log-domain form (HIP kernel) == C restatement."""
+    case = G[name]
+    out = _oracle_run(case, "brute")
+    k0, kmax = out["k0"], out["kmax"]
+    lit = orc.dotp_literal(out["DkNN"], out["w"], out["fs"], out["ndim"], k0, kmax)
+    logd = orc.dotp_logdomain(out["DkNN"], out["w"], out["fs"], out["ndim"], k0, kmax)
+    cc = orc.dotp_c(out["DkNN"], out["w"], out["fs"], out["ndim"], k0, kmax)
+    assert np.allclose(logd[k0:], lit[k0:], rtol=1e-12)
+    assert np.allclose(cc[k0:], lit[k0:], rtol=1e-12)
+
+
+def test_knn_brute_modes_and_numpy_agree():
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((700, 5))
+    d0, i0 = orc.knn_brute(X, X, 6)
+    d2, i2 = orc.knn_brute(X, X, 5, self_mode=2)
+    assert np.all(d0[:, 0] == 0.0) and np.array_equal(i0[:, 0], np.arange(700))
+    assert np.array_equal(d0[:, 1:], d2) and np.array_equal(i0[:, 1:], i2)
+    dn, inn = orc.knn_numpy(X, X, 5, exclude_self=True)
+    assert np.allclose(dn, d2, rtol=1e-13) and np.array_equal(inn, i2)
+    # sharded self-exclusion: shard [200,450) with self_offset=200 == rows of the full result
+    ds, is_ = orc.knn_brute(X[200:450], X, 5, self_mode=2, self_offset=200)
+    assert np.array_equal(ds, d2[200:450]) and np.array_equal(is_, i2[200:450])
+    with pytest.raises(ValueError):
+        orc.knn_brute(X[:3], X[:3], 3, self_mode=2)
+
+
+def test_duplicates_give_zero_volume_terms():
+    """repeated rows (thinning replicates rows): r=0 -> zero volume, no NaN (SURVEY hard parts)."""
+    rng = np.random.default_rng(6)
+    X = rng.standard_normal((300, 4))
+    X[10] = X[11] = X[12]
+    d, _ = orc.knn_brute(X, X, 3, self_mode=2)
+    assert d[10, 0] == 0.0 and d[10, 1] == 0.0
+    full = np.zeros((300, 4)); full[:, 1:] = d
+    w = np.ones(300); fs = np.zeros(300)
+    for f in (orc.dotp_literal, orc.dotp_logdomain, orc.dotp_c):
+        out = f(full, w, fs, 4, 1, 4)
+        assert np.all(np.isfinite(out[1:])) and np.all(out[1:] > 0)
