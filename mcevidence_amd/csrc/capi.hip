@@ -54,7 +54,7 @@ struct Plan {
     int64_t nq_pad = 0;
     int rsplit = 1;
     int L = 4;
-    size_t off_yf = 0, off_pd = 0, off_pi = 0, total = 0;
+    size_t off_yf = 0, off_pd = 0, off_pi = 0, off_center = 0, off_msum = 0, total = 0;
 };
 
 const mce::KnnVariant* variant_for(int KS, int kcap_idx)
@@ -124,6 +124,10 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     off = align_up(off + (size_t)p.L * p.KCAP * (size_t)p.nq_pad * sizeof(double), 256);
     p.off_pi = off;
     off = align_up(off + (size_t)p.L * p.KCAP * (size_t)p.nq_pad * sizeof(int), 256);
+    p.off_center = off;
+    off = align_up(off + (size_t)mce::kMaxDimPad * sizeof(double), 256);
+    p.off_msum = off;
+    off = align_up(off + (size_t)mce::kMeanBlocks * mce::kMaxDimPad * sizeof(double), 256);
     p.total = off;
     return MCE_OK;
 }
@@ -143,10 +147,16 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
     double* yf = reinterpret_cast<double*>(ws + p.off_yf);
     double* pd = reinterpret_cast<double*>(ws + p.off_pd);
     int* pi = reinterpret_cast<int*>(ws + p.off_pi);
+    double* center = reinterpret_cast<double*>(ws + p.off_center);
+    double* msum = reinterpret_cast<double*>(ws + p.off_msum);
     {
+        hipLaunchKernelGGL(mce::col_sum_partial_kernel, dim3(mce::kMeanBlocks), dim3(mce::kMeanThreads), 0, st, dY, nr, (int)d, msum);
+        MCE_HIP(hipGetLastError());
+        hipLaunchKernelGGL(mce::col_mean_final_kernel, dim3(1), dim3(64), 0, st, msum, nr, (int)d, center);
+        MCE_HIP(hipGetLastError());
         const int threads = 256;
         const unsigned blocks = (unsigned)((p.nrow_pad + threads - 1) / threads);
-        hipLaunchKernelGGL(mce::pack_refs_kernel, dim3(blocks), dim3(threads), 0, st, dY, nr, (int)d, p.KS, p.nrow_pad, yf);
+        hipLaunchKernelGGL(mce::pack_refs_kernel, dim3(blocks), dim3(threads), 0, st, dY, nr, (int)d, p.KS, p.nrow_pad, center, yf);
         MCE_HIP(hipGetLastError());
     }
     mce::KnnArgs a;
@@ -154,6 +164,7 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
     a.nchunk_total = p.nchunk;
     a.rsplit = p.rsplit;
     a.X = dX;
+    a.center = center;
     a.nq = nq;
     a.D = d;
     a.nq_pad = p.nq_pad;
@@ -211,7 +222,7 @@ int mce_knn_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t nr, 
     const unsigned blocks = (unsigned)((nq + mce::kRedThreads - 1) / mce::kRedThreads);
     hipLaunchKernelGGL((mce::merge_lists_kernel<true, false>), dim3(blocks), dim3(mce::kRedThreads), 0, st,
                        reinterpret_cast<const double*>(static_cast<char*>(ws) + p.off_pd),
-                       reinterpret_cast<const int*>(static_cast<char*>(ws) + p.off_pi), p.L, p.KCAP, nq, p.nq_pad, dX,
+                       reinterpret_cast<const int*>(static_cast<char*>(ws) + p.off_pi), p.L, p.KCAP, nq, p.nq_pad, dX, dY,
                        (int)d, (int)K, (int)self_mode, self_offset, d_dist, d_idx, (int)K, 0, 0,
                        (const double*)nullptr, (const double*)nullptr, 0.0, (double*)nullptr);
     MCE_HIP(hipGetLastError());
@@ -263,11 +274,11 @@ int mce_knn_dotp_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t
     const int* pi = reinterpret_cast<const int*>(wsc + p.off_pi);
     if (d_dist_out) {
         hipLaunchKernelGGL((mce::merge_lists_kernel<true, true>), dim3(blocks), dim3(mce::kRedThreads), 0, st, pd, pi,
-                           p.L, p.KCAP, nq, p.nq_pad, dX, (int)d, K, self_mode, self_offset, d_dist_out,
+                           p.L, p.KCAP, nq, p.nq_pad, dX, dY, (int)d, K, self_mode, self_offset, d_dist_out,
                            (int64_t*)nullptr, K, (int)k0, (int)kmax, d_w, d_fs, ln_unit_ball(d), partial);
     } else {
         hipLaunchKernelGGL((mce::merge_lists_kernel<false, true>), dim3(blocks), dim3(mce::kRedThreads), 0, st, pd, pi,
-                           p.L, p.KCAP, nq, p.nq_pad, dX, (int)d, K, self_mode, self_offset, (double*)nullptr,
+                           p.L, p.KCAP, nq, p.nq_pad, dX, dY, (int)d, K, self_mode, self_offset, (double*)nullptr,
                            (int64_t*)nullptr, K, (int)k0, (int)kmax, d_w, d_fs, ln_unit_ball(d), partial);
     }
     MCE_HIP(hipGetLastError());

@@ -12,6 +12,7 @@ struct KnnArgs {
     int64_t nchunk_total;
     int rsplit;
     const double* X;        // queries [nq, D]
+    const double* center;   // [64] reference-set column means
     int64_t nq;
     int D;
     int64_t nq_pad;

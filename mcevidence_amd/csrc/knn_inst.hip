@@ -22,7 +22,7 @@ hipError_t launch_variant(const KnnArgs& a, hipStream_t st)
         attr_set = true;
     }
     const dim3 grid((unsigned)(a.nqblk * a.rsplit));
-    hipLaunchKernelGGL(kern, grid, dim3(kThreads), LDS, st, a.Yf, a.nchunk_total, a.rsplit, a.X, a.nq, a.D,
+    hipLaunchKernelGGL(kern, grid, dim3(kThreads), LDS, st, a.Yf, a.nchunk_total, a.rsplit, a.X, a.center, a.nq, a.D,
                        a.nq_pad, a.nqblk, a.self_exclude, a.self_offset, a.ksel, a.part_d, a.part_i);
     return hipGetLastError();
 }
@@ -45,7 +45,7 @@ extern const KnnVariant MCE_CAT(g_knn_kcap, MCE_KCAP)[kMaxKS] = {
 };
 #else
 // device pass: force the kernel instantiations
-#define MCE_INST(KS) template __global__ void knn_mfma_kernel<KS, MCE_KCAP>(const double*, int64_t, int, const double*, int64_t, int, int64_t, int, int, int64_t, int, double*, int*);
+#define MCE_INST(KS) template __global__ void knn_mfma_kernel<KS, MCE_KCAP>(const double*, int64_t, int, const double*, const double*, int64_t, int, int64_t, int, int, int64_t, int, double*, int*);
 MCE_INST(1) MCE_INST(2) MCE_INST(3) MCE_INST(4) MCE_INST(5) MCE_INST(6) MCE_INST(7) MCE_INST(8)
 MCE_INST(9) MCE_INST(10) MCE_INST(11) MCE_INST(12) MCE_INST(13) MCE_INST(14) MCE_INST(15) MCE_INST(16)
 #endif

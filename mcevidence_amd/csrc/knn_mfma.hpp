@@ -3,7 +3,8 @@
 // Replaces `NearestNeighbors(...).fit(Y).kneighbors(X)` of the reference
 // (MCEvidence.py:1093-1104).  Design:
 //
-//  * d2(x,y) = |x|^2 + |y|^2 - 2 x.y.  With the augmented vectors
+//  * d2(x,y) = |x|^2 + |y|^2 - 2 x.y (x, y centred on the reference mean, pack_refs.hpp).
+//    With the augmented vectors
 //        x' = [x, 1, 0..]   y' = [-2y, |y|^2, 0..]       (D+1 padded to 4*KS)
 //    d2 = |x|^2 + x'.y' is KS chained v_mfma_f64_16x16x4_f64 whose C-in is |x|^2:
 //    A = 16 reference rows, B = 16 query rows; the accumulator IS the squared distance.
@@ -68,7 +69,7 @@ __host__ __device__ constexpr size_t lds_bytes(int KS, int KCAP)
 template <int KS, int KCAP>
 __global__ __launch_bounds__(kThreads, 2) void knn_mfma_kernel(
     const double* __restrict__ Yf, int64_t nchunk_total, int rsplit,
-    const double* __restrict__ X, int64_t nq, int D, int64_t nq_pad, int nqblk,
+    const double* __restrict__ X, const double* __restrict__ center, int64_t nq, int D, int64_t nq_pad, int nqblk,
     int self_exclude, int64_t self_offset, int ksel,
     double* __restrict__ part_d, int* __restrict__ part_i)
 {
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(kThreads, 2) void knn_mfma_kernel(
         for (int ks = 0; ks < KS; ++ks) {
             const int dim = 4 * ks + (lane >> 4);
             double v = 0.0;
-            if (live && dim < D) { v = X[q * (int64_t)D + dim]; part = fma(v, v, part); }
+            if (live && dim < D) { v = X[q * (int64_t)D + dim] - center[dim]; part = fma(v, v, part); }
             if (live && dim == D) v = 1.0;
             b[qt][ks] = v;
         }

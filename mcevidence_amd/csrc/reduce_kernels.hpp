@@ -41,9 +41,13 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 }
 
 // ---------------------------------------------------------------------------
-// merge_lists: one thread per query merges its L sorted per-split lists
-// (keys = squared distances) into the K best, converts to Euclidean
-// distance and optionally feeds the evidence reduction.
+// merge_lists: one thread per query merges its L sorted per-split lists into the K best
+// (keys = GEMM-form squared distances, good to ~1e-16*|x|^2 absolute), then REFINES them:
+// the K selected pairs get their exact direct-difference distance sum_i (x_i - y_i)^2 from
+// the original rows and are re-sorted -- so reported distances equal an exact search's
+// (duplicates give exactly 0, like the reference's KD-tree path) and only the choice
+// between candidates that tie to the last bits can differ.  Optionally feeds the
+// evidence reduction directly.
 //   part_d/part_i : [L][KCAP][nq_pad]
 //   self_mode 1 (include): the entry whose reference row is self_offset+q is
 //                          forced to distance 0 and sorts first.
@@ -51,7 +55,7 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 template <bool WRITE_DIST, bool FUSE_DOTP>
 __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
     const double* __restrict__ part_d, const int* __restrict__ part_i, int L, int KCAP,
-    int64_t nq, int64_t nq_pad, const double* __restrict__ X, int D, int K,
+    int64_t nq, int64_t nq_pad, const double* __restrict__ X, const double* __restrict__ Y, int D, int K,
     int self_mode, int64_t self_offset,
     double* __restrict__ dist, int64_t* __restrict__ idx, int ld_out,
     int k0, int kmax, const double* __restrict__ w, const double* __restrict__ fs, double lnc,
@@ -74,10 +78,13 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
         unsigned char head[kMaxLists];
         for (int l = 0; l < L; ++l) head[l] = 0;
 
+        // ---- select: L-way merge on the approximate keys ----------------------
+        double sel_d[kMaxK];
+        int sel_i[kMaxK];
+        int nsel = 0;
         for (int k = 0; k < K; ++k) {
             double bv = INF;
             int bi = 0x7fffffff, bl = -1;
-            bool bself = false;
             for (int l = 0; l < L; ++l) {
                 const int h = head[l];
                 if (h >= KCAP) continue;
@@ -85,20 +92,39 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
                 const int i = part_i[o];
                 if (i < 0) continue;                       // list exhausted
                 double v = part_d[o];
-                const bool isself = (i == selfj);
-                if (isself) v = -INF;
-                if (v < bv || (v == bv && i < bi)) { bv = v; bi = i; bl = l; bself = isself; }
+                if (i == selfj) v = -INF;                  // SELF_INCLUDE: own row sorts first
+                if (v < bv || (v == bv && i < bi)) { bv = v; bi = i; bl = l; }
             }
-            double d2 = INF;
-            int64_t oi = -1;
-            if (bl >= 0) {
-                head[bl]++;
-                d2 = bself ? 0.0 : fmax(bv, 0.0);
-                oi = bi;
+            if (bl < 0) break;
+            head[bl]++;
+            sel_i[nsel++] = bi;
+        }
+        // ---- refine: exact direct-difference distances of the selected pairs ----
+        const double* x = X + q * (int64_t)D;
+        for (int k = 0; k < nsel; ++k) {
+            const double* y = Y + (int64_t)sel_i[k] * D;
+            double s2 = 0.0;
+            for (int i = 0; i < D; ++i) { const double t = x[i] - y[i]; s2 = fma(t, t, s2); }
+            sel_d[k] = (sel_i[k] == selfj) ? -1.0 : s2;      // own row: sentinel, sorts first, reported as 0
+        }
+        // ---- re-sort (insertion sort; K <= 32), ties by reference row; own row first ----
+        for (int k = 1; k < nsel; ++k) {
+            const double dv = sel_d[k];
+            const int iv = sel_i[k];
+            int p = k;
+            while (p > 0 && (sel_d[p - 1] > dv || (sel_d[p - 1] == dv && sel_i[p - 1] > iv))) {
+                sel_d[p] = sel_d[p - 1];
+                sel_i[p] = sel_i[p - 1];
+                --p;
             }
+            sel_d[p] = dv;
+            sel_i[p] = iv;
+        }
+        for (int k = 0; k < K; ++k) {
+            const double d2 = (k < nsel) ? fmax(sel_d[k], 0.0) : INF;
             if (WRITE_DIST) {
                 dist[q * (int64_t)ld_out + k] = sqrt(d2);
-                if (idx) idx[q * (int64_t)ld_out + k] = oi;
+                if (idx) idx[q * (int64_t)ld_out + k] = (k < nsel) ? (int64_t)sel_i[k] : (int64_t)-1;
             }
             if (FUSE_DOTP) {
                 // column k of the K = kmax-k0 true neighbours <-> reference column k0+k

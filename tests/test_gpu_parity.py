@@ -68,7 +68,7 @@ def test_knn_self_modes(capi):
     d2, i2 = capi.knn(X, X, K - 1, self_mode=capi.SELF_EXCLUDE)
     assert np.all(d1[:, 0] == 0.0) and np.array_equal(i1[:, 0], np.arange(len(X)))     # exactly 0, like the kd-tree path
     assert np.array_equal(d1[:, 1:], d2) and np.array_equal(i1[:, 1:], i2)
-    assert np.all(d0[:, 0] < 1e-6) and np.array_equal(d0[:, 1:], d1[:, 1:])          # GEMM-form self distance ~1e-8
+    assert np.all(d0[:, 0] == 0.0) and np.array_equal(d0[:, 1:], d1[:, 1:])
     # query shard with an offset == rows of the full answer (multi-GPU sharding rule)
     ds, is_ = capi.knn(X[1000:1777], X, K - 1, self_mode=capi.SELF_EXCLUDE, self_offset=1000)
     assert np.array_equal(ds, d2[1000:1777]) and np.array_equal(is_, i2[1000:1777])
@@ -81,7 +81,7 @@ def test_knn_duplicates_and_ties(capi):
     X[1500] = X[3]
     d, i = capi.knn(X, X, 4, self_mode=capi.SELF_EXCLUDE)
     od, oi = orc.knn_brute(X, X, 4, self_mode=2)
-    assert np.all(d[99:105, :4] < 1e-7)    # duplicates: 0 up to GEMM-form rounding (sklearn brute: ~1e-8 too)
+    assert np.all(d[99:105, :4] == 0.0)   # duplicates: exactly 0 (final distances are exact differences)
     mask = od > 0
     assert _rel(d[mask], od[mask]) < DIST_RTOL
     # integer grid -> many exact ties: distances must agree exactly in value

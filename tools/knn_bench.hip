@@ -40,14 +40,15 @@ int main(int argc, char** argv)
     CK(hipMalloc(&pd, sizeof(double) * nl));
     CK(hipMalloc(&pi, sizeof(int) * nl));
     CK(hipMemcpy(X, h.data(), sizeof(double) * n * D, hipMemcpyHostToDevice));
-    pack_refs_kernel<<<(unsigned)((nrow_pad + 255) / 256), 256>>>(X, n, D, KS, nrow_pad, Yf);
+    double* center; CK(hipMalloc(&center, 64 * 8)); CK(hipMemset(center, 0, 64 * 8));
+    pack_refs_kernel<<<(unsigned)((nrow_pad + 255) / 256), 256>>>(X, n, D, KS, nrow_pad, center, Yf);
     constexpr size_t LDS = lds_bytes(KS, KCAP);
     auto kern = knn_mfma_kernel<KS, KCAP>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int r = 0; r < reps; ++r) {
         CK(hipEventRecord(e0));
-        kern<<<nqblk * rsplit, kThreads, LDS>>>(Yf, nchunk, rsplit, X, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi);
+        kern<<<nqblk * rsplit, kThreads, LDS>>>(Yf, nchunk, rsplit, X, center, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("KS=%d KCAP=%d QT=%d CT=%d ablate=%d lds=%zu n=%lld rsplit=%d grid=%d: %.2f ms  %.3f Mq/s  %.2f TFLOP/s\n", KS, KCAP, QT, CT, MCE_ABLATE, LDS,
