@@ -34,6 +34,28 @@ sys.path.insert(0, REPO)
 FP64_PEAK_TFLOPS = 78.6
 
 
+def hbm_traffic_from_profile(kernel_desc):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/<round>/pmc_summary.csv: FETCH_SIZE/WRITE_SIZE in KB, separate passes; FETCH_SIZE
+    doubled per MI355X_MICROARCH.md's gfx950 note).  None when no profile of this kernel exists."""
+    import glob
+    want = kernel_desc.split(" ")[0].replace("KS=", "").replace("KCAP=", "").replace(",", ", ")   # knn_mfma_kernel<7, 12>
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*", "pmc_summary.csv")), reverse=True):
+        fetch = write = None
+        for ln in open(f):
+            c = ln.strip().split(",")
+            if len(c) >= 5 and want in ln:
+                name, val, nd = c[-3], float(c[-2]), int(c[-1])
+                if name == "FETCH_SIZE":
+                    fetch = val / nd
+                if name == "WRITE_SIZE":
+                    write = val / nd
+        if fetch is not None and write is not None:
+            return dict(bytes=(2.0 * fetch + write) * 1024.0, source=os.path.relpath(f, REPO),
+                        note="per launch; (2*FETCH_SIZE + WRITE_SIZE) KB, separate --pmc passes")
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,21 +122,19 @@ def main():
     for _ in range(a.warmup):
         step()
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    _capi.set_profiling(True)          # hipEvent brackets around each knn_mfma_kernel launch, on its stream
     t0 = time.perf_counter()
-    for e0, e1 in ev:
-        e0.record(stream)
+    for _ in range(a.steps):
         step()
-        e1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
+    kern_ms = _capi.last_kernel_ms()   # mean over the K timed launches (read after the timed region)
+    _capi.set_profiling(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_step = elapsed / a.steps * 1e3
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))     # whole hot path on the launch stream
-
     # ---- ln E from the device result, and parity against the golden / CPU sample ----
     dp = dotp.cpu().numpy()
     lnE = np.array([math.log(SumW * dp[k] / (n * k + 1.0) * cov["J"]) + logLmax - math.log(1.0) for k in range(1, kmax)])
@@ -123,11 +143,10 @@ def main():
     if rank == 0:
         KS = (d + 1 + 3) // 4
         flops = float(nq) * n * 2.0 * 4 * KS
-        # dominant kernel time: the hot path minus pack/merge/reduce is not separable from
-        # torch events; rocprofv3 (profiles/) attributes >98% of the step to knn_mfma_kernel.
         achieved = flops / (kern_ms * 1e-3) / 1e12
         roof = dict(bound="mfma", achieved=round(achieved, 3), peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved / FP64_PEAK_TFLOPS, 4), traffic=None,
+                    frac=round(achieved / FP64_PEAK_TFLOPS, 4), traffic=hbm_traffic_from_profile(_capi.last_kernel()),
+                    kernel_ms=round(kern_ms, 3),
                     kernel=_capi.last_kernel(), algorithmic_flops_per_launch=flops,
                     note="fp64 MFMA-bound (SURVEY 8d); HBM traffic is the packed reference set streamed once per workgroup round")
         cpu = None

@@ -113,6 +113,13 @@ int mce_knn_dotp_f64_dev(const double *dX, int64_t nq, const double *dY, int64_t
  * geometry (for bench.py / profiles): "knn_mfma_f64<KS=7,KCAP=12>" etc. */
 const char *mce_last_kernel(void);
 
+/* Measurement hook: while enabled, the search-kernel launch of every call on this thread
+ * is bracketed by hipEvents recorded on the launch stream (no synchronisation);
+ * mce_last_kernel_ms() waits for the brackets recorded since the last enable and returns
+ * their MEAN duration in ms (-1 if none).  Used by bench.py for the roofline figure. */
+void mce_set_profiling(int on);
+double mce_last_kernel_ms(void);
+
 #ifdef __cplusplus
 }
 #endif

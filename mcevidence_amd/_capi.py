@@ -39,6 +39,8 @@ SIGNATURES = {
     "mce_device_count": (_c.c_int, []),
     "mce_last_error": (_c.c_char_p, []),
     "mce_last_kernel": (_c.c_char_p, []),
+    "mce_set_profiling": (None, [_c.c_int]),
+    "mce_last_kernel_ms": (_c.c_double, []),
     "mce_knn_f64": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _c.c_int32]),
     "mce_dotp_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_int32]),
     "mce_knn_dotp_f64": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _P, _P, _P, _c.c_int32]),
@@ -86,6 +88,14 @@ def last_error():
 
 def last_kernel():
     return load().mce_last_kernel().decode("utf-8", "replace")
+
+
+def set_profiling(on):
+    load().mce_set_profiling(1 if on else 0)
+
+
+def last_kernel_ms():
+    return float(load().mce_last_kernel_ms())
 
 
 def check(rc):

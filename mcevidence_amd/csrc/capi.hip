@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "knn_dispatch.hpp"
@@ -24,6 +25,10 @@ namespace {
 
 thread_local char g_err[512] = "";
 thread_local char g_last_kernel[256] = "";
+// optional timing of the dominant kernel with HIP events on the launch stream (bench.py)
+thread_local int g_prof_on = 0;
+thread_local std::vector<std::pair<hipEvent_t, hipEvent_t>> g_ev_pool;   // reused brackets
+thread_local size_t g_ev_used = 0;                                        // brackets since enable
 
 int fail(int code, const char* fmt, ...)
 {
@@ -174,7 +179,18 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
     a.ksel = K;
     a.part_d = pd;
     a.part_i = pi;
+    const bool prof = g_prof_on && g_ev_used < 1024;
+    if (prof) {
+        if (g_ev_used == g_ev_pool.size()) {
+            hipEvent_t e0, e1;
+            MCE_HIP(hipEventCreate(&e0));
+            MCE_HIP(hipEventCreate(&e1));
+            g_ev_pool.emplace_back(e0, e1);
+        }
+        MCE_HIP(hipEventRecord(g_ev_pool[g_ev_used].first, st));
+    }
     MCE_HIP(p.v->launch(a, st));
+    if (prof) { MCE_HIP(hipEventRecord(g_ev_pool[g_ev_used].second, st)); ++g_ev_used; }
     snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d", p.v->name,
              p.nqblk * p.rsplit, mce::kThreads, p.v->lds_bytes, p.QT, p.CT, p.rsplit);
     return MCE_OK;
@@ -189,6 +205,25 @@ int mce_abi_version(void) { return MCE_ABI_VERSION; }
 const char* mce_last_error(void) { return g_err; }
 
 const char* mce_last_kernel(void) { return g_last_kernel; }
+
+void mce_set_profiling(int on)
+{
+    g_prof_on = on ? 1 : 0;
+    if (on) g_ev_used = 0;
+}
+
+double mce_last_kernel_ms(void)
+{
+    if (g_ev_used == 0) return -1.0;
+    double sum = 0.0;
+    for (size_t i = 0; i < g_ev_used; ++i) {
+        if (hipEventSynchronize(g_ev_pool[i].second) != hipSuccess) return -1.0;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, g_ev_pool[i].first, g_ev_pool[i].second) != hipSuccess) return -1.0;
+        sum += ms;
+    }
+    return sum / (double)g_ev_used;
+}
 
 int mce_device_count(void)
 {

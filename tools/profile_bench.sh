@@ -1,0 +1,35 @@
+#!/bin/bash
+# GPU box: rocprofv3 kernel-trace stats + HBM counters for `python bench.py` (round-tagged).
+# usage: tools/profile_bench.sh <tag>     -> gpurun_out/prof_<tag>/...
+tag=${1:-r01}
+R=$GRAFT_REPO_ROOT
+out=$R/gpurun_out/prof_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$tag -o kt -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $out/bench_under_kernel_trace.log 2>&1
+cp $(find /tmp/kt_$tag -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv 2>/dev/null
+# HBM traffic counters: separate passes (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf_$tag -o pf -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $out/bench_under_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw_$tag -o pw -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $out/bench_under_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d /tmp/ps_$tag -o ps -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $out/bench_under_sq.log 2>&1
+python3 - $tag $out <<'PY'
+import csv, sys, glob, collections
+tag, out = sys.argv[1], sys.argv[2]
+rows=[]
+for name, d in (("FETCH_SIZE","/tmp/pf_"+tag),("WRITE_SIZE","/tmp/pw_"+tag),("SQ","/tmp/ps_"+tag)):
+    for f in glob.glob(d+"/**/*counter_collection.csv", recursive=True):
+        agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.defaultdict(int)
+        seen=set()
+        for r in csv.DictReader(open(f)):
+            k=r['Kernel_Name'].split('(')[0][:60]
+            agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
+            seen.add((k, r['Dispatch_Id']))
+        for k in agg:
+            nd=len([1 for kk,_ in seen if kk==k])
+            for c,v in agg[k].items(): rows.append((k,c,v,nd))
+with open(out+"/pmc_summary.csv","w") as fh:
+    fh.write("kernel,counter,sum_over_dispatches,dispatches\n")
+    for r in rows: fh.write("%s,%s,%.6g,%d\n"%r)
+print(open(out+"/pmc_summary.csv").read())
+PY
+head -12 $out/kernel_stats.csv
