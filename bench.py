@@ -151,7 +151,7 @@ def main():
                     note="fp64 MFMA-bound (SURVEY 8d); HBM traffic is the packed reference set streamed once per workgroup round")
         cpu = None
         dlnE = None
-        if a.cpu_sample > 0:
+        if a.cpu_sample > 0 and world == 1:         # CPU baseline: rank 0, N=1 only
             from oracle import oracle_np as orc                 # checker / baseline only
             rng = np.random.default_rng(0)
             rows = np.sort(rng.choice(n, size=min(a.cpu_sample, n), replace=False))
