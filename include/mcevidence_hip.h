@@ -113,6 +113,12 @@ int mce_knn_dotp_f64_dev(const double *dX, int64_t nq, const double *dY, int64_t
  * geometry (for bench.py / profiles): "knn_mfma_f64<KS=7,KCAP=12>" etc. */
 const char *mce_last_kernel(void);
 
+/* Search algorithm.  0 (default) / 2: fp16-MFMA filter with exact fp64 refinement where the
+ * shape allows it (2 <= d <= 61, K <= 16), otherwise the fp64 MFMA sweep; 1: always the
+ * fp64 MFMA sweep.  Both return the exact fp64 neighbours and distances.  Process-wide. */
+int mce_set_search_mode(int mode);
+int mce_get_search_mode(void);
+
 /* Measurement hook: while enabled, the search-kernel launch of every call on this thread
  * is bracketed by hipEvents recorded on the launch stream (no synchronisation);
  * mce_last_kernel_ms() waits for the brackets recorded since the last enable and returns

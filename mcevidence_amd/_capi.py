@@ -39,6 +39,8 @@ SIGNATURES = {
     "mce_device_count": (_c.c_int, []),
     "mce_last_error": (_c.c_char_p, []),
     "mce_last_kernel": (_c.c_char_p, []),
+    "mce_set_search_mode": (_c.c_int, [_c.c_int]),
+    "mce_get_search_mode": (_c.c_int, []),
     "mce_set_profiling": (None, [_c.c_int]),
     "mce_last_kernel_ms": (_c.c_double, []),
     "mce_knn_f64": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _c.c_int32]),
@@ -88,6 +90,18 @@ def last_error():
 
 def last_kernel():
     return load().mce_last_kernel().decode("utf-8", "replace")
+
+
+MODE_AUTO, MODE_F64, MODE_F16_FILTER = 0, 1, 2
+
+
+def set_search_mode(mode):
+    """0/2: fp16-MFMA filter + exact fp64 refine where supported; 1: fp64 MFMA sweep only."""
+    check(load().mce_set_search_mode(int(mode)))
+
+
+def get_search_mode():
+    return int(load().mce_get_search_mode())
 
 
 def set_profiling(on):

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -19,6 +20,7 @@
 #include "knn_dispatch.hpp"
 #include "knn_mfma.hpp"
 #include "pack_refs.hpp"
+#include "f16_prep.hpp"
 #include "reduce_kernels.hpp"
 
 namespace {
@@ -46,12 +48,19 @@ int fail(int code, const char* fmt, ...)
             return fail(MCE_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// search mode: 0 auto (fp16 filter + fp64 refine where supported, else fp64 MFMA),
+//              1 fp64 MFMA sweep only, 2 same as 0 (explicit)
+std::atomic<int> g_mode{0};
+
 constexpr int kAssumedCUs = 256;   // MI355X; only steers the reference-split heuristic
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Plan {
     const mce::KnnVariant* v = nullptr;
+    const mce::KnnF16Variant* vh = nullptr;   // non-null: fp16-filter path
+    int KST = 0;
+    size_t off_yh = 0, off_xh = 0, off_qinfo = 0, off_params = 0;
     int KS = 0, KCAP = 0, QT = 0, CT = 0;
     int64_t nchunk = 0;      // reference chunks (CT tiles of 16 rows)
     int64_t nrow_pad = 0;    // padded reference rows
@@ -91,30 +100,49 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     int ki = 0;
     while (ki < mce::kNumKcap - 1 && mce::kKcapList[ki] < K) ++ki;
     p.KCAP = mce::kKcapList[ki];
-    p.v = variant_for(p.KS, ki);
-    p.QT = p.v->qt;
-    p.CT = p.v->ct;
-    const int qpb = mce::queries_per_block(p.QT);
+    const bool f16 = (g_mode.load() != 1) && mce::f16_supported(d, K);
+    int qpb, rows_per_tile;
+    if (f16) {
+        p.KST = mce::f16_ksteps(d);
+        const mce::KnnF16Variant* tab = ki == 0 ? mce::g_knn_f16_kcap4 : ki == 1 ? mce::g_knn_f16_kcap8
+                                        : ki == 2 ? mce::g_knn_f16_kcap12 : mce::g_knn_f16_kcap16;
+        p.vh = &tab[p.KST - 1];
+        p.v = nullptr;
+        p.QT = p.vh->qt;
+        p.CT = p.vh->ct;
+        qpb = mce::f16_qpb(p.KCAP);
+        rows_per_tile = 32;
+    } else {
+        p.v = variant_for(p.KS, ki);
+        p.vh = nullptr;
+        p.QT = p.v->qt;
+        p.CT = p.v->ct;
+        qpb = mce::queries_per_block(p.QT);
+        rows_per_tile = 16;
+    }
     p.nqblk = (int)std::max<int64_t>(1, (nq + qpb - 1) / qpb);
     p.nq_pad = (int64_t)p.nqblk * qpb;
-    const int64_t rows_per_chunk = (int64_t)p.CT * 16;
+    const int64_t rows_per_chunk = (int64_t)p.CT * rows_per_tile;
     p.nchunk = (nr + rows_per_chunk - 1) / rows_per_chunk;
     p.nrow_pad = p.nchunk * rows_per_chunk;
 
     // reference split r: more workgroups fill the chip and trim the last partial round
     // (one 512-thread workgroup per CU), but every split re-pays the list warm-up: a query
     // accepts ~K(1+ln(n/K)) candidates while streaming n references, each a serialised
-    // whole-wave insertion.  Model (cycles per SIMD, measured on MI355X):
-    //   block(r) = 256*KS*tiles(r) + 1000 * 32 * K * (1 + ln(n_r/K)),   n_r = nr/r
-    //   total(r) = ceil(nqblk*r / CUs) * block(r)
+    // whole-wave insertion.  Model (cycles per SIMD, fitted on MI355X):
+    //   fp64 sweep : block(r) = 256*KS*tiles16(r)      + 1000 * 32   * K (1 + ln(n_r/K))
+    //   fp16 filter: block(r) = 64*QT*KST*tiles32(r)   +  300 * 32QT * K (1 + ln(n_r/K))
+    //   total(r)   = ceil(nqblk*r / CUs) * block(r),   n_r = nr/r
     int best_r = 1;
     double best_c = 1e300;
     const int rmax = (int)std::min<int64_t>(mce::kMaxLists, p.nchunk);
-    for (int r = 1; r <= rmax; ++r) {
+    const int rmin = f16 ? (int)((nr + ((int64_t)1 << mce::kHRelBits) - 1) >> mce::kHRelBits) : 1;   // queue entries hold 26-bit row offsets
+    if (rmin > rmax) return fail(MCE_ERR_INVALID, "reference set too large for the fp16-filter path (nr=%lld)", (long long)nr);
+    for (int r = std::max(1, rmin); r <= rmax; ++r) {
         const double n_r = (double)nr / r;
-        const double tiles = n_r / 16.0;
-        const double cand = 32.0 * K * (1.0 + std::log(std::max(1.0, n_r / K)));
-        const double block = 256.0 * p.KS * tiles + 1000.0 * cand;
+        const double lnf = 1.0 + std::log(std::max(1.0, n_r / K));
+        const double block = f16 ? 64.0 * p.QT * p.KST * (n_r / 32.0) + 300.0 * 32.0 * p.QT * K * lnf
+                                 : 256.0 * p.KS * (n_r / 16.0) + 1000.0 * 32.0 * K * lnf;
         const double rounds = std::ceil((double)p.nqblk * r / kAssumedCUs);
         const double c = rounds * block;
         if (c < best_c * 0.98) { best_c = c; best_r = r; }   // need >2% gain to take a bigger split
@@ -124,7 +152,18 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
 
     size_t off = 0;
     p.off_yf = off;
-    off = align_up(off + (size_t)p.nrow_pad * (size_t)(4 * p.KS) * sizeof(double), 256);
+    if (f16) {
+        p.off_yh = off;
+        off = align_up(off + (size_t)p.nrow_pad * (size_t)(16 * p.KST) * 2, 256);
+        p.off_xh = off;
+        off = align_up(off + (size_t)p.nq_pad * (size_t)(16 * p.KST) * 2, 256);
+        p.off_qinfo = off;
+        off = align_up(off + (size_t)p.nq_pad * 2 * sizeof(double), 256);
+        p.off_params = off;
+        off = align_up(off + (size_t)mce::HP_COUNT * sizeof(double), 256);
+    } else {
+        off = align_up(off + (size_t)p.nrow_pad * (size_t)(4 * p.KS) * sizeof(double), 256);
+    }
     p.off_pd = off;
     off = align_up(off + (size_t)p.L * p.KCAP * (size_t)p.nq_pad * sizeof(double), 256);
     p.off_pi = off;
@@ -149,21 +188,69 @@ double ln_unit_ball(int d) { return 0.5 * d * std::log(M_PI) - std::lgamma(1.0 +
 int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, int64_t nr, int32_t d, int32_t K,
                int32_t self_mode, int64_t self_offset, char* ws, hipStream_t st)
 {
-    double* yf = reinterpret_cast<double*>(ws + p.off_yf);
     double* pd = reinterpret_cast<double*>(ws + p.off_pd);
     int* pi = reinterpret_cast<int*>(ws + p.off_pi);
     double* center = reinterpret_cast<double*>(ws + p.off_center);
     double* msum = reinterpret_cast<double*>(ws + p.off_msum);
-    {
-        hipLaunchKernelGGL(mce::col_sum_partial_kernel, dim3(mce::kMeanBlocks), dim3(mce::kMeanThreads), 0, st, dY, nr, (int)d, msum);
+    hipLaunchKernelGGL(mce::col_sum_partial_kernel, dim3(mce::kMeanBlocks), dim3(mce::kMeanThreads), 0, st, dY, nr, (int)d, msum);
+    MCE_HIP(hipGetLastError());
+    hipLaunchKernelGGL(mce::col_mean_final_kernel, dim3(1), dim3(64), 0, st, msum, nr, (int)d, center);
+    MCE_HIP(hipGetLastError());
+    const bool prof = g_prof_on && g_ev_used < 1024;
+    auto prof_begin = [&]() -> int {
+        if (!prof) return MCE_OK;
+        if (g_ev_used == g_ev_pool.size()) {
+            hipEvent_t e0, e1;
+            MCE_HIP(hipEventCreate(&e0));
+            MCE_HIP(hipEventCreate(&e1));
+            g_ev_pool.emplace_back(e0, e1);
+        }
+        MCE_HIP(hipEventRecord(g_ev_pool[g_ev_used].first, st));
+        return MCE_OK;
+    };
+    auto prof_end = [&]() -> int {
+        if (!prof) return MCE_OK;
+        MCE_HIP(hipEventRecord(g_ev_pool[g_ev_used].second, st));
+        ++g_ev_used;
+        return MCE_OK;
+    };
+    const int threads = 256;
+    if (p.vh) {
+        // ---- fp16 filter + exact fp64 refine ------------------------------------
+        _Float16* yh = reinterpret_cast<_Float16*>(ws + p.off_yh);
+        _Float16* xh = reinterpret_cast<_Float16*>(ws + p.off_xh);
+        double* qinfo = reinterpret_cast<double*>(ws + p.off_qinfo);
+        double* params = reinterpret_cast<double*>(ws + p.off_params);
+        MCE_HIP(hipMemsetAsync(params, 0, mce::HP_COUNT * sizeof(double), st));
+        hipLaunchKernelGGL(mce::f16_radius_kernel, dim3(1024), dim3(threads), 0, st, dX, nq, dY, nr, (int)d, center, params);
         MCE_HIP(hipGetLastError());
-        hipLaunchKernelGGL(mce::col_mean_final_kernel, dim3(1), dim3(64), 0, st, msum, nr, (int)d, center);
+        hipLaunchKernelGGL(mce::f16_scale_kernel, dim3(1), dim3(1), 0, st, params);
         MCE_HIP(hipGetLastError());
-        const int threads = 256;
-        const unsigned blocks = (unsigned)((p.nrow_pad + threads - 1) / threads);
-        hipLaunchKernelGGL(mce::pack_refs_kernel, dim3(blocks), dim3(threads), 0, st, dY, nr, (int)d, p.KS, p.nrow_pad, center, yf);
+        hipLaunchKernelGGL(mce::f16_pack_refs_kernel, dim3((unsigned)((p.nrow_pad + threads - 1) / threads)), dim3(threads), 0, st,
+                           dY, nr, (int)d, p.KST, p.nrow_pad, center, params, yh);
         MCE_HIP(hipGetLastError());
+        hipLaunchKernelGGL(mce::f16_pack_queries_kernel, dim3((unsigned)((p.nq_pad + threads - 1) / threads)), dim3(threads), 0, st,
+                           dX, nq, p.nq_pad, (int)d, p.KST, center, params, xh, qinfo);
+        MCE_HIP(hipGetLastError());
+        mce::KnnF16Args a;
+        a.Yh = yh; a.nchunk_total = p.nchunk; a.rsplit = p.rsplit; a.Xh = xh; a.qinfo = qinfo; a.params = params;
+        a.X = dX; a.Y = dY; a.nq = nq; a.nr = nr; a.D = d; a.nq_pad = p.nq_pad; a.nqblk = p.nqblk;
+        a.self_exclude = (self_mode == MCE_SELF_EXCLUDE) ? 1 : 0;
+        a.self_offset = self_offset; a.ksel = K; a.part_d = pd; a.part_i = pi;
+        int rc = prof_begin();
+        if (rc != MCE_OK) return rc;
+        MCE_HIP(p.vh->launch(a, st));
+        rc = prof_end();
+        if (rc != MCE_OK) return rc;
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d", p.vh->name,
+                 p.nqblk * p.rsplit, mce::kHThreads, p.vh->lds_bytes, p.QT, p.CT, p.rsplit);
+        return MCE_OK;
     }
+    // ---- fp64 MFMA sweep ----------------------------------------------------------
+    double* yf = reinterpret_cast<double*>(ws + p.off_yf);
+    hipLaunchKernelGGL(mce::pack_refs_kernel, dim3((unsigned)((p.nrow_pad + threads - 1) / threads)), dim3(threads), 0, st, dY, nr,
+                       (int)d, p.KS, p.nrow_pad, center, yf);
+    MCE_HIP(hipGetLastError());
     mce::KnnArgs a;
     a.Yf = yf;
     a.nchunk_total = p.nchunk;
@@ -179,20 +266,35 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
     a.ksel = K;
     a.part_d = pd;
     a.part_i = pi;
-    const bool prof = g_prof_on && g_ev_used < 1024;
-    if (prof) {
-        if (g_ev_used == g_ev_pool.size()) {
-            hipEvent_t e0, e1;
-            MCE_HIP(hipEventCreate(&e0));
-            MCE_HIP(hipEventCreate(&e1));
-            g_ev_pool.emplace_back(e0, e1);
-        }
-        MCE_HIP(hipEventRecord(g_ev_pool[g_ev_used].first, st));
-    }
+    int rc = prof_begin();
+    if (rc != MCE_OK) return rc;
     MCE_HIP(p.v->launch(a, st));
-    if (prof) { MCE_HIP(hipEventRecord(g_ev_pool[g_ev_used].second, st)); ++g_ev_used; }
+    rc = prof_end();
+    if (rc != MCE_OK) return rc;
     snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d", p.v->name,
              p.nqblk * p.rsplit, mce::kThreads, p.v->lds_bytes, p.QT, p.CT, p.rsplit);
+    return MCE_OK;
+}
+
+// merge (+ optional distance output, + optional fused reduction) of the per-split lists
+int launch_merge(const Plan& p, bool write_dist, bool fuse, const double* dX, const double* dY, int64_t nq, int32_t d, int K,
+                 int self_mode, int64_t self_offset, double* d_dist, int64_t* d_idx, int k0, int kmax,
+                 const double* d_w, const double* d_fs, double* partial, char* ws, hipStream_t st)
+{
+    const unsigned blocks = (unsigned)((nq + mce::kRedThreads - 1) / mce::kRedThreads);
+    const double* pd = reinterpret_cast<const double*>(ws + p.off_pd);
+    const int* pi = reinterpret_cast<const int*>(ws + p.off_pi);
+    const bool refine = p.vh == nullptr;      // fp64 sweep keys are GEMM-form: refine; fp16 path keys are exact
+    const double lnc = fuse ? ln_unit_ball(d) : 0.0;
+#define MCE_MERGE(W, F, R)                                                                                          \
+    hipLaunchKernelGGL((mce::merge_lists_kernel<W, F, R>), dim3(blocks), dim3(mce::kRedThreads), 0, st, pd, pi, p.L,  \
+                       p.KCAP, nq, p.nq_pad, dX, dY, (int)d, K, self_mode, self_offset, d_dist, d_idx, K, k0, kmax, \
+                       d_w, d_fs, lnc, partial)
+    if (write_dist && !fuse) { if (refine) MCE_MERGE(true, false, true); else MCE_MERGE(true, false, false); }
+    else if (write_dist && fuse) { if (refine) MCE_MERGE(true, true, true); else MCE_MERGE(true, true, false); }
+    else { if (refine) MCE_MERGE(false, true, true); else MCE_MERGE(false, true, false); }
+#undef MCE_MERGE
+    MCE_HIP(hipGetLastError());
     return MCE_OK;
 }
 
@@ -205,6 +307,15 @@ int mce_abi_version(void) { return MCE_ABI_VERSION; }
 const char* mce_last_error(void) { return g_err; }
 
 const char* mce_last_kernel(void) { return g_last_kernel; }
+
+int mce_set_search_mode(int mode)
+{
+    if (mode < 0 || mode > 2) return fail(MCE_ERR_INVALID, "search mode must be 0 (auto), 1 (fp64 sweep) or 2 (fp16 filter + fp64 refine)");
+    g_mode.store(mode);
+    return MCE_OK;
+}
+
+int mce_get_search_mode(void) { return g_mode.load(); }
 
 void mce_set_profiling(int on)
 {
@@ -254,13 +365,9 @@ int mce_knn_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t nr, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = run_search(p, dX, nq, dY, nr, d, K, self_mode, self_offset, static_cast<char*>(ws), st);
     if (rc != MCE_OK) return rc;
-    const unsigned blocks = (unsigned)((nq + mce::kRedThreads - 1) / mce::kRedThreads);
-    hipLaunchKernelGGL((mce::merge_lists_kernel<true, false>), dim3(blocks), dim3(mce::kRedThreads), 0, st,
-                       reinterpret_cast<const double*>(static_cast<char*>(ws) + p.off_pd),
-                       reinterpret_cast<const int*>(static_cast<char*>(ws) + p.off_pi), p.L, p.KCAP, nq, p.nq_pad, dX, dY,
-                       (int)d, (int)K, (int)self_mode, self_offset, d_dist, d_idx, (int)K, 0, 0,
-                       (const double*)nullptr, (const double*)nullptr, 0.0, (double*)nullptr);
-    MCE_HIP(hipGetLastError());
+    rc = launch_merge(p, true, false, dX, dY, nq, d, K, self_mode, self_offset, d_dist, d_idx, 0, 0, nullptr, nullptr, nullptr,
+                      static_cast<char*>(ws), st);
+    if (rc != MCE_OK) return rc;
     return MCE_OK;
 }
 
@@ -305,18 +412,9 @@ int mce_knn_dotp_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t
     if (rc != MCE_OK) return rc;
     double* partial = reinterpret_cast<double*>(wsc + p.total);
     const unsigned blocks = (unsigned)((nq + mce::kRedThreads - 1) / mce::kRedThreads);
-    const double* pd = reinterpret_cast<const double*>(wsc + p.off_pd);
-    const int* pi = reinterpret_cast<const int*>(wsc + p.off_pi);
-    if (d_dist_out) {
-        hipLaunchKernelGGL((mce::merge_lists_kernel<true, true>), dim3(blocks), dim3(mce::kRedThreads), 0, st, pd, pi,
-                           p.L, p.KCAP, nq, p.nq_pad, dX, dY, (int)d, K, self_mode, self_offset, d_dist_out,
-                           (int64_t*)nullptr, K, (int)k0, (int)kmax, d_w, d_fs, ln_unit_ball(d), partial);
-    } else {
-        hipLaunchKernelGGL((mce::merge_lists_kernel<false, true>), dim3(blocks), dim3(mce::kRedThreads), 0, st, pd, pi,
-                           p.L, p.KCAP, nq, p.nq_pad, dX, dY, (int)d, K, self_mode, self_offset, (double*)nullptr,
-                           (int64_t*)nullptr, K, (int)k0, (int)kmax, d_w, d_fs, ln_unit_ball(d), partial);
-    }
-    MCE_HIP(hipGetLastError());
+    rc = launch_merge(p, d_dist_out != nullptr, true, dX, dY, nq, d, K, self_mode, self_offset, d_dist_out, nullptr, (int)k0,
+                      (int)kmax, d_w, d_fs, partial, wsc, st);
+    if (rc != MCE_OK) return rc;
     hipLaunchKernelGGL(mce::dotp_final_kernel, dim3((unsigned)kmax), dim3(mce::kRedThreads), 0, st, partial,
                        (int64_t)blocks, (int)k0, (int)kmax, d_dotp);
     MCE_HIP(hipGetLastError());

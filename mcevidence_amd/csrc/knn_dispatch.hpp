@@ -33,6 +33,39 @@ struct KnnVariant {
     const char* name;
 };
 
+// ---- fp16-filter variants (knn_f16.hpp): KST = 1..4 sixteen-wide k-steps, KCAP <= 16 ----
+struct KnnF16Args {
+    const void* Yh;         // packed fp16 references
+    int64_t nchunk_total;
+    int rsplit;
+    const void* Xh;         // fp16 query rows [nq_pad][16*KST]
+    const double* qinfo;    // [nq_pad][2]
+    const double* params;   // HP_* scalars
+    const double* X;
+    const double* Y;
+    int64_t nq, nr;
+    int D;
+    int64_t nq_pad;
+    int nqblk;
+    int self_exclude;
+    int64_t self_offset;
+    int ksel;
+    double* part_d;
+    int* part_i;
+};
+typedef hipError_t (*knn_f16_launch_fn)(const KnnF16Args&, hipStream_t);
+struct KnnF16Variant {
+    knn_f16_launch_fn launch;
+    int kst, kcap, qt, ct;
+    size_t lds_bytes;
+    const char* name;
+};
+constexpr int kMaxKST = 4;
+extern const KnnF16Variant g_knn_f16_kcap4[kMaxKST];
+extern const KnnF16Variant g_knn_f16_kcap8[kMaxKST];
+extern const KnnF16Variant g_knn_f16_kcap12[kMaxKST];
+extern const KnnF16Variant g_knn_f16_kcap16[kMaxKST];
+
 constexpr int kMaxKS = 16;
 constexpr int kNumKcap = 6;
 constexpr int kKcapList[kNumKcap] = {4, 8, 12, 16, 24, 32};

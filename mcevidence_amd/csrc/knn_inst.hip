@@ -1,6 +1,7 @@
 // knn_inst.hip -- instantiates knn_mfma_kernel<KS, MCE_KCAP, QT> for KS = 1..16.
 // Compile with -DMCE_KCAP=<4|8|12|16|24|32>.
 #include "knn_mfma.hpp"
+#include "knn_f16.hpp"
 #include "knn_dispatch.hpp"
 
 #ifndef MCE_KCAP
@@ -27,6 +28,27 @@ hipError_t launch_variant(const KnnArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
+#if MCE_KCAP <= 16
+template <int KST, int KCAP>
+hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
+{
+    constexpr size_t LDS = f16_lds_bytes(KST, KCAP);
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    auto kern = knn_f16_kernel<KST, KCAP>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)(a.nqblk * a.rsplit));
+    hipLaunchKernelGGL(kern, grid, dim3(kHThreads), LDS, st, static_cast<const _Float16*>(a.Yh), a.nchunk_total, a.rsplit,
+                       static_cast<const _Float16*>(a.Xh), a.qinfo, a.params, a.X, a.Y, a.nq, a.nr, a.D, a.nq_pad, a.nqblk,
+                       a.self_exclude, a.self_offset, a.ksel, a.part_d, a.part_i);
+    return hipGetLastError();
+}
+#endif
+
 #define MCE_STR2(x) #x
 #define MCE_STR(x) MCE_STR2(x)
 #define MCE_VARIANT(KS)                                                                                  \
@@ -43,8 +65,20 @@ extern const KnnVariant MCE_CAT(g_knn_kcap, MCE_KCAP)[kMaxKS] = {
     MCE_VARIANT(7),  MCE_VARIANT(8),  MCE_VARIANT(9),  MCE_VARIANT(10), MCE_VARIANT(11), MCE_VARIANT(12),
     MCE_VARIANT(13), MCE_VARIANT(14), MCE_VARIANT(15), MCE_VARIANT(16),
 };
+#if MCE_KCAP <= 16
+#define MCE_F16_VARIANT(KST)                                                                             \
+    {&launch_f16_variant<KST, MCE_KCAP>, KST, MCE_KCAP, f16_qt(MCE_KCAP), f16_chunk_tiles(KST),          \
+     f16_lds_bytes(KST, MCE_KCAP), "knn_f16_kernel<KST=" #KST ",KCAP=" MCE_STR(MCE_KCAP) ">"}
+extern const KnnF16Variant MCE_CAT(g_knn_f16_kcap, MCE_KCAP)[kMaxKST] = {
+    MCE_F16_VARIANT(1), MCE_F16_VARIANT(2), MCE_F16_VARIANT(3), MCE_F16_VARIANT(4),
+};
+#endif
 #else
 // device pass: force the kernel instantiations
+#if MCE_KCAP <= 16
+#define MCE_F16_INST(KST) template __global__ void knn_f16_kernel<KST, MCE_KCAP>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*);
+MCE_F16_INST(1) MCE_F16_INST(2) MCE_F16_INST(3) MCE_F16_INST(4)
+#endif
 #define MCE_INST(KS) template __global__ void knn_mfma_kernel<KS, MCE_KCAP>(const double*, int64_t, int, const double*, const double*, int64_t, int, int64_t, int, int, int64_t, int, double*, int*);
 MCE_INST(1) MCE_INST(2) MCE_INST(3) MCE_INST(4) MCE_INST(5) MCE_INST(6) MCE_INST(7) MCE_INST(8)
 MCE_INST(9) MCE_INST(10) MCE_INST(11) MCE_INST(12) MCE_INST(13) MCE_INST(14) MCE_INST(15) MCE_INST(16)

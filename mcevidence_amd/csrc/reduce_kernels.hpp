@@ -46,13 +46,14 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 // the K selected pairs get their exact direct-difference distance sum_i (x_i - y_i)^2 from
 // the original rows and are re-sorted -- so reported distances equal an exact search's
 // (duplicates give exactly 0, like the reference's KD-tree path) and only the choice
-// between candidates that tie to the last bits can differ.  Optionally feeds the
-// evidence reduction directly.
+// between candidates that tie to the last bits can differ.  (REFINE=false when the lists
+// already hold exact distances: the fp16-filter path.)  Optionally feeds the evidence
+// reduction directly.
 //   part_d/part_i : [L][KCAP][nq_pad]
 //   self_mode 1 (include): the entry whose reference row is self_offset+q is
 //                          forced to distance 0 and sorts first.
 // ---------------------------------------------------------------------------
-template <bool WRITE_DIST, bool FUSE_DOTP>
+template <bool WRITE_DIST, bool FUSE_DOTP, bool REFINE>
 __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
     const double* __restrict__ part_d, const int* __restrict__ part_i, int L, int KCAP,
     int64_t nq, int64_t nq_pad, const double* __restrict__ X, const double* __restrict__ Y, int D, int K,
@@ -97,18 +98,20 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
             }
             if (bl < 0) break;
             head[bl]++;
+            sel_d[nsel] = (bi == selfj) ? -1.0 : bv;     // own row: sentinel, sorts first, reported as 0
             sel_i[nsel++] = bi;
         }
         // ---- refine: exact direct-difference distances of the selected pairs ----
+        // (REFINE=false: the lists already hold exact distances -- fp16-filter path)
         const double* x = X + q * (int64_t)D;
-        for (int k = 0; k < nsel; ++k) {
+        for (int k = 0; REFINE && k < nsel; ++k) {
             const double* y = Y + (int64_t)sel_i[k] * D;
             double s2 = 0.0;
             for (int i = 0; i < D; ++i) { const double t = x[i] - y[i]; s2 = fma(t, t, s2); }
             sel_d[k] = (sel_i[k] == selfj) ? -1.0 : s2;      // own row: sentinel, sorts first, reported as 0
         }
         // ---- re-sort (insertion sort; K <= 32), ties by reference row; own row first ----
-        for (int k = 1; k < nsel; ++k) {
+        for (int k = 1; REFINE && k < nsel; ++k) {
             const double dv = sel_d[k];
             const int iv = sel_i[k];
             int p = k;

@@ -64,7 +64,7 @@ def timing(n, d, kmax, reps=2):
     return out.cpu().numpy()
 
 if __name__ == "__main__":
-    print("devices:", _capi.device_count())
+    print("devices:", _capi.device_count(), "mode", _capi.get_search_mode())
     check_knn(5000, 6, 5, 0, nq=3000)
     check_knn(5000, 6, 5, 1)
     check_knn(5000, 6, 5, 2)
