@@ -31,7 +31,8 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-FP64_PEAK_TFLOPS = 78.6
+FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 matrix = vector peak
+F16_PEAK_TFLOPS = 2500.0     # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
 def hbm_traffic_from_profile(kernel_desc):
@@ -39,7 +40,7 @@ def hbm_traffic_from_profile(kernel_desc):
     (profiles/<round>/pmc_summary.csv: FETCH_SIZE/WRITE_SIZE in KB, separate passes; FETCH_SIZE
     doubled per MI355X_MICROARCH.md's gfx950 note).  None when no profile of this kernel exists."""
     import glob
-    want = kernel_desc.split(" ")[0].replace("KS=", "").replace("KCAP=", "").replace(",", ", ")   # knn_mfma_kernel<7, 12>
+    want = kernel_desc.split(" ")[0].replace("KST=", "").replace("KS=", "").replace("KCAP=", "").replace(",", ", ")   # knn_mfma_kernel<7, 12>
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*", "pmc_summary.csv")), reverse=True):
         fetch = write = None
         for ln in open(f):
@@ -65,6 +66,7 @@ def main():
     ap.add_argument("--d", type=int, default=27)
     ap.add_argument("--kmax", type=int, default=10)
     ap.add_argument("--cpu-sample", type=int, default=4000, help="queries timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--mode", type=int, default=0, help="0 auto (fp16 filter + fp64 refine), 1 fp64 MFMA sweep")
     a = ap.parse_args()
 
     import torch
@@ -81,6 +83,7 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     from mcevidence_amd import _capi, parallel
+    _capi.set_search_mode(a.mode)
     from mcevidence_amd.synth import gaussian_chain
     import mcevidence_amd as pkg
 
@@ -141,14 +144,22 @@ def main():
 
     out = None
     if rank == 0:
-        KS = (d + 1 + 3) // 4
-        flops = float(nq) * n * 2.0 * 4 * KS
+        kdesc = _capi.last_kernel()
+        if kdesc.startswith("knn_f16"):
+            # fp16-MFMA filter sweep: algorithmic flops = the padded augmented dot product it evaluates
+            # for every (query, reference) pair, 2 * 16*KST per pair; peak = dense fp16 MFMA.
+            kst = (d + 3 + 15) // 16
+            flops = float(nq) * n * 2.0 * 16 * kst
+            peak, note = F16_PEAK_TFLOPS, "fp16 MFMA pre-filter over all pairs (2*16*KST flop/pair) + exact fp64 refine of the survivors"
+        else:
+            KS = (d + 1 + 3) // 4
+            flops = float(nq) * n * 2.0 * 4 * KS
+            peak, note = FP64_PEAK_TFLOPS, "fp64 MFMA sweep (2*4*KS flop/pair), fp64 MFMA-bound (SURVEY 8d)"
         achieved = flops / (kern_ms * 1e-3) / 1e12
-        roof = dict(bound="mfma", achieved=round(achieved, 3), peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved / FP64_PEAK_TFLOPS, 4), traffic=hbm_traffic_from_profile(_capi.last_kernel()),
-                    kernel_ms=round(kern_ms, 3),
-                    kernel=_capi.last_kernel(), algorithmic_flops_per_launch=flops,
-                    note="fp64 MFMA-bound (SURVEY 8d); HBM traffic is the packed reference set streamed once per workgroup round")
+        roof = dict(bound="mfma", achieved=round(achieved, 3), peak=peak, unit="TFLOP/s",
+                    frac=round(achieved / peak, 4), traffic=hbm_traffic_from_profile(kdesc),
+                    kernel_ms=round(kern_ms, 3), kernel=kdesc, algorithmic_flops_per_launch=flops, note=note,
+                    fp64_equivalent_tflops=round(float(nq) * n * 2.0 * 4 * ((d + 4) // 4) / (kern_ms * 1e-3) / 1e12, 2))
         cpu = None
         dlnE = None
         if a.cpu_sample > 0 and world == 1:         # CPU baseline: rank 0, N=1 only
@@ -172,7 +183,7 @@ def main():
                     dlnE = float(np.max(np.abs(lnE - np.array(c["lnE"]))))
         out = dict(metric="knn_queries_per_sec", value=round(n / (ms_step * 1e-3), 1), unit="queries/s", n_gpus=world,
                    steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True,
-                   scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
+                   scaling="strong", vs_baseline=None, dtype="f64" if a.mode == 1 else "f16 filter + f64 refine (exact f64 results)", data="synthetic",
                    config=dict(workload="C3: auto-evidence, seeded Gaussian chain N=%d D=%d kmax=%d (K=%d true neighbours/query), query-sharded over %d GPU(s)" % (n, d, kmax, K, world),
                                N=n, D=d, kmax=kmax, queries_per_rank=nq),
                    max_abs_dlnE_vs_reference=dlnE, lnE=[round(float(x), 10) for x in lnE],

@@ -18,22 +18,49 @@
 //      A  <=  (s sqrt(thr) + e_x + max_j e_y)^2 - |x^|^2 + eps_q  =: G_q      (rounded up, fp32)
 // Lane gate:  min over the lane's 16 accumulators  <=  G_q   (8 v_min3_f32 + 1 compare).
 //
-// Survivors are queued per wave in LDS and drained in batches: every lane takes one
-// (query,row) pair and computes the exact fp64 distance from the ORIGINAL rows; accepted
-// ones go through the same whole-wave sorted insertion into the per-query LDS list as in
-// knn_mfma.hpp, and the gates G_q are refreshed from the lists.
+// Survivors are queued per wave in LDS and drained in batches by the whole workgroup at a
+// chunk boundary: phase A, every lane takes one queued (query,row) pair, computes the exact
+// fp64 distance from the ORIGINAL rows and links the entry into its query's chain; phase B,
+// lane l -- which OWNS wave-local query l and keeps its sorted top-K list in registers --
+// walks its chain and applies a static compare/select insertion network.  Then the gates
+// G_q are refreshed from the owners' K-th best.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef MCE_STATS
+#define MCE_STATS 0    // tools/knn_f16_bench.hip only: event counters in part_i[0..7] (results invalid)
+#endif
+#ifndef MCE_ABLATE
+#define MCE_ABLATE 0   // tools/knn_f16_bench.hip only: 1 = gate never passes, 2 = no gate
+#endif
+
 namespace mce {
+
+// v_min3_f32 without the NaN-canonicalising v_max the compiler adds around fminf()
+__device__ __forceinline__ float min3f(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int kHWaves = 8;
 constexpr int kHThreads = kHWaves * 64;
-constexpr int kHQueue = 640;          // candidate queue entries (4 B) per wave: 512 (half a tile) + 128
+#ifndef MCE_H_QUEUE
+#define MCE_H_QUEUE 640
+#endif
+#ifndef MCE_H_TRIGGER
+#define MCE_H_TRIGGER 96
+#endif
+#ifndef MCE_H_STAGE_KB
+#define MCE_H_STAGE_KB 32
+#endif
+constexpr int kHQueue = MCE_H_QUEUE;          // candidate queue entries (4 B) per wave: 512 (half a tile) + 128
+constexpr int kHDrainTrigger = MCE_H_TRIGGER;    // a wave with this many queued candidates asks the workgroup to drain
 constexpr int kHRelBits = 26;         // queue entry = query-local (6 bits) << 26 | row - first row of the split
 constexpr double kHTargetRadius = 200.0;
 
@@ -41,17 +68,17 @@ constexpr double kHTargetRadius = 200.0;
 enum { HP_RMAX = 0, HP_SCALE = 1, HP_EY = 2, HP_YHATMAX = 3, HP_RHO = 4, HP_COUNT = 8 };
 
 __host__ __device__ constexpr int f16_ksteps(int D) { return (D + 3 + 15) / 16; }          // 16-wide k-steps
-__host__ __device__ constexpr int f16_qt(int KCAP) { return KCAP > 12 ? 1 : 2; }          // 32-query tiles per wave
+__host__ __device__ constexpr int f16_qt(int) { return 2; }          // 32-query tiles per wave: 64 queries <-> 64 owner lanes
 __host__ __device__ constexpr bool f16_supported(int D, int K) { return D >= 2 && f16_ksteps(D) <= 4 && K <= 16; }
 __host__ __device__ constexpr int f16_qpb(int KCAP) { return kHWaves * f16_qt(KCAP) * 32; }
 // 32-row reference tiles per LDS chunk (tile = KST KB): <= 32 KB per buffer, even count,
 // and a whole number of 16-byte vectors per thread (CT*KST % 8 == 0)
-__host__ __device__ constexpr int f16_chunk_tiles(int KST) { return KST == 1 ? 32 : (KST == 2 ? 16 : 8); }
+__host__ __device__ constexpr int f16_chunk_tiles(int KST) { return (MCE_H_STAGE_KB / 32) * (KST == 1 ? 32 : (KST == 2 ? 16 : 8)) + ((MCE_H_STAGE_KB % 32) ? (KST == 2 ? 8 : 0) : 0); }
 __host__ __device__ constexpr size_t f16_lds_bytes(int KST, int KCAP)
 {
     return (size_t)2 * f16_chunk_tiles(KST) * KST * 1024             // staging
-           + (size_t)f16_qpb(KCAP) * KCAP * 12                         // lists
-           + (size_t)kHWaves * kHQueue * 4 + 1024;                     // queues + slack
+           + (size_t)kHWaves * kHQueue * 16                            // queues: packed(4) + next(4) + d2(8)
+           + (size_t)kHWaves * 64 * 4 + 64;                            // chain heads + votes
 }
 
 // ---------------------------------------------------------------------------
@@ -77,12 +104,17 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_f16_kernel(
     constexpr int VPT = (CHUNK_VEC + kHThreads - 1) / kHThreads;
     static_assert(CHUNK_VEC % kHThreads == 0, "chunk must be a whole number of 16-byte vectors per thread");
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    // LDS map: [2 staging buffers][list keys QPB*KCAP f64][list rows QPB*KCAP i32][queues][slack]
+    // LDS map: [2 staging buffers][queue d2: W*Q f64][queue packed: W*Q i32][queue next: W*Q i32][heads W*64][votes 2]
     char* const stage0 = lds_raw;
-    double* const list_d = reinterpret_cast<double*>(lds_raw + 2 * CHUNK_BYTES);
-    int* const list_i = reinterpret_cast<int*>(list_d + QPB * KCAP);
-    int* const queue_all = list_i + QPB * KCAP;
+    double* const qd2_all = reinterpret_cast<double*>(lds_raw + 2 * CHUNK_BYTES);
+    int* const qpk_all = reinterpret_cast<int*>(qd2_all + kHWaves * kHQueue);
+    int* const qnx_all = qpk_all + kHWaves * kHQueue;
+    int* const head_all = qnx_all + kHWaves * kHQueue;
 
+#if MCE_STATS
+    const long long t_kernel0 = clock64();
+    long long st_drains = 0, st_enq = 0, st_steps = 0, st_events = 0, st_tA = 0, st_tD = 0, st_tB = 0;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -95,11 +127,19 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_f16_kernel(
     if (c_end > nchunk_total) c_end = nchunk_total;
 
     const double INF = __builtin_huge_val();
-    double* const wl_d = list_d + wave * (QPW * KCAP);
-    int* const wl_i = list_i + wave * (QPW * KCAP);
-    int* const wq = queue_all + wave * kHQueue;                // packed (query-local, relative row)
-    const int jsplit0 = (int)(c_begin * (CT * 32));            // first reference row of this split
-    for (int e = lane; e < QPW * KCAP; e += 64) { wl_d[e] = INF; wl_i[e] = -1; }
+    double* const wqd = qd2_all + wave * kHQueue;               // exact distance of a queued entry (phase A)
+    int* const wq = qpk_all + wave * kHQueue;                   // packed (query-local, relative row)
+    int* const wnx = qnx_all + wave * kHQueue;                  // next entry of the same query
+    int* const whead = head_all + wave * 64;                    // chain head per wave-local query
+    volatile int* const wvote = head_all + kHWaves * 64;        // [2] drain votes (chunk parity)
+    const int jsplit0 = (int)(c_begin * (CT * 32));             // first reference row of this split
+    whead[lane] = -1;
+
+    // lane l OWNS wave-local query l = qt*32 + column: its sorted top-KCAP list lives here
+    double own_d[KCAP];
+    int own_i[KCAP];
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) { own_d[k] = INF; own_i[k] = -1; }
 
     const int64_t qwave0 = (int64_t)qblk * QPB + wave * QPW;     // first query of this wave
 
@@ -123,12 +163,12 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_f16_kernel(
             gate_xn[qt] = xn;
             gate_eps[qt] = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 1e-9) + rho + 1e-30;
             qlive[qt] = q < nq;
-            G[qt] = qlive[qt] ? __builtin_huge_valf() : -__builtin_huge_valf();     // padding queries never pass
+            G[qt] = (qlive[qt] && MCE_ABLATE != 1) ? __builtin_huge_valf() : -__builtin_huge_valf();     // padding queries never pass
         }
     }
     const int k_last = ksel - 1;
     auto gate_of = [&](double thr, int qt) -> float {       // thr: exact squared distance, input units
-        if (!qlive[qt]) return -__builtin_huge_valf();
+        if (!qlive[qt] || MCE_ABLATE == 1) return -__builtin_huge_valf();
         if (!(thr < INF)) return __builtin_huge_valf();
         const double rr = sqrt(thr * s2) * (1.0 + 1e-12) + gate_a[qt];
         const double g = rr * rr * (1.0 + 1e-12) - gate_xn[qt] + gate_eps[qt];
@@ -148,11 +188,14 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_f16_kernel(
         }
     };
 
-    // one 32-row tile: KST A-fragment reads (16 B per lane) + QT chains of KST MFMAs
-    auto mfma_tile = [&](const char* lp, v16f (&acc)[QT]) {
-        v8h a[KST];
+    // A fragments of one 32-row tile: KST 16-byte LDS reads per lane.  They are fetched one
+    // tile AHEAD of the MFMAs that consume them, so the LDS latency is never exposed.
+    auto load_a = [&](const char* lp, v8h (&a)[KST]) {
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks) a[ks] = *reinterpret_cast<const v8h*>(lp + ks * 1024);
+    };
+    // one 32-row tile: QT chains of KST MFMAs
+    auto mfma_tile = [&](const v8h (&a)[KST], v16f (&acc)[QT]) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             v16f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -164,108 +207,155 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_f16_kernel(
             for (int qt = 0; qt < QT; ++qt) acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], b[qt][ks], acc[qt], 0, 0, 0);
     };
 
-    // whole-wave sorted insertion of one accepted candidate (see knn_mfma.hpp)
-    auto insert_one = [&](int ql, double vv, int jj) {
-        double* ld = wl_d + ql * KCAP;
-        int* li = wl_i + ql * KCAP;
-        const int i = lane;
-        const double e_i = ld[i];
-        const double e_p = ld[i - 1];
-        const int id_i = li[i];
-        const int id_p = li[i - 1];
-        const bool c_i = (vv < e_i) || (vv == e_i && jj < id_i);
-        const bool c_p = (i > 0) && ((vv < e_p) || (vv == e_p && jj < id_p));
-        const double n_e = c_p ? e_p : (c_i ? vv : e_i);
-        const int n_id = c_p ? id_p : (c_i ? jj : id_i);
-        if (i < KCAP) { ld[i] = n_e; li[i] = n_id; }
-    };
-
     int qcount = 0;   // wave-uniform number of queued candidates
 
-    // exact evaluation + insertion of everything queued, then refresh the gates
     auto drain = [&]() {
-        for (int b0 = 0; b0 < qcount; b0 += 64) {
-            const int e = b0 + lane;
-            const bool valid = e < qcount;
-            int ql = 0, j = 0;
-            if (valid) {
-                const unsigned ent = (unsigned)wq[e];
-                ql = (int)(ent >> kHRelBits);
-                j = jsplit0 + (int)(ent & ((1u << kHRelBits) - 1u));
-            }
-            const int64_t q = qwave0 + ql;
-            double d2 = INF;
-            if (valid && j < nr && q < nq && !(self_exclude && (int64_t)j == self_offset + q)) {
-                const double* x = X + q * (int64_t)D;
-                const double* y = Y + (int64_t)j * D;
-                double acc0 = 0.0, acc1 = 0.0;
-                int i = 0;
-                for (; i + 1 < D; i += 2) {
-                    const double t0 = x[i] - y[i], t1 = x[i + 1] - y[i + 1];
-                    acc0 = fma(t0, t0, acc0);
-                    acc1 = fma(t1, t1, acc1);
+#if MCE_STATS
+        const long long t_d0 = clock64();
+        st_drains += 1; st_enq += qcount;
+#endif
+        // ---- phase A: exact distances + chain links.  8 lanes share one queued pair and read
+        // the two rows in 64-byte segments (a row is fetched once, not once per element: the
+        // gather is bandwidth-bound); 4 passes (32 pairs) are kept in flight per trip.
+        const int sub = lane & 7;
+        for (int b0 = 0; b0 < qcount; b0 += 32) {
+            double accp[4];
+            int qlp[4], ep[4];
+            bool okp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = b0 + u * 8 + (lane >> 3);
+                ep[u] = e;
+                int ql = 0, j = 0;
+                const bool valid = e < qcount;
+                if (valid) {
+                    const unsigned ent = (unsigned)wq[e];
+                    ql = (int)(ent >> kHRelBits);
+                    j = jsplit0 + (int)(ent & ((1u << kHRelBits) - 1u));
                 }
-                if (i < D) { const double t0 = x[i] - y[i]; acc0 = fma(t0, t0, acc0); }
-                d2 = acc0 + acc1;
+                qlp[u] = ql;
+                const int64_t q = qwave0 + ql;
+                okp[u] = valid && j < nr && q < nq && !(self_exclude && (int64_t)j == self_offset + q);
+                const double* x = X + (okp[u] ? q : 0) * (int64_t)D;
+                const double* y = Y + (okp[u] ? (int64_t)j : 0) * D;
+                double a0 = 0.0;
+                for (int i = sub; i < D; i += 32) {            // up to 4 elements per lane per trip
+                    double xv[4], yv[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int iv = (i + 8 * v < D) ? i + 8 * v : sub;
+                        xv[v] = x[iv];
+                        yv[v] = y[iv];
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const double t = (i + 8 * v < D) ? xv[v] - yv[v] : 0.0;
+                        a0 = fma(t, t, a0);
+                    }
+                }
+                accp[u] = a0;
             }
-            double thrq = INF;
-            if (valid) thrq = wl_d[ql * KCAP + k_last];
-            unsigned long long m = __ballot(d2 < thrq || (d2 == thrq && d2 < INF));
-            while (m) {
-                const int src = __builtin_ctzll(m);
-                m &= m - 1;
-                const int lo = __builtin_amdgcn_readlane(__double2loint(d2), src);
-                const int hi = __builtin_amdgcn_readlane(__double2hiint(d2), src);
-                const int qq = __builtin_amdgcn_readlane(ql, src);
-                const int jj = __builtin_amdgcn_readlane(j, src);
-                insert_one(qq, __hiloint2double(hi, lo), jj);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                double a0 = accp[u];
+                a0 += __shfl_xor(a0, 1, 64);
+                a0 += __shfl_xor(a0, 2, 64);
+                a0 += __shfl_xor(a0, 4, 64);
+                if (okp[u] && sub == 0) {
+                    wqd[ep[u]] = a0;
+                    wnx[ep[u]] = atomicExch(&whead[qlp[u]], ep[u]);      // push onto the query's chain
+                }
             }
         }
-        qcount = 0;
+#if MCE_STATS
+        st_tA += clock64() - t_d0;
+#endif
+        // ---- phase B: every owner lane folds its chain into its register list -------------
+        int cur = whead[lane];
+        whead[lane] = -1;
+        while (__any(cur >= 0)) {
+#if MCE_STATS
+            st_steps += 1;
+#endif
+            const bool on = cur >= 0;
+            const int ce = on ? cur : 0;
+            const double d2 = on ? wqd[ce] : INF;
+            const int j = jsplit0 + (int)((unsigned)wq[ce] & ((1u << kHRelBits) - 1u));
+            cur = on ? wnx[ce] : -1;
+            // ascending list, ties by row; d2 = +inf (idle lane) changes nothing
+            bool c_hi = (d2 < own_d[KCAP - 1]) || (d2 == own_d[KCAP - 1] && j < own_i[KCAP - 1] && d2 < INF);
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) G[qt] = gate_of(wl_d[(qt * 32 + (lane & 31)) * KCAP + k_last], qt);
+            for (int k = KCAP - 1; k >= 1; --k) {
+                const bool c_lo = (d2 < own_d[k - 1]) || (d2 == own_d[k - 1] && j < own_i[k - 1] && d2 < INF);
+                own_d[k] = c_lo ? own_d[k - 1] : (c_hi ? d2 : own_d[k]);
+                own_i[k] = c_lo ? own_i[k - 1] : (c_hi ? j : own_i[k]);
+                c_hi = c_lo;
+            }
+            own_d[0] = c_hi ? d2 : own_d[0];
+            own_i[0] = c_hi ? j : own_i[0];
+        }
+#if MCE_STATS
+        st_tD += clock64() - t_d0;
+#endif
+        qcount = 0;
+        // ---- refresh the gates: lane l needs the K-th best of queries (qt, l&31), owned by lane qt*32 + (l&31)
+        double thr_own = own_d[KCAP - 1];
+#pragma unroll
+        for (int k = 0; k < KCAP - 1; ++k) thr_own = (k == k_last) ? own_d[k] : thr_own;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) G[qt] = gate_of(__shfl(thr_own, qt * 32 + (lane & 31), 64), qt);
     };
 
     // gate + enqueue for one finished tile; jb0 = first reference row of the tile.
     // C layout of 32x32 f32: lane l -> query column l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5)
     auto process = [&](const v16f (&acc)[QT], int jb0) {
+#if MCE_ABLATE == 2
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) asm volatile("" ::"v"(acc[qt]));
+        return;
+#endif
+        bool passq[QT];
         bool pass = false;
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             const v16f& c = acc[qt];
-            float m0 = fminf(fminf(c[0], c[1]), c[2]);
-            float m1 = fminf(fminf(c[3], c[4]), c[5]);
-            float m2 = fminf(fminf(c[6], c[7]), c[8]);
-            float m3 = fminf(fminf(c[9], c[10]), c[11]);
-            float m4 = fminf(fminf(c[12], c[13]), c[14]);
-            m0 = fminf(fminf(m0, m1), m2);
-            m3 = fminf(fminf(m3, m4), c[15]);
-            pass |= fminf(m0, m3) <= G[qt];
+            float m0 = min3f(c[0], c[1], c[2]);
+            float m1 = min3f(c[3], c[4], c[5]);
+            float m2 = min3f(c[6], c[7], c[8]);
+            float m3 = min3f(c[9], c[10], c[11]);
+            float m4 = min3f(c[12], c[13], c[14]);
+            m0 = min3f(m0, m1, m2);
+            m3 = min3f(m3, m4, c[15]);
+            passq[qt] = min3f(m0, m3, m3) <= G[qt];
+            pass |= passq[qt];
         }
         if (__any(pass)) {
-            const int jrel0 = jb0 - jsplit0;
+#if MCE_STATS
+            st_events += 1;
+#endif
+            const int jrel0 = jb0 - jsplit0 + 4 * (lane >> 5);
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
+                if (!__any(passq[qt])) continue;
+                // per-lane bit mask of the accumulators under the gate (branch-free) ...
+                unsigned pm = 0;
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    if (qcount > kHQueue - 512) drain();          // room for half a tile (8 x 64 entries)
-#pragma unroll
-                    for (int rr = 0; rr < 8; ++rr) {
-                        const int r = half * 8 + rr;
-                        const bool p = acc[qt][r] <= G[qt];
-                        const unsigned long long m = __ballot(p);
-                        if (m) {
-                            if (p) {
-                                const int slot = qcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                                const unsigned rel = (unsigned)(jrel0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
-                                wq[slot] = (int)(((unsigned)(qt * 32 + (lane & 31)) << kHRelBits) | rel);
-                            }
-                            qcount += __builtin_popcountll(m);
-                        }
+                for (int r = 0; r < 16; ++r) pm |= (acc[qt][r] <= G[qt]) ? (1u << r) : 0u;
+                // ... then one queue entry per lane and trip (usually a single trip)
+                unsigned long long m = __ballot(pm != 0);
+                while (m) {
+                    if (qcount > kHQueue - 64) drain();
+                    if (pm != 0) {
+                        const int r = __builtin_ctz(pm);
+                        pm &= pm - 1;
+                        const int slot = qcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                        const unsigned rel = (unsigned)(jrel0 + (r & 3) + 8 * (r >> 2));
+                        wq[slot] = (int)(((unsigned)(qt * 32 + (lane & 31)) << kHRelBits) | rel);
                     }
+                    qcount += __builtin_popcountll(m);
+                    m = __ballot(pm != 0);
                 }
             }
-            if (qcount >= 64) drain();
         }
     };
 
@@ -277,19 +367,38 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_f16_kernel(
         for (int r = 0; r < 16; ++r) accB[qt][r] = __builtin_nanf("");       // "no pending tile": NaN never passes the gate
 
     if (c_begin < c_end) stage_async(c_begin, 0);
+    if (tid < 2) wvote[tid] = 0;
 
+    // Drains are taken by ALL waves of the workgroup at the same chunk boundary (a wave that
+    // drained alone would hold the other seven at the next barrier): before the barrier a
+    // wave whose queue is filling raises the vote of this chunk's parity; after the barrier
+    // everybody reads it.  (process() still drains locally if its queue would overflow.)
     for (int64_t c = c_begin; c < c_end; ++c) {
         const int buf = (int)((c - c_begin) & 1);
+        if (qcount >= kHDrainTrigger && lane == 0) wvote[buf] = 1;
+#if MCE_STATS
+        const long long t_b0 = clock64();
+#endif
         __syncthreads();
+#if MCE_STATS
+        st_tB += clock64() - t_b0;
+#endif
         if ((c + 1) < c_end) stage_async(c + 1, buf ^ 1);
+        const bool all_drain = wvote[buf] != 0;
+        if (tid == 0) wvote[buf ^ 1] = 0;          // re-arm the other parity (read again only after the next barrier)
+        if (all_drain) drain();
         const char* lbuf = stage0 + buf * CHUNK_BYTES + lane * 16;
         const int jchunk = (int)(c * (CT * 32));
+        v8h a0[KST], a1[KST];
+        load_a(lbuf, a0);
 #pragma unroll 1
         for (int t = 0; t < CT; t += 2) {
-            mfma_tile(lbuf + (t * KST) * 1024, accA);
+            load_a(lbuf + ((t + 1) * KST) * 1024, a1);
+            mfma_tile(a0, accA);
             jbA = jchunk + t * 32;
             process(accB, jbB);
-            mfma_tile(lbuf + ((t + 1) * KST) * 1024, accB);
+            load_a(lbuf + ((t + 2 < CT ? t + 2 : t) * KST) * 1024, a0);      // (last trip: harmless re-read)
+            mfma_tile(a1, accB);
             jbB = jchunk + (t + 1) * 32;
             process(accA, jbA);
         }
@@ -297,15 +406,21 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_f16_kernel(
     process(accB, jbB);
     drain();
 
-    // ---- write this wave's lists: lane -> (query lane&31, slots (lane>>5) + 2i) ----
+#if MCE_STATS
+    if (lane == 0) {
+        double* o = const_cast<double*>(params) + 16 + ((int64_t)blockIdx.x * kHWaves + wave) * 8;
+        o[0] = (double)st_drains; o[1] = (double)st_enq; o[2] = (double)st_steps; o[3] = (double)st_events;
+        o[4] = (double)st_tA; o[5] = (double)st_tD; o[6] = (double)(clock64() - t_kernel0); o[7] = (double)st_tB;
+    }
+#endif
+    // ---- write the lists: lane l owns wave-local query l (coalesced over lanes) ----
+    {
+        const int64_t q = qwave0 + lane;
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const int ql = qt * 32 + (lane & 31);
-        const int64_t q = qwave0 + ql;
-        for (int k = lane >> 5; k < KCAP; k += 2) {
+        for (int k = 0; k < KCAP; ++k) {
             const int64_t o = ((int64_t)split * KCAP + k) * nq_pad + q;
-            part_d[o] = wl_d[ql * KCAP + k];
-            part_i[o] = wl_i[ql * KCAP + k];
+            part_d[o] = own_d[k];
+            part_i[o] = own_i[k];
         }
     }
 }

@@ -13,11 +13,15 @@ logging.disable(logging.CRITICAL)
 G = load_golden()
 
 
-@pytest.fixture(scope="module")
-def capi():
+@pytest.fixture(scope="module", params=["auto_f16filter", "f64sweep"])
+def capi(request):
+    """every test that takes `capi` runs twice: default search mode (fp16 filter + fp64 refine
+    where the shape allows it) and the fp64 MFMA sweep."""
     from mcevidence_amd import _capi
     assert _capi.device_count() >= 1, "no GPU visible: the HIP path cannot be tested"
-    return _capi
+    _capi.set_search_mode(_capi.MODE_F64 if request.param == "f64sweep" else _capi.MODE_AUTO)
+    yield _capi
+    _capi.set_search_mode(_capi.MODE_AUTO)
 
 
 def _rel(a, b):
@@ -156,9 +160,11 @@ def test_query_sharding_sums_to_full(capi):
 
 # --------------------------------------------------------------------------- the class, against the reference's outputs
 @pytest.mark.parametrize("name", sorted(G))
-def test_class_on_gpu_reproduces_reference(name):
+def test_class_on_gpu_reproduces_reference(name, capi):
     import mcevidence_amd as pkg
     case = G[name]
+    if case["tag"] == "big" and capi.get_search_mode() == capi.MODE_F64 and case["ndim"] < 10:
+        pytest.skip("1M x 6 through the fp64 sweep is covered by the auto mode")
     if case["seed_split"] is not None:
         np.random.seed(case["seed_split"])
     mce = pkg.MCEvidence([chain_of(case)], verbose=0, **case["mce"])
@@ -176,6 +182,7 @@ def test_sampled_rows_at_full_size_C3(capi):
     rows = np.sort(rng.choice(len(X), 1500, replace=False))
     dist, idx = capi.knn(X, X, K, self_mode=capi.SELF_EXCLUDE)
     assert np.all(np.diff(dist, axis=1) >= 0) and np.all(dist > 0)
+    assert ("knn_f16" in capi.last_kernel()) == (capi.get_search_mode() != capi.MODE_F64)
     assert np.all(idx != np.arange(len(X))[:, None]) and idx.min() >= 0 and idx.max() < len(X)
     d_, i_ = orc.knn_brute(X[rows], X, K + 1)              # exact CPU search incl. self; drop column 0
     ods, ois = d_[:, 1:], i_[:, 1:]

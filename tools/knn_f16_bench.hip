@@ -1,0 +1,74 @@
+// knn_f16_bench.hip -- developer microbench for knn_f16_kernel (ablation/tuning); not part of the product.
+#include "../mcevidence_amd/csrc/f16_prep.hpp"
+#include "../mcevidence_amd/csrc/pack_refs.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <random>
+#ifndef DIM
+#define DIM 27
+#endif
+#ifndef KCAP
+#define KCAP 12
+#endif
+#ifndef KSEL
+#define KSEL 9
+#endif
+using namespace mce;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+int main(int argc, char** argv)
+{
+    const int64_t n = argc > 1 ? atoll(argv[1]) : 200000;
+    const int rsplit = argc > 2 ? atoi(argv[2]) : 1;
+    const int reps = argc > 3 ? atoi(argv[3]) : 2;
+    constexpr int D = DIM;
+    constexpr int KST = f16_ksteps(D);
+    constexpr int CT = f16_chunk_tiles(KST);
+    const int qpb = f16_qpb(KCAP);
+    const int nqblk = (int)((n + qpb - 1) / qpb);
+    const int64_t nq_pad = (int64_t)nqblk * qpb;
+    const int64_t nchunk = (n + CT * 32 - 1) / (CT * 32);
+    const int64_t nrow_pad = nchunk * CT * 32;
+    std::vector<double> h((size_t)n * D);
+    std::mt19937_64 g(1); std::normal_distribution<double> nd;
+    for (auto& v : h) v = nd(g);
+    double *X, *pd, *center, *msum, *params, *qinfo; int* pi; _Float16 *Yh, *Xh;
+    CK(hipMalloc(&X, sizeof(double) * n * D));
+    CK(hipMalloc(&Yh, 2 * nrow_pad * 16 * KST)); CK(hipMalloc(&Xh, 2 * nq_pad * 16 * KST));
+    CK(hipMalloc(&qinfo, 16 * nq_pad)); const size_t pbytes = 256 + (size_t)nqblk * rsplit * 8 * 64; CK(hipMalloc(&params, pbytes)); CK(hipMalloc(&center, 512)); CK(hipMalloc(&msum, 8 * 64 * 256));
+    const size_t nl = (size_t)rsplit * KCAP * nq_pad;
+    CK(hipMalloc(&pd, sizeof(double) * nl)); CK(hipMalloc(&pi, sizeof(int) * nl));
+    CK(hipMemcpy(X, h.data(), sizeof(double) * n * D, hipMemcpyHostToDevice));
+    col_sum_partial_kernel<<<kMeanBlocks, kMeanThreads>>>(X, n, D, msum);
+    col_mean_final_kernel<<<1, 64>>>(msum, n, D, center);
+    CK(hipMemset(params, 0, pbytes));
+    f16_radius_kernel<<<1024, 256>>>(X, n, X, n, D, center, params);
+    f16_scale_kernel<<<1, 1>>>(params);
+    f16_pack_refs_kernel<<<(unsigned)((nrow_pad + 255) / 256), 256>>>(X, n, D, KST, nrow_pad, center, params, Yh);
+    f16_pack_queries_kernel<<<(unsigned)((nq_pad + 255) / 256), 256>>>(X, n, nq_pad, D, KST, center, params, Xh, qinfo);
+    CK(hipDeviceSynchronize());
+    constexpr size_t LDS = f16_lds_bytes(KST, KCAP);
+    auto kern = knn_f16_kernel<KST, KCAP>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(e0));
+        kern<<<nqblk * rsplit, kHThreads, LDS>>>(Yh, nchunk, rsplit, Xh, qinfo, params, X, X, n, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("D=%d KST=%d KCAP=%d K=%d CT=%d ablate=%d lds=%zu n=%lld rsplit=%d grid=%d: %.2f ms  %.3f Mq/s  %.1f TF(f16 flops)\n", D, KST, KCAP, KSEL, CT, MCE_ABLATE, LDS,
+               (long long)n, rsplit, nqblk * rsplit, ms, n / ms / 1e3, (double)n * n * 32.0 * KST / ms / 1e9);
+    }
+#if MCE_STATS
+    {
+        const size_t nw = (size_t)nqblk * rsplit * 8;
+        std::vector<double> hs(nw * 8);
+        CK(hipMemcpy(hs.data(), (char*)params + 128, nw * 64, hipMemcpyDeviceToHost));
+        double m[8] = {0};
+        for (size_t w = 0; w < nw; ++w) for (int k = 0; k < 8; ++k) m[k] += hs[w * 8 + k] / nw;
+        printf("per wave (mean): drains %.1f  enq %.0f (per query %.1f)  chain-steps %.1f  event_tiles %.0f | cycles: phaseA %.3g  drain %.3g  barrier-wait %.3g  kernel %.3g\n",
+               m[0], m[1], m[1] / 64, m[2], m[3], m[4], m[5], m[7], m[6]);
+    }
+#endif
+    return 0;
+}

@@ -13,7 +13,7 @@ import csv, sys, collections
 f=sys.argv[1]
 agg=collections.defaultdict(float)
 for r in csv.DictReader(open(f)):
-    if 'knn_mfma' in r.get('Kernel_Name',''):
+    if 'knn_' in r.get('Kernel_Name',''):
         agg[r['Counter_Name']]+=float(r['Counter_Value'])
 for k,v in agg.items(): print("%-34s %.4g"%(k,v))
 PY
