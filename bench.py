@@ -40,12 +40,17 @@ def hbm_traffic_from_profile(kernel_desc):
     (profiles/<round>/pmc_summary.csv: FETCH_SIZE/WRITE_SIZE in KB, separate passes; FETCH_SIZE
     doubled per MI355X_MICROARCH.md's gfx950 note).  None when no profile of this kernel exists."""
     import glob
-    want = kernel_desc.split(" ")[0].replace("KST=", "").replace("KS=", "").replace("KCAP=", "").replace(",", ", ")   # knn_mfma_kernel<7, 12>
+    import re
+    m = re.match(r"(\w+)<\w+=(\d+),\w+=(\d+)>", kernel_desc)
+    if not m:
+        return None
+    name, p1, p2 = m.groups()
+    wants = ("%s<%s, %s>" % (name, p1, p2), "%sILi%sELi%sE" % (name, p1, p2))     # demangled / mangled spelling
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*", "pmc_summary.csv")), reverse=True):
         fetch = write = None
         for ln in open(f):
             c = ln.strip().split(",")
-            if len(c) >= 5 and want in ln:
+            if len(c) >= 4 and any(w in ln for w in wants):
                 name, val, nd = c[-3], float(c[-2]), int(c[-1])
                 if name == "FETCH_SIZE":
                     fetch = val / nd
