@@ -104,6 +104,46 @@ def test_knn_large_offsets_are_stable(capi):
     assert _rel(d, od) < 1e-8 and np.mean(i == oi) > 0.999
 
 
+ADVERSARIAL = {
+    # name: (generator, n, d) -- inputs chosen to stress the fp16 filter's bound: dynamic range,
+    # clustering far below the fp16 resolution of the extent, offsets, fp16 over/underflow before scaling
+    "heavy_tails": lambda r, n, d: r.standard_t(1.5, size=(n, d)),
+    "tight_clusters": lambda r, n, d: r.integers(0, 3, size=(n, 1)) * 1000.0 + 1e-3 * r.standard_normal((n, d)),
+    "tiny_scale": lambda r, n, d: 1e-9 * r.standard_normal((n, d)),
+    "huge_scale_offset": lambda r, n, d: 1e7 + 3e4 * r.standard_normal((n, d)),
+    "anisotropic": lambda r, n, d: r.standard_normal((n, d)) * np.logspace(-4, 2, d)[None, :],
+    "one_outlier": lambda r, n, d: np.vstack([r.standard_normal((n - 1, d)), np.full((1, d), 1e4)]),
+    "lattice_ties": lambda r, n, d: r.integers(-3, 4, size=(n, d)).astype(float),
+    "subnormal_fp16_coords": lambda r, n, d: np.hstack([r.standard_normal((n, 1)), 1e-6 * r.standard_normal((n, d - 1))]),
+}
+
+
+@pytest.mark.parametrize("kind", sorted(ADVERSARIAL))
+@pytest.mark.parametrize("d", [2, 5, 14])
+def test_knn_adversarial_inputs_stay_exact(capi, kind, d):
+    """the filter must never drop a true neighbour, whatever the data look like: the result is
+    compared with the exact CPU search (distances AND neighbour sets)."""
+    rng = np.random.default_rng(hash((kind, d)) % (2 ** 31))
+    n, K = 4000, 6
+    Y = np.ascontiguousarray(ADVERSARIAL[kind](rng, n, d), dtype=np.float64)
+    dist, idx = capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE)
+    od, oi = orc.knn_brute(Y, Y, K, self_mode=2)
+    # whatever was selected, the reported distance is the exact distance to the reported row
+    exact = np.sqrt(((Y[:, None, :] - Y[idx]) ** 2).sum(-1))
+    assert np.allclose(dist, exact, rtol=1e-13, atol=0)
+    if capi.get_search_mode() == capi.MODE_F64 and kind in ("tight_clusters", "lattice_ties", "huge_scale_offset"):
+        # documented limit of the fp64 GEMM-form sweep (DESIGN.md 3.1): it SELECTS with ~1e-16*R^2
+        # absolute accuracy (R = extent about the mean), so neighbours closer together than that, or
+        # exactly tied, may be swapped for an equally-near row; the default fp16-filter path is exact.
+        if kind != "tight_clusters":      # (clusters 1e6 sigma apart: the GEMM form cannot rank inside a cluster)
+            assert np.all(dist <= od * (1 + 1e-3) + 1e-12)
+    else:
+        assert np.array_equal(dist, od) or _rel(dist, od) < 1e-13
+        same = np.sort(idx, axis=1) == np.sort(oi, axis=1)
+        assert np.mean(same) > 0.999          # identical sets except exact distance ties
+    assert np.all(np.diff(dist, axis=1) >= 0)
+
+
 def test_error_codes_on_gpu(capi):
     X = np.zeros((5, 3))
     with pytest.raises(ValueError):
