@@ -159,7 +159,9 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_f16_kernel(
                 b[qt][ks] = *reinterpret_cast<const v8h*>(Xh + q * (int64_t)(16 * KST) + 16 * ks + 8 * (lane >> 5));
             const double ex = qinfo[2 * q], xn = qinfo[2 * q + 1];
             const double r = sqrt(xn) + Yhm;
-            gate_a[qt] = (ex + Ey) * (1.0 + 1e-9) + 1e-300;
+            // + 2*sqrt(16 KST)*2^-14: even if the matrix unit flushed fp16 subnormal inputs (it does not
+            // on gfx950) the bound would hold
+            gate_a[qt] = (ex + Ey) * (1.0 + 1e-9) + 2.0 * sqrt(16.0 * KST) * 0x1p-14;
             gate_xn[qt] = xn;
             gate_eps[qt] = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 1e-9) + rho + 1e-30;
             qlive[qt] = q < nq;
