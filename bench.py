@@ -161,8 +161,10 @@ def main():
             flops = float(nq) * n * 2.0 * 4 * KS
             peak, note = FP64_PEAK_TFLOPS, "fp64 MFMA sweep (2*4*KS flop/pair), fp64 MFMA-bound (SURVEY 8d)"
         achieved = flops / (kern_ms * 1e-3) / 1e12
+        traffic = hbm_traffic_from_profile(kdesc)
         roof = dict(bound="mfma", achieved=round(achieved, 3), peak=peak, unit="TFLOP/s",
-                    frac=round(achieved / peak, 4), traffic=hbm_traffic_from_profile(kdesc),
+                    frac=round(achieved / peak, 4), traffic=(traffic or {}).get("bytes"), traffic_source=(traffic or {}).get("source"),
+                    traffic_note=(traffic or {}).get("note"),
                     kernel_ms=round(kern_ms, 3), kernel=kdesc, algorithmic_flops_per_launch=flops, note=note,
                     fp64_equivalent_tflops=round(float(nq) * n * 2.0 * 4 * ((d + 4) // 4) / (kern_ms * 1e-3) / 1e12, 2))
         cpu = None

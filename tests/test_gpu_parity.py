@@ -198,6 +198,24 @@ def test_query_sharding_sums_to_full(capi):
     assert np.allclose(parts, full, rtol=1e-13)
 
 
+def test_single_process_multi_device_split(capi):
+    """mce_knn_dotp_f64(devices, ndev): one host thread per listed device, rows split evenly, partials
+    added on the host in device order.  With one GPU on the box the same ordinal is listed 3 times:
+    the sharding, the self-exclusion offsets and the sum are exercised all the same."""
+    rng = np.random.default_rng(21)
+    n, d, kmax = 30011, 7, 5
+    X = rng.standard_normal((n, d))
+    w = rng.integers(1, 4, n).astype(float)
+    fs = -rng.random(n)
+    one, dist1 = capi.knn_dotp(X, None, w, fs, kmax, 1, return_dist=True)
+    three, dist3 = capi.knn_dotp(X, None, w, fs, kmax, 1, return_dist=True, devices=[0, 0, 0])
+    assert np.allclose(three, one, rtol=1e-13) and np.array_equal(dist1, dist3)
+    Y = rng.standard_normal((20000, d))
+    assert np.allclose(capi.knn_dotp(X, Y, w, fs, kmax, 0, devices=[0, 0]), capi.knn_dotp(X, Y, w, fs, kmax, 0), rtol=1e-13)
+    with pytest.raises((ValueError, RuntimeError)):
+        capi.knn_dotp(X, None, w, fs, kmax, 1, devices=[0, 7])
+
+
 # --------------------------------------------------------------------------- the class, against the reference's outputs
 @pytest.mark.parametrize("name", sorted(G))
 def test_class_on_gpu_reproduces_reference(name, capi):
@@ -230,6 +248,25 @@ def test_sampled_rows_at_full_size_C3(capi):
     # symmetry property: if j is i's nearest neighbour at distance r, then i is within r of j
     nn = idx[:, 0]
     assert np.all(dist[nn, 0] <= dist[:, 0] * (1 + 1e-12))
+
+
+def test_filter_and_sweep_agree_on_every_row_at_full_size():
+    """N = 1M, D = 27: the fp16-filter search and the fp64 sweep must return the same neighbours
+    and distances for ALL 9M (query, rank) entries -- a whole-problem check of the filter's bound."""
+    from mcevidence_amd import _capi
+    rng = np.random.default_rng(123)
+    X = rng.standard_normal((1_000_000, 27))
+    _capi.set_search_mode(_capi.MODE_AUTO)
+    d_f, i_f = _capi.knn(X, X, 9, self_mode=_capi.SELF_EXCLUDE)
+    assert "knn_f16" in _capi.last_kernel()
+    _capi.set_search_mode(_capi.MODE_F64)
+    try:
+        d_s, i_s = _capi.knn(X, X, 9, self_mode=_capi.SELF_EXCLUDE)
+        assert "knn_mfma" in _capi.last_kernel()
+    finally:
+        _capi.set_search_mode(_capi.MODE_AUTO)
+    assert np.array_equal(i_f, i_s)
+    assert np.allclose(d_f, d_s, rtol=1e-14, atol=0)
 
 
 def test_neighbors_shim_matches_sklearn_semantics(capi):
