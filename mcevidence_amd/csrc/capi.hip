@@ -169,9 +169,9 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     p.off_pi = off;
     off = align_up(off + (size_t)p.L * p.KCAP * (size_t)p.nq_pad * sizeof(int), 256);
     p.off_center = off;
-    off = align_up(off + (size_t)mce::kMaxDimPad * sizeof(double), 256);
+    off = align_up(off + (size_t)3 * mce::kMaxDimPad * sizeof(double), 256);      // centre | box(Y) | box(X)
     p.off_msum = off;
-    off = align_up(off + (size_t)mce::kMeanBlocks * mce::kMaxDimPad * sizeof(double), 256);
+    off = align_up(off + (size_t)mce::kMeanBlocks * mce::kStatStride * sizeof(double), 256);
     p.total = off;
     return MCE_OK;
 }
@@ -192,9 +192,11 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
     int* pi = reinterpret_cast<int*>(ws + p.off_pi);
     double* center = reinterpret_cast<double*>(ws + p.off_center);
     double* msum = reinterpret_cast<double*>(ws + p.off_msum);
-    hipLaunchKernelGGL(mce::col_sum_partial_kernel, dim3(mce::kMeanBlocks), dim3(mce::kMeanThreads), 0, st, dY, nr, (int)d, msum);
+    double* box_y = center + mce::kMaxDimPad;
+    double* box_x = center + 2 * mce::kMaxDimPad;
+    hipLaunchKernelGGL(mce::col_stats_partial_kernel, dim3(mce::kMeanBlocks), dim3(mce::kMeanThreads), 0, st, dY, nr, (int)d, msum);
     MCE_HIP(hipGetLastError());
-    hipLaunchKernelGGL(mce::col_mean_final_kernel, dim3(1), dim3(64), 0, st, msum, nr, (int)d, center);
+    hipLaunchKernelGGL(mce::col_stats_final_kernel, dim3(1), dim3(64), 0, st, msum, nr, (int)d, center, box_y);
     MCE_HIP(hipGetLastError());
     const bool prof = g_prof_on && g_ev_used < 1024;
     auto prof_begin = [&]() -> int {
@@ -222,12 +224,18 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
         double* qinfo = reinterpret_cast<double*>(ws + p.off_qinfo);
         double* params = reinterpret_cast<double*>(ws + p.off_params);
         MCE_HIP(hipMemsetAsync(params, 0, mce::HP_COUNT * sizeof(double), st));
-        hipLaunchKernelGGL(mce::f16_radius_kernel, dim3(1024), dim3(threads), 0, st, dX, nq, dY, nr, (int)d, center, params);
+        // queries that are literally rows of the reference buffer are inside its bounding box already
+        const bool separate_queries = !(dX >= dY && dX + (size_t)nq * d <= dY + (size_t)nr * d);
+        if (separate_queries) {
+            hipLaunchKernelGGL(mce::col_stats_partial_kernel, dim3(mce::kMeanBlocks), dim3(mce::kMeanThreads), 0, st, dX, nq, (int)d, msum);
+            MCE_HIP(hipGetLastError());
+            hipLaunchKernelGGL(mce::f16_box_about_kernel, dim3(1), dim3(64), 0, st, msum, (int)d, center, box_x);
+            MCE_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(mce::f16_scale_kernel, dim3(1), dim3(64), 0, st, box_y, separate_queries ? box_x : (const double*)nullptr, params);
         MCE_HIP(hipGetLastError());
-        hipLaunchKernelGGL(mce::f16_scale_kernel, dim3(1), dim3(1), 0, st, params);
-        MCE_HIP(hipGetLastError());
-        hipLaunchKernelGGL(mce::f16_pack_refs_kernel, dim3((unsigned)((p.nrow_pad + threads - 1) / threads)), dim3(threads), 0, st,
-                           dY, nr, (int)d, p.KST, p.nrow_pad, center, params, yh);
+        hipLaunchKernelGGL(mce::f16_pack_refs_kernel, dim3((unsigned)((p.nrow_pad + 255) / 256)), dim3(256),
+                           (size_t)256 * (d | 1) * sizeof(double), st, dY, nr, (int)d, p.KST, p.nrow_pad, center, params, yh);
         MCE_HIP(hipGetLastError());
         hipLaunchKernelGGL(mce::f16_pack_queries_kernel, dim3((unsigned)((p.nq_pad + threads - 1) / threads)), dim3(threads), 0, st,
                            dX, nq, p.nq_pad, (int)d, p.KST, center, params, xh, qinfo);

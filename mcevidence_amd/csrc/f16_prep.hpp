@@ -4,6 +4,7 @@
 // (The "fit" step, reference MCEvidence.py:1093-1101.)  Included by capi.hip only.
 #pragma once
 #include "knn_f16.hpp"
+#include "pack_refs.hpp"
 
 namespace mce {
 
@@ -13,31 +14,40 @@ __device__ __forceinline__ void atomic_max_pos(double* p, double v)   // v >= 0
 }
 
 // ---------------------------------------------------------------------------
-// radius of both point sets around the centre -> power-of-two scale
+// power-of-two scale from a radius BOUND: the corner of the centred bounding box of the
+// reference set (box_y, from col_stats) and, for a separate query set, of the queries (box_x,
+// statistics taken about the same centre).  fp16 is floating point, so a loose bound costs no
+// precision; it only has to keep |.| <= 200 (no overflow of -2y^ and of |y^|^2).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void f16_radius_kernel(const double* __restrict__ X, int64_t nq,
-                                                         const double* __restrict__ Y, int64_t nr, int D,
-                                                         const double* __restrict__ center, double* __restrict__ params)
+__global__ __launch_bounds__(64) void f16_scale_kernel(const double* __restrict__ box_y, const double* __restrict__ box_x,
+                                                       double* __restrict__ params)
 {
-    double m = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nq + nr; r += stride) {
-        const double* p = (r < nq) ? X + r * (int64_t)D : Y + (r - nq) * (int64_t)D;
-        double s2 = 0.0;
-        for (int i = 0; i < D; ++i) { const double t = p[i] - center[i]; s2 = fma(t, t, s2); }
-        m = fmax(m, s2);
-    }
+    double b = box_y[threadIdx.x];
+    if (box_x) b = fmax(b, box_x[threadIdx.x]);
+    double r2 = b * b;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomic_max_pos(params + HP_RMAX, sqrt(m));
+    for (int o = 32; o >= 1; o >>= 1) r2 += __shfl_xor(r2, o, 64);
+    if (threadIdx.x == 0) {
+        const double r = sqrt(r2);
+        double s = 1.0;
+        if (r > 0.0 && r < __builtin_huge_val()) s = exp2(floor(log2(kHTargetRadius / r)));
+        params[HP_RMAX] = r;
+        params[HP_SCALE] = s;
+    }
 }
 
-__global__ void f16_scale_kernel(double* __restrict__ params)
+// box of a second point set about an EXISTING centre (cross evidence: queries != references)
+__global__ __launch_bounds__(64) void f16_box_about_kernel(const double* __restrict__ partial, int D,
+                                                           const double* __restrict__ center, double* __restrict__ box)
 {
-    const double r = params[HP_RMAX];
-    double s = 1.0;
-    if (r > 0.0 && r < __builtin_huge_val()) s = exp2(floor(log2(kHTargetRadius / r)));
-    params[HP_SCALE] = s;
+    const int col = threadIdx.x;
+    double lo = __builtin_huge_val(), hi = -__builtin_huge_val();
+    for (int b = 0; b < kMeanBlocks; ++b) {
+        const double* o = partial + (int64_t)b * kStatStride;
+        lo = fmin(lo, o[kMaxDimPad + col]);
+        hi = fmax(hi, o[2 * kMaxDimPad + col]);
+    }
+    box[col] = (col < D && hi >= lo) ? fmax(fabs(hi - center[col]), fabs(lo - center[col])) : 0.0;
 }
 
 // ---------------------------------------------------------------------------
@@ -48,16 +58,30 @@ __global__ __launch_bounds__(256) void f16_pack_refs_kernel(const double* __rest
                                                             int64_t nrow_pad, const double* __restrict__ center,
                                                             double* __restrict__ params, _Float16* __restrict__ Yh)
 {
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // 256 rows per workgroup: the rows are read as ONE contiguous run (coalesced) into LDS, centred and
+    // scaled on the way; then thread t works on row t from LDS (row stride D+1 doubles: conflict-free).
+    extern __shared__ double rows[];                     // 256 * (D+1)
+    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    const double s = params[HP_SCALE];
+    const int ld = D | 1;                                // odd stride
+    {
+        const int64_t e0 = row0 * D;
+        const int64_t e1 = ((row0 + 256 < nr) ? row0 + 256 : nr) * (int64_t)D;
+        for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+            const int r = (int)((e - e0) / D), c = (int)((e - e0) - (int64_t)r * D);
+            rows[r * ld + c] = (Y[e] - center[c]) * s;
+        }
+    }
+    __syncthreads();
+    const int64_t row = row0 + threadIdx.x;
     double ey = 0.0, yn = 0.0, rho = 0.0;
     if (row < nrow_pad) {
         const bool live = row < nr;
-        const double s = params[HP_SCALE];
-        const double* y = Y + row * (int64_t)D;
+        const double* y = rows + threadIdx.x * ld;
         double err2 = 0.0, n2 = 0.0;
         if (live)
             for (int i = 0; i < D; ++i) {
-                const double t = (y[i] - center[i]) * s;
+                const double t = y[i];
                 const double th = (double)(_Float16)t;
                 err2 = fma(t - th, t - th, err2);
                 n2 = fma(th, th, n2);
@@ -78,7 +102,7 @@ __global__ __launch_bounds__(256) void f16_pack_refs_kernel(const double* __rest
                     const int k = 16 * ks + 8 * h + e;
                     _Float16 x = (_Float16)0.0f;
                     if (live) {
-                        if (k < D) x = (_Float16)(-2.0 * (double)(_Float16)((y[k] - center[k]) * s));
+                        if (k < D) x = (_Float16)(-2.0 * (double)(_Float16)y[k]);
                         else if (k == D) x = n_hi;
                         else if (k == D + 1) x = n_mid;
                         else if (k == D + 2) x = n_lo;

@@ -18,40 +18,68 @@ namespace mce {
 constexpr int kMeanBlocks = 256;
 constexpr int kMeanThreads = 256;
 constexpr int kMaxDimPad = 64;
+constexpr int kStatStride = 3 * kMaxDimPad;   // per block: sum[64] | min[64] | max[64]
 
-__global__ __launch_bounds__(kMeanThreads) void col_sum_partial_kernel(const double* __restrict__ Y, int64_t nr, int D,
-                                                                      double* __restrict__ partial /*[kMeanBlocks][64]*/)
+// Column statistics (sum, min, max) of a row-major [n, D] matrix in ONE coalesced pass:
+// a wave covers RPW = 64/D consecutive rows per trip (lane -> row l/D, column l%D: the lanes read
+// one contiguous run of RPW*D doubles), every lane keeps its own column's partial.
+__global__ __launch_bounds__(kMeanThreads) void col_stats_partial_kernel(const double* __restrict__ Y, int64_t nr, int D,
+                                                                        double* __restrict__ partial /*[kMeanBlocks][3][64]*/)
 {
-    __shared__ double red[kMeanThreads];
+    __shared__ double s_sum[kMeanThreads], s_min[kMeanThreads], s_max[kMeanThreads];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int RPW = 64 / D;                       // rows per wave trip (D <= 63 -> >= 1)
+    const int lr = lane / D, col = lane - lr * D;
+    const bool on = lr < RPW;
     const int64_t per = (nr + kMeanBlocks - 1) / kMeanBlocks;
     const int64_t r0 = (int64_t)blockIdx.x * per;
     const int64_t r1 = (r0 + per < nr) ? r0 + per : nr;
-    // thread t owns column t % 64 of rows r0 + t/64, +4, ...  (coalesced along a row)
-    const int col = threadIdx.x & 63;
-    const int sub = threadIdx.x >> 6;
-    double acc = 0.0;
-    if (col < D)
-        for (int64_t r = r0 + sub; r < r1; r += kMeanThreads / 64) acc += Y[r * (int64_t)D + col];
-    red[threadIdx.x] = acc;
+    double sum = 0.0, mn = __builtin_huge_val(), mx = -__builtin_huge_val();
+    if (on)
+        for (int64_t r = r0 + wave * RPW + lr; r < r1; r += (int64_t)(kMeanThreads / 64) * RPW) {
+            const double v = Y[r * (int64_t)D + col];
+            sum += v;
+            mn = fmin(mn, v);
+            mx = fmax(mx, v);
+        }
+    s_sum[threadIdx.x] = sum;
+    s_min[threadIdx.x] = mn;
+    s_max[threadIdx.x] = mx;
     __syncthreads();
     if (threadIdx.x < 64) {
-        double s = 0.0;
-#pragma unroll
-        for (int i = 0; i < kMeanThreads / 64; ++i) s += red[i * 64 + threadIdx.x];
-        partial[(int64_t)blockIdx.x * kMaxDimPad + threadIdx.x] = s;
+        const int c = threadIdx.x;
+        double a = 0.0, lo = __builtin_huge_val(), hi = -__builtin_huge_val();
+        if (c < D)
+            for (int w = 0; w < kMeanThreads / 64; ++w)
+                for (int k = 0; k < RPW; ++k) {            // fixed order: deterministic
+                    const int t = w * 64 + k * D + c;
+                    a += s_sum[t];
+                    lo = fmin(lo, s_min[t]);
+                    hi = fmax(hi, s_max[t]);
+                }
+        double* o = partial + (int64_t)blockIdx.x * kStatStride;
+        o[c] = a;
+        o[kMaxDimPad + c] = lo;
+        o[2 * kMaxDimPad + c] = hi;
     }
 }
 
-__global__ __launch_bounds__(64) void col_mean_final_kernel(const double* __restrict__ partial, int64_t nr, int D,
-                                                            double* __restrict__ center /*[64]*/)
+// centre[c] = column mean;  box[c] = max(|max_c - centre|, |min_c - centre|)  (0 beyond D)
+__global__ __launch_bounds__(64) void col_stats_final_kernel(const double* __restrict__ partial, int64_t nr, int D,
+                                                             double* __restrict__ center /*[64]*/, double* __restrict__ box /*[64]*/)
 {
     const int col = threadIdx.x;
-    double s = 0.0;
-    for (int b = 0; b < kMeanBlocks; ++b) s += partial[(int64_t)b * kMaxDimPad + col];
-    center[col] = (col < D) ? s / (double)nr : 0.0;
+    double s = 0.0, lo = __builtin_huge_val(), hi = -__builtin_huge_val();
+    for (int b = 0; b < kMeanBlocks; ++b) {
+        const double* o = partial + (int64_t)b * kStatStride;
+        s += o[col];
+        lo = fmin(lo, o[kMaxDimPad + col]);
+        hi = fmax(hi, o[2 * kMaxDimPad + col]);
+    }
+    const double c = (col < D) ? s / (double)nr : 0.0;
+    center[col] = c;
+    if (box) box[col] = (col < D && hi >= lo) ? fmax(fabs(hi - c), fabs(lo - c)) : 0.0;
 }
-
-
 
 // ---------------------------------------------------------------------------
 // pack_refs: Y[nr, D] row-major -> Yf[tile][ks][lane], lane l <-> (row tile*16+(l&15), dim 4ks+(l>>4))

@@ -35,16 +35,15 @@ int main(int argc, char** argv)
     double *X, *pd, *center, *msum, *params, *qinfo; int* pi; _Float16 *Yh, *Xh;
     CK(hipMalloc(&X, sizeof(double) * n * D));
     CK(hipMalloc(&Yh, 2 * nrow_pad * 16 * KST)); CK(hipMalloc(&Xh, 2 * nq_pad * 16 * KST));
-    CK(hipMalloc(&qinfo, 16 * nq_pad)); const size_t pbytes = 256 + (size_t)nqblk * rsplit * 8 * 64; CK(hipMalloc(&params, pbytes)); CK(hipMalloc(&center, 512)); CK(hipMalloc(&msum, 8 * 64 * 256));
+    CK(hipMalloc(&qinfo, 16 * nq_pad)); const size_t pbytes = 256 + (size_t)nqblk * rsplit * 8 * 64; CK(hipMalloc(&params, pbytes)); CK(hipMalloc(&center, 3 * 512)); CK(hipMalloc(&msum, 8 * kStatStride * 256));
     const size_t nl = (size_t)rsplit * KCAP * nq_pad;
     CK(hipMalloc(&pd, sizeof(double) * nl)); CK(hipMalloc(&pi, sizeof(int) * nl));
     CK(hipMemcpy(X, h.data(), sizeof(double) * n * D, hipMemcpyHostToDevice));
-    col_sum_partial_kernel<<<kMeanBlocks, kMeanThreads>>>(X, n, D, msum);
-    col_mean_final_kernel<<<1, 64>>>(msum, n, D, center);
+    col_stats_partial_kernel<<<kMeanBlocks, kMeanThreads>>>(X, n, D, msum);
+    col_stats_final_kernel<<<1, 64>>>(msum, n, D, center, center + 64);
     CK(hipMemset(params, 0, pbytes));
-    f16_radius_kernel<<<1024, 256>>>(X, n, X, n, D, center, params);
-    f16_scale_kernel<<<1, 1>>>(params);
-    f16_pack_refs_kernel<<<(unsigned)((nrow_pad + 255) / 256), 256>>>(X, n, D, KST, nrow_pad, center, params, Yh);
+    f16_scale_kernel<<<1, 64>>>(center + 64, nullptr, params);
+    f16_pack_refs_kernel<<<(unsigned)((nrow_pad + 255) / 256), 256, 256 * (D | 1) * 8>>>(X, n, D, KST, nrow_pad, center, params, Yh);
     f16_pack_queries_kernel<<<(unsigned)((nq_pad + 255) / 256), 256>>>(X, n, nq_pad, D, KST, center, params, Xh, qinfo);
     CK(hipDeviceSynchronize());
     constexpr size_t LDS = f16_lds_bytes(KST, KCAP);
