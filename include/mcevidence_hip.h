@@ -45,8 +45,10 @@ extern "C" {
 #define MCE_ERR_WORKSPACE (-5) /* caller workspace too small                 -> ValueError  */
 #define MCE_ERR_DIM_RANGE (-6) /* d larger than MCE_MAX_DIM                  -> ValueError  */
 
-#define MCE_MAX_K 32    /* neighbours per query the MFMA kernel keeps in registers */
-#define MCE_MAX_DIM 63  /* dimensions (d+1 is padded to a multiple of 4, <= 64)     */
+#define MCE_MAX_K 32    /* neighbours per query handled by the MFMA kernels (fp16 filter: 16)  */
+#define MCE_MAX_DIM 63  /* dimensions handled by the MFMA kernels (fp16 filter: 2..61)         */
+#define MCE_GENERIC_MAX_K 1024   /* beyond the MFMA limits a plain exact kernel takes over, up to */
+#define MCE_GENERIC_MAX_DIM 1024 /* these sizes; larger -> MCE_ERR_K_RANGE / MCE_ERR_DIM_RANGE    */
 
 /* self_mode: how the query set relates to the reference set.
  *   MCE_SELF_NONE    Y is a different set (cross evidence, MCEvidence.py:1093-1096, k0=0)

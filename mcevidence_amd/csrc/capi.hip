@@ -21,6 +21,7 @@
 #include "knn_mfma.hpp"
 #include "pack_refs.hpp"
 #include "f16_prep.hpp"
+#include "knn_generic.hpp"
 #include "reduce_kernels.hpp"
 
 namespace {
@@ -59,6 +60,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct Plan {
     const mce::KnnVariant* v = nullptr;
     const mce::KnnF16Variant* vh = nullptr;   // non-null: fp16-filter path
+    bool generic = false;                     // plain exact kernel (d > 63 or K > 32)
     int KST = 0;
     size_t off_yh = 0, off_xh = 0, off_qinfo = 0, off_params = 0;
     int KS = 0, KCAP = 0, QT = 0, CT = 0;
@@ -89,13 +91,34 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
 {
     if (nq < 0 || nr < 1 || d < 1 || K < 1) return fail(MCE_ERR_INVALID, "invalid sizes nq=%lld nr=%lld d=%d K=%d", (long long)nq, (long long)nr, d, K);
     if (self_mode < 0 || self_mode > 2) return fail(MCE_ERR_INVALID, "invalid self_mode %d", self_mode);
-    if (d > MCE_MAX_DIM) return fail(MCE_ERR_DIM_RANGE, "d=%d exceeds MCE_MAX_DIM=%d", d, MCE_MAX_DIM);
-    if (K > MCE_MAX_K) return fail(MCE_ERR_K_RANGE, "K=%d exceeds MCE_MAX_K=%d", K, MCE_MAX_K);
+    if (d > mce::kGenMaxDim) return fail(MCE_ERR_DIM_RANGE, "d=%d exceeds the supported maximum %d", d, mce::kGenMaxDim);
+    if (K > mce::kGenMaxK) return fail(MCE_ERR_K_RANGE, "K=%d exceeds the supported maximum %d", K, mce::kGenMaxK);
     const int64_t usable = (self_mode == MCE_SELF_EXCLUDE) ? nr - 1 : nr;
     if (K > usable)   // sklearn raises ValueError("Expected n_neighbors <= n_samples_fit")
         return fail(MCE_ERR_K_RANGE, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", K, (long long)usable);
     if (nr >= (int64_t)1 << 31) return fail(MCE_ERR_INVALID, "nr=%lld exceeds 2^31-1 reference rows", (long long)nr);
 
+    if (d > MCE_MAX_DIM || K > MCE_MAX_K) {
+        // outside the MFMA kernels' register budgets: plain exact kernel, lists [1][K][nq_pad]
+        p.generic = true;
+        p.v = nullptr;
+        p.vh = nullptr;
+        p.KCAP = K;
+        p.rsplit = 1;
+        p.L = 1;
+        p.nqblk = (int)std::max<int64_t>(1, (nq + mce::kGenThreads - 1) / mce::kGenThreads);
+        p.nq_pad = (int64_t)p.nqblk * mce::kGenThreads;
+        size_t off = 0;
+        p.off_pd = off;
+        off = align_up(off + (size_t)K * (size_t)p.nq_pad * sizeof(double), 256);
+        p.off_pi = off;
+        off = align_up(off + (size_t)K * (size_t)p.nq_pad * sizeof(int), 256);
+        p.off_center = off;      // (generic plans: scratch for the distance matrix of the fused path)
+        off = align_up(off + (size_t)nq * K * sizeof(double), 256);
+        p.off_msum = off;
+        p.total = off + 256;
+        return MCE_OK;
+    }
     p.KS = (d + 1 + 3) / 4;
     int ki = 0;
     while (ki < mce::kNumKcap - 1 && mce::kKcapList[ki] < K) ++ki;
@@ -190,6 +213,14 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
 {
     double* pd = reinterpret_cast<double*>(ws + p.off_pd);
     int* pi = reinterpret_cast<int*>(ws + p.off_pi);
+    if (p.generic) {
+        const size_t lds = (size_t)mce::kGenTileRows * d * sizeof(double);
+        hipLaunchKernelGGL(mce::knn_generic_kernel, dim3((unsigned)p.nqblk), dim3(mce::kGenThreads), lds, st, dX, nq, dY, nr, (int)d,
+                           (int)K, p.nq_pad, (self_mode == MCE_SELF_EXCLUDE) ? 1 : 0, self_offset, pd, pi);
+        MCE_HIP(hipGetLastError());
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "knn_generic_kernel grid=%d block=%d lds=%zu", p.nqblk, mce::kGenThreads, lds);
+        return MCE_OK;
+    }
     double* center = reinterpret_cast<double*>(ws + p.off_center);
     double* msum = reinterpret_cast<double*>(ws + p.off_msum);
     double* box_y = center + mce::kMaxDimPad;
@@ -292,7 +323,7 @@ int launch_merge(const Plan& p, bool write_dist, bool fuse, const double* dX, co
     const unsigned blocks = (unsigned)((nq + mce::kRedThreads - 1) / mce::kRedThreads);
     const double* pd = reinterpret_cast<const double*>(ws + p.off_pd);
     const int* pi = reinterpret_cast<const int*>(ws + p.off_pi);
-    const bool refine = p.vh == nullptr;      // fp64 sweep keys are GEMM-form: refine; fp16 path keys are exact
+    const bool refine = p.vh == nullptr && !p.generic;   // fp64 sweep keys are GEMM-form: refine; the others are exact
     const double lnc = fuse ? ln_unit_ball(d) : 0.0;
 #define MCE_MERGE(W, F, R)                                                                                          \
     hipLaunchKernelGGL((mce::merge_lists_kernel<W, F, R>), dim3(blocks), dim3(mce::kRedThreads), 0, st, pd, pi, p.L,  \
@@ -373,6 +404,14 @@ int mce_knn_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t nr, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = run_search(p, dX, nq, dY, nr, d, K, self_mode, self_offset, static_cast<char*>(ws), st);
     if (rc != MCE_OK) return rc;
+    if (p.generic) {
+        hipLaunchKernelGGL(mce::generic_finalize_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const double*>(static_cast<char*>(ws) + p.off_pd),
+                           reinterpret_cast<const int*>(static_cast<char*>(ws) + p.off_pi), nq, p.nq_pad, (int)K, (int)self_mode,
+                           self_offset, d_dist, d_idx);
+        MCE_HIP(hipGetLastError());
+        return MCE_OK;
+    }
     rc = launch_merge(p, true, false, dX, dY, nq, d, K, self_mode, self_offset, d_dist, d_idx, 0, 0, nullptr, nullptr, nullptr,
                       static_cast<char*>(ws), st);
     if (rc != MCE_OK) return rc;
@@ -420,9 +459,22 @@ int mce_knn_dotp_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t
     if (rc != MCE_OK) return rc;
     double* partial = reinterpret_cast<double*>(wsc + p.total);
     const unsigned blocks = (unsigned)((nq + mce::kRedThreads - 1) / mce::kRedThreads);
-    rc = launch_merge(p, d_dist_out != nullptr, true, dX, dY, nq, d, K, self_mode, self_offset, d_dist_out, nullptr, (int)k0,
-                      (int)kmax, d_w, d_fs, partial, wsc, st);
-    if (rc != MCE_OK) return rc;
+    if (p.generic) {
+        // lists -> distance matrix [nq, K] (caller's buffer or workspace scratch) -> unfused reduction
+        double* dd = d_dist_out ? d_dist_out : reinterpret_cast<double*>(wsc + p.off_center);
+        hipLaunchKernelGGL(mce::generic_finalize_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const double*>(wsc + p.off_pd), reinterpret_cast<const int*>(wsc + p.off_pi), nq,
+                           p.nq_pad, K, self_mode, self_offset, dd, (int64_t*)nullptr);
+        MCE_HIP(hipGetLastError());
+        // dotp_partial reads column (k - k0) of dd for reference column k: shift the base pointer
+        hipLaunchKernelGGL(mce::dotp_partial_kernel, dim3(blocks), dim3(mce::kRedThreads), 0, st, dd - k0, nq, K, (int)k0, (int)kmax,
+                           (int)d, ln_unit_ball(d), d_w, d_fs, partial);
+        MCE_HIP(hipGetLastError());
+    } else {
+        rc = launch_merge(p, d_dist_out != nullptr, true, dX, dY, nq, d, K, self_mode, self_offset, d_dist_out, nullptr, (int)k0,
+                          (int)kmax, d_w, d_fs, partial, wsc, st);
+        if (rc != MCE_OK) return rc;
+    }
     hipLaunchKernelGGL(mce::dotp_final_kernel, dim3((unsigned)kmax), dim3(mce::kRedThreads), 0, st, partial,
                        (int64_t)blocks, (int)k0, (int)kmax, d_dotp);
     MCE_HIP(hipGetLastError());

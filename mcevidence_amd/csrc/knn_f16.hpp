@@ -48,7 +48,15 @@ __device__ __forceinline__ float min3f(float a, float b, float c)
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int kHWaves = 8;
+// Workgroup geometry.  MCE_H_GEOM 0 (shipped): 8 waves (2 per SIMD) x 2 query tiles.  Kept for the
+// record, both measured SLOWER at C3 (tools/knn_f16_bench.hip): 1 = 4 waves (one per SIMD, 512
+// registers) x 4 query tiles: sweep 83 ms vs 56 ms; 2 = 16 waves (4 per SIMD, 128 VGPRs): spills.
+#ifndef MCE_H_GEOM
+#define MCE_H_GEOM 0
+#endif
+constexpr int kHWaves = MCE_H_GEOM == 1 ? 4 : (MCE_H_GEOM == 2 ? 16 : 8);   // GEOM 2: 16 waves (4 per SIMD, <= 128 VGPRs)
+constexpr int kHQT = MCE_H_GEOM == 1 ? 4 : 2;      // 32-query tiles per wave
+constexpr int kHNL = kHQT / 2;                     // top-K lists per owner lane (64 queries per list set)
 constexpr int kHThreads = kHWaves * 64;
 #ifndef MCE_H_QUEUE
 #define MCE_H_QUEUE 640
@@ -61,14 +69,14 @@ constexpr int kHThreads = kHWaves * 64;
 #endif
 constexpr int kHQueue = MCE_H_QUEUE;          // candidate queue entries (4 B) per wave: 512 (half a tile) + 128
 constexpr int kHDrainTrigger = MCE_H_TRIGGER;    // a wave with this many queued candidates asks the workgroup to drain
-constexpr int kHRelBits = 26;         // queue entry = query-local (6 bits) << 26 | row - first row of the split
+constexpr int kHRelBits = MCE_H_GEOM == 1 ? 25 : 26;   // queue entry = query-local (6|7 bits) << kHRelBits | row - first row of the split
 constexpr double kHTargetRadius = 200.0;
 
 // device-side scalars shared by the f16 kernels (doubles; maxima kept as bit patterns)
 enum { HP_RMAX = 0, HP_SCALE = 1, HP_EY = 2, HP_YHATMAX = 3, HP_RHO = 4, HP_COUNT = 8 };
 
 __host__ __device__ constexpr int f16_ksteps(int D) { return (D + 3 + 15) / 16; }          // 16-wide k-steps
-__host__ __device__ constexpr int f16_qt(int) { return 2; }          // 32-query tiles per wave: 64 queries <-> 64 owner lanes
+__host__ __device__ constexpr int f16_qt(int) { return kHQT; }
 __host__ __device__ constexpr bool f16_supported(int D, int K) { return D >= 2 && f16_ksteps(D) <= 4 && K <= 16; }
 __host__ __device__ constexpr int f16_qpb(int KCAP) { return kHWaves * f16_qt(KCAP) * 32; }
 // 32-row reference tiles per LDS chunk (tile = KST KB): <= 32 KB per buffer, even count,
@@ -78,7 +86,7 @@ __host__ __device__ constexpr size_t f16_lds_bytes(int KST, int KCAP)
 {
     return (size_t)2 * f16_chunk_tiles(KST) * KST * 1024             // staging
            + (size_t)kHWaves * kHQueue * 16                            // queues: packed(4) + next(4) + d2(8)
-           + (size_t)kHWaves * 64 * 4 + 64;                            // chain heads + votes
+           + (size_t)kHWaves * kHQT * 32 * 4 + 64;                     // chain heads + votes
 }
 
 // ---------------------------------------------------------------------------
@@ -87,7 +95,7 @@ __host__ __device__ constexpr size_t f16_lds_bytes(int KST, int KCAP)
 //   with EXACT squared distances as keys.
 // ---------------------------------------------------------------------------
 template <int KST, int KCAP>
-__global__ __launch_bounds__(kHThreads, 2) void knn_f16_kernel(
+__global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ? 4 : 2)) void knn_f16_kernel(
     const _Float16* __restrict__ Yh, int64_t nchunk_total, int rsplit,
     const _Float16* __restrict__ Xh, const double* __restrict__ qinfo, const double* __restrict__ params,
     const double* __restrict__ X, const double* __restrict__ Y, int64_t nq, int64_t nr, int D,
@@ -130,50 +138,50 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_f16_kernel(
     double* const wqd = qd2_all + wave * kHQueue;               // exact distance of a queued entry (phase A)
     int* const wq = qpk_all + wave * kHQueue;                   // packed (query-local, relative row)
     int* const wnx = qnx_all + wave * kHQueue;                  // next entry of the same query
-    int* const whead = head_all + wave * 64;                    // chain head per wave-local query
-    volatile int* const wvote = head_all + kHWaves * 64;        // [2] drain votes (chunk parity)
+    int* const whead = head_all + wave * QPW;                   // chain head per wave-local query
+    volatile int* const wvote = head_all + kHWaves * QPW;       // [2] drain votes (chunk parity)
     const int jsplit0 = (int)(c_begin * (CT * 32));             // first reference row of this split
-    whead[lane] = -1;
-
-    // lane l OWNS wave-local query l = qt*32 + column: its sorted top-KCAP list lives here
-    double own_d[KCAP];
-    int own_i[KCAP];
 #pragma unroll
-    for (int k = 0; k < KCAP; ++k) { own_d[k] = INF; own_i[k] = -1; }
+    for (int nl = 0; nl < kHNL; ++nl) whead[nl * 64 + lane] = -1;
+
+    // lane l OWNS wave-local queries nl*64 + l (query ql = qt*32 + column): their sorted top-KCAP lists live here
+    double own_d[kHNL][KCAP];
+    int own_i[kHNL][KCAP];
+#pragma unroll
+    for (int nl = 0; nl < kHNL; ++nl)
+#pragma unroll
+        for (int k = 0; k < KCAP; ++k) { own_d[nl][k] = INF; own_i[nl][k] = -1; }
 
     const int64_t qwave0 = (int64_t)qblk * QPB + wave * QPW;     // first query of this wave
 
     // ---- B fragments (fp16 query rows) + per-query gate constants ---------------
     v8h b[QT][KST];
-    double gate_a[QT], gate_xn[QT], gate_eps[QT];                // e_x + E_y ; |x^|^2 ; eps_q
     float G[QT];
-    bool qlive[QT];
     const double s2 = params[HP_SCALE] * params[HP_SCALE];
-    {
-        const double Ey = params[HP_EY], Yhm = params[HP_YHATMAX], rho = params[HP_RHO];
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const int64_t q = qwave0 + qt * 32 + (lane & 31);
+    for (int qt = 0; qt < QT; ++qt) {
+        const int64_t q = qwave0 + qt * 32 + (lane & 31);
 #pragma unroll
-            for (int ks = 0; ks < KST; ++ks)
-                b[qt][ks] = *reinterpret_cast<const v8h*>(Xh + q * (int64_t)(16 * KST) + 16 * ks + 8 * (lane >> 5));
-            const double ex = qinfo[2 * q], xn = qinfo[2 * q + 1];
-            const double r = sqrt(xn) + Yhm;
-            // + 2*sqrt(16 KST)*2^-14: even if the matrix unit flushed fp16 subnormal inputs (it does not
-            // on gfx950) the bound would hold
-            gate_a[qt] = (ex + Ey) * (1.0 + 1e-9) + 2.0 * sqrt(16.0 * KST) * 0x1p-14;
-            gate_xn[qt] = xn;
-            gate_eps[qt] = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 1e-9) + rho + 1e-30;
-            qlive[qt] = q < nq;
-            G[qt] = (qlive[qt] && MCE_ABLATE != 1) ? __builtin_huge_valf() : -__builtin_huge_valf();     // padding queries never pass
-        }
+        for (int ks = 0; ks < KST; ++ks)
+            b[qt][ks] = *reinterpret_cast<const v8h*>(Xh + q * (int64_t)(16 * KST) + 16 * ks + 8 * (lane >> 5));
+        G[qt] = (q < nq && MCE_ABLATE != 1) ? __builtin_huge_valf() : -__builtin_huge_valf();     // padding queries never pass
     }
     const int k_last = ksel - 1;
-    auto gate_of = [&](double thr, int qt) -> float {       // thr: exact squared distance, input units
-        if (!qlive[qt] || MCE_ABLATE == 1) return -__builtin_huge_valf();
+    // gate of query (qt, lane&31) from its current K-th best `thr` (exact squared distance, input
+    // units).  The per-query constants are re-read from qinfo (L2) here -- this runs once per drain,
+    // and keeping them in registers would cost 6 VGPRs per query tile in the sweep.
+    auto gate_of = [&](double thr, int qt) -> float {
+        const int64_t q = qwave0 + qt * 32 + (lane & 31);
+        if (!(q < nq) || MCE_ABLATE == 1) return -__builtin_huge_valf();
         if (!(thr < INF)) return __builtin_huge_valf();
-        const double rr = sqrt(thr * s2) * (1.0 + 1e-12) + gate_a[qt];
-        const double g = rr * rr * (1.0 + 1e-12) - gate_xn[qt] + gate_eps[qt];
+        const double ex = qinfo[2 * q], xn = qinfo[2 * q + 1];
+        const double r = sqrt(xn) + params[HP_YHATMAX];
+        // + 2*sqrt(16 KST)*2^-14: even if the matrix unit flushed fp16 subnormal inputs (it does not
+        // on gfx950) the bound would hold
+        const double ga = (ex + params[HP_EY]) * (1.0 + 1e-9) + 2.0 * sqrt(16.0 * KST) * 0x1p-14;
+        const double eps = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 1e-9) + params[HP_RHO] + 1e-30;
+        const double rr = sqrt(thr * s2) * (1.0 + 1e-12) + ga;
+        const double g = rr * rr * (1.0 + 1e-12) - xn + eps;
         return __double2float_ru(g);
     };
 
@@ -272,40 +280,48 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_f16_kernel(
 #if MCE_STATS
         st_tA += clock64() - t_d0;
 #endif
-        // ---- phase B: every owner lane folds its chain into its register list -------------
-        int cur = whead[lane];
-        whead[lane] = -1;
-        while (__any(cur >= 0)) {
-#if MCE_STATS
-            st_steps += 1;
-#endif
-            const bool on = cur >= 0;
-            const int ce = on ? cur : 0;
-            const double d2 = on ? wqd[ce] : INF;
-            const int j = jsplit0 + (int)((unsigned)wq[ce] & ((1u << kHRelBits) - 1u));
-            cur = on ? wnx[ce] : -1;
-            // ascending list, ties by row; d2 = +inf (idle lane) changes nothing
-            bool c_hi = (d2 < own_d[KCAP - 1]) || (d2 == own_d[KCAP - 1] && j < own_i[KCAP - 1] && d2 < INF);
+        // ---- phase B: every owner lane folds its chain(s) into its register list(s) ----------
 #pragma unroll
-            for (int k = KCAP - 1; k >= 1; --k) {
-                const bool c_lo = (d2 < own_d[k - 1]) || (d2 == own_d[k - 1] && j < own_i[k - 1] && d2 < INF);
-                own_d[k] = c_lo ? own_d[k - 1] : (c_hi ? d2 : own_d[k]);
-                own_i[k] = c_lo ? own_i[k - 1] : (c_hi ? j : own_i[k]);
-                c_hi = c_lo;
+        for (int nl = 0; nl < kHNL; ++nl) {
+            int cur = whead[nl * 64 + lane];
+            whead[nl * 64 + lane] = -1;
+            while (__any(cur >= 0)) {
+#if MCE_STATS
+                st_steps += 1;
+#endif
+                const bool on = cur >= 0;
+                const int ce = on ? cur : 0;
+                const double d2 = on ? wqd[ce] : INF;
+                const int j = jsplit0 + (int)((unsigned)wq[ce] & ((1u << kHRelBits) - 1u));
+                cur = on ? wnx[ce] : -1;
+                // ascending list, ties by row; d2 = +inf (idle lane) changes nothing
+                bool c_hi = (d2 < own_d[nl][KCAP - 1]) || (d2 == own_d[nl][KCAP - 1] && j < own_i[nl][KCAP - 1] && d2 < INF);
+#pragma unroll
+                for (int k = KCAP - 1; k >= 1; --k) {
+                    const bool c_lo = (d2 < own_d[nl][k - 1]) || (d2 == own_d[nl][k - 1] && j < own_i[nl][k - 1] && d2 < INF);
+                    own_d[nl][k] = c_lo ? own_d[nl][k - 1] : (c_hi ? d2 : own_d[nl][k]);
+                    own_i[nl][k] = c_lo ? own_i[nl][k - 1] : (c_hi ? j : own_i[nl][k]);
+                    c_hi = c_lo;
+                }
+                own_d[nl][0] = c_hi ? d2 : own_d[nl][0];
+                own_i[nl][0] = c_hi ? j : own_i[nl][0];
             }
-            own_d[0] = c_hi ? d2 : own_d[0];
-            own_i[0] = c_hi ? j : own_i[0];
         }
 #if MCE_STATS
         st_tD += clock64() - t_d0;
 #endif
         qcount = 0;
-        // ---- refresh the gates: lane l needs the K-th best of queries (qt, l&31), owned by lane qt*32 + (l&31)
-        double thr_own = own_d[KCAP - 1];
+        // ---- refresh the gates: lane l needs the K-th best of queries ql = qt*32 + (l&31),
+        // owned by lane ql & 63 in list ql >> 6
+        double thr_own[kHNL];
 #pragma unroll
-        for (int k = 0; k < KCAP - 1; ++k) thr_own = (k == k_last) ? own_d[k] : thr_own;
+        for (int nl = 0; nl < kHNL; ++nl) {
+            thr_own[nl] = own_d[nl][KCAP - 1];
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) G[qt] = gate_of(__shfl(thr_own, qt * 32 + (lane & 31), 64), qt);
+            for (int k = 0; k < KCAP - 1; ++k) thr_own[nl] = (k == k_last) ? own_d[nl][k] : thr_own[nl];
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) G[qt] = gate_of(__shfl(thr_own[qt >> 1], (qt & 1) * 32 + (lane & 31), 64), qt);
     };
 
     // gate + enqueue for one finished tile; jb0 = first reference row of the tile.
@@ -415,14 +431,15 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_f16_kernel(
         o[4] = (double)st_tA; o[5] = (double)st_tD; o[6] = (double)(clock64() - t_kernel0); o[7] = (double)st_tB;
     }
 #endif
-    // ---- write the lists: lane l owns wave-local query l (coalesced over lanes) ----
-    {
-        const int64_t q = qwave0 + lane;
+    // ---- write the lists: lane l owns wave-local queries nl*64 + l (coalesced over lanes) ----
+#pragma unroll
+    for (int nl = 0; nl < kHNL; ++nl) {
+        const int64_t q = qwave0 + nl * 64 + lane;
 #pragma unroll
         for (int k = 0; k < KCAP; ++k) {
             const int64_t o = ((int64_t)split * KCAP + k) * nq_pad + q;
-            part_d[o] = own_d[k];
-            part_i[o] = own_i[k];
+            part_d[o] = own_d[nl][k];
+            part_i[o] = own_i[nl][k];
         }
     }
 }

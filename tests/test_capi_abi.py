@@ -46,9 +46,9 @@ def test_argument_validation_without_gpu():
     with pytest.raises(ValueError, match="n_neighbors <= n_samples_fit"):
         _capi.knn(X, X, 5, self_mode=_capi.SELF_EXCLUDE)        # self excluded: only 4 usable rows
     with pytest.raises(ValueError):
-        _capi.knn(np.zeros((5, 64)), np.zeros((5, 64)), 2)      # d > MCE_MAX_DIM
+        _capi.knn(np.zeros((5, 1025)), np.zeros((5, 1025)), 2)  # d > MCE_GENERIC_MAX_DIM
     with pytest.raises(ValueError):
-        _capi.knn(np.zeros((50, 3)), np.zeros((50, 3)), 33)     # K > MCE_MAX_K
+        _capi.knn(np.zeros((2000, 3)), np.zeros((2000, 3)), 1025)   # K > MCE_GENERIC_MAX_K
     with pytest.raises(ValueError):
         _capi.knn(np.zeros((5, 3)), np.zeros((5, 4)), 2)        # column mismatch
     with pytest.raises(ValueError):
@@ -59,8 +59,9 @@ def test_argument_validation_without_gpu():
         _capi.knn_dotp(X, None, np.ones(4), np.zeros(5), kmax=2, k0=1)
     assert _capi.knn_workspace_bytes(1000, 1000, 6, 4) > 0
     assert _capi.dotp_workspace_bytes(1000, 4) >= 4 * 4 * 8
+    assert _capi.knn_workspace_bytes(10, 10, 100, 4) > 0         # d > 63: generic exact kernel
     with pytest.raises(ValueError):
-        _capi.knn_workspace_bytes(10, 10, 100, 4)
+        _capi.knn_workspace_bytes(10, 10, 2000, 4)
 
 
 def test_compute_fails_loudly_without_gpu():

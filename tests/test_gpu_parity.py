@@ -144,6 +144,30 @@ def test_knn_adversarial_inputs_stay_exact(capi, kind, d):
     assert np.all(np.diff(dist, axis=1) >= 0)
 
 
+@pytest.mark.parametrize("d,K", [(64, 5), (100, 12), (10, 40), (200, 33)])
+def test_generic_kernel_beyond_mfma_limits(capi, d, K):
+    """d > 63 or K > 32: plain exact kernel -- no shape the reference accepts is refused."""
+    rng = np.random.default_rng(d * 7 + K)
+    Y = rng.standard_normal((1500, d))
+    X = rng.standard_normal((333, d))
+    dist, idx = capi.knn(X, Y, K)
+    assert "generic" in capi.last_kernel()
+    od, oi = orc.knn_brute(X, Y, K) if K <= 64 else (None, None)
+    assert _rel(dist, od) < 1e-13 and np.array_equal(idx, oi)
+    d1, i1 = capi.knn(Y, Y, K, self_mode=capi.SELF_INCLUDE)
+    d2, i2 = capi.knn(Y, Y, K - 1, self_mode=capi.SELF_EXCLUDE)
+    assert np.all(d1[:, 0] == 0) and np.array_equal(d1[:, 1:], d2) and np.array_equal(i1[:, 1:], i2)
+    kmax = K if K <= 12 else 12
+    w = rng.integers(1, 4, len(Y)).astype(float)
+    fs = -rng.random(len(Y))
+    dp, dd = capi.knn_dotp(Y, None, w, fs, kmax, 1, return_dist=True)
+    full = np.zeros((len(Y), kmax)); full[:, 1:] = d2[:, :kmax - 1]
+    # (log-domain oracle: at d=200 the reference's own pow(pi,d/2)*pow(r,d) overflows to inf)
+    ref = orc.dotp_logdomain(full, w, fs, d, 1, kmax)
+    assert np.allclose(dp[1:], ref[1:], rtol=1e-11) and np.allclose(dd, d2[:, :kmax - 1], rtol=1e-14, atol=0)
+    assert np.allclose(capi.knn_dotp(Y, None, w, fs, kmax, 1), dp, rtol=1e-13)
+
+
 def test_error_codes_on_gpu(capi):
     X = np.zeros((5, 3))
     with pytest.raises(ValueError):
