@@ -115,6 +115,9 @@ ADVERSARIAL = {
     "one_outlier": lambda r, n, d: np.vstack([r.standard_normal((n - 1, d)), np.full((1, d), 1e4)]),
     "lattice_ties": lambda r, n, d: r.integers(-3, 4, size=(n, d)).astype(float),
     "subnormal_fp16_coords": lambda r, n, d: np.hstack([r.standard_normal((n, 1)), 1e-6 * r.standard_normal((n, d - 1))]),
+    "all_identical": lambda r, n, d: np.full((n, d), 3.25),
+    "constant_column": lambda r, n, d: np.hstack([np.full((n, 1), -7.0), r.standard_normal((n, d - 1))]),
+    "few_distinct": lambda r, n, d: r.standard_normal((5, d))[r.integers(0, 5, n)],
 }
 
 
@@ -131,7 +134,9 @@ def test_knn_adversarial_inputs_stay_exact(capi, kind, d):
     # whatever was selected, the reported distance is the exact distance to the reported row
     exact = np.sqrt(((Y[:, None, :] - Y[idx]) ** 2).sum(-1))
     assert np.allclose(dist, exact, rtol=1e-13, atol=0)
-    if capi.get_search_mode() == capi.MODE_F64 and kind in ("tight_clusters", "lattice_ties", "huge_scale_offset"):
+    if kind in ("all_identical", "few_distinct"):
+        assert np.array_equal(dist, od)              # massive exact ties: distances must still be exact
+    elif capi.get_search_mode() == capi.MODE_F64 and kind in ("tight_clusters", "lattice_ties", "huge_scale_offset"):
         # documented limit of the fp64 GEMM-form sweep: it SELECTS with ~1e-16*R^2
         # absolute accuracy (R = extent about the mean), so neighbours closer together than that, or
         # exactly tied, may be swapped for an equally-near row; the default fp16-filter path is exact.
