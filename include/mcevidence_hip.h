@@ -91,6 +91,20 @@ int mce_knn_dotp_f64(const double *X, int64_t nq, const double *Y, int64_t nr, i
                      int32_t k0, int64_t self_offset, const double *w, const double *fs, double *dotp,
                      double *dist_out, const int32_t *devices, int32_t ndev);
 
+/* Whole evidence() inner block with the feeders on the device too: replaces
+ * get_covariance (MCEvidence.py:851-882), diagonalise_chain (:842-849) AND :1093-1117 in one call,
+ * with ONE upload of the parameter columns.
+ *   S1[n1, ld1] / S2[n2, ld2]: raw (un-whitened) parameter rows, row stride ld >= d, first d
+ *       columns used.  S2 = NULL -> auto evidence (k0 = 1); otherwise cross evidence (k0 = 0).
+ *   cov_mode 0 ("all"): covariance of the rows of S1 and S2 together; 1 ("single"): S1 whitened with
+ *       its own eigen-system, S2 with ITS own (the reference's behaviour, :1080-1086).
+ *   Outputs: dotp[kmax]; *jacobian = sqrt(det cov) (of S1's covariance in mode 1);
+ *       eigenvalues[d] (may be NULL).  A non-positive eigenvalue -> MCE_ERR_INVALID (the reference
+ *       raises ValueError: math domain error). */
+int mce_evidence_feed_f64(const double *S1, int64_t n1, int64_t ld1, const double *S2, int64_t n2, int64_t ld2,
+                          int32_t d, int32_t cov_mode, int32_t kmax, const double *w, const double *fs,
+                          double *dotp, double *jacobian, double *eigenvalues, int32_t device);
+
 /* ---- device-pointer entry points (resident data, caller's stream) ------ */
 
 size_t mce_knn_workspace_bytes(int64_t nq, int64_t nr, int32_t d, int32_t K);

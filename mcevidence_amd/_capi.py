@@ -46,6 +46,8 @@ SIGNATURES = {
     "mce_knn_f64": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _c.c_int32]),
     "mce_dotp_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_int32]),
     "mce_knn_dotp_f64": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _P, _P, _P, _c.c_int32]),
+    "mce_evidence_feed_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32,
+                                         _P, _P, _P, _P, _P, _c.c_int32]),
     "mce_knn_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32]),
     "mce_dotp_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int32]),
     "mce_knn_f64_dev": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _P, _c.c_size_t, _P]),
@@ -201,6 +203,38 @@ def knn_dotp(X, Y, w, fs, kmax, k0, self_offset=0, return_dist=False, devices=No
                                w.ctypes.data, fs.ctypes.data, out.ctypes.data,
                                dist.ctypes.data if dist is not None else None, devs, ndev))
     return (out, dist) if return_dist else out
+
+
+def _rows_f64(a, name, d):
+    """2-D fp64 array whose rows are contiguous in their first d columns (row stride arbitrary)."""
+    a = np.asarray(a)
+    if a.ndim != 2 or a.shape[1] < d:
+        raise ValueError("%s must be 2-D with at least %d columns" % (name, d))
+    if a.dtype != np.float64 or a.strides[1] != 8 or a.strides[0] % 8 != 0 or a.strides[0] < 8 * d:
+        a = np.ascontiguousarray(a[:, :d], dtype=np.float64)
+    if not np.all(np.isfinite(a[:, :d])):
+        raise ValueError("%s contains NaN or infinity" % name)
+    return a
+
+
+def evidence_feed(S1, S2, d, cov_mode, kmax, w, fs, device=0):
+    """Covariance + whitening + kNN + reduction on the device from ONE upload of the raw parameter
+    rows.  Returns (dotp[kmax], jacobian, eigenvalues[d])."""
+    lib = load()
+    S1 = _rows_f64(S1, "samples", d)
+    S2 = None if S2 is None else _rows_f64(S2, "samples2", d)
+    w = _f64(w, "weight")
+    fs = _f64(fs, "fs")
+    if w.shape != (S1.shape[0],) or fs.shape != w.shape:
+        raise ValueError("weight and fs must have one entry per s1 row")
+    out = np.zeros(int(kmax))
+    jac = ctypes.c_double(0.0)
+    ev = np.zeros(int(d))
+    check(lib.mce_evidence_feed_f64(S1.ctypes.data, S1.shape[0], S1.strides[0] // 8,
+                                    S2.ctypes.data if S2 is not None else None, 0 if S2 is None else S2.shape[0],
+                                    0 if S2 is None else S2.strides[0] // 8, int(d), int(cov_mode), int(kmax),
+                                    w.ctypes.data, fs.ctypes.data, out.ctypes.data, ctypes.byref(jac), ev.ctypes.data, int(device)))
+    return out, float(jac.value), ev
 
 
 # ---------------------------------------------------------------------------

@@ -22,6 +22,7 @@
 #include "pack_refs.hpp"
 #include "f16_prep.hpp"
 #include "knn_generic.hpp"
+#include "feeders.hpp"
 #include "reduce_kernels.hpp"
 
 namespace {
@@ -564,6 +565,69 @@ int mce_dotp_f64(const double* dist, int64_t nq, int32_t ld, int32_t k0, int32_t
 
 namespace {
 
+// cyclic Jacobi eigen-solver for a symmetric d x d matrix (row-major A, destroyed); eigenvalues in
+// lam[d], eigenvectors in the COLUMNS of V (row-major [d][d]).  d <= 1024; converges to ~1e-15.
+void jacobi_eig(std::vector<double>& A, int d, std::vector<double>& lam, std::vector<double>& V)
+{
+    V.assign((size_t)d * d, 0.0);
+    for (int i = 0; i < d; ++i) V[(size_t)i * d + i] = 1.0;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < d; ++i) {
+            diag += A[(size_t)i * d + i] * A[(size_t)i * d + i];
+            for (int j = i + 1; j < d; ++j) off += A[(size_t)i * d + j] * A[(size_t)i * d + j];
+        }
+        if (off <= 1e-32 * diag || off == 0.0) break;
+        for (int p = 0; p < d - 1; ++p)
+            for (int q = p + 1; q < d; ++q) {
+                const double apq = A[(size_t)p * d + q];
+                if (apq == 0.0) continue;
+                const double app = A[(size_t)p * d + p], aqq = A[(size_t)q * d + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < d; ++k) {          // A <- A J   (columns p, q)
+                    const double akp = A[(size_t)k * d + p], akq = A[(size_t)k * d + q];
+                    A[(size_t)k * d + p] = c * akp - s * akq;
+                    A[(size_t)k * d + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < d; ++k) {          // A <- J^T A (rows p, q)
+                    const double apk = A[(size_t)p * d + k], aqk = A[(size_t)q * d + k];
+                    A[(size_t)p * d + k] = c * apk - s * aqk;
+                    A[(size_t)q * d + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < d; ++k) {          // V <- V J
+                    const double vkp = V[(size_t)k * d + p], vkq = V[(size_t)k * d + q];
+                    V[(size_t)k * d + p] = c * vkp - s * vkq;
+                    V[(size_t)k * d + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    lam.resize(d);
+    for (int i = 0; i < d; ++i) lam[i] = A[(size_t)i * d + i];
+}
+
+// covariance (two-pass, unweighted, n-1) of the device matrix S[n, d] -> host cov[d*d]
+int device_covariance(const double* dS, int64_t n, int d, double* scratch_partial, double* d_mean3, double* d_cov,
+                      std::vector<double>& cov, hipStream_t st)
+{
+    hipLaunchKernelGGL(mce::col_stats_partial_kernel, dim3(mce::kMeanBlocks), dim3(mce::kMeanThreads), 0, st, dS, n, d, scratch_partial);
+    MCE_HIP(hipGetLastError());
+    hipLaunchKernelGGL(mce::col_stats_final_kernel, dim3(1), dim3(64), 0, st, scratch_partial, n, d, d_mean3, (double*)nullptr);
+    MCE_HIP(hipGetLastError());
+    const int npair = d * (d + 1) / 2;
+    hipLaunchKernelGGL(mce::cov_partial_kernel, dim3(mce::kCovBlocks), dim3(mce::kCovThreads), (size_t)mce::kCovTileRows * d * sizeof(double), st,
+                       dS, n, d, d_mean3, scratch_partial);
+    MCE_HIP(hipGetLastError());
+    hipLaunchKernelGGL(mce::cov_final_kernel, dim3(1), dim3(mce::kCovThreads), 0, st, scratch_partial, n, d, d_cov);
+    MCE_HIP(hipGetLastError());
+    cov.resize((size_t)d * d);
+    MCE_HIP(hipMemcpyAsync(cov.data(), d_cov, (size_t)d * d * sizeof(double), hipMemcpyDeviceToHost, st));
+    MCE_HIP(hipStreamSynchronize(st));
+    (void)npair;
+    return MCE_OK;
+}
+
 // one device's share of the fused path: queries [q_lo, q_hi)
 int fused_on_device(int device, const double* X, int64_t q_lo, int64_t q_hi, const double* Y, int64_t nr, int32_t d,
                     int32_t kmax, int32_t k0, int64_t self_offset, const double* w, const double* fs,
@@ -602,6 +666,107 @@ int fused_on_device(int device, const double* X, int64_t q_lo, int64_t q_hi, con
 }  // namespace
 
 extern "C" {
+
+int mce_evidence_feed_f64(const double* S1, int64_t n1, int64_t ld1, const double* S2, int64_t n2, int64_t ld2,
+                          int32_t d, int32_t cov_mode, int32_t kmax, const double* w, const double* fs,
+                          double* dotp, double* jacobian, double* eigenvalues, int32_t device)
+{
+    if (!S1 || !w || !fs || !dotp || !jacobian) return fail(MCE_ERR_INVALID, "null pointer argument");
+    if (n1 < 2 || d < 1 || ld1 < d || (S2 && (n2 < 1 || ld2 < d)) || (cov_mode != 0 && cov_mode != 1))
+        return fail(MCE_ERR_INVALID, "invalid sizes n1=%lld ld1=%lld n2=%lld ld2=%lld d=%d cov_mode=%d", (long long)n1, (long long)ld1,
+                    (long long)n2, (long long)ld2, d, cov_mode);
+    if (d > 63) return fail(MCE_ERR_DIM_RANGE, "device feeders support d <= 63 (got %d)", d);
+    const int k0 = S2 ? 0 : 1;
+    const int K = kmax - k0;
+    if (kmax <= k0) return fail(MCE_ERR_INVALID, "kmax=%d must exceed k0=%d", kmax, k0);
+    const int64_t nr = S2 ? n2 : n1;
+    Plan p;
+    int rc = make_plan(n1, nr, d, K, k0 == 1 ? MCE_SELF_EXCLUDE : MCE_SELF_NONE, p);
+    if (rc != MCE_OK) return rc;
+    rc = select_device(device);
+    if (rc != MCE_OK) return rc;
+    // ---- one upload: [S1 rows ; S2 rows] contiguous [n1+n2, d] (strided host -> packed device) ----
+    const int64_t ntot = n1 + (S2 ? n2 : 0);
+    const size_t wsb = p.total + dotp_ws_bytes(n1, kmax);
+    const int npair = d * (d + 1) / 2;
+    DevBuf dS, dW, dF, dO, ws, dSmall, dPart;
+    MCE_HIP(dS.alloc((size_t)ntot * d * sizeof(double)));
+    MCE_HIP(dW.alloc((size_t)n1 * sizeof(double)));
+    MCE_HIP(dF.alloc((size_t)n1 * sizeof(double)));
+    MCE_HIP(dO.alloc((size_t)kmax * sizeof(double)));
+    MCE_HIP(ws.alloc(wsb));
+    MCE_HIP(dSmall.alloc((size_t)(3 * 64 + 2 * d * d + 2 * d) * sizeof(double)));       // mean3 | cov | evec | scale
+    MCE_HIP(dPart.alloc((size_t)std::max<int64_t>((int64_t)mce::kCovBlocks * npair, (int64_t)mce::kMeanBlocks * mce::kStatStride) * sizeof(double)));
+    double* d1 = dS.as<double>();
+    double* d2 = d1 + (size_t)n1 * d;
+    MCE_HIP(hipMemcpy2D(d1, (size_t)d * sizeof(double), S1, (size_t)ld1 * sizeof(double), (size_t)d * sizeof(double), (size_t)n1, hipMemcpyHostToDevice));
+    if (S2) MCE_HIP(hipMemcpy2D(d2, (size_t)d * sizeof(double), S2, (size_t)ld2 * sizeof(double), (size_t)d * sizeof(double), (size_t)n2, hipMemcpyHostToDevice));
+    MCE_HIP(hipMemcpy(dW.p, w, (size_t)n1 * sizeof(double), hipMemcpyHostToDevice));
+    MCE_HIP(hipMemcpy(dF.p, fs, (size_t)n1 * sizeof(double), hipMemcpyHostToDevice));
+    double* d_mean3 = dSmall.as<double>();
+    double* d_cov = d_mean3 + 3 * 64;
+    double* d_evec = d_cov + (size_t)d * d;
+    double* d_scale = d_evec + (size_t)d * d;
+    hipStream_t st = nullptr;
+
+    auto eig_of = [&](const double* rows, int64_t n, std::vector<double>& lam, std::vector<double>& V) -> int {
+        std::vector<double> cov;
+        int r = device_covariance(rows, n, d, dPart.as<double>(), d_mean3, d_cov, cov, st);
+        if (r != MCE_OK) return r;
+        jacobi_eig(cov, d, lam, V);
+        for (int i = 0; i < d; ++i)
+            if (!(lam[i] > 0.0)) return fail(MCE_ERR_INVALID, "math domain error: covariance eigenvalue %d is %g (use fewer parameters, ndim)", i, lam[i]);
+        return MCE_OK;
+    };
+    auto whiten = [&](double* rows, int64_t n, const std::vector<double>& lam, const std::vector<double>& V) -> int {
+        std::vector<double> sc(d);
+        for (int i = 0; i < d; ++i) sc[i] = 1.0 / std::sqrt(lam[i]);
+        MCE_HIP(hipMemcpy(d_evec, V.data(), (size_t)d * d * sizeof(double), hipMemcpyHostToDevice));
+        MCE_HIP(hipMemcpy(d_scale, sc.data(), (size_t)d * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(mce::whiten_kernel, dim3((unsigned)((n + mce::kWhitenRows - 1) / mce::kWhitenRows)), dim3(mce::kWhitenRows),
+                           mce::whiten_lds_bytes(d), st, rows, n, d, d_evec, d_scale, rows);
+        MCE_HIP(hipGetLastError());
+        return MCE_OK;
+    };
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            MCE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mce::whiten_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mce::whiten_lds_bytes(63)));
+            attr_set = true;
+        }
+    }
+    std::vector<double> lam1, V1, lam2, V2;
+    if (cov_mode == 0) {                        // "all": one eigen-system from s1 U s2
+        rc = eig_of(d1, ntot, lam1, V1);
+        if (rc != MCE_OK) return rc;
+        rc = whiten(d1, ntot, lam1, V1);
+        if (rc != MCE_OK) return rc;
+    } else {                                    // "single": s1's own; s2 whitened with ITS own, J stays s1's
+        rc = eig_of(d1, n1, lam1, V1);
+        if (rc != MCE_OK) return rc;
+        if (S2) {
+            rc = eig_of(d2, n2, lam2, V2);
+            if (rc != MCE_OK) return rc;
+        }
+        rc = whiten(d1, n1, lam1, V1);
+        if (rc != MCE_OK) return rc;
+        if (S2) {
+            rc = whiten(d2, n2, lam2, V2);
+            if (rc != MCE_OK) return rc;
+        }
+    }
+    double logdet = 0.0;
+    for (int i = 0; i < d; ++i) logdet += std::log(lam1[i]);
+    *jacobian = std::exp(0.5 * logdet);
+    if (eigenvalues)
+        for (int i = 0; i < d; ++i) eigenvalues[i] = lam1[i];
+    rc = mce_knn_dotp_f64_dev(d1, n1, S2 ? d2 : d1, nr, d, kmax, k0, 0, dW.as<double>(), dF.as<double>(), dO.as<double>(), nullptr,
+                              ws.p, wsb, st);
+    if (rc != MCE_OK) return rc;
+    MCE_HIP(hipDeviceSynchronize());
+    MCE_HIP(hipMemcpy(dotp, dO.p, (size_t)kmax * sizeof(double), hipMemcpyDeviceToHost));
+    return MCE_OK;
+}
 
 int mce_knn_dotp_f64(const double* X, int64_t nq, const double* Y, int64_t nr, int32_t d, int32_t kmax,
                      int32_t k0, int64_t self_offset, const double* w, const double* fs, double* dotp,

@@ -43,6 +43,16 @@ class HipBackend(object):
     def __init__(self, devices=None):
         self.devices = devices
 
+    def evidence_feed(self, S1, S2, ndim, cov_mode, kmax, weight, fs):
+        """feeders on the device too (get_covariance + diagonalise_chain + the hot path, one upload);
+        returns (dotp, J) or None when this route does not apply (multi-process / multi-device runs)."""
+        from . import parallel
+        if parallel.is_distributed() or self.devices not in (None, [0], (0,)) or ndim > 63:
+            return None
+        from . import _capi
+        dotp, jac, _ = _capi.evidence_feed(S1, S2, ndim, cov_mode, kmax, weight, fs)
+        return dotp, jac
+
     def knn_dotp(self, X, Y, weight, fs, kmax, k0, want_dist=False):
         from . import parallel
         if parallel.is_distributed():
@@ -210,6 +220,29 @@ class MCEvidence(object):
                 s = self.diagonalise_chain(s, cs["eVec"], cs["eVal"])
         return s, lnp, w, stat
 
+    def _evidence_device_feeders(self, covtype, pos_lnp, logPriorVolume):
+        """evidence() with get_covariance/diagonalise_chain done by the library too.  Same quantities as
+        the host route below (reference :1034-1131); returns MLE[kmax] or None if the backend declines."""
+        kmax, ndim = self.kmax, self.ndim
+        s1, lnp, weight = self.gd.arrays("s1")
+        S = s1.shape[0]
+        s2 = self.gd.arrays("s2")[0] if self.split else None
+        logL = -lnp if pos_lnp else lnp
+        logLmax = np.amax(logL)
+        fs = logL - logLmax
+        got = self.backend.evidence_feed(s1, s2, ndim, 0 if covtype == "all" else 1, kmax,
+                                         np.asarray(weight, dtype=np.float64), np.asarray(fs, dtype=np.float64))
+        if got is None:
+            return None
+        dotp, Jacobian = got
+        k0 = 0 if self.split else 1
+        SumW = np.sum(self.gd.data["s1"].adjusted_weights)
+        mle = np.zeros(kmax)
+        for k in range(k0, kmax):
+            k_nn = k if k0 == 1 else k + 1
+            mle[k] = math.log(SumW * (dotp[k] / (S * k_nn + 1.0)) * Jacobian) + logLmax - logPriorVolume
+        return mle
+
     # ------------------------------------------------------------------ the estimator
     def evidence(self, verbose=None, rand=False, info=False, covtype="all",
                  profile=False, pvolume=None, pos_lnp=False,
@@ -225,6 +258,18 @@ class MCEvidence(object):
         MLE = np.zeros((self.nbatch, kmax))
         if covtype is None:
             covtype = self.covtype
+        # ---- device-feeder route: covariance, whitening AND the hot path in one library call ----
+        # (single batch, no per-neighbour debug output, a backend that offers it)
+        if self.brange is None and verbose <= 1 and covtype in ("all", "single") and hasattr(self.backend, "evidence_feed"):
+            out = self._evidence_device_feeders(covtype, pos_lnp, logPriorVolume)
+            if out is not None:
+                MLE[0, :] = out
+                MLE = MLE[0, 1:]
+                if verbose > 0:
+                    for k in range(1, self.kmax):
+                        self.logger.info("   ln(B)[k={}] = {}".format(k, MLE[k - 1]))
+                return (MLE, self.info) if info else MLE
+
         if covtype == "all":
             covstat = self.get_covariance()
             Jacobian = covstat["J"]

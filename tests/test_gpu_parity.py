@@ -260,6 +260,34 @@ def test_class_on_gpu_reproduces_reference(name, capi):
     assert np.max(np.abs(lnE - np.array(case["lnE"]))) < LNE_TOL, (lnE, case["lnE"])
 
 
+@pytest.mark.parametrize("name", [n for n in sorted(G) if G[n]["tag"] != "big"])
+def test_device_feeder_route_matches_reference_and_host_route(name):
+    """covariance + whitening on the device (mce_evidence_feed_f64) vs the reference's outputs, and vs
+    the host-feeder route of the same class."""
+    import mcevidence_amd as pkg
+    case = G[name]
+    calls = {}
+
+    class Spy(pkg.HipBackend):
+        def evidence_feed(self, *a, **k):
+            calls["feed"] = calls.get("feed", 0) + 1
+            return super().evidence_feed(*a, **k)
+
+    def run(backend):
+        if case["seed_split"] is not None:
+            np.random.seed(case["seed_split"])
+        return pkg.MCEvidence([chain_of(case)], verbose=0, backend=backend, **case["mce"]).evidence(**case["ev"])
+
+    dev = run(Spy())
+    host = run(type("H", (), {"name": "hip", "knn_dotp": pkg.HipBackend().knn_dotp})())
+    cov = case["ev"].get("covtype", "all")
+    if cov is None:
+        cov = case["mce"].get("covtype", "single")
+    assert calls.get("feed", 0) == (1 if cov in ("all", "single") else 0)
+    assert np.max(np.abs(dev - np.array(case["lnE"]))) < LNE_TOL
+    assert np.max(np.abs(dev - host)) < 1e-10
+
+
 def test_sampled_rows_at_full_size_C3(capi):
     """N = 1M, D = 27 (BASELINE configs[2]): 1500 sampled query rows against the exact CPU search,
     plus size-independent properties over all rows."""
