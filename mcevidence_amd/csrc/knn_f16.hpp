@@ -59,15 +59,15 @@ constexpr int kHQT = MCE_H_GEOM == 1 ? 4 : 2;      // 32-query tiles per wave
 constexpr int kHNL = kHQT / 2;                     // top-K lists per owner lane (64 queries per list set)
 constexpr int kHThreads = kHWaves * 64;
 #ifndef MCE_H_QUEUE
-#define MCE_H_QUEUE 640
+#define MCE_H_QUEUE 448
 #endif
 #ifndef MCE_H_TRIGGER
 #define MCE_H_TRIGGER 96
 #endif
 #ifndef MCE_H_STAGE_KB
-#define MCE_H_STAGE_KB 32
+#define MCE_H_STAGE_KB 48
 #endif
-constexpr int kHQueue = MCE_H_QUEUE;          // candidate queue entries (4 B) per wave: 512 (half a tile) + 128
+constexpr int kHQueue = MCE_H_QUEUE;          // candidate queue entries per wave (16 B each in LDS)
 constexpr int kHDrainTrigger = MCE_H_TRIGGER;    // a wave with this many queued candidates asks the workgroup to drain
 constexpr int kHRelBits = MCE_H_GEOM == 1 ? 25 : 26;   // queue entry = query-local (6|7 bits) << kHRelBits | row - first row of the split
 constexpr double kHTargetRadius = 200.0;
@@ -79,9 +79,9 @@ __host__ __device__ constexpr int f16_ksteps(int D) { return (D + 3 + 15) / 16; 
 __host__ __device__ constexpr int f16_qt(int) { return kHQT; }
 __host__ __device__ constexpr bool f16_supported(int D, int K) { return D >= 2 && f16_ksteps(D) <= 4 && K <= 16; }
 __host__ __device__ constexpr int f16_qpb(int KCAP) { return kHWaves * f16_qt(KCAP) * 32; }
-// 32-row reference tiles per LDS chunk (tile = KST KB): <= 32 KB per buffer, even count,
+// 32-row reference tiles per LDS chunk (tile = KST KB): MCE_H_STAGE_KB per buffer, even count,
 // and a whole number of 16-byte vectors per thread (CT*KST % 8 == 0)
-__host__ __device__ constexpr int f16_chunk_tiles(int KST) { return (MCE_H_STAGE_KB / 32) * (KST == 1 ? 32 : (KST == 2 ? 16 : 8)) + ((MCE_H_STAGE_KB % 32) ? (KST == 2 ? 8 : 0) : 0); }
+__host__ __device__ constexpr int f16_chunk_tiles(int KST) { return MCE_H_STAGE_KB / KST; }   // 48 KB: 48, 24, 16, 12 tiles
 __host__ __device__ constexpr size_t f16_lds_bytes(int KST, int KCAP)
 {
     return (size_t)2 * f16_chunk_tiles(KST) * KST * 1024             // staging
