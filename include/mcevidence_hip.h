@@ -129,6 +129,10 @@ int mce_knn_dotp_f64_dev(const double *dX, int64_t nq, const double *dY, int64_t
  * geometry (for bench.py / profiles): "knn_mfma_f64<KS=7,KCAP=12>" etc. */
 const char *mce_last_kernel(void);
 
+/* The host-pointer entry points keep their small device buffers (<= 64 MB each) in a per-thread
+ * pool between calls; this frees them. */
+void mce_release_device_memory(void);
+
 /* Search algorithm.  0 (default) / 2: fp16-MFMA filter with exact fp64 refinement where the
  * shape allows it (2 <= d <= 61, K <= 16), otherwise the fp64 MFMA sweep; 1: always the
  * fp64 MFMA sweep.  Both return the exact fp64 neighbours and distances.  Process-wide. */

@@ -39,6 +39,7 @@ SIGNATURES = {
     "mce_device_count": (_c.c_int, []),
     "mce_last_error": (_c.c_char_p, []),
     "mce_last_kernel": (_c.c_char_p, []),
+    "mce_release_device_memory": (None, []),
     "mce_set_search_mode": (_c.c_int, [_c.c_int]),
     "mce_get_search_mode": (_c.c_int, []),
     "mce_set_profiling": (None, [_c.c_int]),
@@ -104,6 +105,10 @@ def set_search_mode(mode):
 
 def get_search_mode():
     return int(load().mce_get_search_mode())
+
+
+def release_device_memory():
+    load().mce_release_device_memory()
 
 
 def set_profiling(on):

@@ -54,6 +54,59 @@ int fail(int code, const char* fmt, ...)
 //              1 fp64 MFMA sweep only, 2 same as 0 (explicit)
 std::atomic<int> g_mode{0};
 
+// Device buffers of the host-pointer entry points.  Small allocations (<= 64 MB) are kept in a
+// per-thread, per-device pool between calls: the reference's typical workload is thousands of
+// Planck-sized chains (planck_mcevidence.py:306-348), where seven hipMalloc/hipFree pairs per call
+// would cost more than the kernels.  Larger buffers are allocated and freed per call.
+// mce_release_device_memory() empties the pool.
+constexpr size_t kPoolMaxBytes = (size_t)64 << 20;
+constexpr int kPoolSlots = 16;
+struct PoolSlot { void* p = nullptr; size_t cap = 0; int dev = -1; bool busy = false; };
+thread_local PoolSlot g_pool[kPoolSlots];
+
+struct DevBuf {
+    void* p = nullptr;
+    int slot = -1;
+    ~DevBuf()
+    {
+        if (slot >= 0) g_pool[slot].busy = false;
+        else if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n)
+    {
+        if (n == 0) n = 1;
+        if (n <= kPoolMaxBytes) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            int pick = -1;
+            for (int i = 0; i < kPoolSlots; ++i)          // best fit among idle slots of this device
+                if (!g_pool[i].busy && g_pool[i].p && g_pool[i].dev == dev && g_pool[i].cap >= n &&
+                    (pick < 0 || g_pool[i].cap < g_pool[pick].cap)) pick = i;
+            if (pick < 0)
+                for (int i = 0; i < kPoolSlots; ++i)
+                    if (!g_pool[i].busy) {                 // (re)allocate an idle slot
+                        if (g_pool[i].p) { (void)hipFree(g_pool[i].p); g_pool[i].p = nullptr; g_pool[i].cap = 0; }
+                        const size_t cap = n + n / 4;
+                        hipError_t e = hipMalloc(&g_pool[i].p, cap);
+                        if (e != hipSuccess) { g_pool[i].p = nullptr; return e; }
+                        g_pool[i].cap = cap;
+                        g_pool[i].dev = dev;
+                        pick = i;
+                        break;
+                    }
+            if (pick >= 0) {
+                g_pool[pick].busy = true;
+                slot = pick;
+                p = g_pool[pick].p;
+                return hipSuccess;
+            }
+        }
+        return hipMalloc(&p, n);
+    }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+
 constexpr int kAssumedCUs = 256;   // MI355X; only steers the reference-split heuristic
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -348,6 +401,19 @@ const char* mce_last_error(void) { return g_err; }
 
 const char* mce_last_kernel(void) { return g_last_kernel; }
 
+void mce_release_device_memory(void)
+{
+    for (int i = 0; i < kPoolSlots; ++i)
+        if (g_pool[i].p && !g_pool[i].busy) {
+            int cur = 0;
+            (void)hipGetDevice(&cur);
+            if (g_pool[i].dev != cur) (void)hipSetDevice(g_pool[i].dev);
+            (void)hipFree(g_pool[i].p);
+            if (g_pool[i].dev != cur) (void)hipSetDevice(cur);
+            g_pool[i] = PoolSlot();
+        }
+}
+
 int mce_set_search_mode(int mode)
 {
     if (mode < 0 || mode > 2) return fail(MCE_ERR_INVALID, "search mode must be 0 (auto), 1 (fp64 sweep) or 2 (fp16 filter + fp64 refine)");
@@ -488,13 +554,6 @@ int mce_knn_dotp_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t
 // host-pointer wrappers
 // ---------------------------------------------------------------------------
 namespace {
-
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
-    template <class T> T* as() { return static_cast<T*>(p); }
-};
 
 int select_device(int device)
 {
