@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--d", type=int, default=27)
     ap.add_argument("--kmax", type=int, default=10)
-    ap.add_argument("--cpu-sample", type=int, default=4000, help="queries timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--mode", type=int, default=0, help="0 auto (fp16 filter + fp64 refine), 1 fp64 MFMA sweep")
     a = ap.parse_args()
 
@@ -165,6 +165,8 @@ def main():
         roof = dict(bound="mfma", achieved=round(achieved, 3), peak=peak, unit="TFLOP/s",
                     frac=round(achieved / peak, 4), traffic=(traffic or {}).get("bytes"), traffic_source=(traffic or {}).get("source"),
                     traffic_note=(traffic or {}).get("note"),
+                    hbm_gbps=(round(traffic["bytes"] / (kern_ms * 1e-3) / 1e9, 1) if traffic else None),
+                    hbm_frac_of_8TBps=(round(traffic["bytes"] / (kern_ms * 1e-3) / 8e12, 4) if traffic else None),
                     kernel_ms=round(kern_ms, 3), kernel=kdesc, algorithmic_flops_per_launch=flops, note=note,
                     fp64_equivalent_tflops=round(float(nq) * n * 2.0 * 4 * ((d + 4) // 4) / (kern_ms * 1e-3) / 1e12, 2))
         cpu = None

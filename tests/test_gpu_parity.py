@@ -173,6 +173,20 @@ def test_generic_kernel_beyond_mfma_limits(capi, d, K):
     assert np.allclose(capi.knn_dotp(Y, None, w, fs, kmax, 1), dp, rtol=1e-13)
 
 
+def test_empty_and_minimal_inputs(capi):
+    Y = np.random.default_rng(0).standard_normal((40, 3))
+    d, i = capi.knn(np.zeros((0, 3)), Y, 4)                    # no queries: empty result, no error
+    assert d.shape == (0, 4) and i.shape == (0, 4)
+    d, i = capi.knn(Y[:1], Y, 40)                              # K == number of reference rows
+    od, oi = orc.knn_brute(Y[:1], Y, 40)
+    assert np.allclose(d, od, rtol=1e-13) and np.array_equal(i, oi)
+    d, i = capi.knn(Y, Y[:2], 1)                               # two reference rows
+    od, oi = orc.knn_brute(Y, Y[:2], 1)
+    assert np.allclose(d, od, rtol=1e-13) and np.array_equal(i, oi)
+    with pytest.raises(ValueError):
+        capi.knn_dotp(np.zeros((0, 3)), Y, np.zeros(0), np.zeros(0), 3, 0)     # an empty chain is an error (as in the reference)
+
+
 def test_error_codes_on_gpu(capi):
     X = np.zeros((5, 3))
     with pytest.raises(ValueError):
