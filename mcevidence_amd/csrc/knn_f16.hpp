@@ -58,6 +58,9 @@ constexpr int kHWaves = MCE_H_GEOM == 1 ? 4 : (MCE_H_GEOM == 2 ? 16 : 8);   // G
 constexpr int kHQT = MCE_H_GEOM == 1 ? 4 : 2;      // 32-query tiles per wave
 constexpr int kHNL = kHQT / 2;                     // top-K lists per owner lane (64 queries per list set)
 constexpr int kHThreads = kHWaves * 64;
+#ifndef MCE_H_SETPRIO
+#define MCE_H_SETPRIO 0
+#endif
 #ifndef MCE_H_QUEUE
 #define MCE_H_QUEUE 448
 #endif
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ?
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks)
             b[qt][ks] = *reinterpret_cast<const v8h*>(Xh + q * (int64_t)(16 * KST) + 16 * ks + 8 * (lane >> 5));
-        G[qt] = (q < nq && MCE_ABLATE != 1) ? __builtin_huge_valf() : -__builtin_huge_valf();     // padding queries never pass
+        G[qt] = (q < nq && MCE_ABLATE != 1 && MCE_ABLATE != 3) ? __builtin_huge_valf() : -__builtin_huge_valf();     // padding queries never pass
     }
     const int k_last = ksel - 1;
     // gate of query (qt, lane&31) from its current K-th best `thr` (exact squared distance, input
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ?
     // and keeping them in registers would cost 6 VGPRs per query tile in the sweep.
     auto gate_of = [&](double thr, int qt) -> float {
         const int64_t q = qwave0 + qt * 32 + (lane & 31);
-        if (!(q < nq) || MCE_ABLATE == 1) return -__builtin_huge_valf();
+        if (!(q < nq) || MCE_ABLATE == 1 || MCE_ABLATE == 3) return -__builtin_huge_valf();
         if (!(thr < INF)) return __builtin_huge_valf();
         const double ex = qinfo[2 * q], xn = qinfo[2 * q + 1];
         const double r = sqrt(xn) + params[HP_YHATMAX];
@@ -206,6 +209,9 @@ __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ?
     };
     // one 32-row tile: QT chains of KST MFMAs
     auto mfma_tile = [&](const v8h (&a)[KST], v16f (&acc)[QT]) {
+#if MCE_H_SETPRIO
+        __builtin_amdgcn_s_setprio(1);      // the wave in its MFMA burst wins issue arbitration; its SIMD partner gates meanwhile
+#endif
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             v16f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -215,6 +221,9 @@ __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ?
         for (int ks = 1; ks < KST; ++ks)
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], b[qt][ks], acc[qt], 0, 0, 0);
+#if MCE_H_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     int qcount = 0;   // wave-uniform number of queued candidates
@@ -397,7 +406,11 @@ __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ?
 #if MCE_STATS
         const long long t_b0 = clock64();
 #endif
+#if MCE_ABLATE != 3
         __syncthreads();
+#else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ablation: no barrier (results invalid)
+#endif
 #if MCE_STATS
         st_tB += clock64() - t_b0;
 #endif
