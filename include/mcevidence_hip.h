@@ -134,7 +134,7 @@ const char *mce_last_kernel(void);
 void mce_release_device_memory(void);
 
 /* Search algorithm.  0 (default) / 2: fp16-MFMA filter with exact fp64 refinement where the
- * shape allows it (2 <= d <= 61, K <= 16), otherwise the fp64 MFMA sweep; 1: always the
+ * shape allows it (d <= 61, K <= 16), otherwise the fp64 MFMA sweep; 1: always the
  * fp64 MFMA sweep.  Both return the exact fp64 neighbours and distances.  Process-wide. */
 int mce_set_search_mode(int mode);
 int mce_get_search_mode(void);

@@ -80,7 +80,7 @@ enum { HP_RMAX = 0, HP_SCALE = 1, HP_EY = 2, HP_YHATMAX = 3, HP_RHO = 4, HP_COUN
 
 __host__ __device__ constexpr int f16_ksteps(int D) { return (D + 3 + 15) / 16; }          // 16-wide k-steps
 __host__ __device__ constexpr int f16_qt(int) { return kHQT; }
-__host__ __device__ constexpr bool f16_supported(int D, int K) { return D >= 2 && f16_ksteps(D) <= 4 && K <= 16; }
+__host__ __device__ constexpr bool f16_supported(int D, int K) { return D >= 1 && f16_ksteps(D) <= 4 && K <= 16; }
 __host__ __device__ constexpr int f16_qpb(int KCAP) { return kHWaves * f16_qt(KCAP) * 32; }
 // 32-row reference tiles per LDS chunk (tile = KST KB): MCE_H_STAGE_KB per buffer, even count,
 // and a whole number of 16-byte vectors per thread (CT*KST % 8 == 0)

@@ -122,12 +122,15 @@ ADVERSARIAL = {
 
 
 @pytest.mark.parametrize("kind", sorted(ADVERSARIAL))
-@pytest.mark.parametrize("d", [2, 5, 14])
+@pytest.mark.parametrize("d", [1, 2, 5, 14])
 def test_knn_adversarial_inputs_stay_exact(capi, kind, d):
     """the filter must never drop a true neighbour, whatever the data look like: the result is
     compared with the exact CPU search (distances AND neighbour sets)."""
-    rng = np.random.default_rng(hash((kind, d)) % (2 ** 31))
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(("%s-%d" % (kind, d)).encode()))
     n, K = 4000, 6
+    if d == 1 and kind in ("anisotropic", "subnormal_fp16_coords", "constant_column"):
+        pytest.skip("needs at least two columns")
     Y = np.ascontiguousarray(ADVERSARIAL[kind](rng, n, d), dtype=np.float64)
     dist, idx = capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE)
     od, oi = orc.knn_brute(Y, Y, K, self_mode=2)
@@ -136,7 +139,7 @@ def test_knn_adversarial_inputs_stay_exact(capi, kind, d):
     assert np.allclose(dist, exact, rtol=1e-13, atol=0)
     if kind in ("all_identical", "few_distinct"):
         assert np.array_equal(dist, od)              # massive exact ties: distances must still be exact
-    elif capi.get_search_mode() == capi.MODE_F64 and kind in ("tight_clusters", "lattice_ties", "huge_scale_offset"):
+    elif capi.get_search_mode() == capi.MODE_F64 and (d == 1 or kind in ("tight_clusters", "lattice_ties", "huge_scale_offset")):
         # documented limit of the fp64 GEMM-form sweep: it SELECTS with ~1e-16*R^2
         # absolute accuracy (R = extent about the mean), so neighbours closer together than that, or
         # exactly tied, may be swapped for an equally-near row; the default fp16-filter path is exact.
