@@ -234,15 +234,22 @@ __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ?
         st_drains += 1; st_enq += qcount;
 #endif
         // ---- phase A: exact distances + chain links.  8 lanes share one queued pair and read
-        // the two rows in 64-byte segments (a row is fetched once, not once per element: the
-        // gather is bandwidth-bound); 4 passes (32 pairs) are kept in flight per trip.
+        // the two rows in 64-byte segments (a row is fetched once, not once per element).  The
+        // gather is latency-bound, so ALL loads of a group of NPASS*8 pairs are issued before the
+        // first use (the compiler otherwise serialises the passes: one round trip each).
         const int sub = lane & 7;
-        for (int b0 = 0; b0 < qcount; b0 += 32) {
-            double accp[4];
-            int qlp[4], ep[4];
-            bool okp[4];
+#ifndef MCE_H_NPASS
+#define MCE_H_NPASS 3
+#endif
+        constexpr int NPASS = MCE_H_NPASS;                         // 8*NPASS pairs, 8*NPASS loads per lane in flight (D <= 32)
+        constexpr int EPL = (16 * KST + 3) / 8 > 4 ? 8 : 4;        // elements per lane: 4 covers D <= 32, 8 covers D <= 61
+        for (int b0 = 0; b0 < qcount; b0 += NPASS * 8) {
+            int qlp[NPASS], ep[NPASS];
+            bool okp[NPASS];
+            const double* xp[NPASS];
+            const double* yp[NPASS];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NPASS; ++u) {
                 const int e = b0 + u * 8 + (lane >> 3);
                 ep[u] = e;
                 int ql = 0, j = 0;
@@ -255,28 +262,26 @@ __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ?
                 qlp[u] = ql;
                 const int64_t q = qwave0 + ql;
                 okp[u] = valid && j < nr && q < nq && !(self_exclude && (int64_t)j == self_offset + q);
-                const double* x = X + (okp[u] ? q : 0) * (int64_t)D;
-                const double* y = Y + (okp[u] ? (int64_t)j : 0) * D;
-                double a0 = 0.0;
-                for (int i = sub; i < D; i += 32) {            // up to 4 elements per lane per trip
-                    double xv[4], yv[4];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int iv = (i + 8 * v < D) ? i + 8 * v : sub;
-                        xv[v] = x[iv];
-                        yv[v] = y[iv];
-                    }
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const double t = (i + 8 * v < D) ? xv[v] - yv[v] : 0.0;
-                        a0 = fma(t, t, a0);
-                    }
-                }
-                accp[u] = a0;
+                xp[u] = X + (okp[u] ? q : 0) * (int64_t)D;
+                yp[u] = Y + (okp[u] ? (int64_t)j : 0) * D;
             }
+            double xv[NPASS][EPL], yv[NPASS][EPL];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                double a0 = accp[u];
+            for (int u = 0; u < NPASS; ++u)
+#pragma unroll
+                for (int v = 0; v < EPL; ++v) {
+                    const int iv = (sub + 8 * v < D) ? sub + 8 * v : sub;     // clamped load, masked use
+                    xv[u][v] = xp[u][iv];
+                    yv[u][v] = yp[u][iv];
+                }
+#pragma unroll
+            for (int u = 0; u < NPASS; ++u) {
+                double a0 = 0.0;
+#pragma unroll
+                for (int v = 0; v < EPL; ++v) {
+                    const double t = (sub + 8 * v < D) ? xv[u][v] - yv[u][v] : 0.0;
+                    a0 = fma(t, t, a0);
+                }
                 a0 += __shfl_xor(a0, 1, 64);
                 a0 += __shfl_xor(a0, 2, 64);
                 a0 += __shfl_xor(a0, 4, 64);
