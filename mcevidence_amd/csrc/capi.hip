@@ -319,12 +319,16 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
         }
         hipLaunchKernelGGL(mce::f16_scale_kernel, dim3(1), dim3(64), 0, st, box_y, separate_queries ? box_x : (const double*)nullptr, params);
         MCE_HIP(hipGetLastError());
-        hipLaunchKernelGGL(mce::f16_pack_refs_kernel, dim3((unsigned)((p.nrow_pad + 255) / 256)), dim3(256),
-                           (size_t)256 * (d | 1) * sizeof(double), st, dY, nr, (int)d, p.KST, p.nrow_pad, center, params, yh);
-        MCE_HIP(hipGetLastError());
-        hipLaunchKernelGGL(mce::f16_pack_queries_kernel, dim3((unsigned)((p.nq_pad + threads - 1) / threads)), dim3(threads), 0, st,
-                           dX, nq, p.nq_pad, (int)d, p.KST, center, params, xh, qinfo);
-        MCE_HIP(hipGetLastError());
+        {
+            const int64_t rows_per_block = 4 * (64 / (2 * p.KST));          // 4 waves x R rows
+            const int64_t pack_blocks = std::min<int64_t>((p.nrow_pad + rows_per_block - 1) / rows_per_block, 2048);   // grid-stride
+            hipLaunchKernelGGL(mce::f16_pack_refs_kernel, dim3((unsigned)pack_blocks), dim3(256), 0, st,
+                               dY, nr, (int)d, p.KST, p.nrow_pad, center, params, yh);
+            MCE_HIP(hipGetLastError());
+            hipLaunchKernelGGL(mce::f16_pack_queries_kernel, dim3((unsigned)((p.nq_pad + rows_per_block - 1) / rows_per_block)), dim3(256), 0, st,
+                               dX, nq, p.nq_pad, (int)d, p.KST, center, params, xh, qinfo);
+            MCE_HIP(hipGetLastError());
+        }
         mce::KnnF16Args a;
         a.Yh = yh; a.nchunk_total = p.nchunk; a.rsplit = p.rsplit; a.Xh = xh; a.qinfo = qinfo; a.params = params;
         a.X = dX; a.Y = dY; a.nq = nq; a.nr = nr; a.D = d; a.nq_pad = p.nq_pad; a.nqblk = p.nqblk;

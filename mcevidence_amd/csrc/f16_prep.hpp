@@ -53,75 +53,83 @@ __global__ __launch_bounds__(64) void f16_box_about_kernel(const double* __restr
 // ---------------------------------------------------------------------------
 // references -> fp16 A fragments.  Packed layout (halfs):
 //   Yh[((tile*KST + ks)*64 + lane)*8 + e],  lane = (row&31) + 32*h,  k = 16*ks + 8*h + e
+// One lane per (row, fragment f = 2*ks + h): it converts the row's elements 8f..8f+7 (a 64-byte
+// segment), the G = 2*KST lanes of a row combine their error / norm partial sums, and each lane
+// writes its own 16-byte fragment piece.  Lane = f*R + r with R = 64/G rows per wave, so the
+// stores of a wave are G contiguous runs (same fragment slot, consecutive rows).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void f16_pack_refs_kernel(const double* __restrict__ Y, int64_t nr, int D, int KST,
                                                             int64_t nrow_pad, const double* __restrict__ center,
                                                             double* __restrict__ params, _Float16* __restrict__ Yh)
 {
-    // 256 rows per workgroup: the rows are read as ONE contiguous run (coalesced) into LDS, centred and
-    // scaled on the way; then thread t works on row t from LDS (row stride D+1 doubles: conflict-free).
-    extern __shared__ double rows[];                     // 256 * (D+1)
-    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    const int G = 2 * KST, R = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int f = lane / R, r = lane - f * R;
+    const bool on = f < G;
     const double s = params[HP_SCALE];
-    const int ld = D | 1;                                // odd stride
-    {
-        const int64_t e0 = row0 * D;
-        const int64_t e1 = ((row0 + 256 < nr) ? row0 + 256 : nr) * (int64_t)D;
-        for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
-            const int r = (int)((e - e0) / D), c = (int)((e - e0) - (int64_t)r * D);
-            rows[r * ld + c] = (Y[e] - center[c]) * s;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t ngroups = (nrow_pad + R - 1) / R;
+    double ey = 0.0, yn = 0.0, rho = 0.0;                     // running maxima of this lane
+    // grid-stride over groups of R rows: the three global maxima cost one atomic per WAVE at the end
+    for (int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g < ngroups; g += nwaves) {
+        const int64_t row = g * R + r;
+        const bool inrange = on && row < nrow_pad;
+        const bool live = inrange && row < nr;
+        double th[8];
+        double err2 = 0.0, n2 = 0.0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * f + e;
+            double t = 0.0;
+            if (live && k < D) t = (Y[row * (int64_t)D + k] - center[k]) * s;
+            const double h = (double)(_Float16)t;
+            th[e] = h;
+            err2 = fma(t - h, t - h, err2);
+            n2 = fma(h, h, n2);
+        }
+        // combine over the row's G lanes (fixed order: bitwise reproducible)
+        double e_tot = 0.0, n_tot = 0.0;
+        for (int m = 0; m < G; ++m) {
+            e_tot += __shfl(err2, m * R + r, 64);
+            n_tot += __shfl(n2, m * R + r, 64);
+        }
+        const _Float16 n_hi = (_Float16)n_tot;
+        const _Float16 n_mid = (_Float16)(n_tot - (double)n_hi);
+        const _Float16 n_lo = (_Float16)(n_tot - (double)n_hi - (double)n_mid);
+        if (inrange) {
+            v8h v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 8 * f + e;
+                _Float16 x = (_Float16)0.0f;
+                if (live) {
+                    if (k < D) x = (_Float16)(-2.0 * th[e]);
+                    else if (k == D) x = n_hi;
+                    else if (k == D + 1) x = n_mid;
+                    else if (k == D + 2) x = n_lo;
+                } else if (k == D) {
+                    x = (_Float16)__builtin_huge_valf();      // padding rows: A = +inf, never below a finite gate
+                }
+                v[e] = x;
+            }
+            const int64_t tile = row >> 5;
+            const int i32 = (int)(row & 31);
+            const int ks = f >> 1, hh = f & 1;
+            *reinterpret_cast<v8h*>(Yh + (((tile * KST + ks) * 64 + i32 + 32 * hh) * 8)) = v;
+        }
+        if (live) {
+            ey = fmax(ey, sqrt(e_tot));
+            yn = fmax(yn, sqrt(n_tot));
+            rho = fmax(rho, fabs(n_tot - (double)n_hi - (double)n_mid - (double)n_lo));
         }
     }
-    __syncthreads();
-    const int64_t row = row0 + threadIdx.x;
-    double ey = 0.0, yn = 0.0, rho = 0.0;
-    if (row < nrow_pad) {
-        const bool live = row < nr;
-        const double* y = rows + threadIdx.x * ld;
-        double err2 = 0.0, n2 = 0.0;
-        if (live)
-            for (int i = 0; i < D; ++i) {
-                const double t = y[i];
-                const double th = (double)(_Float16)t;
-                err2 = fma(t - th, t - th, err2);
-                n2 = fma(th, th, n2);
-            }
-        const _Float16 n_hi = (_Float16)n2;
-        const _Float16 n_mid = (_Float16)(n2 - (double)n_hi);
-        const _Float16 n_lo = (_Float16)(n2 - (double)n_hi - (double)n_mid);
-        ey = sqrt(err2);
-        yn = sqrt(n2);
-        rho = fabs(n2 - (double)n_hi - (double)n_mid - (double)n_lo);
-        const int64_t tile = row >> 5;
-        const int i32 = (int)(row & 31);
-        for (int ks = 0; ks < KST; ++ks)
-            for (int h = 0; h < 2; ++h) {
-                v8h v;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int k = 16 * ks + 8 * h + e;
-                    _Float16 x = (_Float16)0.0f;
-                    if (live) {
-                        if (k < D) x = (_Float16)(-2.0 * (double)(_Float16)y[k]);
-                        else if (k == D) x = n_hi;
-                        else if (k == D + 1) x = n_mid;
-                        else if (k == D + 2) x = n_lo;
-                    } else if (k == D) {
-                        x = (_Float16)__builtin_huge_valf();      // padding rows: A = +inf, never below a finite gate
-                    }
-                    v[e] = x;
-                }
-                *reinterpret_cast<v8h*>(Yh + (((tile * KST + ks) * 64 + i32 + 32 * h) * 8)) = v;
-            }
-    }
-    // block maxima -> global maxima (max is order independent: deterministic)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         ey = fmax(ey, __shfl_xor(ey, o, 64));
         yn = fmax(yn, __shfl_xor(yn, o, 64));
         rho = fmax(rho, __shfl_xor(rho, o, 64));
     }
-    if ((threadIdx.x & 63) == 0) {
+    if (lane == 0) {
         atomic_max_pos(params + HP_EY, ey);
         atomic_max_pos(params + HP_YHATMAX, yn);
         atomic_max_pos(params + HP_RHO, rho);
@@ -130,41 +138,52 @@ __global__ __launch_bounds__(256) void f16_pack_refs_kernel(const double* __rest
 
 // ---------------------------------------------------------------------------
 // queries -> fp16 rows Xh[nq_pad][16*KST] (x' = [x^, 1, 1, 1, 0..]) + qinfo[q] = {e_x, |x^|^2}
+// One lane per (query, 8-element segment); lane = r*G + f, so loads and stores are contiguous.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void f16_pack_queries_kernel(const double* __restrict__ X, int64_t nq, int64_t nq_pad,
                                                                int D, int KST, const double* __restrict__ center,
                                                                const double* __restrict__ params,
                                                                _Float16* __restrict__ Xh, double* __restrict__ qinfo)
 {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq_pad) return;
-    const bool live = q < nq;
+    const int G = 2 * KST, R = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int r = lane / G, f = lane - r * G;
+    const bool on = r < R;
+    const int64_t q = wave * R + r;
+    const bool inrange = on && q < nq_pad;
+    const bool live = inrange && q < nq;
     const double s = params[HP_SCALE];
-    const double* x = X + q * (int64_t)D;
     double err2 = 0.0, n2 = 0.0;
-    const int KD = 16 * KST;
-    for (int c0 = 0; c0 < KD; c0 += 8) {
-        v8h v;
+    v8h v;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = c0 + e;
-            _Float16 xv = (_Float16)0.0f;
-            if (live) {
-                if (k < D) {
-                    const double t = (x[k] - center[k]) * s;
-                    xv = (_Float16)t;
-                    err2 = fma(t - (double)xv, t - (double)xv, err2);
-                    n2 = fma((double)xv, (double)xv, n2);
-                } else if (k < D + 3) {
-                    xv = (_Float16)1.0f;
-                }
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * f + e;
+        _Float16 xv = (_Float16)0.0f;
+        if (live) {
+            if (k < D) {
+                const double t = (X[q * (int64_t)D + k] - center[k]) * s;
+                xv = (_Float16)t;
+                err2 = fma(t - (double)xv, t - (double)xv, err2);
+                n2 = fma((double)xv, (double)xv, n2);
+            } else if (k < D + 3) {
+                xv = (_Float16)1.0f;
             }
-            v[e] = xv;
         }
-        *reinterpret_cast<v8h*>(Xh + q * (int64_t)KD + c0) = v;
+        v[e] = xv;
     }
-    qinfo[2 * q + 0] = sqrt(err2);
-    qinfo[2 * q + 1] = n2;
+    double e_tot = 0.0, n_tot = 0.0;
+    for (int m = 0; m < G; ++m) {
+        e_tot += __shfl(err2, r * G + m, 64);
+        n_tot += __shfl(n2, r * G + m, 64);
+    }
+    if (inrange) {
+        *reinterpret_cast<v8h*>(Xh + q * (int64_t)(16 * KST) + 8 * f) = v;
+        if (f == 0) {
+            qinfo[2 * q + 0] = sqrt(e_tot);
+            qinfo[2 * q + 1] = n_tot;
+        }
+    }
 }
 
 }  // namespace mce

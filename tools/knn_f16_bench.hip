@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include <random>
 #ifndef DIM
 #define DIM 27
@@ -43,8 +44,9 @@ int main(int argc, char** argv)
     col_stats_final_kernel<<<1, 64>>>(msum, n, D, center, center + 64);
     CK(hipMemset(params, 0, pbytes));
     f16_scale_kernel<<<1, 64>>>(center + 64, nullptr, params);
-    f16_pack_refs_kernel<<<(unsigned)((nrow_pad + 255) / 256), 256, 256 * (D | 1) * 8>>>(X, n, D, KST, nrow_pad, center, params, Yh);
-    f16_pack_queries_kernel<<<(unsigned)((nq_pad + 255) / 256), 256>>>(X, n, nq_pad, D, KST, center, params, Xh, qinfo);
+    const int64_t rpb = 4 * (64 / (2 * KST));
+    f16_pack_refs_kernel<<<(unsigned)std::min<int64_t>((nrow_pad + rpb - 1) / rpb, 2048), 256>>>(X, n, D, KST, nrow_pad, center, params, Yh);
+    f16_pack_queries_kernel<<<(unsigned)((nq_pad + rpb - 1) / rpb), 256>>>(X, n, nq_pad, D, KST, center, params, Xh, qinfo);
     CK(hipDeviceSynchronize());
     constexpr size_t LDS = f16_lds_bytes(KST, KCAP);
     auto kern = knn_f16_kernel<KST, KCAP>;
