@@ -19,8 +19,9 @@
 // Lane gate:  min over the lane's 16 accumulators  <=  G_q   (8 v_min3_f32 + 1 compare).
 //
 // Survivors are queued per wave in LDS and drained in batches by the whole workgroup at a
-// chunk boundary: phase A, every lane takes one queued (query,row) pair, computes the exact
-// fp64 distance from the ORIGINAL rows and links the entry into its query's chain; phase B,
+// chunk boundary: phase A, 8 lanes share one queued (query,row) pair, read the two ORIGINAL fp64
+// rows in 64-byte segments, sum the exact squared distance and link the entry into its query's
+// chain (24 pairs per trip, all loads in flight before the first use); phase B,
 // lane l -- which OWNS wave-local query l and keeps its sorted top-K list in registers --
 // walks its chain and applies a static compare/select insertion network.  Then the gates
 // G_q are refreshed from the owners' K-th best.
@@ -29,10 +30,10 @@
 #include <stdint.h>
 
 #ifndef MCE_STATS
-#define MCE_STATS 0    // tools/knn_f16_bench.hip only: event counters in part_i[0..7] (results invalid)
+#define MCE_STATS 0    // tools/knn_f16_bench.hip only: per-wave clock64/event counters appended to `params`
 #endif
 #ifndef MCE_ABLATE
-#define MCE_ABLATE 0   // tools/knn_f16_bench.hip only: 1 = gate never passes, 2 = no gate
+#define MCE_ABLATE 0   // tools/knn_f16_bench.hip only: 1 = gate never passes, 3 = also no barriers (results invalid)
 #endif
 
 namespace mce {
