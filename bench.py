@@ -81,8 +81,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 or world > 1:
         assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+        # (MCE_BENCH_BACKEND=gloo MCE_BENCH_ONE_DEVICE=1: functional check of the N>1 path on a 1-GPU box)
+        if os.environ.get("MCE_BENCH_ONE_DEVICE") == "1":
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("MCE_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
