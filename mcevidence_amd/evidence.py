@@ -309,9 +309,12 @@ class MCEvidence(object):
                 amax = dotp[k] / (S * k_nn + 1.0)
                 MLE[ipow, k] = math.log(SumW * amax * Jacobian) + logLmax - logPriorVolume
                 if verbose > 1:
-                    lnc = 0.5 * ndim * math.log(math.pi) - math.lgamma(1.0 + 0.5 * ndim)
-                    with np.errstate(divide="ignore"):
-                        medvol = math.exp(lnc + ndim * math.log(statistics.median(dist[:, k - k0]))) if dist is not None else float("nan")
+                    # the reference logs statistics.median(volume[:, k]) (:1143-1145); same quantity from the distances
+                    medvol = float("nan")
+                    if dist is not None:
+                        lnc = 0.5 * ndim * math.log(math.pi) - math.lgamma(1.0 + 0.5 * ndim)
+                        rmed = statistics.median(dist[:, k - k0])
+                        medvol = math.exp(lnc + ndim * math.log(rmed)) if rmed > 0 else 0.0
                     self.logger.debug("k={},nsample={}, dotp={}, median_volume={}, a_max={}, MLE={}".format(
                         k, S, dotp[k], medvol, amax, MLE[ipow, k]))
 

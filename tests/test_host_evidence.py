@@ -67,6 +67,22 @@ def test_inmemory_quirks():
     assert np.allclose(e, PINS["isfunc"]["lnE"], atol=LNE_TOL)
 
 
+def test_verbose_debug_route_same_numbers(caplog):
+    """verbose > 1 takes the host-feeder route with the distances returned (debug median volume, reference
+    :1143-1145) and must give the same ln E."""
+    ch = gaussian_chain(seed=0, n=3000, d=4)
+    quiet = pkg.MCEvidence([ch], kmax=4, verbose=0, backend=OracleBackend()).evidence()
+    logging.disable(logging.NOTSET)
+    try:
+        with caplog.at_level(logging.DEBUG, logger="mcevidence_amd"):
+            loud = pkg.MCEvidence([ch], kmax=4, verbose=2, backend=OracleBackend()).evidence()
+    finally:
+        logging.disable(logging.CRITICAL)
+    assert np.array_equal(quiet, loud)
+    assert any("median_volume" in r.getMessage() for r in caplog.records)
+    assert any("ln(B)[k=1]" in r.getMessage() for r in caplog.records)
+
+
 def test_batch_logpower():
     ch = gaussian_chain(seed=0, n=4000, d=4)
     p = PINS["batch_logpower"]
