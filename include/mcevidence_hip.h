@@ -98,12 +98,39 @@ int mce_knn_dotp_f64(const double *X, int64_t nq, const double *Y, int64_t nr, i
  *       columns used.  S2 = NULL -> auto evidence (k0 = 1); otherwise cross evidence (k0 = 0).
  *   cov_mode 0 ("all"): covariance of the rows of S1 and S2 together; 1 ("single"): S1 whitened with
  *       its own eigen-system, S2 with ITS own (the reference's behaviour, :1080-1086).
+ *       (Eigen-systems are canonical: eigenvalues descending, each eigenvector's largest component
+ *       positive.  With cov_mode 1 AND S2 the result depends on that convention -- as the reference's
+ *       depends on LAPACK's -- so the Python class keeps np.linalg.eig for that one combination.)
  *   Outputs: dotp[kmax]; *jacobian = sqrt(det cov) (of S1's covariance in mode 1);
- *       eigenvalues[d] (may be NULL).  A non-positive eigenvalue -> MCE_ERR_INVALID (the reference
+ *       eigenvalues[d] (may be NULL), descending.  A non-positive eigenvalue -> MCE_ERR_INVALID (the reference
  *       raises ValueError: math domain error). */
 int mce_evidence_feed_f64(const double *S1, int64_t n1, int64_t ld1, const double *S2, int64_t n2, int64_t ld2,
                           int32_t d, int32_t cov_mode, int32_t kmax, const double *w, const double *fs,
                           double *dotp, double *jacobian, double *eigenvalues, int32_t device);
+
+/* Many independent evidence problems in one call: the reference's Planck driver
+ * runs MCEvidence(...).evidence() once per (data set, model, chain) -- ~600-2400 chains of 6k-100k
+ * rows, D = 6-8 -- farmed over MPI ranks (planck_mcevidence.py:306-348).  One such chain fills a
+ * fraction of the device, so here the problems of a batch are pipelined over several HIP streams
+ * with two host synchronisations per batch.  Each problem has exactly the semantics of
+ * mce_evidence_feed_f64 and yields bit-identical dotp / jacobian / eigenvalues.
+ *   in : S1,n1,ld1,S2,n2,ld2,d,cov_mode,kmax,w,fs   (as mce_evidence_feed_f64; S2 = NULL -> auto)
+ *   out: dotp[kmax], eigenvalues[d] (may be NULL), jacobian, status (MCE_OK or MCE_ERR_*)
+ * Problems are spread over `devices` (NULL/0 -> device 0) balanced by n1*nr.  A failing problem does
+ * not stop the others; the return value is the status of the first failing problem (its message in
+ * mce_last_error(), prefixed "problem <i>: "), or MCE_OK. */
+typedef struct mce_feed_problem {
+    const double *S1; int64_t n1, ld1;
+    const double *S2; int64_t n2, ld2;
+    int32_t d, cov_mode, kmax, status;
+    const double *w, *fs;
+    double *dotp;
+    double *eigenvalues;
+    double jacobian;
+} mce_feed_problem;
+
+int mce_evidence_feed_batch_f64(mce_feed_problem *problems, int64_t nprob, const int32_t *devices, int32_t ndev);
+size_t mce_feed_problem_size(void);   /* sizeof(mce_feed_problem) as built: lets a binding check its struct layout */
 
 /* ---- device-pointer entry points (resident data, caller's stream) ------ */
 

@@ -56,6 +56,19 @@ SIGNATURES = {
     "mce_knn_dotp_f64_dev": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
 }
 
+
+
+class FeedProblem(ctypes.Structure):
+    """``mce_feed_problem`` of include/mcevidence_hip.h (one evidence problem of a batch)."""
+    _fields_ = [("S1", _P), ("n1", _c.c_int64), ("ld1", _c.c_int64),
+                ("S2", _P), ("n2", _c.c_int64), ("ld2", _c.c_int64),
+                ("d", _c.c_int32), ("cov_mode", _c.c_int32), ("kmax", _c.c_int32), ("status", _c.c_int32),
+                ("w", _P), ("fs", _P), ("dotp", _P), ("eigenvalues", _P), ("jacobian", _c.c_double)]
+
+
+SIGNATURES["mce_evidence_feed_batch_f64"] = (_c.c_int, [_c.POINTER(FeedProblem), _c.c_int64, _P, _c.c_int32])
+SIGNATURES["mce_feed_problem_size"] = (_c.c_size_t, [])
+
 _lib = None
 
 
@@ -81,7 +94,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.mce_abi_version() != 1:
+        if lib.mce_abi_version() != 1 or lib.mce_feed_problem_size() != ctypes.sizeof(FeedProblem):
             raise RuntimeError("mcevidence_amd: ABI version mismatch")
         _lib = lib
     return _lib
@@ -240,6 +253,68 @@ def evidence_feed(S1, S2, d, cov_mode, kmax, w, fs, device=0):
                                     0 if S2 is None else S2.strides[0] // 8, int(d), int(cov_mode), int(kmax),
                                     w.ctypes.data, fs.ctypes.data, out.ctypes.data, ctypes.byref(jac), ev.ctypes.data, int(device)))
     return out, float(jac.value), ev
+
+
+def _devices_arg(devices):
+    if devices is None:
+        return None, 0
+    arr = (ctypes.c_int32 * len(devices))(*[int(x) for x in devices])
+    return arr, len(devices)
+
+
+def _raise_for(rc, msg):
+    if rc in (MCE_ERR_INVALID, MCE_ERR_K_RANGE, MCE_ERR_WORKSPACE, MCE_ERR_DIM_RANGE):
+        return ValueError(msg)
+    return RuntimeError("mcevidence_amd HIP backend: " + msg)
+
+
+def evidence_feed_batch(problems, devices=None, return_exceptions=False):
+    """Many independent evidence problems in ONE library call (``mce_evidence_feed_batch_f64``).
+
+    ``problems``: sequence of ``(S1, S2, d, cov_mode, kmax, w, fs)`` with the meaning of
+    :func:`evidence_feed`.  Returns a list of ``(dotp[kmax], jacobian, eigenvalues[d])`` in the same
+    order.  A failing problem raises (the first one, like a loop of single calls would) unless
+    ``return_exceptions`` is set, in which case its slot holds the exception instead."""
+    lib = load()
+    n = len(problems)
+    arr = (FeedProblem * max(n, 1))()
+    keep = []                                  # arrays the C struct points into
+    outs = []
+    for i, (S1, S2, d, cov_mode, kmax, w, fs) in enumerate(problems):
+        d, kmax = int(d), int(kmax)
+        S1 = _rows_f64(S1, "samples", d)
+        S2 = None if S2 is None else _rows_f64(S2, "samples2", d)
+        w = _f64(w, "weight")
+        fs = _f64(fs, "fs")
+        if w.shape != (S1.shape[0],) or fs.shape != w.shape:
+            raise ValueError("problem %d: weight and fs must have one entry per s1 row" % i)
+        out = np.zeros(max(kmax, 0))
+        ev = np.zeros(max(d, 0))
+        keep.append((S1, S2, w, fs))
+        outs.append((out, ev))
+        q = arr[i]
+        q.S1, q.n1, q.ld1 = S1.ctypes.data, S1.shape[0], S1.strides[0] // 8
+        if S2 is not None:
+            q.S2, q.n2, q.ld2 = S2.ctypes.data, S2.shape[0], S2.strides[0] // 8
+        q.d, q.cov_mode, q.kmax = d, int(cov_mode), kmax
+        q.w, q.fs, q.dotp, q.eigenvalues = w.ctypes.data, fs.ctypes.data, out.ctypes.data, ev.ctypes.data
+    devs, ndev = _devices_arg(devices)
+    rc = lib.mce_evidence_feed_batch_f64(arr, n, ctypes.cast(devs, _P) if devs is not None else None, ndev)
+    if rc != MCE_OK and all(arr[i].status == MCE_OK for i in range(n)):
+        check(rc)                              # the machinery failed (allocation, device), not a problem
+    results = []
+    for i in range(n):
+        st = int(arr[i].status)
+        if st == MCE_OK:
+            results.append((outs[i][0], float(arr[i].jacobian), outs[i][1]))
+            continue
+        # the library keeps only the first failure's text; later ones get a generic message
+        first = all(int(arr[j].status) == MCE_OK for j in range(i))
+        exc = _raise_for(st, last_error() if first else "problem %d failed with status %d" % (i, st))
+        if not return_exceptions:
+            raise exc
+        results.append(exc)
+    return results
 
 
 # ---------------------------------------------------------------------------

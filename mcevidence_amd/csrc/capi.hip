@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -62,7 +63,48 @@ std::atomic<int> g_mode{0};
 constexpr size_t kPoolMaxBytes = (size_t)64 << 20;
 constexpr int kPoolSlots = 16;
 struct PoolSlot { void* p = nullptr; size_t cap = 0; int dev = -1; bool busy = false; };
-thread_local PoolSlot g_pool[kPoolSlots];
+struct Pool {
+    PoolSlot slot[kPoolSlots];
+    PoolSlot& operator[](int i) { return slot[i]; }
+    void release_idle()
+    {
+        for (int i = 0; i < kPoolSlots; ++i)
+            if (slot[i].p && !slot[i].busy) {
+                int cur = 0;
+                (void)hipGetDevice(&cur);
+                if (slot[i].dev != cur) (void)hipSetDevice(slot[i].dev);
+                (void)hipFree(slot[i].p);
+                if (slot[i].dev != cur) (void)hipSetDevice(cur);
+                slot[i] = PoolSlot();
+            }
+    }
+    ~Pool() { release_idle(); }   // worker threads of the multi-device paths give their buffers back
+};
+thread_local Pool g_pool;
+
+// pinned host staging for the small result copies of the feed path (grow-only, per thread)
+struct PinnedArena {
+    void* p = nullptr;
+    size_t cap = 0;
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        release();
+        const size_t c = std::max<size_t>(n + n / 2, (size_t)64 << 10);
+        hipError_t e = hipHostMalloc(&p, c, hipHostMallocPortable);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = c;
+        return hipSuccess;
+    }
+    ~PinnedArena() { release(); }
+};
+thread_local PinnedArena g_pinned;
 
 struct DevBuf {
     void* p = nullptr;
@@ -107,6 +149,7 @@ struct DevBuf {
 };
 
 
+using mce::kMaxDevices;
 constexpr int kAssumedCUs = 256;   // MI355X; only steers the reference-split heuristic
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -407,15 +450,8 @@ const char* mce_last_kernel(void) { return g_last_kernel; }
 
 void mce_release_device_memory(void)
 {
-    for (int i = 0; i < kPoolSlots; ++i)
-        if (g_pool[i].p && !g_pool[i].busy) {
-            int cur = 0;
-            (void)hipGetDevice(&cur);
-            if (g_pool[i].dev != cur) (void)hipSetDevice(g_pool[i].dev);
-            (void)hipFree(g_pool[i].p);
-            if (g_pool[i].dev != cur) (void)hipSetDevice(cur);
-            g_pool[i] = PoolSlot();
-        }
+    g_pool.release_idle();
+    g_pinned.release();
 }
 
 int mce_set_search_mode(int mode)
@@ -666,28 +702,38 @@ void jacobi_eig(std::vector<double>& A, int d, std::vector<double>& lam, std::ve
                 }
             }
     }
+    // canonical form: eigenvalues descending, each eigenvector's largest component positive.  Two
+    // sets whitened with their OWN systems (covtype 'single' cross evidence) are then rotated
+    // consistently whenever their covariances are close, whatever the sweep order did.
+    std::vector<int> order(d);
+    for (int i = 0; i < d; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return A[(size_t)a * d + a] > A[(size_t)b * d + b]; });
     lam.resize(d);
-    for (int i = 0; i < d; ++i) lam[i] = A[(size_t)i * d + i];
+    std::vector<double> Vs((size_t)d * d);
+    for (int c = 0; c < d; ++c) {
+        const int src = order[c];
+        lam[c] = A[(size_t)src * d + src];
+        int big = 0;
+        for (int k = 1; k < d; ++k)
+            if (std::fabs(V[(size_t)k * d + src]) > std::fabs(V[(size_t)big * d + src])) big = k;
+        const double sgn = V[(size_t)big * d + src] < 0.0 ? -1.0 : 1.0;
+        for (int k = 0; k < d; ++k) Vs[(size_t)k * d + c] = sgn * V[(size_t)k * d + src];
+    }
+    V.swap(Vs);
 }
 
-// covariance (two-pass, unweighted, n-1) of the device matrix S[n, d] -> host cov[d*d]
-int device_covariance(const double* dS, int64_t n, int d, double* scratch_partial, double* d_mean3, double* d_cov,
-                      std::vector<double>& cov, hipStream_t st)
+// covariance (two-pass, unweighted, n-1) of the device matrix S[n, d] -> device cov[d*d]; enqueue only
+int launch_covariance(const double* dS, int64_t n, int d, double* scratch_partial, double* d_mean3, double* d_cov, hipStream_t st)
 {
     hipLaunchKernelGGL(mce::col_stats_partial_kernel, dim3(mce::kMeanBlocks), dim3(mce::kMeanThreads), 0, st, dS, n, d, scratch_partial);
     MCE_HIP(hipGetLastError());
     hipLaunchKernelGGL(mce::col_stats_final_kernel, dim3(1), dim3(64), 0, st, scratch_partial, n, d, d_mean3, (double*)nullptr);
     MCE_HIP(hipGetLastError());
-    const int npair = d * (d + 1) / 2;
     hipLaunchKernelGGL(mce::cov_partial_kernel, dim3(mce::kCovBlocks), dim3(mce::kCovThreads), (size_t)mce::kCovTileRows * d * sizeof(double), st,
                        dS, n, d, d_mean3, scratch_partial);
     MCE_HIP(hipGetLastError());
     hipLaunchKernelGGL(mce::cov_final_kernel, dim3(1), dim3(mce::kCovThreads), 0, st, scratch_partial, n, d, d_cov);
     MCE_HIP(hipGetLastError());
-    cov.resize((size_t)d * d);
-    MCE_HIP(hipMemcpyAsync(cov.data(), d_cov, (size_t)d * d * sizeof(double), hipMemcpyDeviceToHost, st));
-    MCE_HIP(hipStreamSynchronize(st));
-    (void)npair;
     return MCE_OK;
 }
 
@@ -726,109 +772,368 @@ int fused_on_device(int device, const double* X, int64_t q_lo, int64_t q_hi, con
     return MCE_OK;
 }
 
+// ---- evidence feed: covariance -> eigen-system -> whitening -> search -> reduction ---------------
+// One problem is four stages; only B runs on the host:
+//   A  upload the raw rows, enqueue the covariance kernels, copy cov back (async, pinned)
+//   B  d x d Jacobi eigen-solve, whitening scales, Jacobian
+//   C  upload eVec/scale, whiten in place, fused search + reduction, copy dotp back (async, pinned)
+//   D  hand the results to the caller
+// A batch is pipelined two deep in groups of kFeedGroup problems: while the device runs stage C of
+// group g, the host performs the (blocking, pageable) uploads of group g+1 and that group's
+// covariance kernels run beside the searches on a second stream set.  The searches themselves fill
+// the device (make_plan splits the reference set of a small problem over all CUs), so the gain is
+// hiding the PCIe upload, the host eigen-solves and the per-problem synchronisations.  Problems are
+// processed in waves bounded by kWaveBytes of device memory.
+constexpr size_t kWaveBytes = (size_t)8 << 30;
+constexpr int kWaveMaxJobs = 1024;
+constexpr int kFeedStreams = 4;   // per set (upload+covariance | whiten+search)
+constexpr int kFeedGroup = 8;     // problems per pipeline step
+
+struct FeedJob {
+    mce_feed_problem* q = nullptr;
+    int64_t index = 0;
+    Plan plan;
+    int k0 = 1, K = 0, rc = MCE_OK;
+    int64_t nr = 0, ntot = 0;
+    size_t wsb = 0, dev_bytes = 0, host_bytes = 0;
+    size_t o_S = 0, o_W = 0, o_F = 0, o_O = 0, o_small = 0, o_part = 0, o_ws = 0;
+    char* dbase = nullptr;    // this job's slice of the wave's device arena
+    double* hbase = nullptr;  // this job's slice of the pinned host arena: cov[2] | evec[2] | scale[2] | dotp
+    double jac = 0.0;
+    std::vector<double> lam;  // eigenvalues of the system that defines J (s1's in 'single' mode)
+    std::string err;
+
+    int d() const { return q->d; }
+    double* dS1() const { return reinterpret_cast<double*>(dbase + o_S); }
+    double* dS2() const { return dS1() + (size_t)q->n1 * q->d; }
+    double* dW() const { return reinterpret_cast<double*>(dbase + o_W); }
+    double* dF() const { return reinterpret_cast<double*>(dbase + o_F); }
+    double* dO() const { return reinterpret_cast<double*>(dbase + o_O); }
+    double* d_mean3() const { return reinterpret_cast<double*>(dbase + o_small); }
+    double* d_cov() const { return d_mean3() + 3 * 64; }
+    double* d_evec() const { return d_cov() + (size_t)q->d * q->d; }
+    double* d_scale() const { return d_evec() + (size_t)q->d * q->d; }
+    double* d_part() const { return reinterpret_cast<double*>(dbase + o_part); }
+    char* ws() const { return dbase + o_ws; }
+    double* h_cov(int i) const { return hbase + (size_t)i * q->d * q->d; }
+    double* h_evec(int i) const { return hbase + (size_t)(2 + i) * q->d * q->d; }
+    double* h_scale(int i) const { return hbase + (size_t)4 * q->d * q->d + (size_t)i * q->d; }
+    double* h_dotp() const { return hbase + (size_t)4 * q->d * q->d + (size_t)2 * q->d; }
+    bool two_systems() const { return q->cov_mode == 1 && q->S2 != nullptr; }
+    void set_error(int code) { rc = code; err = g_err; }
+};
+
+// argument checks + sizes; no device work
+int feed_plan(FeedJob& j)
+{
+    const mce_feed_problem& q = *j.q;
+    if (!q.S1 || !q.w || !q.fs || !q.dotp) return fail(MCE_ERR_INVALID, "null pointer argument");
+    if (q.n1 < 2 || q.d < 1 || q.ld1 < q.d || (q.S2 && (q.n2 < 1 || q.ld2 < q.d)) || (q.cov_mode != 0 && q.cov_mode != 1))
+        return fail(MCE_ERR_INVALID, "invalid sizes n1=%lld ld1=%lld n2=%lld ld2=%lld d=%d cov_mode=%d", (long long)q.n1, (long long)q.ld1,
+                    (long long)q.n2, (long long)q.ld2, q.d, q.cov_mode);
+    if (q.d > 63) return fail(MCE_ERR_DIM_RANGE, "device feeders support d <= 63 (got %d)", q.d);
+    j.k0 = q.S2 ? 0 : 1;
+    j.K = q.kmax - j.k0;
+    if (q.kmax <= j.k0) return fail(MCE_ERR_INVALID, "kmax=%d must exceed k0=%d", q.kmax, j.k0);
+    j.nr = q.S2 ? q.n2 : q.n1;
+    j.ntot = q.n1 + (q.S2 ? q.n2 : 0);
+    int rc = make_plan(q.n1, j.nr, q.d, j.K, j.k0 == 1 ? MCE_SELF_EXCLUDE : MCE_SELF_NONE, j.plan);
+    if (rc != MCE_OK) return rc;
+    j.wsb = j.plan.total + dotp_ws_bytes(q.n1, q.kmax);
+    const int d = q.d, npair = d * (d + 1) / 2;
+    size_t off = 0;
+    j.o_S = off;     off = align_up(off + (size_t)j.ntot * d * sizeof(double), 256);
+    j.o_W = off;     off = align_up(off + (size_t)q.n1 * sizeof(double), 256);
+    j.o_F = off;     off = align_up(off + (size_t)q.n1 * sizeof(double), 256);
+    j.o_O = off;     off = align_up(off + (size_t)q.kmax * sizeof(double), 256);
+    j.o_small = off; off = align_up(off + (size_t)(3 * 64 + 2 * d * d + d) * sizeof(double), 256);     // mean3 | cov | evec | scale
+    j.o_part = off;  off = align_up(off + (size_t)std::max<int64_t>((int64_t)mce::kCovBlocks * npair, (int64_t)mce::kMeanBlocks * mce::kStatStride) * sizeof(double), 256);
+    j.o_ws = off;    off = align_up(off + j.wsb, 256);
+    j.dev_bytes = off;
+    j.host_bytes = align_up((size_t)(4 * d * d + 2 * d + q.kmax) * sizeof(double), 64);
+    return MCE_OK;
+}
+
+int feed_stage_a(FeedJob& j, hipStream_t st)
+{
+    const mce_feed_problem& q = *j.q;
+    const int d = q.d;
+    const size_t row = (size_t)d * sizeof(double);
+    // pageable sources: plain (blocking) copies; the streams used here do not synchronise with them
+    MCE_HIP(hipMemcpy2D(j.dS1(), row, q.S1, (size_t)q.ld1 * sizeof(double), row, (size_t)q.n1, hipMemcpyHostToDevice));
+    if (q.S2) MCE_HIP(hipMemcpy2D(j.dS2(), row, q.S2, (size_t)q.ld2 * sizeof(double), row, (size_t)q.n2, hipMemcpyHostToDevice));
+    MCE_HIP(hipMemcpy(j.dW(), q.w, (size_t)q.n1 * sizeof(double), hipMemcpyHostToDevice));
+    MCE_HIP(hipMemcpy(j.dF(), q.fs, (size_t)q.n1 * sizeof(double), hipMemcpyHostToDevice));
+    // "all": one eigen-system from s1 U s2; "single": s1's own, and s2's own for s2 (J stays s1's)
+    int rc = launch_covariance(j.dS1(), q.cov_mode == 0 ? j.ntot : q.n1, d, j.d_part(), j.d_mean3(), j.d_cov(), st);
+    if (rc != MCE_OK) return rc;
+    MCE_HIP(hipMemcpyAsync(j.h_cov(0), j.d_cov(), (size_t)d * d * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (j.two_systems()) {
+        rc = launch_covariance(j.dS2(), q.n2, d, j.d_part(), j.d_mean3(), j.d_cov(), st);
+        if (rc != MCE_OK) return rc;
+        MCE_HIP(hipMemcpyAsync(j.h_cov(1), j.d_cov(), (size_t)d * d * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    return MCE_OK;
+}
+
+int feed_stage_b(FeedJob& j)
+{
+    const int d = j.d();
+    const int nsys = j.two_systems() ? 2 : 1;
+    for (int sidx = 0; sidx < nsys; ++sidx) {
+        std::vector<double> cov(j.h_cov(sidx), j.h_cov(sidx) + (size_t)d * d), lam, V;
+        jacobi_eig(cov, d, lam, V);
+        for (int i = 0; i < d; ++i)
+            if (!(lam[i] > 0.0)) return fail(MCE_ERR_INVALID, "math domain error: covariance eigenvalue %d is %g (use fewer parameters, ndim)", i, lam[i]);
+        std::copy(V.begin(), V.end(), j.h_evec(sidx));
+        for (int i = 0; i < d; ++i) j.h_scale(sidx)[i] = 1.0 / std::sqrt(lam[i]);
+        if (sidx == 0) {
+            double logdet = 0.0;
+            for (int i = 0; i < d; ++i) logdet += std::log(lam[i]);
+            j.jac = std::exp(0.5 * logdet);
+            j.lam = lam;
+        }
+    }
+    return MCE_OK;
+}
+
+int feed_whiten(FeedJob& j, int sidx, double* rows, int64_t n, hipStream_t st)
+{
+    const int d = j.d();
+    MCE_HIP(hipMemcpyAsync(j.d_evec(), j.h_evec(sidx), (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, st));
+    MCE_HIP(hipMemcpyAsync(j.d_scale(), j.h_scale(sidx), (size_t)d * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(mce::whiten_kernel, dim3((unsigned)((n + mce::kWhitenRows - 1) / mce::kWhitenRows)), dim3(mce::kWhitenRows),
+                       mce::whiten_lds_bytes(d), st, rows, n, d, j.d_evec(), j.d_scale(), rows);
+    MCE_HIP(hipGetLastError());
+    return MCE_OK;
+}
+
+int feed_stage_c(FeedJob& j, hipStream_t st)
+{
+    const mce_feed_problem& q = *j.q;
+    {
+        static std::atomic<bool> attr_set[kMaxDevices];
+        int dev = 0;
+        MCE_HIP(hipGetDevice(&dev));
+        if (dev < kMaxDevices && !attr_set[dev].load()) {
+            MCE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mce::whiten_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mce::whiten_lds_bytes(63)));
+            attr_set[dev].store(true);
+        }
+    }
+    int rc;
+    if (j.two_systems()) {
+        rc = feed_whiten(j, 0, j.dS1(), q.n1, st);
+        if (rc != MCE_OK) return rc;
+        rc = feed_whiten(j, 1, j.dS2(), q.n2, st);
+    } else {
+        rc = feed_whiten(j, 0, j.dS1(), q.cov_mode == 0 ? j.ntot : q.n1, st);
+    }
+    if (rc != MCE_OK) return rc;
+    rc = mce_knn_dotp_f64_dev(j.dS1(), q.n1, q.S2 ? j.dS2() : j.dS1(), j.nr, q.d, q.kmax, j.k0, 0, j.dW(), j.dF(), j.dO(), nullptr,
+                              j.ws(), j.wsb, st);
+    if (rc != MCE_OK) return rc;
+    MCE_HIP(hipMemcpyAsync(j.h_dotp(), j.dO(), (size_t)q.kmax * sizeof(double), hipMemcpyDeviceToHost, st));
+    return MCE_OK;
+}
+
+void feed_stage_d(FeedJob& j)
+{
+    mce_feed_problem& q = *j.q;
+    std::copy(j.h_dotp(), j.h_dotp() + q.kmax, q.dotp);
+    q.jacobian = j.jac;
+    if (q.eigenvalues) std::copy(j.lam.begin(), j.lam.end(), q.eigenvalues);
+}
+
+// all jobs of one device, in waves; per-job failures are recorded in the job, a failure of the
+// machinery itself (allocation, stream) is returned
+int feed_run_on_device(int device, std::vector<FeedJob*>& jobs)
+{
+    int rc = select_device(device);
+    if (rc != MCE_OK) return rc;
+    // two stream sets so that the covariance of the NEXT group never queues behind the searches of
+    // the current one; a single problem runs on the default stream
+    std::vector<hipStream_t> sa, sc;
+    std::vector<hipEvent_t> events;
+    struct Guard {
+        std::vector<hipStream_t>&a, &c;
+        std::vector<hipEvent_t>& e;
+        ~Guard()
+        {
+            for (hipStream_t x : a) (void)hipStreamDestroy(x);
+            for (hipStream_t x : c) (void)hipStreamDestroy(x);
+            for (hipEvent_t x : e) (void)hipEventDestroy(x);
+        }
+    } guard{sa, sc, events};
+    const bool piped = jobs.size() > 1;
+    if (piped) {
+        const int ns = (int)std::min<size_t>(kFeedStreams, jobs.size());
+        for (int i = 0; i < ns; ++i) {
+            hipStream_t s;
+            MCE_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            sa.push_back(s);
+            MCE_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            sc.push_back(s);
+        }
+        for (int i = 0; i < kFeedGroup; ++i) {
+            hipEvent_t e;
+            MCE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            events.push_back(e);
+        }
+    }
+    size_t wave_bytes = kWaveBytes;
+    if (const char* e = std::getenv("MCE_FEED_WAVE_BYTES")) wave_bytes = (size_t)std::strtoull(e, nullptr, 10);   // tests: force several waves
+    size_t lo = 0;
+    while (lo < jobs.size()) {
+        size_t hi = lo, dev_bytes = 0, host_bytes = 0;
+        while (hi < jobs.size() && (hi == lo || (dev_bytes + jobs[hi]->dev_bytes <= wave_bytes && hi - lo < (size_t)kWaveMaxJobs))) {
+            dev_bytes += jobs[hi]->dev_bytes;
+            host_bytes += jobs[hi]->host_bytes;
+            ++hi;
+        }
+        DevBuf arena;
+        PinnedArena& pinned = g_pinned;
+        MCE_HIP(arena.alloc(dev_bytes));
+        MCE_HIP(pinned.reserve(host_bytes));
+        size_t doff = 0, hoff = 0;
+        for (size_t i = lo; i < hi; ++i) {
+            jobs[i]->dbase = static_cast<char*>(arena.p) + doff;
+            jobs[i]->hbase = reinterpret_cast<double*>(static_cast<char*>(pinned.p) + hoff);
+            doff += jobs[i]->dev_bytes;
+            hoff += jobs[i]->host_bytes;
+        }
+        if (!piped) {
+            FeedJob& j = *jobs[lo];
+            if (j.rc == MCE_OK) {
+                int r = feed_stage_a(j, nullptr);
+                if (r == MCE_OK) { MCE_HIP(hipStreamSynchronize(nullptr)); r = feed_stage_b(j); }
+                if (r == MCE_OK) r = feed_stage_c(j, nullptr);
+                if (r == MCE_OK) { MCE_HIP(hipStreamSynchronize(nullptr)); feed_stage_d(j); }
+                else j.set_error(r);
+            }
+            lo = hi;
+            continue;
+        }
+        // groups of kFeedGroup problems, two deep: while the device searches group g the host uploads
+        // group g+1 (blocking pageable copies) and its covariance kernels run beside the searches
+        auto stage_a_group = [&](size_t g0, size_t g1) -> int {
+            for (size_t i = g0; i < g1; ++i) {
+                FeedJob& j = *jobs[i];
+                if (j.rc != MCE_OK) continue;
+                hipStream_t st = sa[i % sa.size()];
+                const int r = feed_stage_a(j, st);
+                if (r != MCE_OK) { j.set_error(r); continue; }
+                MCE_HIP(hipEventRecord(events[i - g0], st));
+            }
+            return MCE_OK;
+        };
+        rc = stage_a_group(lo, std::min(hi, lo + (size_t)kFeedGroup));
+        if (rc != MCE_OK) return rc;
+        for (size_t g0 = lo; g0 < hi; g0 += kFeedGroup) {
+            const size_t g1 = std::min(hi, g0 + (size_t)kFeedGroup);
+            for (size_t i = g0; i < g1; ++i) {
+                FeedJob& j = *jobs[i];
+                if (j.rc != MCE_OK) continue;
+                MCE_HIP(hipEventSynchronize(events[i - g0]));
+                int r = feed_stage_b(j);
+                if (r == MCE_OK) r = feed_stage_c(j, sc[i % sc.size()]);
+                if (r != MCE_OK) j.set_error(r);
+            }
+            if (g1 < hi) {
+                rc = stage_a_group(g1, std::min(hi, g1 + (size_t)kFeedGroup));
+                if (rc != MCE_OK) return rc;
+            }
+        }
+        for (hipStream_t st : sc) MCE_HIP(hipStreamSynchronize(st));
+        for (size_t i = lo; i < hi; ++i)
+            if (jobs[i]->rc == MCE_OK) feed_stage_d(*jobs[i]);
+        lo = hi;
+    }
+    return MCE_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t mce_feed_problem_size(void) { return sizeof(mce_feed_problem); }
+
+int mce_evidence_feed_batch_f64(mce_feed_problem* problems, int64_t nprob, const int32_t* devices, int32_t ndev)
+{
+    if (nprob < 0 || (nprob > 0 && !problems)) return fail(MCE_ERR_INVALID, "invalid problem list");
+    if (nprob == 0) return MCE_OK;
+    std::vector<FeedJob> jobs((size_t)nprob);
+    for (int64_t i = 0; i < nprob; ++i) {
+        jobs[i].q = &problems[i];
+        jobs[i].index = i;
+        problems[i].status = MCE_OK;
+        problems[i].jacobian = 0.0;
+        const int r = feed_plan(jobs[i]);
+        if (r != MCE_OK) jobs[i].set_error(r);
+    }
+    std::vector<int> devs;
+    if (!devices || ndev <= 0) devs.push_back(0);
+    else devs.assign(devices, devices + ndev);
+    const int n = (int)std::min<int64_t>((int64_t)devs.size(), nprob);
+    // greedy balance by pair count (largest first), then restore the caller's order per device
+    std::vector<std::vector<FeedJob*>> per_dev(n);
+    if (n == 1) {
+        for (auto& j : jobs) if (j.rc == MCE_OK) per_dev[0].push_back(&j);
+    } else {
+        std::vector<FeedJob*> order;
+        for (auto& j : jobs) if (j.rc == MCE_OK) order.push_back(&j);
+        std::stable_sort(order.begin(), order.end(), [](const FeedJob* a, const FeedJob* b) {
+            return (double)a->q->n1 * (double)a->nr > (double)b->q->n1 * (double)b->nr;
+        });
+        std::vector<double> load(n, 0.0);
+        for (FeedJob* j : order) {
+            const int t = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            load[t] += (double)j->q->n1 * (double)j->nr + 1e6;
+            per_dev[t].push_back(j);
+        }
+        for (auto& v : per_dev) std::sort(v.begin(), v.end(), [](const FeedJob* a, const FeedJob* b) { return a->index < b->index; });
+    }
+    std::vector<int> rcs(n, MCE_OK);
+    std::vector<std::string> errs(n);
+    auto work = [&](int i) {
+        if (per_dev[i].empty()) return;
+        rcs[i] = feed_run_on_device(devs[i], per_dev[i]);
+        if (rcs[i] != MCE_OK) errs[i] = g_err;
+    };
+    if (n == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < n; ++i) th.emplace_back(work, i);
+        for (auto& t : th) t.join();
+    }
+    for (int i = 0; i < n; ++i)
+        if (rcs[i] != MCE_OK) return fail(rcs[i], "device %d: %s", devs[i], errs[i].c_str());
+    int first = MCE_OK;
+    for (int64_t i = 0; i < nprob; ++i) {
+        problems[i].status = jobs[i].rc;
+        if (jobs[i].rc != MCE_OK && first == MCE_OK) {
+            first = jobs[i].rc;
+            if (nprob == 1) fail(first, "%s", jobs[i].err.c_str());
+            else fail(first, "problem %lld: %s", (long long)i, jobs[i].err.c_str());
+        }
+    }
+    return first;
+}
 
 int mce_evidence_feed_f64(const double* S1, int64_t n1, int64_t ld1, const double* S2, int64_t n2, int64_t ld2,
                           int32_t d, int32_t cov_mode, int32_t kmax, const double* w, const double* fs,
                           double* dotp, double* jacobian, double* eigenvalues, int32_t device)
 {
-    if (!S1 || !w || !fs || !dotp || !jacobian) return fail(MCE_ERR_INVALID, "null pointer argument");
-    if (n1 < 2 || d < 1 || ld1 < d || (S2 && (n2 < 1 || ld2 < d)) || (cov_mode != 0 && cov_mode != 1))
-        return fail(MCE_ERR_INVALID, "invalid sizes n1=%lld ld1=%lld n2=%lld ld2=%lld d=%d cov_mode=%d", (long long)n1, (long long)ld1,
-                    (long long)n2, (long long)ld2, d, cov_mode);
-    if (d > 63) return fail(MCE_ERR_DIM_RANGE, "device feeders support d <= 63 (got %d)", d);
-    const int k0 = S2 ? 0 : 1;
-    const int K = kmax - k0;
-    if (kmax <= k0) return fail(MCE_ERR_INVALID, "kmax=%d must exceed k0=%d", kmax, k0);
-    const int64_t nr = S2 ? n2 : n1;
-    Plan p;
-    int rc = make_plan(n1, nr, d, K, k0 == 1 ? MCE_SELF_EXCLUDE : MCE_SELF_NONE, p);
-    if (rc != MCE_OK) return rc;
-    rc = select_device(device);
-    if (rc != MCE_OK) return rc;
-    // ---- one upload: [S1 rows ; S2 rows] contiguous [n1+n2, d] (strided host -> packed device) ----
-    const int64_t ntot = n1 + (S2 ? n2 : 0);
-    const size_t wsb = p.total + dotp_ws_bytes(n1, kmax);
-    const int npair = d * (d + 1) / 2;
-    DevBuf dS, dW, dF, dO, ws, dSmall, dPart;
-    MCE_HIP(dS.alloc((size_t)ntot * d * sizeof(double)));
-    MCE_HIP(dW.alloc((size_t)n1 * sizeof(double)));
-    MCE_HIP(dF.alloc((size_t)n1 * sizeof(double)));
-    MCE_HIP(dO.alloc((size_t)kmax * sizeof(double)));
-    MCE_HIP(ws.alloc(wsb));
-    MCE_HIP(dSmall.alloc((size_t)(3 * 64 + 2 * d * d + 2 * d) * sizeof(double)));       // mean3 | cov | evec | scale
-    MCE_HIP(dPart.alloc((size_t)std::max<int64_t>((int64_t)mce::kCovBlocks * npair, (int64_t)mce::kMeanBlocks * mce::kStatStride) * sizeof(double)));
-    double* d1 = dS.as<double>();
-    double* d2 = d1 + (size_t)n1 * d;
-    MCE_HIP(hipMemcpy2D(d1, (size_t)d * sizeof(double), S1, (size_t)ld1 * sizeof(double), (size_t)d * sizeof(double), (size_t)n1, hipMemcpyHostToDevice));
-    if (S2) MCE_HIP(hipMemcpy2D(d2, (size_t)d * sizeof(double), S2, (size_t)ld2 * sizeof(double), (size_t)d * sizeof(double), (size_t)n2, hipMemcpyHostToDevice));
-    MCE_HIP(hipMemcpy(dW.p, w, (size_t)n1 * sizeof(double), hipMemcpyHostToDevice));
-    MCE_HIP(hipMemcpy(dF.p, fs, (size_t)n1 * sizeof(double), hipMemcpyHostToDevice));
-    double* d_mean3 = dSmall.as<double>();
-    double* d_cov = d_mean3 + 3 * 64;
-    double* d_evec = d_cov + (size_t)d * d;
-    double* d_scale = d_evec + (size_t)d * d;
-    hipStream_t st = nullptr;
-
-    auto eig_of = [&](const double* rows, int64_t n, std::vector<double>& lam, std::vector<double>& V) -> int {
-        std::vector<double> cov;
-        int r = device_covariance(rows, n, d, dPart.as<double>(), d_mean3, d_cov, cov, st);
-        if (r != MCE_OK) return r;
-        jacobi_eig(cov, d, lam, V);
-        for (int i = 0; i < d; ++i)
-            if (!(lam[i] > 0.0)) return fail(MCE_ERR_INVALID, "math domain error: covariance eigenvalue %d is %g (use fewer parameters, ndim)", i, lam[i]);
-        return MCE_OK;
-    };
-    auto whiten = [&](double* rows, int64_t n, const std::vector<double>& lam, const std::vector<double>& V) -> int {
-        std::vector<double> sc(d);
-        for (int i = 0; i < d; ++i) sc[i] = 1.0 / std::sqrt(lam[i]);
-        MCE_HIP(hipMemcpy(d_evec, V.data(), (size_t)d * d * sizeof(double), hipMemcpyHostToDevice));
-        MCE_HIP(hipMemcpy(d_scale, sc.data(), (size_t)d * sizeof(double), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(mce::whiten_kernel, dim3((unsigned)((n + mce::kWhitenRows - 1) / mce::kWhitenRows)), dim3(mce::kWhitenRows),
-                           mce::whiten_lds_bytes(d), st, rows, n, d, d_evec, d_scale, rows);
-        MCE_HIP(hipGetLastError());
-        return MCE_OK;
-    };
-    {
-        static bool attr_set = false;
-        if (!attr_set) {
-            MCE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mce::whiten_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mce::whiten_lds_bytes(63)));
-            attr_set = true;
-        }
-    }
-    std::vector<double> lam1, V1, lam2, V2;
-    if (cov_mode == 0) {                        // "all": one eigen-system from s1 U s2
-        rc = eig_of(d1, ntot, lam1, V1);
-        if (rc != MCE_OK) return rc;
-        rc = whiten(d1, ntot, lam1, V1);
-        if (rc != MCE_OK) return rc;
-    } else {                                    // "single": s1's own; s2 whitened with ITS own, J stays s1's
-        rc = eig_of(d1, n1, lam1, V1);
-        if (rc != MCE_OK) return rc;
-        if (S2) {
-            rc = eig_of(d2, n2, lam2, V2);
-            if (rc != MCE_OK) return rc;
-        }
-        rc = whiten(d1, n1, lam1, V1);
-        if (rc != MCE_OK) return rc;
-        if (S2) {
-            rc = whiten(d2, n2, lam2, V2);
-            if (rc != MCE_OK) return rc;
-        }
-    }
-    double logdet = 0.0;
-    for (int i = 0; i < d; ++i) logdet += std::log(lam1[i]);
-    *jacobian = std::exp(0.5 * logdet);
-    if (eigenvalues)
-        for (int i = 0; i < d; ++i) eigenvalues[i] = lam1[i];
-    rc = mce_knn_dotp_f64_dev(d1, n1, S2 ? d2 : d1, nr, d, kmax, k0, 0, dW.as<double>(), dF.as<double>(), dO.as<double>(), nullptr,
-                              ws.p, wsb, st);
-    if (rc != MCE_OK) return rc;
-    MCE_HIP(hipDeviceSynchronize());
-    MCE_HIP(hipMemcpy(dotp, dO.p, (size_t)kmax * sizeof(double), hipMemcpyDeviceToHost));
-    return MCE_OK;
+    if (!jacobian) return fail(MCE_ERR_INVALID, "null pointer argument");
+    mce_feed_problem q;
+    std::memset(&q, 0, sizeof(q));
+    q.S1 = S1; q.n1 = n1; q.ld1 = ld1;
+    q.S2 = S2; q.n2 = S2 ? n2 : 0; q.ld2 = S2 ? ld2 : 0;
+    q.d = d; q.cov_mode = cov_mode; q.kmax = kmax;
+    q.w = w; q.fs = fs; q.dotp = dotp; q.eigenvalues = eigenvalues;
+    const int rc = mce_evidence_feed_batch_f64(&q, 1, &device, 1);
+    if (rc == MCE_OK) *jacobian = q.jacobian;
+    return rc;
 }
 
 int mce_knn_dotp_f64(const double* X, int64_t nq, const double* Y, int64_t nr, int32_t d, int32_t kmax,

@@ -7,6 +7,8 @@
 
 namespace mce {
 
+constexpr int kMaxDevices = 64;   // per-device one-time kernel attributes
+
 struct KnnArgs {
     const double* Yf;       // packed references [nchunk_total*CT][KS][64]
     int64_t nchunk_total;

@@ -15,12 +15,14 @@ hipError_t launch_variant(const KnnArgs& a, hipStream_t st)
 {
     constexpr size_t LDS = lds_bytes(KS, KCAP);
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;   // benign race: idempotent
+    static bool attr_set[kMaxDevices] = {};   // per device; benign race: idempotent
     auto kern = knn_mfma_kernel<KS, KCAP>;
-    if (!attr_set) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= kMaxDevices || !attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev < kMaxDevices) attr_set[dev] = true;
     }
     const dim3 grid((unsigned)(a.nqblk * a.rsplit));
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), LDS, st, a.Yf, a.nchunk_total, a.rsplit, a.X, a.center, a.nq, a.D,
@@ -34,12 +36,14 @@ hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
 {
     constexpr size_t LDS = f16_lds_bytes(KST, KCAP);
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
+    static bool attr_set[kMaxDevices] = {};
     auto kern = knn_f16_kernel<KST, KCAP>;
-    if (!attr_set) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= kMaxDevices || !attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev < kMaxDevices) attr_set[dev] = true;
     }
     const dim3 grid((unsigned)(a.nqblk * a.rsplit));
     hipLaunchKernelGGL(kern, grid, dim3(kHThreads), LDS, st, static_cast<const _Float16*>(a.Yh), a.nchunk_total, a.rsplit,

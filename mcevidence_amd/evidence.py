@@ -31,7 +31,7 @@ from .chains import MCSamples
 FORMAT = "%(levelname)s:%(filename)s.%(funcName)s():%(lineno)-8s %(message)s"
 logger = logging.getLogger("mcevidence_amd")
 
-__all__ = ["MCEvidence", "HipBackend"]
+__all__ = ["MCEvidence", "HipBackend", "evidence_many"]
 
 
 class HipBackend(object):
@@ -52,6 +52,18 @@ class HipBackend(object):
         from . import _capi
         dotp, jac, _ = _capi.evidence_feed(S1, S2, ndim, cov_mode, kmax, weight, fs)
         return dotp, jac
+
+    def evidence_feed_batch(self, problems):
+        """many problems (tuples with evidence_feed's arguments) in one library call; under torchrun
+        the problems are farmed over the ranks instead (parallel.farm_evidence_feed).  Returns a list
+        of (dotp, J) or None when this route does not apply."""
+        from . import parallel
+        if any(p[2] > 63 for p in problems):
+            return None
+        if parallel.is_distributed():
+            return parallel.farm_evidence_feed(problems)
+        from . import _capi
+        return [(dotp, jac) for dotp, jac, _ in _capi.evidence_feed_batch(problems, devices=self.devices)]
 
     def knn_dotp(self, X, Y, weight, fs, kmax, k0, want_dist=False):
         from . import parallel
@@ -220,21 +232,22 @@ class MCEvidence(object):
                 s = self.diagonalise_chain(s, cs["eVec"], cs["eVal"])
         return s, lnp, w, stat
 
-    def _evidence_device_feeders(self, covtype, pos_lnp, logPriorVolume):
-        """evidence() with get_covariance/diagonalise_chain done by the library too.  Same quantities as
-        the host route below (reference :1034-1131); returns MLE[kmax] or None if the backend declines."""
-        kmax, ndim = self.kmax, self.ndim
+    def _feed_problem(self, covtype, pos_lnp):
+        """Inputs of the device-feeder route for this object: the problem tuple of
+        ``_capi.evidence_feed`` and what ``_feed_finish`` needs (reference :1034-1064)."""
         s1, lnp, weight = self.gd.arrays("s1")
-        S = s1.shape[0]
         s2 = self.gd.arrays("s2")[0] if self.split else None
         logL = -lnp if pos_lnp else lnp
         logLmax = np.amax(logL)
         fs = logL - logLmax
-        got = self.backend.evidence_feed(s1, s2, ndim, 0 if covtype == "all" else 1, kmax,
-                                         np.asarray(weight, dtype=np.float64), np.asarray(fs, dtype=np.float64))
-        if got is None:
-            return None
-        dotp, Jacobian = got
+        problem = (s1, s2, self.ndim, 0 if covtype == "all" else 1, self.kmax,
+                   np.asarray(weight, dtype=np.float64), np.asarray(fs, dtype=np.float64))
+        return problem, (s1.shape[0], logLmax)
+
+    def _feed_finish(self, ctx, dotp, Jacobian, logPriorVolume):
+        """ln E_k from the reduced sums (reference :1120-1131); returns MLE[kmax]."""
+        S, logLmax = ctx
+        kmax = self.kmax
         k0 = 0 if self.split else 1
         SumW = np.sum(self.gd.data["s1"].adjusted_weights)
         mle = np.zeros(kmax)
@@ -242,6 +255,29 @@ class MCEvidence(object):
             k_nn = k if k0 == 1 else k + 1
             mle[k] = math.log(SumW * (dotp[k] / (S * k_nn + 1.0)) * Jacobian) + logLmax - logPriorVolume
         return mle
+
+    def _feed_route_applies(self, verbose, covtype):
+        # cross evidence with covtype 'single' whitens s1 and s2 with DIFFERENT eigen-systems, so the
+        # distances depend on the eigenvector order/sign conventions of the solver: that case keeps the
+        # reference's own np.linalg.eig (host route)
+        if self.split and covtype == "single":
+            return False
+        return self.brange is None and verbose <= 1 and covtype in ("all", "single")
+
+    def _evidence_device_feeders(self, covtype, pos_lnp, logPriorVolume):
+        """evidence() with get_covariance/diagonalise_chain done by the library too.  Same quantities as
+        the host route below (reference :1034-1131); returns MLE[kmax] or None if the backend declines."""
+        problem, ctx = self._feed_problem(covtype, pos_lnp)
+        got = self.backend.evidence_feed(*problem)
+        if got is None:
+            return None
+        return self._feed_finish(ctx, got[0], got[1], logPriorVolume)
+
+    def _report(self, MLE, verbose, info):
+        if verbose > 0:
+            for k in range(1, self.kmax):
+                self.logger.info("   ln(B)[k={}] = {}".format(k, MLE[k - 1] if self.brange is None else MLE[:, k - 1]))
+        return (MLE, self.info) if info else MLE
 
     # ------------------------------------------------------------------ the estimator
     def evidence(self, verbose=None, rand=False, info=False, covtype="all",
@@ -260,15 +296,10 @@ class MCEvidence(object):
             covtype = self.covtype
         # ---- device-feeder route: covariance, whitening AND the hot path in one library call ----
         # (single batch, no per-neighbour debug output, a backend that offers it)
-        if self.brange is None and verbose <= 1 and covtype in ("all", "single") and hasattr(self.backend, "evidence_feed"):
+        if self._feed_route_applies(verbose, covtype) and hasattr(self.backend, "evidence_feed"):
             out = self._evidence_device_feeders(covtype, pos_lnp, logPriorVolume)
             if out is not None:
-                MLE[0, :] = out
-                MLE = MLE[0, 1:]
-                if verbose > 0:
-                    for k in range(1, self.kmax):
-                        self.logger.info("   ln(B)[k={}] = {}".format(k, MLE[k - 1]))
-                return (MLE, self.info) if info else MLE
+                return self._report(out[1:], verbose, info)
 
         if covtype == "all":
             covstat = self.get_covariance()
@@ -319,9 +350,42 @@ class MCEvidence(object):
                         k, S, dotp[k], medvol, amax, MLE[ipow, k]))
 
         MLE = MLE[0, 1:] if self.brange is None else MLE[:, 1:]
-        if verbose > 0:
-            for k in range(1, self.kmax):
-                self.logger.info("   ln(B)[k={}] = {}".format(k, MLE[k - 1] if self.brange is None else MLE[:, k - 1]))
-        if info:
-            return MLE, self.info
-        return MLE
+        return self._report(MLE, verbose, info)
+
+
+def evidence_many(mces, verbose=None, info=False, covtype="all", pvolume=None, pos_lnp=False, **kwargs):
+    """``[m.evidence(...) for m in mces]`` with the device work of all objects in ONE batched library
+    call (``mce_evidence_feed_batch_f64``).
+
+    This is the reference's Planck driver pattern -- one ``MCEvidence(...).evidence(info=True)``
+    per (data set, model, chain), farmed over MPI ranks (planck_mcevidence.py:306-348) -- where a
+    single chain (6k-100k rows, D = 6-8) fills a fraction of the GPU.  Same arguments and the same
+    per-object results as ``evidence()``; ``pvolume`` may be a sequence (one per object).  Objects
+    the batched route does not cover (batching ranges, ``verbose > 1``, ``covtype`` other than
+    'all'/'single', a backend without ``evidence_feed_batch``) are evaluated one by one.  Under
+    ``torchrun`` the problems are farmed over the ranks and every rank returns all results."""
+    mces = list(mces)
+    pvols = list(pvolume) if isinstance(pvolume, (list, tuple, np.ndarray)) else [pvolume] * len(mces)
+    if len(pvols) != len(mces):
+        raise ValueError("pvolume: expected %d entries, got %d" % (len(mces), len(pvols)))
+    results = [None] * len(mces)
+    groups = {}                                   # backend -> [(index, ctx, problem)]
+    for i, m in enumerate(mces):
+        v = m.verbose if verbose is None else verbose
+        ct = m.covtype if covtype is None else covtype
+        if m._feed_route_applies(v, ct) and hasattr(m.backend, "evidence_feed_batch"):
+            problem, ctx = m._feed_problem(ct, pos_lnp)
+            groups.setdefault(id(m.backend), (m.backend, []))[1].append((i, ctx, problem))
+    for backend, items in groups.values():
+        got = backend.evidence_feed_batch([p for _, _, p in items])
+        if got is None:
+            continue
+        for (i, ctx, _), (dotp, jac) in zip(items, got):
+            m = mces[i]
+            lpv = math.log(m.priorvolume if pvols[i] is None else pvols[i])
+            v = m.verbose if verbose is None else verbose
+            results[i] = m._report(m._feed_finish(ctx, dotp, jac, lpv)[1:], v, info)
+    for i, m in enumerate(mces):
+        if results[i] is None:
+            results[i] = m.evidence(verbose=verbose, info=info, covtype=covtype, pvolume=pvols[i], pos_lnp=pos_lnp, **kwargs)
+    return results

@@ -68,3 +68,63 @@ def sharded_knn_dotp(X, Y, weight, fs, kmax, k0, want_dist=False, group=None, lo
         dist.all_gather_object(gathered, dpart, group=group)
         dist_full = np.concatenate(gathered, axis=0)
     return dotp, dist_full
+
+
+def farm_assignment(costs, world):
+    """Greedy longest-first assignment of independent problems to ranks (the build's replacement for
+    the reference's mpi4py farm, planck_mcevidence.py:149-160, which splits the list evenly by
+    count).  Returns owner[i] in [0, world); deterministic, identical on every rank."""
+    order = sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i))
+    load = [0.0] * world
+    owner = [0] * len(costs)
+    for i in order:
+        r = min(range(world), key=lambda t: (load[t], t))
+        owner[i] = r
+        load[r] += float(costs[i]) + 1e6
+    return owner
+
+
+def _local_feed_batch(problems):
+    import torch
+    from . import _capi
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    return [(dotp, jac) for dotp, jac, _ in _capi.evidence_feed_batch(problems, devices=[dev])]
+
+
+def farm_evidence_feed(problems, group=None, local_fn=None):
+    """Independent evidence problems farmed over the ranks: rank r runs the problems it owns as one
+    batched library call on its GPU; ONE all-reduce(sum) of a [nprob, kmax_max + 2] table (each row
+    written by exactly one rank, zeros elsewhere, so the sum is exact) hands every rank all results.
+    Returns [(dotp[kmax], J)] in input order.  A problem that fails on its owner raises on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = len(problems)
+    costs = [float(p[0].shape[0]) * float((p[0] if p[1] is None else p[1]).shape[0]) for p in problems]
+    owner = farm_assignment(costs, world)
+    mine = [i for i in range(n) if owner[i] == rank]
+    kcol = max([int(p[4]) for p in problems] + [1])
+    table = np.zeros((n, kcol + 2))
+    error = None
+    if mine:
+        fn = local_fn or _local_feed_batch
+        try:
+            got = fn([problems[i] for i in mine])
+            for i, (dotp, jac) in zip(mine, got):
+                table[i, :len(dotp)] = dotp
+                table[i, kcol] = jac
+        except Exception as exc:          # reported to every rank through the table
+            error = exc
+            table[mine, kcol + 1] = 1.0
+    backend = dist.get_backend(group)
+    device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    t = torch.as_tensor(table, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    table = t.cpu().numpy()
+    if error is not None:
+        raise error
+    if table[:, kcol + 1].any():
+        bad = int(np.flatnonzero(table[:, kcol + 1])[0])
+        raise RuntimeError("evidence problem %d failed on rank %d" % (bad, owner[bad]))
+    return [(table[i, :int(problems[i][4])].copy(), float(table[i, kcol])) for i in range(n)]

@@ -72,6 +72,39 @@ class OracleBackend(object):
         return dotp, (d if want_dist else None)
 
 
+class OracleFeedBackend(OracleBackend):
+    """OracleBackend that also offers the device-feeder routes (``evidence_feed`` and its batched
+    form) -- NumPy covariance/eigen-system/whitening in front of the same oracle search."""
+
+    def evidence_feed(self, S1, S2, ndim, cov_mode, kmax, weight, fs):
+        s1 = np.asarray(S1)[:, :ndim]
+        s2 = None if S2 is None else np.asarray(S2)[:, :ndim]
+
+        def eig(rows):
+            ev, U = np.linalg.eigh(np.atleast_2d(np.cov(rows.T)))
+            if (ev <= 0).any():
+                raise ValueError("math domain error")
+            # the library's documented canonical form (include/mcevidence_hip.h): eigenvalues
+            # descending, largest component of each eigenvector positive
+            ev, U = ev[::-1], U[:, ::-1]
+            sgn = np.sign(U[np.argmax(np.abs(U), axis=0), np.arange(U.shape[1])])
+            return ev, U * sgn
+        if cov_mode == 0:
+            ev, U = eig(s1 if s2 is None else np.concatenate([s1, s2]))
+            ev2, U2 = ev, U
+        else:
+            ev, U = eig(s1)
+            ev2, U2 = (ev, U) if s2 is None else eig(s2)
+        X = (s1 @ U) / np.sqrt(ev)
+        Y = None if s2 is None else (s2 @ U2) / np.sqrt(ev2)
+        dotp, _ = self.knn_dotp(X, Y, weight, fs, kmax, 0 if s2 is not None else 1)
+        return dotp, math.sqrt(float(np.prod(ev)))
+
+    def evidence_feed_batch(self, problems):
+        self.batches = getattr(self, "batches", []) + [len(problems)]
+        return [self.evidence_feed(*p) for p in problems]
+
+
 def lnE_from_dotp(case, dotp):
     return orc.mle_from_dotp(np.asarray(dotp), case["S"], case["k0"], case["kmax"], case["SumW"], case["J"],
                              case["logLmax"], case["lnPriorVolume"])

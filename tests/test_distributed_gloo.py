@@ -97,3 +97,70 @@ def test_shard_bounds_cover_everything():
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+
+
+def _farm_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import logging
+    logging.disable(logging.CRITICAL)
+    import mcevidence_amd as pkg
+    from mcevidence_amd import parallel
+    from mcevidence_amd.synth import gaussian_chain
+    from helpers import OracleFeedBackend
+    seen = []
+
+    class Farm(OracleFeedBackend):
+        def evidence_feed_batch(self, problems):
+            def local(ps):
+                seen.append(len(ps))
+                return [OracleFeedBackend.evidence_feed(self, *p) for p in ps]
+            return parallel.farm_evidence_feed(problems, local_fn=local)
+    ms = [pkg.MCEvidence([gaussian_chain(seed=30 + i, n=500 + 130 * i, d=3)], kmax=3 + (i % 2), verbose=0, backend=Farm()) for i in range(7)]
+    be = ms[0].backend
+    for m in ms:
+        m.backend = be
+    out = pkg.evidence_many(ms)
+    failed = None
+    try:                                            # a failing problem raises on EVERY rank
+        def boom(ps):
+            raise ValueError("math domain error")
+        parallel.farm_evidence_feed([m._feed_problem("all", False)[0] for m in ms[:1]], local_fn=boom)
+    except (ValueError, RuntimeError) as exc:
+        failed = type(exc).__name__
+    q.put((rank, out, seen, failed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_problem_farm_matches_single_process():
+    """evidence_many under a 2-rank group: problems are split over the ranks (each runs its share as
+    one batch), one all-reduce returns every result to every rank, identical to a single process."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_farm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import mcevidence_amd as pkg
+    from mcevidence_amd.synth import gaussian_chain
+    from mcevidence_amd.parallel import farm_assignment
+    from helpers import OracleFeedBackend
+    be = OracleFeedBackend()
+    ref = [pkg.MCEvidence([gaussian_chain(seed=30 + i, n=500 + 130 * i, d=3)], kmax=3 + (i % 2), verbose=0, backend=be).evidence() for i in range(7)]
+    for rank, out, seen, failed in got:
+        assert len(out) == 7
+        for a, b in zip(out, ref):
+            assert np.array_equal(a, b)
+        assert failed in ("ValueError", "RuntimeError")
+    assert got[0][2][0] + got[1][2][0] == 7 and min(got[0][2][0], got[1][2][0]) >= 2      # both ranks worked
+    owner = farm_assignment([float(n) ** 2 for n in (500 + 130 * i for i in range(7))], 2)
+    assert sorted(set(owner)) == [0, 1]
+    loads = [sum((500 + 130 * i) ** 2 for i in range(7) if owner[i] == r) for r in (0, 1)]
+    assert max(loads) < 1.35 * min(loads)

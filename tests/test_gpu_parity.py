@@ -300,9 +300,107 @@ def test_device_feeder_route_matches_reference_and_host_route(name):
     cov = case["ev"].get("covtype", "all")
     if cov is None:
         cov = case["mce"].get("covtype", "single")
-    assert calls.get("feed", 0) == (1 if cov in ("all", "single") else 0)
+    two_systems = cov == "single" and case["mce"].get("split", False)   # keeps np.linalg.eig's conventions: host route
+    assert calls.get("feed", 0) == (1 if cov in ("all", "single") and not two_systems else 0)
     assert np.max(np.abs(dev - np.array(case["lnE"]))) < LNE_TOL
     assert np.max(np.abs(dev - host)) < 1e-10
+
+
+def _feed_problems(rng, count):
+    """mixed bag of small evidence problems: auto/cross, both covariance modes, ragged sizes, padded rows"""
+    probs = []
+    for i in range(count):
+        d = int(rng.integers(1, 9)) if i % 7 else int(rng.integers(9, 30))
+        n1 = int(rng.integers(40, 3000))
+        kmax = int(rng.integers(2, 7))
+        A = rng.standard_normal((d, d)) + 2.0 * np.eye(d)
+        ld = d + int(rng.integers(0, 4))                      # nuisance columns behind the first d
+        S1 = np.zeros((n1, ld))
+        S1[:, :d] = rng.standard_normal((n1, d)) @ A + rng.standard_normal(d) * 5
+        S1[:, d:] = 1e6
+        S2 = None
+        if i % 3 == 1:
+            n2 = int(rng.integers(40, 3000))
+            S2 = rng.standard_normal((n2, d)) @ A
+        w = rng.integers(1, 5, n1).astype(float)
+        fs = -rng.random(n1) * 3
+        probs.append((S1, S2, d, int(i % 2), kmax, w, fs))
+    return probs
+
+
+def test_batched_feed_is_bit_identical_to_single_calls(capi, monkeypatch):
+    """mce_evidence_feed_batch_f64: same dotp / J / eigenvalues as one
+    mce_evidence_feed_f64 call per problem -- bit for bit -- in one wave and in several."""
+    rng = np.random.default_rng(77)
+    probs = _feed_problems(rng, 60)
+    singles = [capi.evidence_feed(*p) for p in probs]
+    for wave_bytes in (None, "3000000"):
+        if wave_bytes:
+            monkeypatch.setenv("MCE_FEED_WAVE_BYTES", wave_bytes)
+        batch = capi.evidence_feed_batch(probs)
+        assert len(batch) == len(probs)
+        for (d1, j1, e1), (d2, j2, e2) in zip(singles, batch):
+            assert np.array_equal(d1, d2) and j1 == j2 and np.array_equal(e1, e2)
+    monkeypatch.delenv("MCE_FEED_WAVE_BYTES")
+    # and against the oracle (NumPy feeders + exact CPU search)
+    for p, (dotp, jac, ev) in list(zip(probs, batch))[:12]:
+        S1, S2, d, cov_mode, kmax, w, fs = p
+        from helpers import OracleFeedBackend
+        odot, ojac = OracleFeedBackend().evidence_feed(S1, S2, d, cov_mode, kmax, w, fs)
+        k0 = 0 if S2 is not None else 1
+        assert np.allclose(dotp[k0:], odot[k0:], rtol=1e-9) and abs(jac - ojac) <= 1e-11 * ojac
+    assert capi.evidence_feed_batch([]) == []
+
+
+def test_batched_feed_isolates_failing_problems(capi):
+    rng = np.random.default_rng(78)
+    probs = _feed_problems(rng, 9)
+    good = capi.evidence_feed_batch(probs)
+    bad = list(probs)
+    S1, S2, d, cm, kmax, w, fs = bad[4]
+    bad[4] = (S1[:3], None, d, cm, 9, w[:3], fs[:3])            # kmax-1 = 8 neighbours from 2 usable rows
+    dup = np.concatenate([bad[6][0][:, :2], bad[6][0][:, :1]], axis=1)   # third column == first: singular covariance
+    bad[6] = (np.ascontiguousarray(dup), None, 3, 0, 3, bad[6][5], bad[6][6])
+    with pytest.raises(ValueError, match="problem 4: Expected n_neighbors <= n_samples_fit"):
+        capi.evidence_feed_batch(bad)
+    out = capi.evidence_feed_batch(bad, return_exceptions=True)
+    assert isinstance(out[4], ValueError)
+    for i in (0, 1, 2, 3, 5, 7, 8):
+        assert np.array_equal(out[i][0], good[i][0]) and out[i][1] == good[i][1]
+    # a (numerically) singular covariance either raises "math domain error" or yields a tiny positive
+    # eigenvalue, as NumPy's eig would; it must not disturb its neighbours either way
+    assert isinstance(out[6], ValueError) or out[6][2].min() < 1e-9 * out[6][2].max()
+
+
+@pytest.mark.parametrize("nobj", [25])
+def test_evidence_many_matches_evidence_one_by_one(nobj):
+    """the class-level batch (reference pattern: planck_mcevidence.py:306-348) against per-object
+    evidence() and against the reference's golden numbers."""
+    import mcevidence_amd as pkg
+    names = [n for n in sorted(G) if G[n]["tag"] == "small" and G[n]["seed_split"] is None
+             and G[n]["ev"].get("covtype", "all") in ("all", "single")][:nobj]
+    assert len(names) >= 3
+
+    def objs():
+        return [pkg.MCEvidence([chain_of(G[n])], verbose=0, **G[n]["mce"]) for n in names]
+    # the goldens use different evidence() kwargs per case: group by kwargs
+    by_kw = {}
+    for n in names:
+        by_kw.setdefault(tuple(sorted(G[n]["ev"].items())), []).append(n)
+    for kw, group in by_kw.items():
+        ms = [pkg.MCEvidence([chain_of(G[n])], verbose=0, **G[n]["mce"]) for n in group]
+        many = pkg.evidence_many(ms, **dict(kw))
+        for n, m, got in zip(group, ms, many):
+            one = m.evidence(**dict(kw))
+            assert np.array_equal(got, one)
+            assert np.max(np.abs(got - np.array(G[n]["lnE"]))) < LNE_TOL
+    # Planck-shaped farm: many chains, 6 parameters, kmax = 2, info=True
+    from mcevidence_amd.synth import gaussian_chain
+    ms = [pkg.MCEvidence([gaussian_chain(seed=900 + i, n=3000 + 137 * i, d=6)], kmax=2, verbose=0, priorvolume=1.0 + i) for i in range(40)]
+    many = pkg.evidence_many(ms, info=True)
+    for m, (lnE, info) in zip(ms, many):
+        one, info1 = m.evidence(info=True)
+        assert np.array_equal(lnE, one) and info is m.info and info1 is m.info
 
 
 def test_sampled_rows_at_full_size_C3(capi):

@@ -10,7 +10,7 @@ import pytest
 
 import mcevidence_amd as pkg
 from mcevidence_amd.synth import gaussian_chain, planck_like_chains, write_cosmomc_chains
-from helpers import LNE_TOL, OracleBackend, chain_of, host_pins, load_golden
+from helpers import LNE_TOL, OracleBackend, OracleFeedBackend, chain_of, host_pins, load_golden
 
 logging.disable(logging.CRITICAL)
 G = load_golden()
@@ -81,6 +81,33 @@ def test_verbose_debug_route_same_numbers(caplog):
     assert np.array_equal(quiet, loud)
     assert any("median_volume" in r.getMessage() for r in caplog.records)
     assert any("ln(B)[k=1]" in r.getMessage() for r in caplog.records)
+
+
+def test_evidence_many_host_logic():
+    """evidence_many(): one batched backend call for the objects the feed route covers, per-object
+    evidence() for the rest, results identical to evidence() one by one, per-object prior volumes."""
+    be = OracleFeedBackend()
+    chains = [gaussian_chain(seed=10 + i, n=900 + 50 * i, d=3 + (i % 3)) for i in range(6)]
+    ms = [pkg.MCEvidence([c], kmax=3 + (i % 2), verbose=0, backend=be, priorvolume=2.0 + i) for i, c in enumerate(chains)]
+    ms.append(pkg.MCEvidence([chains[0]], kmax=3, verbose=0, backend=OracleBackend()))            # no batch route
+    ms.append(pkg.MCEvidence([chains[1]], kmax=3, verbose=0, backend=be, nbatch=2, brange=[2.0, 2.5], bscale="logpower"))
+    np.random.seed(5)
+    ms.append(pkg.MCEvidence([chains[2]], kmax=3, verbose=0, backend=be, split=True))              # cross evidence
+    many = pkg.evidence_many(ms)
+    assert be.batches == [7]                      # 6 autos + the split object, ONE call
+    for m, got in zip(ms, many):
+        assert np.array_equal(got, m.evidence())
+    # the feed route agrees with the host-feeder route of the same oracle
+    host = pkg.MCEvidence([chains[3]], kmax=4, verbose=0, backend=OracleBackend(), priorvolume=5.0).evidence()
+    assert np.max(np.abs(many[3] - host)) < 1e-10
+    # per-object pvolume override and info=True
+    pv = [1.5] * len(ms)
+    outs = pkg.evidence_many(ms, pvolume=pv, info=True)
+    for m, (lnE, info) in zip(ms, outs):
+        assert np.array_equal(lnE, m.evidence(pvolume=1.5)) and info is m.info
+    with pytest.raises(ValueError):
+        pkg.evidence_many(ms, pvolume=[1.0, 2.0])
+    assert pkg.evidence_many([]) == []
 
 
 def test_batch_logpower():
