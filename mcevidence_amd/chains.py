@@ -28,6 +28,16 @@ import numpy as np
 logger = logging.getLogger("mcevidence_amd")
 
 
+def read_chain_file(path):
+    """One chain text file -> fp64 array [rows, columns]: what ``np.loadtxt(f)`` gives the reference
+    (:564), read by the native multi-threaded reader (``chain_io`` / ``libmcechains.so``).
+    ``MCE_CHAIN_READER=numpy`` selects NumPy's reader instead."""
+    if os.environ.get("MCE_CHAIN_READER", "native") == "numpy":
+        return np.loadtxt(path, ndmin=2)
+    from . import chain_io
+    return chain_io.loadtxt(path)
+
+
 class Partition(object):
     """One partition (s1 or s2) of the samples."""
 
@@ -176,7 +186,7 @@ class MCSamples(object):
         if not flist:
             raise IOError("no chain files found for %r" % (fname,))
         self.logger.debug("Reading from files: " + ", ".join(flist))
-        self.chains = [np.loadtxt(f, ndmin=2) for f in flist]
+        self.chains = [read_chain_file(f) for f in flist]
         return self.chains2samples(**kwargs)
 
     # -- burn / concatenate / thin / split -----------------------------------
