@@ -166,6 +166,19 @@ void mce_release_device_memory(void);
 int mce_set_search_mode(int mode);
 int mce_get_search_mode(void);
 
+/* Spatial pruning of the fp16-filter search for low-dimensional, large reference sets (d <= 13):
+ * both point sets are put in k-d order on the device (cells of 32 rows) and every wave of 64 queries
+ * visits the reference chunks nearest-box-first, multiplies only the 32-row tiles whose box is within
+ * reach, and stops once no remaining chunk can hold a neighbour.  Same neighbours, distances and
+ * tie-breaks as the exhaustive search.  0 (default): used for d <= 6 from 0.7 M reference rows and for
+ * d <= 8 from 3 M; 1: never; 2: whenever the shape allows it (d <= 13, K <= 16).  Process-wide. */
+int mce_set_prune_mode(int mode);
+int mce_get_prune_mode(void);
+/* Work actually done by the last pruned search launched by this thread through a *_dev entry point
+ * (its workspace must still be alive): fraction of (query block, reference chunk) pairs staged, and
+ * fraction of (wave, 32-row tile) products multiplied.  Synchronises the device. */
+int mce_last_prune_stats(double *chunk_fraction, double *tile_fraction);
+
 /* Measurement hook: while enabled, the search-kernel launch of every call on this thread
  * is bracketed by hipEvents recorded on the launch stream (no synchronisation);
  * mce_last_kernel_ms() waits for the brackets recorded since the last enable and returns

@@ -42,6 +42,9 @@ SIGNATURES = {
     "mce_release_device_memory": (None, []),
     "mce_set_search_mode": (_c.c_int, [_c.c_int]),
     "mce_get_search_mode": (_c.c_int, []),
+    "mce_set_prune_mode": (_c.c_int, [_c.c_int]),
+    "mce_get_prune_mode": (_c.c_int, []),
+    "mce_last_prune_stats": (_c.c_int, [_c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "mce_set_profiling": (None, [_c.c_int]),
     "mce_last_kernel_ms": (_c.c_double, []),
     "mce_knn_f64": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _c.c_int32]),
@@ -118,6 +121,26 @@ def set_search_mode(mode):
 
 def get_search_mode():
     return int(load().mce_get_search_mode())
+
+
+PRUNE_AUTO, PRUNE_OFF, PRUNE_FORCE = 0, 1, 2
+
+
+def set_prune_mode(mode):
+    """spatial pruning of the search (low d, large reference sets): 0 auto, 1 never, 2 whenever possible"""
+    check(load().mce_set_prune_mode(int(mode)))
+
+
+def get_prune_mode():
+    return int(load().mce_get_prune_mode())
+
+
+def last_prune_stats():
+    """(fraction of block x chunk pairs staged, fraction of wave x tile products multiplied) of the last
+    pruned search run through a ``*_dev`` call on this thread (its workspace must still exist)."""
+    a, b = _c.c_double(), _c.c_double()
+    check(load().mce_last_prune_stats(ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value
 
 
 def release_device_memory():

@@ -25,6 +25,7 @@
 #include "knn_generic.hpp"
 #include "feeders.hpp"
 #include "reduce_kernels.hpp"
+#include "prune.hpp"
 
 namespace {
 
@@ -34,6 +35,8 @@ thread_local char g_last_kernel[256] = "";
 thread_local int g_prof_on = 0;
 thread_local std::vector<std::pair<hipEvent_t, hipEvent_t>> g_ev_pool;   // reused brackets
 thread_local size_t g_ev_used = 0;                                        // brackets since enable
+thread_local const double* g_last_params = nullptr;                       // HP_* scalars of the last pruned launch (in the caller's workspace)
+thread_local double g_last_prune_geom[3] = {0, 0, 0};                     // blocks, chunks, tiles per chunk
 
 int fail(int code, const char* fmt, ...)
 {
@@ -54,6 +57,13 @@ int fail(int code, const char* fmt, ...)
 // search mode: 0 auto (fp16 filter + fp64 refine where supported, else fp64 MFMA),
 //              1 fp64 MFMA sweep only, 2 same as 0 (explicit)
 std::atomic<int> g_mode{0};
+// spatial pruning (prune.hpp): 0 auto (low d, large reference sets), 1 never, 2 whenever the shape allows it
+std::atomic<int> g_prune_mode{0};
+// measured on MI355X (tools/prune_sweep.sh, K = 10): the walk wins from ~0.7 M reference rows at d <= 6
+// (1 M x 6: 40 vs 57 ms; 10 M x 6: 0.52 vs 3.95 s; 10 M x 3: 0.35 vs 4.0 s) and from ~3 M rows at d = 7..8
+// (4 M x 8: 0.53 vs 0.69 s); at d >= 9 the boxes overlap too much (4 M x 10: 1.2 vs 0.69 s)
+constexpr int kPruneAutoMaxDimLow = 6, kPruneAutoMaxDimHigh = 8;
+constexpr int64_t kPruneAutoMinRowsLow = 700000, kPruneAutoMinRowsHigh = 3000000;
 
 // Device buffers of the host-pointer entry points.  Small allocations (<= 64 MB) are kept in a
 // per-thread, per-device pool between calls: the reference's typical workload is thousands of
@@ -168,6 +178,10 @@ struct Plan {
     int rsplit = 1;
     int L = 4;
     size_t off_yf = 0, off_pd = 0, off_pi = 0, off_center = 0, off_msum = 0, total = 0;
+    bool prune = false;                       // fp16 filter walking k-d ordered chunk lists (prune.hpp)
+    int64_t pl_nr = 0;                        // reference rows the plan was made for
+    mce::PruneLayout pl;
+    size_t off_prune = 0;
 };
 
 const mce::KnnVariant* variant_for(int KS, int kcap_idx)
@@ -246,6 +260,12 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     p.nchunk = (nr + rows_per_chunk - 1) / rows_per_chunk;
     p.nrow_pad = p.nchunk * rows_per_chunk;
 
+    if (f16 && p.KST == 1 && d <= mce::kPruneMaxDim && p.vh->launch_prune && nq > 0 &&
+        p.nrow_pad <= ((int64_t)1 << mce::kHRelBits) && (int64_t)p.nqblk * p.nchunk <= mce::kPruneMaxPairs) {
+        const int pm = g_prune_mode.load();
+        p.prune = pm == 2 || (pm == 0 && ((d <= kPruneAutoMaxDimLow && nr >= kPruneAutoMinRowsLow) ||
+                                           (d <= kPruneAutoMaxDimHigh && nr >= kPruneAutoMinRowsHigh)));
+    }
     // reference split r: more workgroups fill the chip and trim the last partial round
     // (one 512-thread workgroup per CU), but every split re-pays the list warm-up: a query
     // accepts ~K(1+ln(n/K)) candidates while streaming n references, each a serialised
@@ -267,6 +287,7 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
         const double c = rounds * block;
         if (c < best_c * 0.98) { best_c = c; best_r = r; }   // need >2% gain to take a bigger split
     }
+    if (p.prune) best_r = 1;                  // every workgroup walks its own chunk list
     p.rsplit = best_r;
     p.L = p.rsplit;
 
@@ -292,6 +313,12 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     off = align_up(off + (size_t)3 * mce::kMaxDimPad * sizeof(double), 256);      // centre | box(Y) | box(X)
     p.off_msum = off;
     off = align_up(off + (size_t)mce::kMeanBlocks * mce::kStatStride * sizeof(double), 256);
+    if (p.prune) {
+        mce::prune_layout(nq, p.nq_pad, p.nqblk, nr, p.nrow_pad, p.nchunk, d, p.pl);
+        p.pl_nr = nr;
+        p.off_prune = off;
+        off = align_up(off + p.pl.total, 256);
+    }
     p.total = off;
     return MCE_OK;
 }
@@ -353,7 +380,18 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
         double* params = reinterpret_cast<double*>(ws + p.off_params);
         MCE_HIP(hipMemsetAsync(params, 0, mce::HP_COUNT * sizeof(double), st));
         // queries that are literally rows of the reference buffer are inside its bounding box already
-        const bool separate_queries = !(dX >= dY && dX + (size_t)nq * d <= dY + (size_t)nr * d);
+        bool separate_queries = !(dX >= dY && dX + (size_t)nq * d <= dY + (size_t)nr * d);
+        const double* sX = dX;     // the rows the search reads: the caller's, or their k-d ordered copies
+        const double* sY = dY;
+        mce::PruneOut po;
+        if (p.prune) {
+            const bool same_set = (dX == dY && nq == nr);
+            MCE_HIP(mce::prune_prepare(dX, nq, dY, nr, (int)d, same_set, mce::f16_qpb(p.KCAP), p.CT * 32, p.nq_pad, p.nqblk, p.nrow_pad,
+                                       p.nchunk, ws + p.off_prune, p.pl, st, po));
+            sX = po.Xs;
+            sY = po.Ys;
+            separate_queries = separate_queries && !same_set;
+        }
         if (separate_queries) {
             hipLaunchKernelGGL(mce::col_stats_partial_kernel, dim3(mce::kMeanBlocks), dim3(mce::kMeanThreads), 0, st, dX, nq, (int)d, msum);
             MCE_HIP(hipGetLastError());
@@ -366,17 +404,31 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
             const int64_t rows_per_block = 4 * (64 / (2 * p.KST));          // 4 waves x R rows
             const int64_t pack_blocks = std::min<int64_t>((p.nrow_pad + rows_per_block - 1) / rows_per_block, 2048);   // grid-stride
             hipLaunchKernelGGL(mce::f16_pack_refs_kernel, dim3((unsigned)pack_blocks), dim3(256), 0, st,
-                               dY, nr, (int)d, p.KST, p.nrow_pad, center, params, yh);
+                               sY, nr, (int)d, p.KST, p.nrow_pad, center, params, yh);
             MCE_HIP(hipGetLastError());
             hipLaunchKernelGGL(mce::f16_pack_queries_kernel, dim3((unsigned)((p.nq_pad + rows_per_block - 1) / rows_per_block)), dim3(256), 0, st,
-                               dX, nq, p.nq_pad, (int)d, p.KST, center, params, xh, qinfo);
+                               sX, nq, p.nq_pad, (int)d, p.KST, center, params, xh, qinfo);
             MCE_HIP(hipGetLastError());
         }
         mce::KnnF16Args a;
         a.Yh = yh; a.nchunk_total = p.nchunk; a.rsplit = p.rsplit; a.Xh = xh; a.qinfo = qinfo; a.params = params;
-        a.X = dX; a.Y = dY; a.nq = nq; a.nr = nr; a.D = d; a.nq_pad = p.nq_pad; a.nqblk = p.nqblk;
+        a.X = sX; a.Y = sY; a.nq = nq; a.nr = nr; a.D = d; a.nq_pad = p.nq_pad; a.nqblk = p.nqblk;
         a.self_exclude = (self_mode == MCE_SELF_EXCLUDE) ? 1 : 0;
         a.self_offset = self_offset; a.ksel = K; a.part_d = pd; a.part_i = pi;
+        if (p.prune) {
+            a.clist = po.clist; a.cdist = po.cdist; a.list_len = (int)p.nchunk; a.rperm = po.rperm; a.qperm = po.qperm;
+            a.tbox_r = po.tbox_r; a.tbox_q = po.tbox_q; a.cbox_r = po.cbox_r;
+            int rc = prof_begin();
+            if (rc != MCE_OK) return rc;
+            MCE_HIP(p.vh->launch_prune(a, st));
+            rc = prof_end();
+            if (rc != MCE_OK) return rc;
+            g_last_params = params;
+            g_last_prune_geom[0] = p.nqblk; g_last_prune_geom[1] = (double)p.nchunk; g_last_prune_geom[2] = p.CT;
+            snprintf(g_last_kernel, sizeof(g_last_kernel), "%s pruned grid=%d block=64 lds=%zu qt=%d ct=%d chunks=%lld", p.vh->name,
+                     p.nqblk * mce::kHWaves, mce::f16_prune_lds_bytes(p.KST), p.QT, p.CT, (long long)p.nchunk);
+            return MCE_OK;
+        }
         int rc = prof_begin();
         if (rc != MCE_OK) return rc;
         MCE_HIP(p.vh->launch(a, st));
@@ -426,10 +478,16 @@ int launch_merge(const Plan& p, bool write_dist, bool fuse, const double* dX, co
     const int* pi = reinterpret_cast<const int*>(ws + p.off_pi);
     const bool refine = p.vh == nullptr && !p.generic;   // fp64 sweep keys are GEMM-form: refine; the others are exact
     const double lnc = fuse ? ln_unit_ball(d) : 0.0;
+    // pruned search: list column q is the q-th query in k-d order; its caller row is qperm[q]
+    const int* qperm = nullptr;
+    if (p.prune) {
+        const bool same_set = (dX == dY && nq == p.pl_nr);
+        qperm = reinterpret_cast<const int*>(ws + p.off_prune + (same_set ? p.pl.perm_r : p.pl.perm_q));
+    }
 #define MCE_MERGE(W, F, R)                                                                                          \
     hipLaunchKernelGGL((mce::merge_lists_kernel<W, F, R>), dim3(blocks), dim3(mce::kRedThreads), 0, st, pd, pi, p.L,  \
                        p.KCAP, nq, p.nq_pad, dX, dY, (int)d, K, self_mode, self_offset, d_dist, d_idx, K, k0, kmax, \
-                       d_w, d_fs, lnc, partial)
+                       d_w, d_fs, lnc, partial, qperm)
     if (write_dist && !fuse) { if (refine) MCE_MERGE(true, false, true); else MCE_MERGE(true, false, false); }
     else if (write_dist && fuse) { if (refine) MCE_MERGE(true, true, true); else MCE_MERGE(true, true, false); }
     else { if (refine) MCE_MERGE(false, true, true); else MCE_MERGE(false, true, false); }
@@ -462,6 +520,32 @@ int mce_set_search_mode(int mode)
 }
 
 int mce_get_search_mode(void) { return g_mode.load(); }
+
+int mce_set_prune_mode(int mode)
+{
+    if (mode < 0 || mode > 2) return fail(MCE_ERR_INVALID, "prune mode must be 0 (auto), 1 (never) or 2 (whenever the shape allows it)");
+    g_prune_mode.store(mode);
+    return MCE_OK;
+}
+
+int mce_get_prune_mode(void) { return g_prune_mode.load(); }
+
+int mce_last_prune_stats(double* chunk_fraction, double* tile_fraction)
+{
+    if (!chunk_fraction || !tile_fraction) return fail(MCE_ERR_INVALID, "null pointer argument");
+    if (!g_last_params) return fail(MCE_ERR_INVALID, "no pruned search has run on this thread");
+    double hp[mce::HP_COUNT];
+    MCE_HIP(hipDeviceSynchronize());
+    MCE_HIP(hipMemcpy(hp, g_last_params, sizeof(hp), hipMemcpyDeviceToHost));
+    const double pairs = g_last_prune_geom[0] * g_last_prune_geom[1];
+    *chunk_fraction = hp[mce::HP_STAT_CHUNKS] / pairs;
+    *tile_fraction = hp[mce::HP_STAT_TILES] / (pairs * mce::kHWaves * g_last_prune_geom[2]);
+    if (std::getenv("MCE_PRUNE_PROF")) {
+        const double nw = g_last_prune_geom[0] * mce::kHWaves;
+        fprintf(stderr, "[prune prof] per wave (cycles@100MHz): walk %.0f stage %.0f mul %.0f drain %.0f total %.0f  candidates drained %.0f\n", hp[8] / nw, hp[9] / nw, hp[10] / nw, hp[11] / nw, hp[12] / nw, hp[13] / nw);
+    }
+    return MCE_OK;
+}
 
 void mce_set_profiling(int on)
 {

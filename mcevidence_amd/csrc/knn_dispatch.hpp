@@ -54,10 +54,20 @@ struct KnnF16Args {
     int ksel;
     double* part_d;
     int* part_i;
+    // pruned walk (prune.hpp); all null / 0 for the exhaustive sweep
+    const int* clist = nullptr;
+    const float* cdist = nullptr;
+    int list_len = 0;
+    const int* rperm = nullptr;
+    const int* qperm = nullptr;
+    const float* tbox_r = nullptr;
+    const float* tbox_q = nullptr;
+    const float* cbox_r = nullptr;
 };
 typedef hipError_t (*knn_f16_launch_fn)(const KnnF16Args&, hipStream_t);
 struct KnnF16Variant {
     knn_f16_launch_fn launch;
+    knn_f16_launch_fn launch_prune;   // PRUNE = true instantiation (KST = 1 only), else null
     int kst, kcap, qt, ct;
     size_t lds_bytes;
     const char* name;

@@ -68,6 +68,12 @@ constexpr int kHThreads = kHWaves * 64;
 #ifndef MCE_H_TRIGGER
 #define MCE_H_TRIGGER 96
 #endif
+#ifndef MCE_PRUNE_PROF
+#define MCE_PRUNE_PROF 0
+#endif
+#ifndef MCE_H_PRUNE_TRIGGER
+#define MCE_H_PRUNE_TRIGGER 48
+#endif
 #ifndef MCE_H_STAGE_KB
 #define MCE_H_STAGE_KB 48
 #endif
@@ -75,9 +81,10 @@ constexpr int kHQueue = MCE_H_QUEUE;          // candidate queue entries per wav
 constexpr int kHDrainTrigger = MCE_H_TRIGGER;    // a wave with this many queued candidates asks the workgroup to drain
 constexpr int kHRelBits = MCE_H_GEOM == 1 ? 25 : 26;   // queue entry = query-local (6|7 bits) << kHRelBits | row - first row of the split
 constexpr double kHTargetRadius = 200.0;
+constexpr int kPruneDims = 13;                // pruned walk: largest d (KST = 1)
 
 // device-side scalars shared by the f16 kernels (doubles; maxima kept as bit patterns)
-enum { HP_RMAX = 0, HP_SCALE = 1, HP_EY = 2, HP_YHATMAX = 3, HP_RHO = 4, HP_COUNT = 8 };
+enum { HP_RMAX = 0, HP_SCALE = 1, HP_EY = 2, HP_YHATMAX = 3, HP_RHO = 4, HP_STAT_CHUNKS = 5, HP_STAT_TILES = 6, HP_COUNT = 16 };   // STAT_*: pruned walk, totals over the launch
 
 __host__ __device__ constexpr int f16_ksteps(int D) { return (D + 3 + 15) / 16; }          // 16-wide k-steps
 __host__ __device__ constexpr int f16_qt(int) { return kHQT; }
@@ -90,7 +97,13 @@ __host__ __device__ constexpr size_t f16_lds_bytes(int KST, int KCAP)
 {
     return (size_t)2 * f16_chunk_tiles(KST) * KST * 1024             // staging
            + (size_t)kHWaves * kHQueue * 16                            // queues: packed(4) + next(4) + d2(8)
-           + (size_t)kHWaves * kHQT * 32 * 4 + 64;                     // chain heads + votes
+           + (size_t)kHWaves * kHQT * 32 * 4 + 128;                    // chain heads + votes + block thresholds (pruned walk)
+}
+
+__host__ __device__ constexpr int f16_prune_slice_bytes(int KST) { return 8 * KST * 1024 + 256; }   // kBatch tiles + pending ids
+__host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST)
+{
+    return (size_t)f16_prune_slice_bytes(KST) + (size_t)kHQueue * 16 + (size_t)kHQT * 32 * 4 + 128;
 }
 
 // ---------------------------------------------------------------------------
@@ -98,13 +111,26 @@ __host__ __device__ constexpr size_t f16_lds_bytes(int KST, int KCAP)
 //   grid.x = nqblk * rsplit (as knn_mfma_kernel); lists out: part_d/part_i [rsplit][KCAP][nq_pad]
 //   with EXACT squared distances as keys.
 // ---------------------------------------------------------------------------
-template <int KST, int KCAP>
+//
+// PRUNE = true (prune.hpp): X / Y / Xh / Yh are in k-d order; the workgroup walks ITS list of
+// reference chunks (clist/cdist [nqblk][list_len], nearest box first) and stops at the first
+// entry whose lower bound exceeds the largest current K-th distance of its 512 queries; inside
+// every wave walks the list on its own (no staging, no barriers) and multiplies only the 32-row
+// tiles whose box (tbox_r, [chunk][2][D][CT]) is within reach of one of its two query tiles
+// (tbox_q [tile][2][D], per-tile thresholds); cbox_r [chunk][2][D] are the chunk boxes, tested 64 list
+// entries at a time before any tile box is read.  The lists then carry the CALLER's
+// row numbers (rperm), so ties break exactly as without pruning; the own row of query q is
+// rperm-row self_offset + qperm[q].  rsplit must be 1.
+template <int KST, int KCAP, bool PRUNE = false>
 __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ? 4 : 2)) void knn_f16_kernel(
     const _Float16* __restrict__ Yh, int64_t nchunk_total, int rsplit,
     const _Float16* __restrict__ Xh, const double* __restrict__ qinfo, const double* __restrict__ params,
     const double* __restrict__ X, const double* __restrict__ Y, int64_t nq, int64_t nr, int D,
     int64_t nq_pad, int nqblk, int self_exclude, int64_t self_offset, int ksel,
-    double* __restrict__ part_d, int* __restrict__ part_i)
+    double* __restrict__ part_d, int* __restrict__ part_i,
+    const int* __restrict__ clist, const float* __restrict__ cdist, int list_len,
+    const int* __restrict__ rperm, const int* __restrict__ qperm,
+    const float* __restrict__ tbox_r, const float* __restrict__ tbox_q, const float* __restrict__ cbox_r)
 {
     constexpr int QT = f16_qt(KCAP);
     constexpr int QPW = QT * 32;                         // queries per wave
@@ -112,16 +138,22 @@ __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ?
     constexpr int CT = f16_chunk_tiles(KST);
     static_assert(CT % 2 == 0, "tile loop is unrolled by two");
     constexpr int CHUNK_BYTES = CT * KST * 1024;
+    (void)QPB;
     constexpr int CHUNK_VEC = CHUNK_BYTES / 16;
     constexpr int VPT = (CHUNK_VEC + kHThreads - 1) / kHThreads;
     static_assert(CHUNK_VEC % kHThreads == 0, "chunk must be a whole number of 16-byte vectors per thread");
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     // LDS map: [2 staging buffers][queue d2: W*Q f64][queue packed: W*Q i32][queue next: W*Q i32][heads W*64][votes 2]
+    // PRUNE: ONE wave per workgroup (the waves share nothing in that mode, and single-wave
+    // workgroups let the hardware balance their very uneven walks): [tile slice + pending ids]
+    // [queue d2][queue packed][queue next][heads]; workgroup g serves wave g%8 of query block g/8.
+    constexpr int LW = PRUNE ? 1 : kHWaves;                       // waves sharing this LDS allocation
+    constexpr int STAGE_BYTES = PRUNE ? f16_prune_slice_bytes(KST) : 2 * CT * KST * 1024;
     char* const stage0 = lds_raw;
-    double* const qd2_all = reinterpret_cast<double*>(lds_raw + 2 * CHUNK_BYTES);
-    int* const qpk_all = reinterpret_cast<int*>(qd2_all + kHWaves * kHQueue);
-    int* const qnx_all = qpk_all + kHWaves * kHQueue;
-    int* const head_all = qnx_all + kHWaves * kHQueue;
+    double* const qd2_all = reinterpret_cast<double*>(lds_raw + STAGE_BYTES);
+    int* const qpk_all = reinterpret_cast<int*>(qd2_all + LW * kHQueue);
+    int* const qnx_all = qpk_all + LW * kHQueue;
+    int* const head_all = qnx_all + LW * kHQueue;
 
 #if MCE_STATS
     const long long t_kernel0 = clock64();
@@ -129,9 +161,10 @@ __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ?
 #endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qblk = blockIdx.x % nqblk;
-    const int split = blockIdx.x / nqblk;
+    const int lwave = PRUNE ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);                  // index into the LDS regions
+    const int wave = PRUNE ? (int)(blockIdx.x % kHWaves) : lwave;                            // position inside the query block
+    const int qblk = PRUNE ? (int)(blockIdx.x / kHWaves) : (int)(blockIdx.x % nqblk);
+    const int split = PRUNE ? 0 : (int)(blockIdx.x / nqblk);
 
     const int64_t cps = (nchunk_total + rsplit - 1) / rsplit;
     const int64_t c_begin = (int64_t)split * cps;
@@ -139,11 +172,15 @@ __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ?
     if (c_end > nchunk_total) c_end = nchunk_total;
 
     const double INF = __builtin_huge_val();
-    double* const wqd = qd2_all + wave * kHQueue;               // exact distance of a queued entry (phase A)
-    int* const wq = qpk_all + wave * kHQueue;                   // packed (query-local, relative row)
-    int* const wnx = qnx_all + wave * kHQueue;                  // next entry of the same query
-    int* const whead = head_all + wave * QPW;                   // chain head per wave-local query
-    volatile int* const wvote = head_all + kHWaves * QPW;       // [2] drain votes (chunk parity)
+    double* const wqd = qd2_all + lwave * kHQueue;              // exact distance of a queued entry (phase A)
+    int* const wq = qpk_all + lwave * kHQueue;                  // packed (query-local, relative row)
+    int* const wnx = qnx_all + lwave * kHQueue;                 // next entry of the same query
+    int* const whead = head_all + lwave * QPW;                  // chain head per wave-local query
+    volatile int* const wvote = head_all + LW * QPW;            // [2] drain votes (chunk parity)
+    float mythr = __builtin_huge_valf();                        // PRUNE: largest K-th squared distance among this wave's queries (rounded up)
+    float Tq[kHQT];                                             // PRUNE: the same per 32-query tile (wave-uniform)
+#pragma unroll
+    for (int qt = 0; qt < kHQT; ++qt) Tq[qt] = __builtin_huge_valf();
     const int jsplit0 = (int)(c_begin * (CT * 32));             // first reference row of this split
 #pragma unroll
     for (int nl = 0; nl < kHNL; ++nl) whead[nl * 64 + lane] = -1;
@@ -245,7 +282,7 @@ __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ?
         constexpr int NPASS = MCE_H_NPASS;                         // 8*NPASS pairs, 8*NPASS loads per lane in flight (D <= 32)
         constexpr int EPL = (16 * KST + 3) / 8 > 4 ? 8 : 4;        // elements per lane: 4 covers D <= 32, 8 covers D <= 61
         for (int b0 = 0; b0 < qcount; b0 += NPASS * 8) {
-            int qlp[NPASS], ep[NPASS];
+            int qlp[NPASS], ep[NPASS], ojp[NPASS], qop[NPASS];
             bool okp[NPASS];
             const double* xp[NPASS];
             const double* yp[NPASS];
@@ -262,7 +299,15 @@ __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ?
                 }
                 qlp[u] = ql;
                 const int64_t q = qwave0 + ql;
-                okp[u] = valid && j < nr && q < nq && !(self_exclude && (int64_t)j == self_offset + q);
+                if constexpr (PRUNE) {
+                    okp[u] = valid && j < nr && q < nq;            // own-row test below, once the row numbers are here
+                    ojp[u] = rperm[okp[u] ? j : 0];
+                    qop[u] = qperm[okp[u] ? q : 0];
+                } else {
+                    okp[u] = valid && j < nr && q < nq && !(self_exclude && (int64_t)j == self_offset + q);
+                    ojp[u] = j;
+                    qop[u] = 0;
+                }
                 xp[u] = X + (okp[u] ? q : 0) * (int64_t)D;
                 yp[u] = Y + (okp[u] ? (int64_t)j : 0) * D;
             }
@@ -286,8 +331,11 @@ __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ?
                 a0 += __shfl_xor(a0, 1, 64);
                 a0 += __shfl_xor(a0, 2, 64);
                 a0 += __shfl_xor(a0, 4, 64);
-                if (okp[u] && sub == 0) {
+                bool ok = okp[u];
+                if constexpr (PRUNE) ok = ok && !(self_exclude && (int64_t)ojp[u] == self_offset + qop[u]);
+                if (ok && sub == 0) {
                     wqd[ep[u]] = a0;
+                    if constexpr (PRUNE) wq[ep[u]] = ojp[u];             // from here on the entry is the caller's row number
                     wnx[ep[u]] = atomicExch(&whead[qlp[u]], ep[u]);      // push onto the query's chain
                 }
             }
@@ -307,7 +355,7 @@ __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ?
                 const bool on = cur >= 0;
                 const int ce = on ? cur : 0;
                 const double d2 = on ? wqd[ce] : INF;
-                const int j = jsplit0 + (int)((unsigned)wq[ce] & ((1u << kHRelBits) - 1u));
+                const int j = PRUNE ? wq[ce] : jsplit0 + (int)((unsigned)wq[ce] & ((1u << kHRelBits) - 1u));
                 cur = on ? wnx[ce] : -1;
                 // ascending list, ties by row; d2 = +inf (idle lane) changes nothing
                 bool c_hi = (d2 < own_d[nl][KCAP - 1]) || (d2 == own_d[nl][KCAP - 1] && j < own_i[nl][KCAP - 1] && d2 < INF);
@@ -337,6 +385,18 @@ __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ?
         }
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) G[qt] = gate_of(__shfl(thr_own[qt >> 1], (qt & 1) * 32 + (lane & 31), 64), qt);
+        if constexpr (PRUNE) {
+            mythr = 0.0f;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const double tl = __shfl(thr_own[qt >> 1], (qt & 1) * 32 + (lane & 31), 64);
+                double m = (qwave0 + qt * 32 + (lane & 31) < nq) ? tl : 0.0;     // padding queries do not hold the tile back
+#pragma unroll
+                for (int o = 16; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+                Tq[qt] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(__double2float_ru(m))));
+                mythr = fmaxf(mythr, Tq[qt]);
+            }
+        }
     };
 
     // gate + enqueue for one finished tile; jb0 = first reference row of the tile.
@@ -399,48 +459,215 @@ __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ?
 #pragma unroll
         for (int r = 0; r < 16; ++r) accB[qt][r] = __builtin_nanf("");       // "no pending tile": NaN never passes the gate
 
-    if (c_begin < c_end) stage_async(c_begin, 0);
-    if (tid < 2) wvote[tid] = 0;
+    if (!PRUNE && tid < 2) wvote[tid] = 0;
+
+    // one staged chunk (vote / barrier / prefetch are done around it).  A macro, not a lambda: the
+    // accumulators must stay in registers across the two call sites.
+#define MCE_SWEEP_CHUNK(BUF, JCHUNK)                                                                       \
+    do {                                                                                                   \
+        const char* lbuf = stage0 + (BUF) * CHUNK_BYTES + lane * 16;                                       \
+        const int jchunk = (JCHUNK);                                                                       \
+        v8h a0[KST], a1[KST];                                                                              \
+        load_a(lbuf, a0);                                                                                  \
+        _Pragma("unroll 1") for (int t = 0; t < CT; t += 2)                                                \
+        {                                                                                                  \
+            load_a(lbuf + ((t + 1) * KST) * 1024, a1);                                                     \
+            mfma_tile(a0, accA);                                                                           \
+            jbA = jchunk + t * 32;                                                                         \
+            process(accB, jbB);                                                                            \
+            load_a(lbuf + ((t + 2 < CT ? t + 2 : t) * KST) * 1024, a0); /* last trip: harmless re-read */  \
+            mfma_tile(a1, accB);                                                                           \
+            jbB = jchunk + (t + 1) * 32;                                                                   \
+            process(accA, jbA);                                                                            \
+        }                                                                                                  \
+    } while (0)
 
     // Drains are taken by ALL waves of the workgroup at the same chunk boundary (a wave that
     // drained alone would hold the other seven at the next barrier): before the barrier a
     // wave whose queue is filling raises the vote of this chunk's parity; after the barrier
     // everybody reads it.  (process() still drains locally if its queue would overflow.)
-    for (int64_t c = c_begin; c < c_end; ++c) {
-        const int buf = (int)((c - c_begin) & 1);
-        if (qcount >= kHDrainTrigger && lane == 0) wvote[buf] = 1;
+    if constexpr (!PRUNE) {
+        if (c_begin < c_end) stage_async(c_begin, 0);
+        for (int64_t c = c_begin; c < c_end; ++c) {
+            const int buf = (int)((c - c_begin) & 1);
+            if (qcount >= kHDrainTrigger && lane == 0) wvote[buf] = 1;
 #if MCE_STATS
-        const long long t_b0 = clock64();
+            const long long t_b0 = clock64();
 #endif
 #if MCE_ABLATE != 3
-        __syncthreads();
+            __syncthreads();
 #else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ablation: no barrier (results invalid)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ablation: no barrier (results invalid)
 #endif
 #if MCE_STATS
-        st_tB += clock64() - t_b0;
+            st_tB += clock64() - t_b0;
 #endif
-        if ((c + 1) < c_end) stage_async(c + 1, buf ^ 1);
-        const bool all_drain = wvote[buf] != 0;
-        if (tid == 0) wvote[buf ^ 1] = 0;          // re-arm the other parity (read again only after the next barrier)
-        if (all_drain) drain();
-        const char* lbuf = stage0 + buf * CHUNK_BYTES + lane * 16;
-        const int jchunk = (int)(c * (CT * 32));
-        v8h a0[KST], a1[KST];
-        load_a(lbuf, a0);
+            if ((c + 1) < c_end) stage_async(c + 1, buf ^ 1);
+            const bool all_drain = wvote[buf] != 0;
+            if (tid == 0) wvote[buf ^ 1] = 0;          // re-arm the other parity (read again only after the next barrier)
+            if (all_drain) drain();
+            MCE_SWEEP_CHUNK(buf, (int)(c * (CT * 32)));
+        }
+    } else {
+        // Sparse walk: no chunk staging and no workgroup barriers -- every wave goes down the block's
+        // chunk list (nearest box first) on its own, stops at the first entry whose bound exceeds
+        // the largest K-th distance among ITS 64 queries, tests the 48 tile boxes of a chunk in one
+        // pass (lane t <-> tile t), collects the tiles within reach and multiplies them in batches
+        // of kBatch: the batch's A tiles (1 KB each) go through registers into the wave's private
+        // slice of the staging area and are swept from there.
+        constexpr int kBatch = 8;
+        constexpr int kPruneDrainTrigger = MCE_H_PRUNE_TRIGGER;
+        static_assert(f16_prune_slice_bytes(KST) >= kBatch * KST * 1024 + 256, "tile slice");
+        const int* const mylist = clist + (int64_t)qblk * list_len;
+        const float* const mydist = cdist + (int64_t)qblk * list_len;
+        char* const wbuf = stage0;                                          // [kBatch tiles][pending ids]
+        int* const wl = reinterpret_cast<int*>(wbuf + kBatch * KST * 1024);
+        const float* const qb = tbox_q + (qwave0 / 32) * (int64_t)(2 * D);   // this wave's QT query-tile boxes
+        int pend = 0;
+        int st_tiles = 0, st_chunks = 0;
+#if MCE_PRUNE_PROF
+        long long pt_enq = 0;
+        long long pt_walk = 0, pt_stage = 0, pt_mul = 0, pt_drain = 0; const long long pt_begin = clock64(); long long pt_t = pt_begin;
+#define MCE_PT(acc) do { const long long n_ = clock64(); acc += n_ - pt_t; pt_t = n_; } while (0)
+#else
+#define MCE_PT(acc) do {} while (0)
+#endif
+        int e = 0;
+        unsigned long long need = 0, cand = 0;
+        int c = 0, win_c = 0;
+        for (;;) {
+            // ---- collect: fill the pending list from the current chunk's mask, moving down the list
+            while (pend < kBatch) {
+                if (need == 0) {
+                    if (cand == 0) {
+                        if (e >= list_len) break;
+                        // next window of 64 list entries, lane l <-> entry e + l: still within this wave's
+                        // reach?  chunk box within reach of one of the query tiles?
+                        const int idx = e + lane;
+                        const bool in = idx < list_len;
+                        const float cd = in ? mydist[idx] : __builtin_huge_valf();
+                        win_c = in ? mylist[idx] : 0;
+                        const bool far = cd > mythr;                   // sorted: once true, true for all later entries
+                        const float* bb = cbox_r + (int64_t)win_c * (2 * D);
+                        float acc[QT];
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) acc[qt] = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < kPruneDims; ++i) {
+                            if (i < D) {
+                                const float rlo = bb[i], rhi = bb[D + i];
+#pragma unroll
+                                for (int qt = 0; qt < QT; ++qt) {
+                                    const float g = fmaxf(0.0f, fmaxf(qb[qt * 2 * D + i] - rhi, rlo - qb[qt * 2 * D + D + i]));
+                                    acc[qt] = fmaf(g, g, acc[qt]);
+                                }
+                            }
+                        }
+                        bool reach = false;
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) reach |= !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]);
+                        cand = __ballot(in && !far && reach);
+                        e = (__ballot(in && far) != 0) ? list_len : e + 64;
+                        st_chunks += 1;
+                        if (cand == 0) continue;
+                    }
+                    const int bsel = (int)__builtin_ctzll(cand);
+                    cand &= cand - 1;
+                    c = __shfl(win_c, bsel, 64);
+                    const float* cb = tbox_r + (int64_t)c * (2 * D * CT) + (lane < CT ? lane : 0);
+                    // fp32 is enough for a rigorous bound: a gap fl(a - b) of two floats is within 2^-24
+                    // of exact, the sum of <= 13 squares within 2^-19; the comparison gives back 2^-18
+                    float acc[QT];
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) acc[qt] = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < kPruneDims; ++i) {
+                        if (i < D) {
+                            const float rlo = cb[i * CT], rhi = cb[(D + i) * CT];
+#pragma unroll
+                            for (int qt = 0; qt < QT; ++qt) {
+                                const float g = fmaxf(0.0f, fmaxf(qb[qt * 2 * D + i] - rhi, rlo - qb[qt * 2 * D + D + i]));
+                                acc[qt] = fmaf(g, g, acc[qt]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) need |= __ballot(lane < CT && !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]));
+                    st_tiles += __builtin_popcountll(need);
+                    if (need == 0) continue;
+                }
+                // append the lowest (kBatch - pend) set bits
+                const bool mine = (need >> lane) & 1ull;
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
+                const bool take = mine && rank < kBatch - pend;
+                if (take) wl[pend + rank] = c * CT + lane;
+                const unsigned long long taken = __ballot(take);
+                need &= ~taken;
+                pend += __builtin_popcountll(taken);
+            }
+            MCE_PT(pt_walk);
+            if (pend == 0) break;
+            // ---- multiply the pending tiles
+            // global -> registers -> the wave's LDS slice (all loads of the batch in flight together).
+            // Not LDS-DMA: a DMA's landing is ordered for ds_read only by vmcnt PLUS a workgroup
+            // barrier, and these waves share no barrier.
+            {
+                v8h stg[kBatch][KST];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    if (u < pend) {
+                        const int id = __builtin_amdgcn_readfirstlane(wl[u]);
+                        const _Float16* src = Yh + (int64_t)id * (KST * 512) + lane * 8;
+#pragma unroll
+                        for (int ks = 0; ks < KST; ++ks) stg[u][ks] = *reinterpret_cast<const v8h*>(src + ks * 512);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    if (u < pend) {
+#pragma unroll
+                        for (int ks = 0; ks < KST; ++ks) *reinterpret_cast<v8h*>(wbuf + (u * KST + ks) * 1024 + lane * 16) = stg[u][ks];
+                    }
+                }
+            }
+            MCE_PT(pt_stage);
+            {
+                // (no mfma/gate overlap across tiles: measured, the multiply phase is bound by the gate and
+                // enqueue work, and a second accumulator tile costs 50+ spilled registers here.)  The gate
+                // reads the accumulators through inline asm (v_min3_f32), which the compiler's hazard
+                // recogniser does not cover: the MFMA result latency (16 passes -> 18 wait states) is
+                // waited out by hand, tied to the registers so it cannot be scheduled away.
+                const char* lbuf = wbuf + lane * 16;
+                v8h a0[KST];
 #pragma unroll 1
-        for (int t = 0; t < CT; t += 2) {
-            load_a(lbuf + ((t + 1) * KST) * 1024, a1);
-            mfma_tile(a0, accA);
-            jbA = jchunk + t * 32;
-            process(accB, jbB);
-            load_a(lbuf + ((t + 2 < CT ? t + 2 : t) * KST) * 1024, a0);      // (last trip: harmless re-read)
-            mfma_tile(a1, accB);
-            jbB = jchunk + (t + 1) * 32;
-            process(accA, jbA);
+                for (int u = 0; u < pend; ++u) {
+                    load_a(lbuf + (u * KST) * 1024, a0);
+                    mfma_tile(a0, accA);
+                    static_assert(QT == 2, "wait-state asm names both accumulator tiles");
+                    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(accA[0]), "+v"(accA[1]));
+                    process(accA, __builtin_amdgcn_readfirstlane(wl[u]) * 32);
+                }
+            }
+            pend = 0;
+            MCE_PT(pt_mul);
+#if MCE_PRUNE_PROF
+            if (qcount >= kPruneDrainTrigger) pt_enq += qcount;
+#endif
+            if (qcount >= kPruneDrainTrigger) drain();
+            MCE_PT(pt_drain);
+        }
+        if (lane == 0) {                                   // launch totals: chunks tested and tiles multiplied, per wave
+            double* stat = const_cast<double*>(params);
+            unsafeAtomicAdd(stat + HP_STAT_CHUNKS, (double)st_chunks);
+            unsafeAtomicAdd(stat + HP_STAT_TILES, (double)st_tiles);
+#if MCE_PRUNE_PROF
+            unsafeAtomicAdd(stat + 8, (double)pt_walk); unsafeAtomicAdd(stat + 9, (double)pt_stage); unsafeAtomicAdd(stat + 10, (double)pt_mul);
+            unsafeAtomicAdd(stat + 11, (double)pt_drain); unsafeAtomicAdd(stat + 12, (double)(clock64() - pt_begin)); unsafeAtomicAdd(stat + 13, (double)pt_enq);
+#endif
         }
     }
-    process(accB, jbB);
+#undef MCE_SWEEP_CHUNK
+    if constexpr (!PRUNE) process(accB, jbB);
     drain();
 
 #if MCE_STATS

@@ -31,13 +31,13 @@ hipError_t launch_variant(const KnnArgs& a, hipStream_t st)
 }
 
 #if MCE_KCAP <= 16
-template <int KST, int KCAP>
+template <int KST, int KCAP, bool PRUNE>
 hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
 {
-    constexpr size_t LDS = f16_lds_bytes(KST, KCAP);
+    constexpr size_t LDS = PRUNE ? f16_prune_lds_bytes(KST) : f16_lds_bytes(KST, KCAP);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set[kMaxDevices] = {};
-    auto kern = knn_f16_kernel<KST, KCAP>;
+    auto kern = knn_f16_kernel<KST, KCAP, PRUNE>;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= kMaxDevices || !attr_set[dev]) {
@@ -45,10 +45,11 @@ hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
         if (e != hipSuccess) return e;
         if (dev < kMaxDevices) attr_set[dev] = true;
     }
-    const dim3 grid((unsigned)(a.nqblk * a.rsplit));
-    hipLaunchKernelGGL(kern, grid, dim3(kHThreads), LDS, st, static_cast<const _Float16*>(a.Yh), a.nchunk_total, a.rsplit,
+    // pruned walk: one 64-thread workgroup per wave of a query block
+    const dim3 grid((unsigned)(PRUNE ? a.nqblk * kHWaves : a.nqblk * a.rsplit));
+    hipLaunchKernelGGL(kern, grid, dim3(PRUNE ? 64 : kHThreads), LDS, st, static_cast<const _Float16*>(a.Yh), a.nchunk_total, a.rsplit,
                        static_cast<const _Float16*>(a.Xh), a.qinfo, a.params, a.X, a.Y, a.nq, a.nr, a.D, a.nq_pad, a.nqblk,
-                       a.self_exclude, a.self_offset, a.ksel, a.part_d, a.part_i);
+                       a.self_exclude, a.self_offset, a.ksel, a.part_d, a.part_i, a.clist, a.cdist, a.list_len, a.rperm, a.qperm, a.tbox_r, a.tbox_q, a.cbox_r);
     return hipGetLastError();
 }
 #endif
@@ -70,18 +71,19 @@ extern const KnnVariant MCE_CAT(g_knn_kcap, MCE_KCAP)[kMaxKS] = {
     MCE_VARIANT(13), MCE_VARIANT(14), MCE_VARIANT(15), MCE_VARIANT(16),
 };
 #if MCE_KCAP <= 16
-#define MCE_F16_VARIANT(KST)                                                                             \
-    {&launch_f16_variant<KST, MCE_KCAP>, KST, MCE_KCAP, f16_qt(MCE_KCAP), f16_chunk_tiles(KST),          \
+#define MCE_F16_VARIANT(KST, PRUNE_FN)                                                                   \
+    {&launch_f16_variant<KST, MCE_KCAP, false>, PRUNE_FN, KST, MCE_KCAP, f16_qt(MCE_KCAP), f16_chunk_tiles(KST), \
      f16_lds_bytes(KST, MCE_KCAP), "knn_f16_kernel<KST=" #KST ",KCAP=" MCE_STR(MCE_KCAP) ">"}
 extern const KnnF16Variant MCE_CAT(g_knn_f16_kcap, MCE_KCAP)[kMaxKST] = {
-    MCE_F16_VARIANT(1), MCE_F16_VARIANT(2), MCE_F16_VARIANT(3), MCE_F16_VARIANT(4),
+    MCE_F16_VARIANT(1, (&launch_f16_variant<1, MCE_KCAP, true>)), MCE_F16_VARIANT(2, nullptr), MCE_F16_VARIANT(3, nullptr),
+    MCE_F16_VARIANT(4, nullptr),
 };
 #endif
 #else
 // device pass: force the kernel instantiations
 #if MCE_KCAP <= 16
-#define MCE_F16_INST(KST) template __global__ void knn_f16_kernel<KST, MCE_KCAP>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*);
-MCE_F16_INST(1) MCE_F16_INST(2) MCE_F16_INST(3) MCE_F16_INST(4)
+#define MCE_F16_INST(KST, PR) template __global__ void knn_f16_kernel<KST, MCE_KCAP, PR>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*);
+MCE_F16_INST(1, false) MCE_F16_INST(2, false) MCE_F16_INST(3, false) MCE_F16_INST(4, false) MCE_F16_INST(1, true)
 #endif
 #define MCE_INST(KS) template __global__ void knn_mfma_kernel<KS, MCE_KCAP>(const double*, int64_t, int, const double*, const double*, int64_t, int, int64_t, int, int, int64_t, int, double*, int*);
 MCE_INST(1) MCE_INST(2) MCE_INST(3) MCE_INST(4) MCE_INST(5) MCE_INST(6) MCE_INST(7) MCE_INST(8)

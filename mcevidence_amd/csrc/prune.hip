@@ -1,0 +1,303 @@
+// prune.hip -- k-d ordering, boxes and sorted chunk lists for the pruned search (see prune.hpp).
+#include "prune.hpp"
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+#include <algorithm>
+
+namespace mce {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int tree_levels(int64_t n_units)
+{
+    int L = 0;
+    while (((int64_t)1 << L) < n_units) ++L;
+    return L;
+}
+
+// key = (node id at `level`) << 32 | order-preserving bits of (float) coordinate; padding rows
+// sort behind everything in their node (which is always the last node).
+__global__ __launch_bounds__(kThreads) void kd_key_kernel(const int* __restrict__ perm_in, int64_t n, int64_t n_pad, int unit_rows,
+                                                          int n_units, int level, const double* __restrict__ P, int d, int dim,
+                                                          unsigned long long* __restrict__ keys, int* __restrict__ vals)
+{
+    const int64_t pos = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (pos >= n_pad) return;
+    const int row = perm_in ? perm_in[pos] : (pos < n ? (int)pos : -1);
+    const int u = (int)(pos / unit_rows);
+    int lo = 0, hi = n_units;
+    unsigned id = 0;
+    for (int l = 0; l < level; ++l) {
+        if (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (u < mid) { hi = mid; id = 2 * id; }
+            else { lo = mid; id = 2 * id + 1; }
+        } else {
+            id = 2 * id;
+        }
+    }
+    unsigned b = 0xFFFFFFFFu;
+    if (row >= 0) {
+        const float c = (float)P[(int64_t)row * d + dim];
+        b = __float_as_uint(c);
+        b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+        if (b == 0xFFFFFFFFu) b = 0xFFFFFFFEu;
+    }
+    keys[pos] = ((unsigned long long)id << 32) | b;
+    vals[pos] = row;
+}
+
+__global__ __launch_bounds__(kThreads) void identity_perm_kernel(int64_t n, int64_t n_pad, int* __restrict__ perm)
+{
+    const int64_t pos = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (pos < n_pad) perm[pos] = pos < n ? (int)pos : -1;
+}
+
+// out[pos][:] = P[perm[pos]][:] for the n real rows (they occupy the first n sorted positions)
+__global__ __launch_bounds__(kThreads) void gather_rows_kernel(const double* __restrict__ P, const int* __restrict__ perm, int64_t n, int d,
+                                                               double* __restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (e >= n * d) return;
+    const int64_t pos = e / d;
+    const int c = (int)(e - pos * d);
+    out[e] = P[(int64_t)perm[pos] * d + c];
+}
+
+// bounding boxes of the 32-row tiles, as floats rounded OUTWARD (still enclosing):
+// tbox[t][0][i] = lo, tbox[t][1][i] = hi; tiles past the last row are empty (lo = +inf, hi = -inf)
+__global__ __launch_bounds__(kThreads) void tile_box_kernel(const double* __restrict__ Ps, int64_t n, int d, int64_t ntiles,
+                                                            float* __restrict__ tbox)
+{
+    const int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (e >= ntiles * d) return;
+    const int64_t t = e / d;
+    const int i = (int)(e - t * d);
+    const int64_t r0 = t * kPruneTileRows;
+    const int64_t r1 = (r0 + kPruneTileRows < n) ? r0 + kPruneTileRows : n;
+    double lo = __builtin_huge_val(), hi = -__builtin_huge_val();
+    for (int64_t r = r0; r < r1; ++r) {
+        const double v = Ps[r * d + i];
+        lo = fmin(lo, v);
+        hi = fmax(hi, v);
+    }
+    tbox[(t * 2 + 0) * d + i] = __double2float_rd(lo);
+    tbox[(t * 2 + 1) * d + i] = __double2float_ru(hi);
+}
+
+// tbT[c][s][i][t] = tbox[c*group + t][s][i]: lane t of a wave reads tile t of chunk c with unit stride
+__global__ __launch_bounds__(kThreads) void transpose_tile_box_kernel(const float* __restrict__ tbox, int64_t ntiles, int d, int group,
+                                                                      float* __restrict__ tbT)
+{
+    const int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (e >= ntiles * 2 * d) return;
+    const int64_t t = e / (2 * d);
+    const int si = (int)(e - t * 2 * d);                 // s*d + i
+    const int64_t c = t / group;
+    const int tt = (int)(t - c * group);
+    tbT[(c * 2 * d + si) * group + tt] = tbox[e];
+}
+
+// box of `group` consecutive tiles (a staging chunk / a query block)
+__global__ __launch_bounds__(kThreads) void group_box_kernel(const float* __restrict__ tbox, int64_t ntiles, int d, int group, int ngroups,
+                                                             float* __restrict__ gbox)
+{
+    const int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (e >= (int64_t)ngroups * d) return;
+    const int64_t g = e / d;
+    const int i = (int)(e - g * d);
+    float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf();
+    for (int64_t t = g * group; t < (g + 1) * group && t < ntiles; ++t) {
+        lo = fminf(lo, tbox[(t * 2 + 0) * d + i]);
+        hi = fmaxf(hi, tbox[(t * 2 + 1) * d + i]);
+    }
+    gbox[(g * 2 + 0) * d + i] = lo;
+    gbox[(g * 2 + 1) * d + i] = hi;
+}
+
+// lower bound on the squared distance between any point of query block b and any point of
+// chunk c, rounded DOWN to float (an empty box gives +inf)
+__global__ __launch_bounds__(kThreads) void box_dist_kernel(const float* __restrict__ qbox, int nqblk, const float* __restrict__ rbox,
+                                                            int nchunk, int d, float* __restrict__ out_d, int* __restrict__ out_c)
+{
+    const int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (e >= (int64_t)nqblk * nchunk) return;
+    const int b = (int)(e / nchunk);
+    const int c = (int)(e - (int64_t)b * nchunk);
+    const float* ql = qbox + ((int64_t)b * 2) * d;
+    const float* qh = ql + d;
+    const float* rl = rbox + ((int64_t)c * 2) * d;
+    const float* rh = rl + d;
+    double s = 0.0;
+    for (int i = 0; i < d; ++i) {
+        const double g = fmax(0.0, fmax((double)ql[i] - (double)rh[i], (double)rl[i] - (double)qh[i]));     // NaN-free: empty boxes give +inf
+        s = fma(g, g, s);
+    }
+    out_d[e] = __double2float_rd(s * (1.0 - 1e-12));
+    out_c[e] = c;
+}
+
+struct SegmentOffset {
+    unsigned stride;
+    __host__ __device__ unsigned operator()(unsigned i) const { return i * stride; }
+};
+
+using OffsetIt = rocprim::transform_iterator<rocprim::counting_iterator<unsigned>, SegmentOffset, unsigned>;
+
+OffsetIt offsets(unsigned first, unsigned stride)
+{
+    return rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned>(first), SegmentOffset{stride});
+}
+
+size_t sort_tmp_bytes(int64_t n)
+{
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr,
+                                    (int*)nullptr, (size_t)n, 0u, 64u);
+    return bytes;
+}
+
+size_t segsort_tmp_bytes(int nqblk, int64_t nchunk)
+{
+    size_t bytes = 0;
+    (void)rocprim::segmented_radix_sort_pairs(nullptr, bytes, (const float*)nullptr, (float*)nullptr, (const int*)nullptr, (int*)nullptr,
+                                              (unsigned)((int64_t)nqblk * nchunk), (unsigned)nqblk, offsets(0, (unsigned)nchunk),
+                                              offsets(1, (unsigned)nchunk), 0u, 32u);
+    return bytes;
+}
+
+// k-d order of P[n, d] in units of unit_rows; final permutation in `perm` ([n_pad])
+hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_rows, int n_units, int* perm, unsigned long long* keys_a,
+                   unsigned long long* keys_b, int* vals_b, void* tmp, size_t tmp_bytes, hipStream_t st)
+{
+    const int L = tree_levels(n_units);
+    const unsigned blocks = (unsigned)((n_pad + kThreads - 1) / kThreads);
+    if (L == 0) {
+        hipLaunchKernelGGL(identity_perm_kernel, dim3(blocks), dim3(kThreads), 0, st, n, n_pad, perm);
+        return hipGetLastError();
+    }
+    for (int level = 0; level < L; ++level) {
+        hipLaunchKernelGGL(kd_key_kernel, dim3(blocks), dim3(kThreads), 0, st, level == 0 ? (const int*)nullptr : perm, n, n_pad, unit_rows,
+                           n_units, level, P, d, level % d, keys_a, vals_b);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        size_t tb = tmp_bytes;
+        e = rocprim::radix_sort_pairs(tmp, tb, (const unsigned long long*)keys_a, keys_b, (const int*)vals_b, perm, (size_t)n_pad, 0u,
+                                      (unsigned)(32 + level), st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace
+
+int prune_layout(int64_t nq, int64_t nq_pad, int nqblk, int64_t nr, int64_t nr_pad, int64_t nchunk, int d, PruneLayout& L)
+{
+    const int64_t nmax = std::max(nq_pad, nr_pad);
+    const int64_t pairs = (int64_t)nqblk * nchunk;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L.perm_r = take((size_t)nr_pad * 4);
+    L.perm_q = take((size_t)nq_pad * 4);
+    L.keys_a = take((size_t)nmax * 8);
+    L.keys_b = take((size_t)nmax * 8);
+    L.vals_b = take((size_t)nmax * 4);
+    L.Ys = take((size_t)nr * d * 8);
+    L.Xs = take((size_t)nq * d * 8);
+    L.tbox_r = take((size_t)(nr_pad / kPruneTileRows) * 2 * d * 4);
+    L.tbox_q = take((size_t)(nq_pad / kPruneTileRows) * 2 * d * 4);
+    L.tboxT_r = take((size_t)(nr_pad / kPruneTileRows) * 2 * d * 4);
+    L.box_r = take((size_t)nchunk * 2 * d * 4);
+    L.box_q = take((size_t)nqblk * 2 * d * 4);
+    L.list_d_a = take((size_t)pairs * 4);
+    L.list_c_a = take((size_t)pairs * 4);
+    L.list_d_b = take((size_t)pairs * 4);
+    L.list_c_b = take((size_t)pairs * 4);
+    L.tmp_bytes = std::max(sort_tmp_bytes(nmax), segsort_tmp_bytes(nqblk, nchunk));
+    L.tmp = take(L.tmp_bytes);
+    L.total = off;
+    return 0;
+}
+
+hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t nr, int d, bool same_set, int qpb, int chunk_rows,
+                         int64_t nq_pad, int nqblk, int64_t nr_pad, int64_t nchunk, char* ws, const PruneLayout& L, hipStream_t st,
+                         PruneOut& out)
+{
+    int* perm_r = reinterpret_cast<int*>(ws + L.perm_r);
+    int* perm_q = reinterpret_cast<int*>(ws + L.perm_q);
+    unsigned long long* keys_a = reinterpret_cast<unsigned long long*>(ws + L.keys_a);
+    unsigned long long* keys_b = reinterpret_cast<unsigned long long*>(ws + L.keys_b);
+    int* vals_b = reinterpret_cast<int*>(ws + L.vals_b);
+    double* Ys = reinterpret_cast<double*>(ws + L.Ys);
+    double* Xs = reinterpret_cast<double*>(ws + L.Xs);
+    float* tbox_r = reinterpret_cast<float*>(ws + L.tbox_r);
+    float* tbox_q = reinterpret_cast<float*>(ws + L.tbox_q);
+    float* tboxT_r = reinterpret_cast<float*>(ws + L.tboxT_r);
+    float* box_r = reinterpret_cast<float*>(ws + L.box_r);
+    float* box_q = reinterpret_cast<float*>(ws + L.box_q);
+    float* list_d_a = reinterpret_cast<float*>(ws + L.list_d_a);
+    int* list_c_a = reinterpret_cast<int*>(ws + L.list_c_a);
+    float* list_d_b = reinterpret_cast<float*>(ws + L.list_d_b);
+    int* list_c_b = reinterpret_cast<int*>(ws + L.list_c_b);
+    void* tmp = ws + L.tmp;
+    const int64_t ntile_r = nr_pad / kPruneTileRows, ntile_q = nq_pad / kPruneTileRows;
+    auto blocks_for = [](int64_t n) { return dim3((unsigned)((n + kThreads - 1) / kThreads)); };
+
+    // references: k-d order down to single 32-row tiles, reordered copy, tile and chunk boxes
+    hipError_t e = kd_sort(dY, nr, nr_pad, d, kPruneTileRows, (int)ntile_r, perm_r, keys_a, keys_b, vals_b, tmp, L.tmp_bytes, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gather_rows_kernel, blocks_for(nr * d), dim3(kThreads), 0, st, dY, perm_r, nr, d, Ys);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(tile_box_kernel, blocks_for(ntile_r * d), dim3(kThreads), 0, st, Ys, nr, d, ntile_r, tbox_r);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(group_box_kernel, blocks_for(nchunk * d), dim3(kThreads), 0, st, tbox_r, ntile_r, d, chunk_rows / kPruneTileRows, (int)nchunk, box_r);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (same_set) {
+        out.Xs = Ys;
+        out.qperm = perm_r;          // query tile t IS reference tile t
+        out.tbox_q = tbox_r;
+    } else {
+        e = kd_sort(dX, nq, nq_pad, d, kPruneTileRows, (int)ntile_q, perm_q, keys_a, keys_b, vals_b, tmp, L.tmp_bytes, st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gather_rows_kernel, blocks_for(nq * d), dim3(kThreads), 0, st, dX, perm_q, nq, d, Xs);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(tile_box_kernel, blocks_for(ntile_q * d), dim3(kThreads), 0, st, Xs, nq, d, ntile_q, tbox_q);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        out.Xs = Xs;
+        out.qperm = perm_q;
+        out.tbox_q = tbox_q;
+    }
+    hipLaunchKernelGGL(transpose_tile_box_kernel, blocks_for(ntile_r * 2 * d), dim3(kThreads), 0, st, tbox_r, ntile_r, d,
+                       chunk_rows / kPruneTileRows, tboxT_r);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    out.tbox_r = tboxT_r;
+    out.cbox_r = box_r;
+    hipLaunchKernelGGL(group_box_kernel, blocks_for((int64_t)nqblk * d), dim3(kThreads), 0, st, out.tbox_q, same_set ? ntile_r : ntile_q, d,
+                       qpb / kPruneTileRows, nqblk, box_q);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    const int64_t pairs = (int64_t)nqblk * nchunk;
+    hipLaunchKernelGGL(box_dist_kernel, dim3((unsigned)((pairs + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, box_q, nqblk, box_r,
+                       (int)nchunk, d, list_d_a, list_c_a);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    size_t tb = L.tmp_bytes;
+    e = rocprim::segmented_radix_sort_pairs(tmp, tb, (const float*)list_d_a, list_d_b, (const int*)list_c_a, list_c_b, (unsigned)pairs,
+                                            (unsigned)nqblk, offsets(0, (unsigned)nchunk), offsets(1, (unsigned)nchunk), 0u, 32u, st);
+    if (e != hipSuccess) return e;
+    out.Ys = Ys;
+    out.rperm = perm_r;
+    out.clist = list_c_b;
+    out.cdist = list_d_b;
+    return hipSuccess;
+}
+
+}  // namespace mce

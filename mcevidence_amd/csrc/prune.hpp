@@ -1,0 +1,65 @@
+// prune.hpp -- interface of prune.hip: spatial pruning for low-dimensional, large reference sets
+// (SURVEY.md section 8f.2(ii)).
+//
+// The brute-force sweep of knn_f16.hpp visits every (query block, reference chunk) pair.  For
+// D <~ 10 and N >~ 10^6 almost all of them are provably irrelevant: if both point sets are laid
+// out in k-d order, a block of 512 queries sits in a small box, and a chunk of references whose
+// box is farther from it than the block's current worst K-th distance cannot contribute.  This
+// module produces, entirely on the device and stream-ordered (no host synchronisation):
+//   * a k-d ordering of the references and of the queries down to cells of 32 rows (= one MFMA
+//     tile): recursive median splits cycling through the dimensions, implemented as one radix
+//     sort per tree level on the key (node id, coordinate);
+//   * the reordered fp64 copies Ys / Xs and the permutations back to the caller's row numbers;
+//   * the bounding box of every 32-row tile (floats rounded outward);
+//   * per query block, the list of ALL reference chunks sorted by box-to-box distance (a rigorous
+//     lower bound, rounded down) -- the search kernel walks it, stops at the first entry whose
+//     bound exceeds the block's current threshold, and inside a chunk multiplies only the tiles
+//     whose box is within reach of one of the wave's two query tiles.
+// Results are those of the exhaustive search, bit for bit (same exact distances, same tie-breaks
+// on the caller's row numbers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mce {
+
+constexpr int kPruneTileRows = 32;                        // k-d cells = MFMA reference tiles = query tiles
+constexpr int kPruneMaxDim = 13;                          // KST = 1 variants only
+constexpr int64_t kPruneMaxPairs = (int64_t)1 << 30;      // nqblk * nchunk list entries
+
+struct PruneLayout {
+    size_t perm_r = 0, perm_q = 0;          // int32 [nr_pad], [nq_pad]: sorted position -> caller's row (-1: padding)
+    size_t keys_a = 0, keys_b = 0;          // uint64 [max(nr_pad, nq_pad)] sort keys (ping-pong)
+    size_t vals_b = 0;                      // int32 [max(nr_pad, nq_pad)]
+    size_t Ys = 0, Xs = 0;                  // double [nr * d], [nq * d] reordered rows
+    size_t tbox_r = 0, tbox_q = 0;          // float [tiles][2][d] (lo | hi), rounded outward
+    size_t tboxT_r = 0;                     // float [nchunk][2][d][tiles per chunk]: the kernel's layout
+    size_t box_r = 0, box_q = 0;            // float [nchunk][2][d], [nqblk][2][d]
+    size_t list_d_a = 0, list_c_a = 0;      // float / int32 [nqblk * nchunk] unsorted
+    size_t list_d_b = 0, list_c_b = 0;      // sorted
+    size_t tmp = 0, tmp_bytes = 0;          // rocPRIM scratch
+    size_t total = 0;
+};
+
+// pure function of its arguments (host-only size queries)
+int prune_layout(int64_t nq, int64_t nq_pad, int nqblk, int64_t nr, int64_t nr_pad, int64_t nchunk, int d, PruneLayout& L);
+
+struct PruneOut {
+    const double* Xs = nullptr;
+    const double* Ys = nullptr;
+    const int* qperm = nullptr;
+    const int* rperm = nullptr;
+    const int* clist = nullptr;             // [nqblk][nchunk] chunk ids, nearest box first
+    const float* cdist = nullptr;           // [nqblk][nchunk] matching lower bounds on the squared distance
+    const float* tbox_r = nullptr;          // reference tile boxes, [chunk][2][d][tiles per chunk]
+    const float* tbox_q = nullptr;          // query tile boxes
+    const float* cbox_r = nullptr;          // reference chunk boxes [chunk][2][d]
+};
+
+// same_set: the queries ARE the reference rows (same pointer, nq == nr): one ordering serves both
+hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t nr, int d, bool same_set, int qpb,
+                         int chunk_rows, int64_t nq_pad, int nqblk, int64_t nr_pad, int64_t nchunk, char* ws,
+                         const PruneLayout& L, hipStream_t st, PruneOut& out);
+
+}  // namespace mce

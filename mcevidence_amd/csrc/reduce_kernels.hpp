@@ -60,11 +60,14 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
     int self_mode, int64_t self_offset,
     double* __restrict__ dist, int64_t* __restrict__ idx, int ld_out,
     int k0, int kmax, const double* __restrict__ w, const double* __restrict__ fs, double lnc,
-    double* __restrict__ partial)
+    double* __restrict__ partial, const int* __restrict__ qperm)
 {
     __shared__ double red[kRedThreads / 64];
     const int64_t q = (int64_t)blockIdx.x * kRedThreads + threadIdx.x;
     const bool live = q < nq;
+    // list column q belongs to caller row qo (pruned search: queries were reordered; the lists
+    // already carry caller row numbers for the references)
+    const int64_t qo = (live && qperm) ? (int64_t)qperm[q] : q;
     const double INF = __builtin_huge_val();
 
     double term[kMaxK];
@@ -72,9 +75,9 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
     for (int k = 0; k < kMaxK; ++k) term[k] = 0.0;
 
     if (live) {
-        const int selfj = (self_mode == 1) ? (int)(self_offset + q) : -1;
+        const int selfj = (self_mode == 1) ? (int)(self_offset + qo) : -1;
         double base = 0.0;
-        if (FUSE_DOTP) base = lnc - log(w[q]) + fs[q];
+        if (FUSE_DOTP) base = lnc - log(w[qo]) + fs[qo];
 
         unsigned char head[kMaxLists];
         for (int l = 0; l < L; ++l) head[l] = 0;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
         }
         // ---- refine: exact direct-difference distances of the selected pairs ----
         // (REFINE=false: the lists already hold exact distances -- fp16-filter path)
-        const double* x = X + q * (int64_t)D;
+        const double* x = X + qo * (int64_t)D;
         for (int k = 0; REFINE && k < nsel; ++k) {
             const double* y = Y + (int64_t)sel_i[k] * D;
             double s2 = 0.0;
@@ -126,8 +129,8 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
         for (int k = 0; k < K; ++k) {
             const double d2 = (k < nsel) ? fmax(sel_d[k], 0.0) : INF;
             if (WRITE_DIST) {
-                dist[q * (int64_t)ld_out + k] = sqrt(d2);
-                if (idx) idx[q * (int64_t)ld_out + k] = (k < nsel) ? (int64_t)sel_i[k] : (int64_t)-1;
+                dist[qo * (int64_t)ld_out + k] = sqrt(d2);
+                if (idx) idx[qo * (int64_t)ld_out + k] = (k < nsel) ? (int64_t)sel_i[k] : (int64_t)-1;
             }
             if (FUSE_DOTP) {
                 // column k of the K = kmax-k0 true neighbours <-> reference column k0+k

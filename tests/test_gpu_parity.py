@@ -403,6 +403,105 @@ def test_evidence_many_matches_evidence_one_by_one(nobj):
         assert np.array_equal(lnE, one) and info is m.info and info1 is m.info
 
 
+# --------------------------------------------------------------------------- spatial pruning
+@pytest.fixture()
+def prune_modes():
+    from mcevidence_amd import _capi
+    _capi.set_search_mode(_capi.MODE_AUTO)
+    yield _capi
+    _capi.set_prune_mode(_capi.PRUNE_AUTO)
+
+
+def _both(capi, fn):
+    capi.set_prune_mode(capi.PRUNE_OFF)
+    a = fn()
+    ka = capi.last_kernel()
+    capi.set_prune_mode(capi.PRUNE_FORCE)
+    b = fn()
+    kb = capi.last_kernel()
+    assert "pruned" in kb and "pruned" not in ka, (ka, kb)
+    return a, b
+
+
+@pytest.mark.parametrize("n,d,K", [(5000, 1, 3), (20000, 2, 5), (40000, 3, 1), (60000, 6, 10), (33333, 6, 16), (25000, 9, 4), (20000, 13, 7)])
+def test_pruned_search_is_bit_identical_auto(prune_modes, n, d, K):
+    """k-d ordered, box-pruned walk vs the exhaustive sweep: same distances,
+    same neighbour rows, same order -- bit for bit -- with the own row excluded, included, ignored."""
+    capi = prune_modes
+    rng = np.random.default_rng(n + d)
+    Y = rng.standard_normal((n, d)) @ (np.eye(d) + 0.3 * rng.standard_normal((d, d)))
+    for sm in (capi.SELF_EXCLUDE, capi.SELF_INCLUDE, capi.SELF_NONE):
+        (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(Y, Y, K, self_mode=sm))
+        assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+    od, oi = orc.knn_brute(Y[:3000], Y, K, self_mode=2)
+    assert _rel(d1[:3000] if sm == capi.SELF_EXCLUDE else capi.knn(Y[:3000], Y, K, self_mode=capi.SELF_EXCLUDE)[0], od) < DIST_RTOL
+
+
+@pytest.mark.parametrize("nq,nr,d,K", [(7000, 50000, 4, 6), (513, 200000, 6, 3), (30000, 9000, 3, 12), (100, 5000, 8, 2)])
+def test_pruned_search_is_bit_identical_cross_and_shards(prune_modes, nq, nr, d, K):
+    capi = prune_modes
+    rng = np.random.default_rng(nq + nr)
+    Y = rng.standard_normal((nr, d))
+    X = rng.standard_normal((nq, d)) * 1.3 + 0.2
+    (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(X, Y, K))
+    assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+    od, oi = orc.knn_brute(X[:2000], Y, K)
+    assert _rel(d1[:2000], od) < DIST_RTOL and np.array_equal(i1[:2000], oi)
+    # a query shard of an auto search: rows [lo, hi) of Y with their own rows excluded by offset
+    lo, hi = nr // 3, nr // 3 + min(nq, nr // 2)
+    (s0, j0), (s1, j1) = _both(capi, lambda: capi.knn(Y[lo:hi], Y, K, self_mode=capi.SELF_EXCLUDE, self_offset=lo))
+    assert np.array_equal(s0, s1) and np.array_equal(j0, j1)
+    assert not np.any(j1 == np.arange(lo, hi)[:, None])
+
+
+def test_pruned_search_duplicates_clusters_and_ties(prune_modes):
+    """exact ties must break on the caller's row numbers, also after reordering; tight far-apart
+    clusters make boxes degenerate; a constant column makes a zero-width dimension."""
+    capi = prune_modes
+    rng = np.random.default_rng(9)
+    base = rng.standard_normal((3000, 4))
+    Y = np.concatenate([base, base, base[:1500], rng.standard_normal((2000, 4)) * 1e-3 + 50.0, base[::-1]])
+    Y[:, 3] = 1.25
+    Y = np.ascontiguousarray(Y[rng.permutation(len(Y))])
+    for K in (1, 4, 9):
+        (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE))
+        assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+    od, oi = orc.knn_brute(Y[:1500], Y, 4, self_mode=2)
+    g, gi = capi.knn(Y[:1500], Y, 4, self_mode=capi.SELF_EXCLUDE)
+    assert np.array_equal(g, od) and np.array_equal(gi, oi)
+    grid = np.stack(np.meshgrid(*[np.arange(12.0)] * 4), -1).reshape(-1, 4)     # 20736 lattice points: massive ties
+    (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(grid, grid, 9, self_mode=capi.SELF_EXCLUDE))
+    assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+
+
+@pytest.mark.parametrize("k0", [1, 0])
+def test_pruned_fused_reduction_and_class(prune_modes, k0):
+    capi = prune_modes
+    rng = np.random.default_rng(31 + k0)
+    n, d, kmax = 120000, 6, 5
+    X = rng.standard_normal((n, d))
+    Y = None if k0 == 1 else rng.standard_normal((90000, d))
+    w = rng.integers(1, 5, n).astype(float)
+    fs = -rng.random(n) * 4
+    (p0, q0), (p1, q1) = _both(capi, lambda: capi.knn_dotp(X, Y, w, fs, kmax, k0, return_dist=True))
+    assert np.array_equal(q0, q1)                          # the distances that entered the sums
+    assert np.allclose(p0, p1, rtol=1e-13, atol=0)         # sums: same terms, different association
+    import mcevidence_amd as pkg
+    case = G["auto_n100000_d6_k4_C2"]
+    (a, b) = _both(capi, lambda: pkg.MCEvidence([chain_of(case)], verbose=0, **case["mce"]).evidence(**case["ev"]))
+    assert np.max(np.abs(b - np.array(case["lnE"]))) < LNE_TOL and np.max(np.abs(a - b)) < 1e-12
+
+
+def test_pruned_search_at_1M_x_6_matches_reference_golden(prune_modes):
+    """N = 1M, D = 6: automatic mode picks the pruned walk; ln E against the reference's own output."""
+    capi = prune_modes
+    import mcevidence_amd as pkg
+    case = G["auto_n1000000_d6_k4_unit"]
+    lnE = pkg.MCEvidence([chain_of(case)], verbose=0, **case["mce"]).evidence(**case["ev"])
+    assert "pruned" in capi.last_kernel()
+    assert np.max(np.abs(lnE - np.array(case["lnE"]))) < LNE_TOL
+
+
 def test_sampled_rows_at_full_size_C3(capi):
     """N = 1M, D = 27 (BASELINE configs[2]): 1500 sampled query rows against the exact CPU search,
     plus size-independent properties over all rows."""
