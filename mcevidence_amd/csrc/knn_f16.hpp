@@ -71,6 +71,12 @@ constexpr int kHThreads = kHWaves * 64;
 #ifndef MCE_PRUNE_PROF
 #define MCE_PRUNE_PROF 0
 #endif
+#ifndef MCE_H_PRUNE_WAVES
+#define MCE_H_PRUNE_WAVES 2     // pruned walk: waves per SIMD the register allocation aims for
+#endif
+#ifndef MCE_H_PRUNE_BATCH
+#define MCE_H_PRUNE_BATCH 8     // pruned walk: tiles multiplied per batch (LDS slice = BATCH KB per wave)
+#endif
 #ifndef MCE_H_PRUNE_TRIGGER
 #define MCE_H_PRUNE_TRIGGER 48
 #endif
@@ -100,7 +106,7 @@ __host__ __device__ constexpr size_t f16_lds_bytes(int KST, int KCAP)
            + (size_t)kHWaves * kHQT * 32 * 4 + 128;                    // chain heads + votes + block thresholds (pruned walk)
 }
 
-__host__ __device__ constexpr int f16_prune_slice_bytes(int KST) { return 8 * KST * 1024 + 256; }   // kBatch tiles + pending ids
+__host__ __device__ constexpr int f16_prune_slice_bytes(int KST) { return MCE_H_PRUNE_BATCH * KST * 1024 + 256; }   // kBatch tiles + pending ids
 __host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST)
 {
     return (size_t)f16_prune_slice_bytes(KST) + (size_t)kHQueue * 16 + (size_t)kHQT * 32 * 4 + 128;
@@ -122,7 +128,7 @@ __host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST)
 // row numbers (rperm), so ties break exactly as without pruning; the own row of query q is
 // rperm-row self_offset + qperm[q].  rsplit must be 1.
 template <int KST, int KCAP, bool PRUNE = false>
-__global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ? 4 : 2)) void knn_f16_kernel(
+__global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES : (MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ? 4 : 2))) void knn_f16_kernel(
     const _Float16* __restrict__ Yh, int64_t nchunk_total, int rsplit,
     const _Float16* __restrict__ Xh, const double* __restrict__ qinfo, const double* __restrict__ params,
     const double* __restrict__ X, const double* __restrict__ Y, int64_t nq, int64_t nr, int D,
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(kHThreads, MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ?
         // pass (lane t <-> tile t), collects the tiles within reach and multiplies them in batches
         // of kBatch: the batch's A tiles (1 KB each) go through registers into the wave's private
         // slice of the staging area and are swept from there.
-        constexpr int kBatch = 8;
+        constexpr int kBatch = MCE_H_PRUNE_BATCH;
         constexpr int kPruneDrainTrigger = MCE_H_PRUNE_TRIGGER;
         static_assert(f16_prune_slice_bytes(KST) >= kBatch * KST * 1024 + 256, "tile slice");
         const int* const mylist = clist + (int64_t)qblk * list_len;

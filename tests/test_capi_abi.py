@@ -64,6 +64,31 @@ def test_argument_validation_without_gpu():
         _capi.knn_workspace_bytes(10, 10, 2000, 4)
 
 
+def test_mode_switches_validate_without_gpu():
+    assert _capi.get_search_mode() in (0, 1, 2) and _capi.get_prune_mode() in (0, 1, 2)
+    for setter, getter in ((_capi.set_search_mode, _capi.get_search_mode), (_capi.set_prune_mode, _capi.get_prune_mode)):
+        old = getter()
+        for m in (1, 2, 0):
+            setter(m)
+            assert getter() == m
+        with pytest.raises(ValueError):
+            setter(3)
+        with pytest.raises(ValueError):
+            setter(-1)
+        setter(old)
+    # the pruned walk needs more scratch (k-d ordering, boxes, chunk lists); the plan is a pure function
+    _capi.set_prune_mode(_capi.PRUNE_OFF)
+    plain = _capi.knn_workspace_bytes(200000, 200000, 6, 4)
+    _capi.set_prune_mode(_capi.PRUNE_FORCE)
+    pruned = _capi.knn_workspace_bytes(200000, 200000, 6, 4)
+    assert _capi.knn_workspace_bytes(200000, 200000, 27, 4) > 0          # d > 13: never pruned
+    _capi.set_prune_mode(_capi.PRUNE_AUTO)
+    assert pruned > plain and _capi.knn_workspace_bytes(200000, 200000, 6, 4) == plain   # 200k rows: below the automatic threshold
+    assert _capi.knn_workspace_bytes(1000000, 1000000, 6, 4) > 4 * plain                 # 1M x 6: automatic
+    with pytest.raises(ValueError, match="no pruned search"):
+        _capi.last_prune_stats()
+
+
 def test_compute_fails_loudly_without_gpu():
     if _capi.device_count() > 0:
         pytest.skip("a GPU is visible")

@@ -582,3 +582,87 @@ def test_device_pointer_entry_points(capi):
     with pytest.raises(ValueError):
         capi.knn_dotp_dev(X.data_ptr(), n, X.data_ptr(), n, d, kmax, 1, 0, w.data_ptr(), fs.data_ptr(), out.data_ptr(),
                           0, ws.data_ptr(), 1024, 0)
+
+
+@pytest.mark.parametrize("pruned", [False, True])
+def test_dev_entry_point_under_graph_capture(capi, pruned):
+    """the *_dev entry points promise: enqueue only -- no synchronisation, no allocation -- so a call can be
+    captured into a HIP graph and replayed on new data in the same buffers (include/mcevidence_hip.h)."""
+    import torch
+    if pruned and capi.get_search_mode() == capi.MODE_F64:
+        pytest.skip("the pruned walk belongs to the fp16-filter path")
+    capi.set_prune_mode(capi.PRUNE_FORCE if pruned else capi.PRUNE_OFF)
+    try:
+        rng = np.random.default_rng(21)
+        n, d, kmax = 20000, 5, 4
+        K = kmax - 1
+        X = torch.empty((n, d), dtype=torch.float64, device="cuda")
+        w = torch.ones(n, dtype=torch.float64, device="cuda")
+        fs = torch.zeros(n, dtype=torch.float64, device="cuda")
+        wsb = capi.knn_workspace_bytes(n, n, d, K) + capi.dotp_workspace_bytes(n, kmax)
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        out = torch.zeros(kmax, dtype=torch.float64, device="cuda")
+        dd = torch.zeros((n, K), dtype=torch.float64, device="cuda")
+
+        def call(stream):
+            capi.knn_dotp_dev(X.data_ptr(), n, X.data_ptr(), n, d, kmax, 1, 0, w.data_ptr(), fs.data_ptr(), out.data_ptr(),
+                              dd.data_ptr(), ws.data_ptr(), wsb, stream)
+        data = [rng.standard_normal((n, d)) for _ in range(3)]
+        X.copy_(torch.from_numpy(data[0]))
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):                       # warm-up outside capture (one-time kernel attributes)
+            call(side.cuda_stream)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            call(torch.cuda.current_stream().cuda_stream)
+        assert "pruned" in capi.last_kernel() if pruned else "pruned" not in capi.last_kernel()
+        for h in data[1:]:
+            X.copy_(torch.from_numpy(h))
+            graph.replay()
+            torch.cuda.synchronize()
+            want_dotp, want_dist = capi.knn_dotp(h, None, np.ones(n), np.zeros(n), kmax, 1, return_dist=True)
+            assert np.array_equal(dd.cpu().numpy(), want_dist)
+            assert np.allclose(out.cpu().numpy(), want_dotp, rtol=1e-13, atol=0)
+    finally:
+        capi.set_prune_mode(capi.PRUNE_AUTO)
+
+
+def test_random_shapes_against_oracle(capi):
+    """seeded sweep over ragged shapes, all self modes, pruning forced or off: distances and rows against
+    the exact CPU search."""
+    rng = np.random.default_rng(2024)
+    try:
+        for case in range(36):
+            d = int(rng.choice([1, 2, 3, 5, 6, 8, 13, 14, 27, 40]))
+            nr = int(rng.integers(40, 20000))
+            K = int(rng.integers(1, min(32, nr - 1) + 1))
+            kind = int(rng.integers(0, 3))            # 0 cross, 1 shard with own rows excluded, 2 shard with own rows included
+            Y = rng.standard_normal((nr, d)) * rng.uniform(0.1, 30.0) + rng.standard_normal(d) * rng.uniform(0, 50.0)
+            if case % 5 == 0:
+                Y[rng.integers(0, nr, nr // 3)] = Y[rng.integers(0, nr, nr // 3)]          # exact duplicates
+            if kind == 0:
+                nq = int(rng.integers(1, 3000))
+                X = rng.standard_normal((nq, d)) * 20.0
+                sm, off = capi.SELF_NONE, 0
+            else:
+                nq = int(rng.integers(1, min(nr, 3000) + 1))
+                off = int(rng.integers(0, nr - nq + 1))
+                X = np.ascontiguousarray(Y[off:off + nq])
+                sm = capi.SELF_EXCLUDE if kind == 1 else capi.SELF_INCLUDE
+            capi.set_prune_mode(capi.PRUNE_FORCE if case % 2 else capi.PRUNE_OFF)
+            dist, idx = capi.knn(X, Y, K, self_mode=sm, self_offset=off)
+            od, oi = orc.knn_brute(X, Y, K, self_mode={capi.SELF_NONE: 0, capi.SELF_INCLUDE: 1, capi.SELF_EXCLUDE: 2}[sm], self_offset=off)
+            tag = (case, d, nr, nq, K, kind, capi.last_kernel())
+            assert np.allclose(dist, od, rtol=DIST_RTOL, atol=0), tag
+            assert np.all(np.diff(dist, axis=1) >= 0), tag
+            agree = np.mean(idx == oi)
+            assert agree > 0.999 or case % 5 == 0, tag              # duplicates: equal distances may swap rows
+            # whatever rows were chosen, they are at the reported distances
+            pick = rng.integers(0, nq, min(nq, 50))
+            true = np.sqrt(((X[pick, None, :] - Y[idx[pick]]) ** 2).sum(-1))
+            if sm == capi.SELF_INCLUDE:
+                true[:, 0] = np.where(idx[pick, 0] == off + pick, 0.0, true[:, 0])
+            assert np.allclose(true, dist[pick], rtol=1e-9, atol=1e-300), tag
+    finally:
+        capi.set_prune_mode(capi.PRUNE_AUTO)
