@@ -542,7 +542,7 @@ int mce_last_prune_stats(double* chunk_fraction, double* tile_fraction)
     *tile_fraction = hp[mce::HP_STAT_TILES] / (pairs * mce::kHWaves * g_last_prune_geom[2]);
     if (std::getenv("MCE_PRUNE_PROF")) {
         const double nw = g_last_prune_geom[0] * mce::kHWaves;
-        fprintf(stderr, "[prune prof] per wave (cycles@100MHz): walk %.0f stage %.0f mul %.0f drain %.0f total %.0f  candidates drained %.0f\n", hp[8] / nw, hp[9] / nw, hp[10] / nw, hp[11] / nw, hp[12] / nw, hp[13] / nw);
+        fprintf(stderr, "[prune prof] per wave (cycles@100MHz): walk %.0f stage %.0f mul %.0f drain %.0f total %.0f  candidates drained %.0f | tiles with enqueue %.0f (process %.0f cyc each), without: process total %.0f\n", hp[8] / nw, hp[9] / nw, hp[10] / nw, hp[11] / nw, hp[12] / nw, hp[13] / nw, hp[14] / nw, hp[15] / std::max(1.0, hp[14]), hp[7] / nw);
     }
     return MCE_OK;
 }

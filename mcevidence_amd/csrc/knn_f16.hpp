@@ -532,7 +532,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
         int pend = 0;
         int st_tiles = 0, st_chunks = 0;
 #if MCE_PRUNE_PROF
-        long long pt_enq = 0;
+        long long pt_enq = 0, pt_pass_n = 0, pt_pass_t = 0, pt_nopass_t = 0;
         long long pt_walk = 0, pt_stage = 0, pt_mul = 0, pt_drain = 0; const long long pt_begin = clock64(); long long pt_t = pt_begin;
 #define MCE_PT(acc) do { const long long n_ = clock64(); acc += n_ - pt_t; pt_t = n_; } while (0)
 #else
@@ -651,7 +651,13 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
                     mfma_tile(a0, accA);
                     static_assert(QT == 2, "wait-state asm names both accumulator tiles");
                     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(accA[0]), "+v"(accA[1]));
+#if MCE_PRUNE_PROF
+                    const long long q0_ = qcount; const long long tp0 = clock64();
+#endif
                     process(accA, __builtin_amdgcn_readfirstlane(wl[u]) * 32);
+#if MCE_PRUNE_PROF
+                    { const long long dt = clock64() - tp0; if (qcount != q0_) { pt_pass_n += 1; pt_pass_t += dt; } else pt_nopass_t += dt; }
+#endif
                 }
             }
             pend = 0;
@@ -668,7 +674,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
             unsafeAtomicAdd(stat + HP_STAT_TILES, (double)st_tiles);
 #if MCE_PRUNE_PROF
             unsafeAtomicAdd(stat + 8, (double)pt_walk); unsafeAtomicAdd(stat + 9, (double)pt_stage); unsafeAtomicAdd(stat + 10, (double)pt_mul);
-            unsafeAtomicAdd(stat + 11, (double)pt_drain); unsafeAtomicAdd(stat + 12, (double)(clock64() - pt_begin)); unsafeAtomicAdd(stat + 13, (double)pt_enq);
+            unsafeAtomicAdd(stat + 11, (double)pt_drain); unsafeAtomicAdd(stat + 12, (double)(clock64() - pt_begin)); unsafeAtomicAdd(stat + 13, (double)pt_enq); unsafeAtomicAdd(stat + 14, (double)pt_pass_n); unsafeAtomicAdd(stat + 15, (double)pt_pass_t); unsafeAtomicAdd(stat + 7, (double)pt_nopass_t);
 #endif
         }
     }
