@@ -5,7 +5,7 @@
  * per 1M x 29 text rows -- comparable to, or larger than, the whole GPU evidence computation
  * (SURVEY.md section 8f.4).  Same semantics as that call on such files:
  *   - fields separated by ASCII whitespace; '#' starts a comment that runs to the end of the line;
- *     blank / comment-only lines are skipped; "\r\n" line ends are accepted;
+ *     blank / comment-only lines are skipped; lines end at "\n", "\r\n" or a bare "\r";
  *   - every field is parsed to the correctly rounded fp64 value (bit-identical to Python's float());
  *     "inf", "nan", "infinity" (any case, optional sign) are accepted;
  *   - all data lines must have the same number of fields (np.loadtxt raises ValueError otherwise).

@@ -39,7 +39,7 @@ int fail(int code, const char* fmt, ...)
 const double kP10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
                          1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
 
-inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\v' || c == '\f'; }
 inline bool is_digit(char c) { return c >= '0' && c <= '9'; }
 
 locale_t c_locale()
@@ -155,11 +155,19 @@ struct Chain {
     }
 };
 
-// end of the line starting at p (index of '\n' or size)
-inline size_t line_end(const char* d, size_t p, size_t size)
+// end of the '\n'-terminated line starting at p (index of '\n' or size): the unit thread ranges are cut at
+inline size_t nl_end(const char* d, size_t p, size_t size)
 {
     const void* nl = std::memchr(d + p, '\n', size - p);
     return nl ? (size_t)(static_cast<const char*>(nl) - d) : size;
+}
+
+// end of the line starting at p; a bare '\r' ends a line too (universal newlines, as np.loadtxt reads)
+inline size_t line_end(const char* d, size_t p, size_t size)
+{
+    const size_t e = nl_end(d, p, size);
+    const void* cr = std::memchr(d + p, '\r', e - p);
+    return cr ? (size_t)(static_cast<const char*>(cr) - d) : e;
 }
 
 // does [p, e) hold anything but whitespace before a '#'?
@@ -308,7 +316,7 @@ int mce_chain_open(const char* path, int32_t nthreads, void** handle, int64_t* n
     for (int t = 1; t < nt; ++t) {
         size_t b = c->size / (size_t)nt * (size_t)t;
         if (b == 0 || b >= c->size) continue;
-        const size_t nl = line_end(c->data, b - 1, c->size);      // first '\n' at or after b-1
+        const size_t nl = nl_end(c->data, b - 1, c->size);        // first '\n' at or after b-1
         const size_t start = std::min(nl + 1, c->size);
         if (start > cuts.back() && start < c->size) cuts.push_back(start);
     }

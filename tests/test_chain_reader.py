@@ -142,3 +142,57 @@ def test_mcsamples_reads_files_through_the_native_reader(tmp_path, monkeypatch):
     monkeypatch.setenv("MCE_CHAIN_READER", "numpy")
     b = MCSamples(root, burnlen=0.2, thinlen=2)
     assert same(a.samples, b.samples)
+
+
+_ALPHABET = "0123456789+-.eE \t\n#naifNI\r"
+
+
+@settings(max_examples=400, deadline=None)
+@given(st.text(alphabet=_ALPHABET, max_size=120))
+def test_fuzzed_text_never_crashes_and_agrees_with_numpy(tmp_path_factory, text):
+    """arbitrary bytes from the chain-file alphabet: the reader either returns exactly what np.loadtxt
+    returns or raises ValueError where np.loadtxt raises -- never crashes, never invents numbers."""
+    import warnings
+    p = tmp_path_factory.mktemp("fz") / "f.txt"
+    p.write_bytes(text.encode("ascii"))
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = np.loadtxt(str(p), ndmin=2)
+        ok = True
+    except ValueError:
+        ok = False
+    if ok:
+        got = chain_io.loadtxt(str(p))
+        assert got.shape == want.shape and np.array_equal(got, want, equal_nan=True), (text, got, want)
+    else:
+        try:
+            got = chain_io.loadtxt(str(p))
+        except ValueError:
+            return
+        # np.loadtxt is stricter in a few spellings Python's float() accepts or vice versa; whatever the
+        # native reader accepted must be what float() says, field by field
+        fields = [[float(t) for t in line.split("#")[0].split()] for line in text.replace("\r", " ").split("\n")]
+        fields = [f for f in fields if f]
+        assert got.shape[0] == len(fields) and all(np.array_equal(np.array(f), g, equal_nan=True) for f, g in zip(fields, got)), text
+
+
+def test_reader_under_address_and_ub_sanitizers(tmp_path):
+    """the native reader built with -fsanitize=address,undefined (CPU build; GPU sanitizers are not
+    available on this pool) and driven over mmap edge cases at every thread count."""
+    import subprocess
+    exe = str(tmp_path / "chain_reader_sanitize")
+    src = [os.path.join(REPO, "tests", "native", "chain_reader_sanitize.cpp"), os.path.join(REPO, "mcevidence_amd", "csrc", "chain_reader.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-pthread"] + src + ["-o", exe])
+    work = tmp_path / "files"
+    work.mkdir()
+    out = subprocess.run([exe, str(work)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr[-3000:]
+    # and the thread split under ThreadSanitizer
+    exe_t = str(tmp_path / "chain_reader_tsan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread"] + src + ["-o", exe_t])
+    work_t = tmp_path / "files_t"
+    work_t.mkdir()
+    out = subprocess.run([exe_t, str(work_t)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout and "WARNING: ThreadSanitizer" not in out.stderr, out.stdout + out.stderr[-3000:]

@@ -666,3 +666,19 @@ def test_random_shapes_against_oracle(capi):
             assert np.allclose(true, dist[pick], rtol=1e-9, atol=1e-300), tag
     finally:
         capi.set_prune_mode(capi.PRUNE_AUTO)
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """the boundary is a C ABI, not a Python extension: examples/knn_from_c.c built with gcc against
+    include/mcevidence_hip.h and run as its own process."""
+    import os
+    import subprocess
+    from helpers import REPO
+    exe = str(tmp_path / "knn_from_c")
+    libdir = os.path.join(REPO, "mcevidence_amd")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(REPO, "include"), os.path.join(REPO, "examples", "knn_from_c.c"), "-o", exe,
+                           "-L" + libdir, "-lmcevidence_hip", "-Wl,-rpath," + libdir, "-lm"])
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OK" in out.stdout and "rc -2" in out.stdout
