@@ -38,6 +38,17 @@ def read_chain_file(path):
     return chain_io.loadtxt(path)
 
 
+def read_chain_files(paths):
+    """The chain files of one root, in order.  Small files (a Planck chain is ~3 MB: one reader thread
+    each) are parsed concurrently -- the native reader runs outside the GIL."""
+    paths = list(paths)
+    if len(paths) < 2 or os.environ.get("MCE_CHAIN_READER", "native") == "numpy":
+        return [read_chain_file(f) for f in paths]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(paths), 8)) as pool:
+        return list(pool.map(read_chain_file, paths))
+
+
 class Partition(object):
     """One partition (s1 or s2) of the samples."""
 
@@ -186,7 +197,7 @@ class MCSamples(object):
         if not flist:
             raise IOError("no chain files found for %r" % (fname,))
         self.logger.debug("Reading from files: " + ", ".join(flist))
-        self.chains = [read_chain_file(f) for f in flist]
+        self.chains = read_chain_files(flist)
         return self.chains2samples(**kwargs)
 
     # -- burn / concatenate / thin / split -----------------------------------

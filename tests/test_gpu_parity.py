@@ -682,3 +682,18 @@ def test_c_abi_from_plain_c(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "OK" in out.stdout and "rc -2" in out.stdout
+
+
+def test_reference_set_beyond_the_26_bit_row_offsets(capi):
+    """queue entries hold 26-bit row offsets relative to the workgroup's reference split: a reference set
+    with more than 2^26 rows must be split (and is too large for the pruned walk), not silently wrapped."""
+    rng = np.random.default_rng(5)
+    nr, d, nq, K = (1 << 26) + 5000, 2, 600, 3
+    Y = rng.standard_normal((nr, d))
+    X = np.concatenate([Y[-300:] + 1e-4, rng.standard_normal((nq - 300, d))])     # half of them next to the LAST rows
+    dist, idx = capi.knn(X, Y, K)
+    if capi.get_search_mode() != capi.MODE_F64:
+        assert "rsplit=1 " not in capi.last_kernel() + " " and "pruned" not in capi.last_kernel(), capi.last_kernel()
+    od, oi = orc.knn_brute(X, Y, K)
+    assert _rel(dist, od) < DIST_RTOL and np.array_equal(idx, oi)
+    assert (idx[:300] >= nr - 400).any()                 # neighbours were found beyond row 2^26
