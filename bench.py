@@ -4,18 +4,20 @@
 Metric (BASELINE.json): kNN queries/s (+ |dlnE|) at N = 1M, D = 27, kmax = 10 (config C3:
 seeded synthetic Gaussian chain, `mcevidence_amd.synth.CONFIGS['C3']`), inputs resident in
 HBM when the timed region starts.  One "step" = one full pass of the hot path (pack ->
-fp64 MFMA kNN -> merge -> volume/weight reduction -> dotp[kmax]) over this rank's query
+kNN search -> merge -> volume/weight reduction -> dotp[kmax]) over this rank's query
 shard; with --gpus N the 1M queries are sharded over N ranks (reference set replicated),
 one RCCL all-reduce of kmax doubles per step: strong scaling.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 1000000] [--d 27] [--kmax 10]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 1000000] [--d 27] [--kmax 10] [--mode 0|1]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (knn_mfma_kernel):
-algorithmic flops per launch = nq * nr * 2 * 4*KS (the augmented dot product
-|x|^2 + x'.y' the MFMA evaluates) over its launch duration measured with HIP
-events on the launch stream; peak = 78.6 TFLOP/s fp64 (MI355X matrix = vector fp64 peak;
-the f64 MFMA microbenchmark tools/mfma_f64_peak.hip reaches 72-74 on this part).
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel, its launch duration
+measured with HIP events on the launch stream.  Default (--mode 0): knn_f16_kernel, the fp16-MFMA
+all-pairs filter + exact fp64 refine -- algorithmic flops per launch = nq * nr * 2 * 16*KST (the
+augmented product |y^|^2 - 2 x^.y^ the MFMA evaluates) against the 2.5 PFLOP/s dense
+fp16 peak.  --mode 1: knn_mfma_kernel, the pure fp64 MFMA sweep -- nq * nr * 2 * 4*KS flops against
+78.6 TFLOP/s (tools/mfma_f64_peak.hip reaches 72-74 on this part).  `traffic` = HBM bytes per launch
+from the committed rocprofv3 PMC passes (profiles/).
 `cpu_baseline` = the reference's own CPU path (scikit-learn NearestNeighbors with its
 default algorithm + NumPy reduction, via the oracle) on a bounded query sample, rank 0.
 """
