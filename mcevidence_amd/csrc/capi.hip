@@ -35,7 +35,6 @@ thread_local char g_last_kernel[256] = "";
 thread_local int g_prof_on = 0;
 thread_local std::vector<std::pair<hipEvent_t, hipEvent_t>> g_ev_pool;   // reused brackets
 thread_local size_t g_ev_used = 0;                                        // brackets since enable
-thread_local const double* g_last_params = nullptr;                       // HP_* scalars of the last pruned launch (in the caller's workspace)
 thread_local double g_last_prune_geom[3] = {0, 0, 0};                     // blocks, chunks, tiles per chunk
 
 int fail(int code, const char* fmt, ...)
@@ -116,17 +115,26 @@ struct PinnedArena {
 };
 thread_local PinnedArena g_pinned;
 
+thread_local const double* g_last_params = nullptr;                       // HP_* scalars of the last pruned launch (in the caller's workspace)
+
 struct DevBuf {
     void* p = nullptr;
     int slot = -1;
     ~DevBuf()
     {
+        // a host-pointer entry point is returning its scratch: the statistics of a pruned search that
+        // lived in it are gone with it
+        if (p && g_last_params >= static_cast<const double*>(p) &&
+            reinterpret_cast<const char*>(g_last_params) < static_cast<const char*>(p) + bytes)
+            g_last_params = nullptr;
         if (slot >= 0) g_pool[slot].busy = false;
         else if (p) (void)hipFree(p);
     }
+    size_t bytes = 0;
     hipError_t alloc(size_t n)
     {
         if (n == 0) n = 1;
+        bytes = n;
         if (n <= kPoolMaxBytes) {
             int dev = 0;
             (void)hipGetDevice(&dev);

@@ -697,3 +697,25 @@ def test_reference_set_beyond_the_26_bit_row_offsets(capi):
     od, oi = orc.knn_brute(X, Y, K)
     assert _rel(dist, od) < DIST_RTOL and np.array_equal(idx, oi)
     assert (idx[:300] >= nr - 400).any()                 # neighbours were found beyond row 2^26
+
+
+def test_prune_stats_lifetime(prune_modes):
+    """mce_last_prune_stats reads counters that live in the search's workspace: available after a *_dev
+    call (caller-owned workspace), refused after a host-pointer call (the library's scratch is gone)."""
+    import torch
+    capi = prune_modes
+    capi.set_prune_mode(capi.PRUNE_FORCE)
+    rng = np.random.default_rng(3)
+    n, d, K = 40000, 4, 5
+    Yh = rng.standard_normal((n, d))
+    capi.knn(Yh, Yh, K, self_mode=capi.SELF_EXCLUDE)
+    assert "pruned" in capi.last_kernel()
+    with pytest.raises(ValueError, match="no pruned search"):
+        capi.last_prune_stats()
+    Y = torch.from_numpy(Yh).cuda()
+    wsb = capi.knn_workspace_bytes(n, n, d, K)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    dist = torch.empty((n, K), dtype=torch.float64, device="cuda")
+    capi.knn_dev(Y.data_ptr(), n, Y.data_ptr(), n, d, K, capi.SELF_EXCLUDE, 0, dist.data_ptr(), 0, ws.data_ptr(), wsb, 0)
+    windows, tiles = capi.last_prune_stats()
+    assert 0.0 < tiles < 0.5 and windows > 0.0           # most tile products were never multiplied
