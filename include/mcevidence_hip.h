@@ -170,8 +170,8 @@ int mce_get_search_mode(void);
  * both point sets are put in k-d order on the device (cells of 32 rows) and every wave of 64 queries
  * visits the reference chunks nearest-box-first, multiplies only the 32-row tiles whose box is within
  * reach, and stops once no remaining chunk can hold a neighbour.  Same neighbours, distances and
- * tie-breaks as the exhaustive search.  0 (default): used for d <= 6 from 0.7 M reference rows and for
- * d <= 8 from 3 M; 1: never; 2: whenever the shape allows it (d <= 13, K <= 16).  Process-wide. */
+ * tie-breaks as the exhaustive search.  0 (default): used where it was measured faster -- d <= 4 from
+ * 150 k reference rows, d <= 6 from 300 k, d = 7 from 800 k, d = 8 from 2.5 M; 1: never; 2: whenever the shape allows it (d <= 13, K <= 16).  Process-wide. */
 int mce_set_prune_mode(int mode);
 int mce_get_prune_mode(void);
 /* Work actually done by the last pruned search launched by this thread through a *_dev entry point

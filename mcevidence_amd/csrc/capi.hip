@@ -58,11 +58,12 @@ int fail(int code, const char* fmt, ...)
 std::atomic<int> g_mode{0};
 // spatial pruning (prune.hpp): 0 auto (low d, large reference sets), 1 never, 2 whenever the shape allows it
 std::atomic<int> g_prune_mode{0};
-// measured on MI355X (tools/prune_sweep.sh, K = 10): the walk wins from ~0.7 M reference rows at d <= 6
-// (1 M x 6: 40 vs 57 ms; 10 M x 6: 0.52 vs 3.95 s; 10 M x 3: 0.35 vs 4.0 s) and from ~3 M rows at d = 7..8
-// (4 M x 8: 0.53 vs 0.69 s); at d >= 9 the boxes overlap too much (4 M x 10: 1.2 vs 0.69 s)
-constexpr int kPruneAutoMaxDimLow = 6, kPruneAutoMaxDimHigh = 8;
-constexpr int64_t kPruneAutoMinRowsLow = 700000, kPruneAutoMinRowsHigh = 3000000;
+// measured on MI355X (tools/prune_sweep.sh, tools/prune_sweep_small.sh; search + preparation, K = 10):
+//   d = 3: 0.1 M 1.3 vs 1.5 ms, 1 M 17 vs 59 ms, 10 M 0.17 vs 4.0 s      d = 6: 0.2 M 4.6 vs 4.0, 0.3 M 8.5 vs 10.8,
+//   1 M 28 vs 58 ms, 4 M 0.14 vs 0.69 s, 10 M 0.37 vs 3.95 s      d = 7: 1 M 48 vs 59 ms      d = 8: 2 M 197 vs 200,
+//   3 M 342 vs 401, 4 M 504 vs 694 ms      d = 10: 4 M 1.43 vs 0.69 s (the boxes overlap too much)
+// smallest reference set for which the automatic mode takes the pruned walk, by dimension (0: never)
+constexpr int64_t kPruneAutoMinRows[14] = {0, 150000, 150000, 150000, 150000, 300000, 300000, 800000, 2500000, 0, 0, 0, 0, 0};
 
 // Device buffers of the host-pointer entry points.  Small allocations (<= 64 MB) are kept in a
 // per-thread, per-device pool between calls: the reference's typical workload is thousands of
@@ -271,8 +272,7 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     if (f16 && p.KST == 1 && d <= mce::kPruneMaxDim && p.vh->launch_prune && nq > 0 &&
         p.nrow_pad <= ((int64_t)1 << mce::kHRelBits) && (int64_t)p.nqblk * p.nchunk <= mce::kPruneMaxPairs) {
         const int pm = g_prune_mode.load();
-        p.prune = pm == 2 || (pm == 0 && ((d <= kPruneAutoMaxDimLow && nr >= kPruneAutoMinRowsLow) ||
-                                           (d <= kPruneAutoMaxDimHigh && nr >= kPruneAutoMinRowsHigh)));
+        p.prune = pm == 2 || (pm == 0 && kPruneAutoMinRows[d] > 0 && nr >= kPruneAutoMinRows[d]);
     }
     // reference split r: more workgroups fill the chip and trim the last partial round
     // (one 512-thread workgroup per CU), but every split re-pays the list warm-up: a query
@@ -434,7 +434,7 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
             g_last_params = params;
             g_last_prune_geom[0] = p.nqblk; g_last_prune_geom[1] = (double)p.nchunk; g_last_prune_geom[2] = p.CT;
             snprintf(g_last_kernel, sizeof(g_last_kernel), "%s pruned grid=%d block=64 lds=%zu qt=%d ct=%d chunks=%lld", p.vh->name,
-                     p.nqblk * mce::kHWaves, mce::f16_prune_lds_bytes(p.KST), p.QT, p.CT, (long long)p.nchunk);
+                     p.nqblk * mce::kHWaves, mce::f16_prune_lds_bytes(p.KST, d), p.QT, p.CT, (long long)p.nchunk);
             return MCE_OK;
         }
         int rc = prof_begin();

@@ -107,9 +107,19 @@ __host__ __device__ constexpr size_t f16_lds_bytes(int KST, int KCAP)
 }
 
 __host__ __device__ constexpr int f16_prune_slice_bytes(int KST) { return MCE_H_PRUNE_BATCH * KST * 1024 + 256; }   // kBatch tiles + pending ids
-__host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST)
+#ifndef MCE_H_PRUNE_BOOT_ORDER
+#define MCE_H_PRUNE_BOOT_ORDER 1   // 1: own tiles first, then outward; 0: ascending tile number
+#endif
+#ifndef MCE_H_PRUNE_BOOT
+#define MCE_H_PRUNE_BOOT 12
+#endif
+constexpr int kHPruneBoot = MCE_H_PRUNE_BOOT;   // pruned walk: k-d neighbour tiles on either side multiplied before the walk
+constexpr int kHPruneQueue = 256;   // pruned walk: queue entries per wave (already exact: only the list insertion is deferred)
+// [tile slice + pending ids][queue d2 | row | next][heads][the wave's 64 fp64 query rows][one fp64 reference tile][its caller row numbers]
+__host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST, int D)
 {
-    return (size_t)f16_prune_slice_bytes(KST) + (size_t)kHQueue * 16 + (size_t)kHQT * 32 * 4 + 128;
+    return (size_t)f16_prune_slice_bytes(KST) + (size_t)kHPruneQueue * 16 + (size_t)kHQT * 32 * 4 + 128 +
+           (size_t)(kHQT * 32 + 32) * D * 8 + 128 + (size_t)kHQT * 32 * 8;
 }
 
 // ---------------------------------------------------------------------------
@@ -156,10 +166,11 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
     constexpr int LW = PRUNE ? 1 : kHWaves;                       // waves sharing this LDS allocation
     constexpr int STAGE_BYTES = PRUNE ? f16_prune_slice_bytes(KST) : 2 * CT * KST * 1024;
     char* const stage0 = lds_raw;
+    constexpr int QN = PRUNE ? kHPruneQueue : kHQueue;            // queue entries per wave
     double* const qd2_all = reinterpret_cast<double*>(lds_raw + STAGE_BYTES);
-    int* const qpk_all = reinterpret_cast<int*>(qd2_all + LW * kHQueue);
-    int* const qnx_all = qpk_all + LW * kHQueue;
-    int* const head_all = qnx_all + LW * kHQueue;
+    int* const qpk_all = reinterpret_cast<int*>(qd2_all + LW * QN);
+    int* const qnx_all = qpk_all + LW * QN;
+    int* const head_all = qnx_all + LW * QN;
 
 #if MCE_STATS
     const long long t_kernel0 = clock64();
@@ -178,11 +189,16 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
     if (c_end > nchunk_total) c_end = nchunk_total;
 
     const double INF = __builtin_huge_val();
-    double* const wqd = qd2_all + lwave * kHQueue;              // exact distance of a queued entry (phase A)
-    int* const wq = qpk_all + lwave * kHQueue;                  // packed (query-local, relative row)
-    int* const wnx = qnx_all + lwave * kHQueue;                 // next entry of the same query
+    double* const wqd = qd2_all + lwave * QN;                   // exact distance of a queued entry (phase A)
+    int* const wq = qpk_all + lwave * QN;                       // packed (query-local, relative row)
+    int* const wnx = qnx_all + lwave * QN;                      // next entry of the same query
     int* const whead = head_all + lwave * QPW;                  // chain head per wave-local query
     volatile int* const wvote = head_all + LW * QPW;            // [2] drain votes (chunk parity)
+    // PRUNE: the wave's fp64 query rows, one fp64 reference tile and its caller row numbers
+    double* const xq = reinterpret_cast<double*>(head_all + LW * QPW + 32);
+    double* const ytile = xq + QPW * D;
+    int* const yorig = reinterpret_cast<int*>(ytile + 32 * D);
+    double* const thrq = reinterpret_cast<double*>(yorig + 32);      // current exact K-th squared distance per wave-local query
     float mythr = __builtin_huge_valf();                        // PRUNE: largest K-th squared distance among this wave's queries (rounded up)
     float Tq[kHQT];                                             // PRUNE: the same per 32-query tile (wave-uniform)
 #pragma unroll
@@ -277,6 +293,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
         const long long t_d0 = clock64();
         st_drains += 1; st_enq += qcount;
 #endif
+        if constexpr (!PRUNE) {     // (pruned walk: entries arrive evaluated and linked, see gate_exact)
         // ---- phase A: exact distances + chain links.  8 lanes share one queued pair and read
         // the two rows in 64-byte segments (a row is fetched once, not once per element).  The
         // gather is latency-bound, so ALL loads of a group of NPASS*8 pairs are issued before the
@@ -346,6 +363,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
                 }
             }
         }
+        }
 #if MCE_STATS
         st_tA += clock64() - t_d0;
 #endif
@@ -392,6 +410,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) G[qt] = gate_of(__shfl(thr_own[qt >> 1], (qt & 1) * 32 + (lane & 31), 64), qt);
         if constexpr (PRUNE) {
+#pragma unroll
+            for (int nl = 0; nl < kHNL; ++nl) thrq[nl * 64 + lane] = thr_own[nl];
             mythr = 0.0f;
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
@@ -457,6 +477,104 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
             }
         }
     };
+
+    // PRUNE: gate + EXACT evaluation of one finished tile.  The tiles that yield candidates are few
+    // (~7 %) but yield them in bursts (~16 each), so instead of queueing (query, row) pairs for a later
+    // scattered gather, the tile's 32 fp64 rows are fetched once, contiguously, into LDS and every
+    // passing pair is evaluated on the spot against the query rows staged at kernel start -- with the
+    // SAME summation tree as the sweep's phase A (8 partial sums over i = s, s+8, ... combined pairwise),
+    // so the distances stay bit-identical.  What is queued is (exact d2, caller row), already linked
+    // into its query's chain; drain() is then insertion (phase B) only.
+#if MCE_PRUNE_PROF
+    long long gx_iter = 0, gx_cand = 0, gx_useful = 0;
+#endif
+    int qorig[QT];
+    auto gate_exact = [&](const v16f (&acc)[QT], int jb0) {
+        bool passq[QT];
+        bool pass = false;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const v16f& c = acc[qt];
+            float m0 = min3f(c[0], c[1], c[2]);
+            float m1 = min3f(c[3], c[4], c[5]);
+            float m2 = min3f(c[6], c[7], c[8]);
+            float m3 = min3f(c[9], c[10], c[11]);
+            float m4 = min3f(c[12], c[13], c[14]);
+            m0 = min3f(m0, m1, m2);
+            m3 = min3f(m3, m4, c[15]);
+            passq[qt] = min3f(m0, m3, m3) <= G[qt];
+            pass |= passq[qt];
+        }
+        if (!__any(pass)) return;
+        {   // the tile's rows (contiguous in the k-d ordered copy) and their caller row numbers
+            const int nrow = (nr - jb0 < 32) ? (int)(nr - jb0) : 32;
+            const double* yt = Y + (int64_t)jb0 * D;
+            for (int e = lane; e < nrow * D; e += 64) ytile[(e % D) * 32 + e / D] = yt[e];     // [i][row]: conflict-free reads
+            if (lane < 32) yorig[lane] = (lane < nrow) ? rperm[jb0 + lane] : -1;
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            if (!__any(passq[qt])) continue;
+            unsigned pm = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pm |= (acc[qt][r] <= G[qt]) ? (1u << r) : 0u;
+            const int ql = qt * 32 + (lane & 31);
+            const double* xr = xq + ql;                            // xq[i][ql]
+            while (__any(pm != 0)) {
+                if (qcount > QN - 64) drain();
+                const bool has = pm != 0;
+                const int r = has ? __builtin_ctz(pm) : 0;
+                pm &= pm - 1;
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const double* yr = ytile + row;                    // ytile[i][row]
+                double sp[8];
+#pragma unroll
+                for (int sb = 0; sb < 8; ++sb) {
+                    double a0 = 0.0;
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {                  // D <= 13: at most two elements per partial sum
+                        const int i = sb + 8 * v;
+                        if (i < D) {
+                            const double t = xr[i * QPW] - yr[i * 32];
+                            a0 = fma(t, t, a0);
+                        }
+                    }
+                    sp[sb] = a0;
+                }
+                const double d2 = ((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7]));
+                const int oj = yorig[row];
+                const bool ok = has && oj >= 0 && qwave0 + ql < nq && !(self_exclude && (int64_t)oj == self_offset + qorig[qt]);
+                const unsigned long long m = __ballot(ok);
+                if (ok) {
+                    const int slot = qcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                    wqd[slot] = d2;
+                    wq[slot] = oj;
+                    wnx[slot] = atomicExch(&whead[ql], slot);
+                }
+#if MCE_PRUNE_PROF
+                gx_iter += 1; gx_cand += __builtin_popcountll(m); gx_useful += __builtin_popcountll(__ballot(ok && d2 <= thrq[ql]));
+#endif
+                qcount += __builtin_popcountll(m);
+            }
+        }
+    };
+    if constexpr (PRUNE) {
+        static_assert(KST == 1, "pruned walk: d <= 13");
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const int64_t q = qwave0 + qt * 32 + (lane & 31);
+            qorig[qt] = q < nq ? qperm[q] : -1;
+        }
+#pragma unroll
+        for (int nl = 0; nl < kHNL; ++nl) thrq[nl * 64 + lane] = INF;
+        for (int e = lane; e < QPW * D; e += 64) {
+            const int64_t q = qwave0 + e / D;
+            xq[(e % D) * QPW + e / D] = q < nq ? X[q * (int64_t)D + (e % D)] : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) qorig[qt] = 0;
+    }
 
     v16f accA[QT], accB[QT];
     int jbA = 0, jbB = 0;
@@ -541,9 +659,39 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
         int e = 0;
         unsigned long long need = 0, cand = 0;
         int c = 0, win_c = 0;
+        // Bootstrap (queries that ARE the references, same k-d order): the tiles next to the wave's own in
+        // k-d order are spatial neighbours, so they go first -- the thresholds are then almost final before
+        // the walk starts, far fewer pairs beat them later and far fewer tiles stay within reach.  The walk
+        // skips these tiles.
+        const bool same_order = (qperm == rperm);
+        const int own_t = (int)(qwave0 / 32);
+        const int boot_lo = same_order ? (own_t - kHPruneBoot > 0 ? own_t - kHPruneBoot : 0) : 0;
+        const int boot_hi0 = own_t + QT + kHPruneBoot;
+        const int n_rtiles = (int)((nr + 31) / 32);
+        const int boot_hi = same_order ? (boot_hi0 < n_rtiles ? boot_hi0 : n_rtiles) : 0;
+        // own tiles first, then alternately right and left: k -> own_t + (k odd ? (k+1)/2 : -k/2)
+        const int boot_n = same_order ? 2 * kHPruneBoot + QT : 0;
+        int boot_k = 0;
+        bool boot_flush = false;
         for (;;) {
             // ---- collect: fill the pending list from the current chunk's mask, moving down the list
             while (pend < kBatch) {
+                if (boot_k < boot_n) {
+                    const int room = kBatch - pend;                 // the next `room` positions of the sequence
+                    const int k = boot_k + lane;
+#if MCE_H_PRUNE_BOOT_ORDER == 1
+                    const int id = own_t + ((k & 1) ? (k + 1) / 2 : -(k / 2));
+#else
+                    const int id = own_t - kHPruneBoot + k;
+#endif
+                    const bool take = lane < room && k < boot_n && id >= boot_lo && id < boot_hi;   // (off the ends: skipped)
+                    const unsigned long long tm = __ballot(take);
+                    if (take) wl[pend + __builtin_amdgcn_mbcnt_hi((unsigned)(tm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)tm, 0))] = id;
+                    pend += __builtin_popcountll(tm);
+                    boot_k += room;
+                    if (boot_k >= boot_n && pend > 0) { boot_flush = true; break; }    // settle the thresholds before walking
+                    continue;
+                }
                 if (need == 0) {
                     if (cand == 0) {
                         if (e >= list_len) break;
@@ -597,8 +745,12 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
                             }
                         }
                     }
+                    {
+                        const int tile_id = c * CT + lane;
+                        const bool booted = tile_id >= boot_lo && tile_id < boot_hi;
 #pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) need |= __ballot(lane < CT && !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]));
+                        for (int qt = 0; qt < QT; ++qt) need |= __ballot(lane < CT && !booted && !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]));
+                    }
                     st_tiles += __builtin_popcountll(need);
                     if (need == 0) continue;
                 }
@@ -654,7 +806,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
 #if MCE_PRUNE_PROF
                     const long long q0_ = qcount; const long long tp0 = clock64();
 #endif
-                    process(accA, __builtin_amdgcn_readfirstlane(wl[u]) * 32);
+                    gate_exact(accA, __builtin_amdgcn_readfirstlane(wl[u]) * 32);
 #if MCE_PRUNE_PROF
                     { const long long dt = clock64() - tp0; if (qcount != q0_) { pt_pass_n += 1; pt_pass_t += dt; } else pt_nopass_t += dt; }
 #endif
@@ -665,7 +817,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
 #if MCE_PRUNE_PROF
             if (qcount >= kPruneDrainTrigger) pt_enq += qcount;
 #endif
-            if (qcount >= kPruneDrainTrigger) drain();
+            if (qcount >= kPruneDrainTrigger || boot_flush) drain();
+            boot_flush = false;
             MCE_PT(pt_drain);
         }
         if (lane == 0) {                                   // launch totals: chunks tested and tiles multiplied, per wave
@@ -674,7 +827,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
             unsafeAtomicAdd(stat + HP_STAT_TILES, (double)st_tiles);
 #if MCE_PRUNE_PROF
             unsafeAtomicAdd(stat + 8, (double)pt_walk); unsafeAtomicAdd(stat + 9, (double)pt_stage); unsafeAtomicAdd(stat + 10, (double)pt_mul);
-            unsafeAtomicAdd(stat + 11, (double)pt_drain); unsafeAtomicAdd(stat + 12, (double)(clock64() - pt_begin)); unsafeAtomicAdd(stat + 13, (double)pt_enq); unsafeAtomicAdd(stat + 14, (double)pt_pass_n); unsafeAtomicAdd(stat + 15, (double)pt_pass_t); unsafeAtomicAdd(stat + 7, (double)pt_nopass_t);
+            unsafeAtomicAdd(stat + 11, (double)pt_drain); unsafeAtomicAdd(stat + 12, (double)(clock64() - pt_begin)); unsafeAtomicAdd(stat + 13, (double)gx_cand); unsafeAtomicAdd(stat + 9, (double)gx_useful - (double)pt_stage); unsafeAtomicAdd(stat + 14, (double)pt_pass_n); unsafeAtomicAdd(stat + 15, (double)pt_pass_t); unsafeAtomicAdd(stat + 7, (double)pt_nopass_t);
 #endif
         }
     }

@@ -78,13 +78,13 @@ def test_mode_switches_validate_without_gpu():
         setter(old)
     # the pruned walk needs more scratch (k-d ordering, boxes, chunk lists); the plan is a pure function
     _capi.set_prune_mode(_capi.PRUNE_OFF)
-    plain = _capi.knn_workspace_bytes(200000, 200000, 6, 4)
+    plain = _capi.knn_workspace_bytes(100000, 100000, 6, 4)
     _capi.set_prune_mode(_capi.PRUNE_FORCE)
-    pruned = _capi.knn_workspace_bytes(200000, 200000, 6, 4)
+    pruned = _capi.knn_workspace_bytes(100000, 100000, 6, 4)
     assert _capi.knn_workspace_bytes(200000, 200000, 27, 4) > 0          # d > 13: never pruned
     _capi.set_prune_mode(_capi.PRUNE_AUTO)
-    assert pruned > plain and _capi.knn_workspace_bytes(200000, 200000, 6, 4) == plain   # 200k rows: below the automatic threshold
-    assert _capi.knn_workspace_bytes(1000000, 1000000, 6, 4) > 4 * plain                 # 1M x 6: automatic
+    assert pruned > plain and _capi.knn_workspace_bytes(100000, 100000, 6, 4) == plain   # 100k x 6: below the automatic threshold
+    assert _capi.knn_workspace_bytes(1000000, 1000000, 6, 4) > 12 * plain                # 1M x 6: automatic
     with pytest.raises(ValueError, match="no pruned search"):
         _capi.last_prune_stats()
 

@@ -437,6 +437,32 @@ def test_pruned_search_is_bit_identical_auto(prune_modes, n, d, K):
     assert _rel(d1[:3000] if sm == capi.SELF_EXCLUDE else capi.knn(Y[:3000], Y, K, self_mode=capi.SELF_EXCLUDE)[0], od) < DIST_RTOL
 
 
+@pytest.mark.parametrize("n,d,K", [(5000, 1, 3), (70001, 3, 9), (150000, 6, 10), (40000, 6, 2), (33000, 10, 16)])
+def test_pruned_search_same_buffer_is_bit_identical(prune_modes, n, d, K):
+    """queries and references in ONE device buffer (what evidence() passes): the k-d order is shared, the
+    walk starts from the tiles next to the wave's own (bootstrap) -- results still bit-identical, at the
+    array ends too."""
+    import torch
+    capi = prune_modes
+    rng = np.random.default_rng(n * 3 + d)
+    Yh = rng.standard_normal((n, d)) @ (np.eye(d) + 0.2 * rng.standard_normal((d, d)))
+    Y = torch.from_numpy(Yh).cuda()
+    dist = torch.empty((n, K), dtype=torch.float64, device="cuda")
+    idx = torch.empty((n, K), dtype=torch.int64, device="cuda")
+
+    def run(sm):
+        wsb = capi.knn_workspace_bytes(n, n, d, K)
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        capi.knn_dev(Y.data_ptr(), n, Y.data_ptr(), n, d, K, sm, 0, dist.data_ptr(), idx.data_ptr(), ws.data_ptr(), wsb, 0)
+        torch.cuda.synchronize()
+        return dist.cpu().numpy().copy(), idx.cpu().numpy().copy()
+    for sm in (capi.SELF_EXCLUDE, capi.SELF_INCLUDE):
+        (d0, i0), (d1, i1) = _both(capi, lambda: run(sm))
+        assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+    od, oi = orc.knn_brute(Yh[-2500:], Yh, K, self_mode=1)
+    assert _rel(d1[-2500:], od) < DIST_RTOL and np.mean(i1[-2500:] == oi) > 0.999
+
+
 @pytest.mark.parametrize("nq,nr,d,K", [(7000, 50000, 4, 6), (513, 200000, 6, 3), (30000, 9000, 3, 12), (100, 5000, 8, 2)])
 def test_pruned_search_is_bit_identical_cross_and_shards(prune_modes, nq, nr, d, K):
     capi = prune_modes
