@@ -305,7 +305,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
         constexpr int NPASS = MCE_H_NPASS;                         // 8*NPASS pairs, 8*NPASS loads per lane in flight (D <= 32)
         constexpr int EPL = (16 * KST + 3) / 8 > 4 ? 8 : 4;        // elements per lane: 4 covers D <= 32, 8 covers D <= 61
         for (int b0 = 0; b0 < qcount; b0 += NPASS * 8) {
-            int qlp[NPASS], ep[NPASS], ojp[NPASS], qop[NPASS];
+            int qlp[NPASS], ep[NPASS];
             bool okp[NPASS];
             const double* xp[NPASS];
             const double* yp[NPASS];
@@ -322,15 +322,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
                 }
                 qlp[u] = ql;
                 const int64_t q = qwave0 + ql;
-                if constexpr (PRUNE) {
-                    okp[u] = valid && j < nr && q < nq;            // own-row test below, once the row numbers are here
-                    ojp[u] = rperm[okp[u] ? j : 0];
-                    qop[u] = qperm[okp[u] ? q : 0];
-                } else {
-                    okp[u] = valid && j < nr && q < nq && !(self_exclude && (int64_t)j == self_offset + q);
-                    ojp[u] = j;
-                    qop[u] = 0;
-                }
+                okp[u] = valid && j < nr && q < nq && !(self_exclude && (int64_t)j == self_offset + q);
                 xp[u] = X + (okp[u] ? q : 0) * (int64_t)D;
                 yp[u] = Y + (okp[u] ? (int64_t)j : 0) * D;
             }
@@ -354,11 +346,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
                 a0 += __shfl_xor(a0, 1, 64);
                 a0 += __shfl_xor(a0, 2, 64);
                 a0 += __shfl_xor(a0, 4, 64);
-                bool ok = okp[u];
-                if constexpr (PRUNE) ok = ok && !(self_exclude && (int64_t)ojp[u] == self_offset + qop[u]);
-                if (ok && sub == 0) {
+                if (okp[u] && sub == 0) {
                     wqd[ep[u]] = a0;
-                    if constexpr (PRUNE) wq[ep[u]] = ojp[u];             // from here on the entry is the caller's row number
                     wnx[ep[u]] = atomicExch(&whead[qlp[u]], ep[u]);      // push onto the query's chain
                 }
             }
@@ -543,7 +532,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
                 }
                 const double d2 = ((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7]));
                 const int oj = yorig[row];
-                const bool ok = has && oj >= 0 && qwave0 + ql < nq && !(self_exclude && (int64_t)oj == self_offset + qorig[qt]);
+                // (beyond the K-th best of the last drain: can never enter -- the thresholds only shrink)
+                const bool ok = has && oj >= 0 && qwave0 + ql < nq && !(d2 > thrq[ql]) &&
+                                !(self_exclude && (int64_t)oj == self_offset + qorig[qt]);
                 const unsigned long long m = __ballot(ok);
                 if (ok) {
                     const int slot = qcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
@@ -552,7 +543,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
                     wnx[slot] = atomicExch(&whead[ql], slot);
                 }
 #if MCE_PRUNE_PROF
-                gx_iter += 1; gx_cand += __builtin_popcountll(m); gx_useful += __builtin_popcountll(__ballot(ok && d2 <= thrq[ql]));
+                gx_iter += 1; gx_cand += __builtin_popcountll(m); gx_useful += __builtin_popcountll(__ballot(ok));
 #endif
                 qcount += __builtin_popcountll(m);
             }
@@ -650,7 +641,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
         int pend = 0;
         int st_tiles = 0, st_chunks = 0;
 #if MCE_PRUNE_PROF
-        long long pt_enq = 0, pt_pass_n = 0, pt_pass_t = 0, pt_nopass_t = 0;
+        long long pt_pass_n = 0, pt_pass_t = 0, pt_nopass_t = 0;
         long long pt_walk = 0, pt_stage = 0, pt_mul = 0, pt_drain = 0; const long long pt_begin = clock64(); long long pt_t = pt_begin;
 #define MCE_PT(acc) do { const long long n_ = clock64(); acc += n_ - pt_t; pt_t = n_; } while (0)
 #else
@@ -814,9 +805,6 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
             }
             pend = 0;
             MCE_PT(pt_mul);
-#if MCE_PRUNE_PROF
-            if (qcount >= kPruneDrainTrigger) pt_enq += qcount;
-#endif
             if (qcount >= kPruneDrainTrigger || boot_flush) drain();
             boot_flush = false;
             MCE_PT(pt_drain);
