@@ -124,9 +124,20 @@ def main():
     dotp = torch.zeros(kmax, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream()
 
+    w_all = torch.from_numpy(np.ascontiguousarray(weight)).to(dev) if world > 1 else w
+    fs_all = torch.from_numpy(np.ascontiguousarray(fsh)).to(dev) if world > 1 else fs
+    if world > 1:
+        wsb = _capi.knn_workspace_bytes(n, n, d, K) + _capi.dotp_workspace_bytes(n, kmax)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+
     def step():
-        _capi.knn_dotp_dev(Xq.data_ptr(), nq, X.data_ptr(), n, d, kmax, 1, lo, w.data_ptr(), fs.data_ptr(),
-                           dotp.data_ptr(), 0, ws.data_ptr(), wsb, stream.cuda_stream)
+        if world > 1:
+            # this rank's part of the queries (the library picks the partition: rows [lo, hi) for the sweep)
+            _capi.knn_dotp_part_dev(X.data_ptr(), n, d, kmax, rank, world, w_all.data_ptr(), fs_all.data_ptr(),
+                                    dotp.data_ptr(), ws.data_ptr(), wsb, stream.cuda_stream)
+        else:
+            _capi.knn_dotp_dev(Xq.data_ptr(), nq, X.data_ptr(), n, d, kmax, 1, lo, w.data_ptr(), fs.data_ptr(),
+                               dotp.data_ptr(), 0, ws.data_ptr(), wsb, stream.cuda_stream)
         if world > 1:
             dist.all_reduce(dotp, op=dist.ReduceOp.SUM)    # the single collective of the path
 

@@ -152,6 +152,20 @@ int mce_knn_dotp_f64_dev(const double *dX, int64_t nq, const double *dY, int64_t
                          int32_t k0, int64_t self_offset, const double *d_w, const double *d_fs,
                          double *d_dotp, double *d_dist_out, void *ws, size_t ws_bytes, void *stream);
 
+/* Multi-GPU building block for the auto evidence (queries = references, k0 = 1): the partial sums over
+ * part `part` of `nparts` of the queries.  The LIBRARY chooses the partition -- contiguous rows for the
+ * exhaustive sweep (the query shard of SURVEY.md section 8e), every nparts-th 512-query block of the k-d
+ * order for the pruned walk (spatially compact work units, one shared ordering, statistically equal
+ * shares; a row-range shard would go through the much less efficient separate-sets path) -- the parts are disjoint and cover every row, so adding the
+ * nparts results gives mce_knn_dotp_f64_dev's dotp up to summation order.  d_w / d_fs: all nr entries.
+ * workspace: mce_knn_workspace_bytes(nr, nr, d, kmax-1) + mce_dotp_workspace_bytes(nr, kmax). */
+int mce_knn_dotp_part_f64_dev(const double *dY, int64_t nr, int32_t d, int32_t kmax, int32_t part, int32_t nparts,
+                              const double *d_w, const double *d_fs, double *d_dotp, void *ws, size_t ws_bytes,
+                              void *stream);
+/* the same from host buffers (upload, compute, download) */
+int mce_knn_dotp_part_f64(const double *Y, int64_t nr, int32_t d, int32_t kmax, int32_t part, int32_t nparts,
+                          const double *w, const double *fs, double *dotp, int32_t device);
+
 /* Name of the dominant kernel last launched by this thread and its launch
  * geometry (for bench.py / profiles): "knn_mfma_f64<KS=7,KCAP=12>" etc. */
 const char *mce_last_kernel(void);
@@ -171,7 +185,7 @@ int mce_get_search_mode(void);
  * visits the reference chunks nearest-box-first, multiplies only the 32-row tiles whose box is within
  * reach, and stops once no remaining chunk can hold a neighbour.  Same neighbours, distances and
  * tie-breaks as the exhaustive search.  0 (default): used where it was measured faster -- d <= 4 from
- * 150 k reference rows, d <= 6 from 300 k, d = 7 from 800 k, d = 8 from 2.5 M; 1: never; 2: whenever the shape allows it (d <= 13, K <= 16).  Process-wide. */
+ * 150 k reference rows, d <= 6 from 300 k, d = 7 from 800 k, d = 8 from 2 M; 1: never; 2: whenever the shape allows it (d <= 13, K <= 16).  Process-wide. */
 int mce_set_prune_mode(int mode);
 int mce_get_prune_mode(void);
 /* Work actually done by the last pruned search launched by this thread through a *_dev entry point

@@ -52,6 +52,8 @@ SIGNATURES = {
     "mce_knn_dotp_f64": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _P, _P, _P, _c.c_int32]),
     "mce_evidence_feed_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32,
                                          _P, _P, _P, _P, _P, _c.c_int32]),
+    "mce_knn_dotp_part_f64_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _c.c_size_t, _P]),
+    "mce_knn_dotp_part_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_int32]),
     "mce_knn_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32]),
     "mce_dotp_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int32]),
     "mce_knn_f64_dev": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _P, _c.c_size_t, _P]),
@@ -246,6 +248,21 @@ def knn_dotp(X, Y, w, fs, kmax, k0, self_offset=0, return_dist=False, devices=No
     return (out, dist) if return_dist else out
 
 
+def knn_dotp_part(Y, w, fs, kmax, part, nparts, device=0):
+    """Partial auto-evidence sums over part ``part`` of ``nparts`` of the queries (the library chooses the
+    partition; the parts add up to ``knn_dotp(Y, None, w, fs, kmax, 1)``).  One call per rank / device."""
+    lib = load()
+    Y = _f64(Y, "Y")
+    w = _f64(w, "weight")
+    fs = _f64(fs, "fs")
+    if Y.ndim != 2 or w.shape != (Y.shape[0],) or fs.shape != w.shape:
+        raise ValueError("Y must be 2-D, weight and fs one entry per row")
+    out = np.zeros(int(kmax), dtype=np.float64)
+    check(lib.mce_knn_dotp_part_f64(Y.ctypes.data, Y.shape[0], Y.shape[1], int(kmax), int(part), int(nparts),
+                                    w.ctypes.data, fs.ctypes.data, out.ctypes.data, int(device)))
+    return out
+
+
 def _rows_f64(a, name, d):
     """2-D fp64 array whose rows are contiguous in their first d columns (row stride arbitrary)."""
     a = np.asarray(a)
@@ -360,6 +377,10 @@ def knn_dev(dX, nq, dY, nr, d, K, self_mode, self_offset, d_dist, d_idx, ws, ws_
 
 def dotp_dev(d_dist, nq, ld, k0, kmax, d, d_w, d_fs, d_dotp, ws, ws_bytes, stream=0):
     check(load().mce_dotp_f64_dev(d_dist, nq, ld, k0, kmax, d, d_w, d_fs, d_dotp, ws, ws_bytes, stream or None))
+
+
+def knn_dotp_part_dev(dY, nr, d, kmax, part, nparts, d_w, d_fs, d_dotp, ws, ws_bytes, stream=0):
+    check(load().mce_knn_dotp_part_f64_dev(dY, nr, d, kmax, part, nparts, d_w, d_fs, d_dotp, ws, ws_bytes, stream or None))
 
 
 def knn_dotp_dev(dX, nq, dY, nr, d, kmax, k0, self_offset, d_w, d_fs, d_dotp, d_dist_out, ws, ws_bytes, stream=0):

@@ -63,7 +63,7 @@ std::atomic<int> g_prune_mode{0};
 //   1 M 28 vs 58 ms, 4 M 0.14 vs 0.69 s, 10 M 0.37 vs 3.95 s      d = 7: 1 M 48 vs 59 ms      d = 8: 2 M 197 vs 200,
 //   3 M 342 vs 401, 4 M 504 vs 694 ms      d = 10: 4 M 1.43 vs 0.69 s (the boxes overlap too much)
 // smallest reference set for which the automatic mode takes the pruned walk, by dimension (0: never)
-constexpr int64_t kPruneAutoMinRows[14] = {0, 150000, 150000, 150000, 150000, 300000, 300000, 800000, 2500000, 0, 0, 0, 0, 0};
+constexpr int64_t kPruneAutoMinRows[14] = {0, 150000, 150000, 150000, 150000, 300000, 300000, 800000, 2000000, 0, 0, 0, 0, 0};
 
 // Device buffers of the host-pointer entry points.  Small allocations (<= 64 MB) are kept in a
 // per-thread, per-device pool between calls: the reference's typical workload is thousands of
@@ -188,6 +188,7 @@ struct Plan {
     int L = 4;
     size_t off_yf = 0, off_pd = 0, off_pi = 0, off_center = 0, off_msum = 0, total = 0;
     bool prune = false;                       // fp16 filter walking k-d ordered chunk lists (prune.hpp)
+    int part = 0, nparts = 1;                 // pruned walk over query blocks part, part + nparts, ... only
     int64_t pl_nr = 0;                        // reference rows the plan was made for
     mce::PruneLayout pl;
     size_t off_prune = 0;
@@ -273,6 +274,19 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
         p.nrow_pad <= ((int64_t)1 << mce::kHRelBits) && (int64_t)p.nqblk * p.nchunk <= mce::kPruneMaxPairs) {
         const int pm = g_prune_mode.load();
         p.prune = pm == 2 || (pm == 0 && kPruneAutoMinRows[d] > 0 && nr >= kPruneAutoMinRows[d]);
+    }
+    if (p.prune) {
+        // no chunk staging in this mode: a "chunk" is just a list entry of 64 tiles (one per lane) = an aligned
+        // k-d subtree of 2048 rows
+        p.CT = mce::kHPruneChunkTiles;
+        p.nchunk = (nr + p.CT * 32 - 1) / (p.CT * 32);
+        p.nrow_pad = p.nchunk * p.CT * 32;
+        if (p.nrow_pad > ((int64_t)1 << mce::kHRelBits)) p.prune = false;
+        if (!p.prune) {
+            p.CT = p.vh->ct;
+            p.nchunk = (nr + rows_per_chunk - 1) / rows_per_chunk;
+            p.nrow_pad = p.nchunk * rows_per_chunk;
+        }
     }
     // reference split r: more workgroups fill the chip and trim the last partial round
     // (one 512-thread workgroup per CU), but every split re-pays the list warm-up: a query
@@ -425,7 +439,8 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
         a.self_offset = self_offset; a.ksel = K; a.part_d = pd; a.part_i = pi;
         if (p.prune) {
             a.clist = po.clist; a.cdist = po.cdist; a.list_len = (int)p.nchunk; a.rperm = po.rperm; a.qperm = po.qperm;
-            a.tbox_r = po.tbox_r; a.tbox_q = po.tbox_q; a.cbox_r = po.cbox_r;
+            a.tbox_r = po.tbox_r; a.tbox_q = po.tbox_q; a.cbox_r = po.cbox_r; a.border = po.border;
+            if (p.nparts > 1) { a.qblk0 = p.part; a.qblk_stride = p.nparts; a.nqblk_run = (p.nqblk - p.part + p.nparts - 1) / p.nparts; }
             int rc = prof_begin();
             if (rc != MCE_OK) return rc;
             MCE_HIP(p.vh->launch_prune(a, st));
@@ -481,21 +496,25 @@ int launch_merge(const Plan& p, bool write_dist, bool fuse, const double* dX, co
                  int self_mode, int64_t self_offset, double* d_dist, int64_t* d_idx, int k0, int kmax,
                  const double* d_w, const double* d_fs, double* partial, char* ws, hipStream_t st)
 {
-    const unsigned blocks = (unsigned)((nq + mce::kRedThreads - 1) / mce::kRedThreads);
+    const bool same_set = (dX == dY && nq == p.pl_nr);
+    // a part of a pruned search: only the list columns of its query blocks were filled; the merge threads
+    // enumerate those columns compactly
+    const int qpb = p.vh ? mce::f16_qpb(p.KCAP) : 1;
+    int64_t ncol = nq;
+    if (p.nparts > 1) ncol = (int64_t)((p.nqblk - p.part + p.nparts - 1) / p.nparts) * qpb;
+    const unsigned blocks = (unsigned)((ncol + mce::kRedThreads - 1) / mce::kRedThreads);
     const double* pd = reinterpret_cast<const double*>(ws + p.off_pd);
     const int* pi = reinterpret_cast<const int*>(ws + p.off_pi);
     const bool refine = p.vh == nullptr && !p.generic;   // fp64 sweep keys are GEMM-form: refine; the others are exact
     const double lnc = fuse ? ln_unit_ball(d) : 0.0;
     // pruned search: list column q is the q-th query in k-d order; its caller row is qperm[q]
     const int* qperm = nullptr;
-    if (p.prune) {
-        const bool same_set = (dX == dY && nq == p.pl_nr);
-        qperm = reinterpret_cast<const int*>(ws + p.off_prune + (same_set ? p.pl.perm_r : p.pl.perm_q));
-    }
+    if (p.prune) qperm = reinterpret_cast<const int*>(ws + p.off_prune + (same_set ? p.pl.perm_r : p.pl.perm_q));
+    const int* border = p.prune ? reinterpret_cast<const int*>(ws + p.off_prune + p.pl.border) : nullptr;
 #define MCE_MERGE(W, F, R)                                                                                          \
     hipLaunchKernelGGL((mce::merge_lists_kernel<W, F, R>), dim3(blocks), dim3(mce::kRedThreads), 0, st, pd, pi, p.L,  \
                        p.KCAP, nq, p.nq_pad, dX, dY, (int)d, K, self_mode, self_offset, d_dist, d_idx, K, k0, kmax, \
-                       d_w, d_fs, lnc, partial, qperm)
+                       d_w, d_fs, lnc, partial, qperm, p.part, p.nparts, qpb, border, p.nqblk)
     if (write_dist && !fuse) { if (refine) MCE_MERGE(true, false, true); else MCE_MERGE(true, false, false); }
     else if (write_dist && fuse) { if (refine) MCE_MERGE(true, true, true); else MCE_MERGE(true, true, false); }
     else { if (refine) MCE_MERGE(false, true, true); else MCE_MERGE(false, true, false); }
@@ -676,6 +695,43 @@ int mce_knn_dotp_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t
     }
     hipLaunchKernelGGL(mce::dotp_final_kernel, dim3((unsigned)kmax), dim3(mce::kRedThreads), 0, st, partial,
                        (int64_t)blocks, (int)k0, (int)kmax, d_dotp);
+    MCE_HIP(hipGetLastError());
+    return MCE_OK;
+}
+
+int mce_knn_dotp_part_f64_dev(const double* dY, int64_t nr, int32_t d, int32_t kmax, int32_t part, int32_t nparts,
+                              const double* d_w, const double* d_fs, double* d_dotp, void* ws, size_t ws_bytes, void* stream)
+{
+    if (!dY || !d_w || !d_fs || !d_dotp || !ws) return fail(MCE_ERR_INVALID, "null pointer argument");
+    if (nparts < 1 || part < 0 || part >= nparts) return fail(MCE_ERR_INVALID, "part %d of %d", part, nparts);
+    if (kmax <= 1) return fail(MCE_ERR_INVALID, "kmax=%d must exceed k0=1", kmax);
+    const int K = kmax - 1;
+    Plan p;
+    int rc = make_plan(nr, nr, d, K, MCE_SELF_EXCLUDE, p);
+    if (rc != MCE_OK) return rc;
+    const size_t need = p.total + dotp_ws_bytes(nr, kmax);
+    if (ws_bytes < need) return fail(MCE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!p.prune) {
+        // contiguous rows: exactly the query shard of SURVEY.md section 8e
+        const int64_t lo = nr * part / nparts, hi = nr * (int64_t)(part + 1) / nparts;
+        if (hi == lo) { MCE_HIP(hipMemsetAsync(d_dotp, 0, (size_t)kmax * sizeof(double), st)); return MCE_OK; }
+        return mce_knn_dotp_f64_dev(dY + lo * (int64_t)d, hi - lo, dY, nr, d, kmax, 1, lo, d_w + lo, d_fs + lo, d_dotp, nullptr, ws, ws_bytes, stream);
+    }
+    // pruned walk: every nparts-th query block of the k-d order -- spatially compact work units, one shared
+    // ordering, and statistically equal shares (contiguous ranges of the order differ 2x in cost)
+    if (part >= p.nqblk) { MCE_HIP(hipMemsetAsync(d_dotp, 0, (size_t)kmax * sizeof(double), st)); return MCE_OK; }
+    p.part = part;
+    p.nparts = nparts;
+    char* wsc = static_cast<char*>(ws);
+    rc = run_search(p, dY, nr, dY, nr, d, K, MCE_SELF_EXCLUDE, 0, wsc, st);
+    if (rc != MCE_OK) return rc;
+    double* partial = reinterpret_cast<double*>(wsc + p.total);
+    rc = launch_merge(p, false, true, dY, dY, nr, d, K, MCE_SELF_EXCLUDE, 0, nullptr, nullptr, 1, (int)kmax, d_w, d_fs, partial, wsc, st);
+    if (rc != MCE_OK) return rc;
+    const int64_t ncol = (int64_t)((p.nqblk - part + nparts - 1) / nparts) * mce::f16_qpb(p.KCAP);
+    const unsigned blocks = (unsigned)((ncol + mce::kRedThreads - 1) / mce::kRedThreads);
+    hipLaunchKernelGGL(mce::dotp_final_kernel, dim3((unsigned)kmax), dim3(mce::kRedThreads), 0, st, partial, (int64_t)blocks, 1, (int)kmax, d_dotp);
     MCE_HIP(hipGetLastError());
     return MCE_OK;
 }
@@ -1266,6 +1322,33 @@ int mce_knn_dotp_f64(const double* X, int64_t nq, const double* Y, int64_t nr, i
         for (int i = 0; i < n; ++i) s += parts[i][k];
         dotp[k] = s;
     }
+    return MCE_OK;
+}
+
+int mce_knn_dotp_part_f64(const double* Y, int64_t nr, int32_t d, int32_t kmax, int32_t part, int32_t nparts, const double* w,
+                          const double* fs, double* dotp, int32_t device)
+{
+    if (!Y || !w || !fs || !dotp) return fail(MCE_ERR_INVALID, "null pointer argument");
+    if (kmax <= 1 || nr < 1) return fail(MCE_ERR_INVALID, "invalid kmax=%d nr=%lld", kmax, (long long)nr);
+    Plan p;
+    int rc = make_plan(nr, nr, d, kmax - 1, MCE_SELF_EXCLUDE, p);
+    if (rc != MCE_OK) return rc;
+    rc = select_device(device);
+    if (rc != MCE_OK) return rc;
+    const size_t wsb = p.total + dotp_ws_bytes(nr, kmax);
+    DevBuf dY, dW, dF, dO, ws;
+    MCE_HIP(dY.alloc((size_t)nr * d * sizeof(double)));
+    MCE_HIP(dW.alloc((size_t)nr * sizeof(double)));
+    MCE_HIP(dF.alloc((size_t)nr * sizeof(double)));
+    MCE_HIP(dO.alloc((size_t)kmax * sizeof(double)));
+    MCE_HIP(ws.alloc(wsb));
+    MCE_HIP(hipMemcpy(dY.p, Y, (size_t)nr * d * sizeof(double), hipMemcpyHostToDevice));
+    MCE_HIP(hipMemcpy(dW.p, w, (size_t)nr * sizeof(double), hipMemcpyHostToDevice));
+    MCE_HIP(hipMemcpy(dF.p, fs, (size_t)nr * sizeof(double), hipMemcpyHostToDevice));
+    rc = mce_knn_dotp_part_f64_dev(dY.as<double>(), nr, d, kmax, part, nparts, dW.as<double>(), dF.as<double>(), dO.as<double>(), ws.p, wsb, nullptr);
+    if (rc != MCE_OK) return rc;
+    MCE_HIP(hipDeviceSynchronize());
+    MCE_HIP(hipMemcpy(dotp, dO.p, (size_t)kmax * sizeof(double), hipMemcpyDeviceToHost));
     return MCE_OK;
 }
 

@@ -63,6 +63,8 @@ struct KnnF16Args {
     const float* tbox_r = nullptr;
     const float* tbox_q = nullptr;
     const float* cbox_r = nullptr;
+    const int* border = nullptr;   // pruned walk: dispatch order of the query blocks
+    int qblk0 = 0, qblk_stride = 1, nqblk_run = 0;   // pruned walk: nqblk_run query blocks qblk0, qblk0 + stride, ... (0: all)
 };
 typedef hipError_t (*knn_f16_launch_fn)(const KnnF16Args&, hipStream_t);
 struct KnnF16Variant {

@@ -114,6 +114,7 @@ __host__ __device__ constexpr int f16_prune_slice_bytes(int KST) { return MCE_H_
 #define MCE_H_PRUNE_BOOT 12
 #endif
 constexpr int kHPruneBoot = MCE_H_PRUNE_BOOT;   // pruned walk: k-d neighbour tiles on either side multiplied before the walk
+constexpr int kHPruneChunkTiles = 64; // pruned walk: tiles per list entry ("chunk" = 2048 rows, an aligned k-d subtree)
 constexpr int kHPruneQueue = 256;   // pruned walk: queue entries per wave (already exact: only the list insertion is deferred)
 // [tile slice + pending ids][queue d2 | row | next][heads][the wave's 64 fp64 query rows][one fp64 reference tile][its caller row numbers]
 __host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST, int D)
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
     double* __restrict__ part_d, int* __restrict__ part_i,
     const int* __restrict__ clist, const float* __restrict__ cdist, int list_len,
     const int* __restrict__ rperm, const int* __restrict__ qperm,
-    const float* __restrict__ tbox_r, const float* __restrict__ tbox_q, const float* __restrict__ cbox_r)
+    const float* __restrict__ tbox_r, const float* __restrict__ tbox_q, const float* __restrict__ cbox_r, int qblk0, int qblk_stride, const int* __restrict__ border)
 {
     constexpr int QT = f16_qt(KCAP);
     constexpr int QPW = QT * 32;                         // queries per wave
@@ -180,7 +181,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
     const int lane = tid & 63;
     const int lwave = PRUNE ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);                  // index into the LDS regions
     const int wave = PRUNE ? (int)(blockIdx.x % kHWaves) : lwave;                            // position inside the query block
-    const int qblk = PRUNE ? (int)(blockIdx.x / kHWaves) : (int)(blockIdx.x % nqblk);
+    // PRUNE: the launch's (or part's) blocks are border[qblk0], border[qblk0 + stride], ...: the dispatch
+    // order puts the largest boxes -- the longest walks -- first
+    const int qblk = PRUNE ? border[qblk0 + (int)(blockIdx.x / kHWaves) * qblk_stride] : (int)(blockIdx.x % nqblk);
     const int split = PRUNE ? 0 : (int)(blockIdx.x / nqblk);
 
     const int64_t cps = (nchunk_total + rsplit - 1) / rsplit;
@@ -631,6 +634,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
         // of kBatch: the batch's A tiles (1 KB each) go through registers into the wave's private
         // slice of the staging area and are swept from there.
         constexpr int kBatch = MCE_H_PRUNE_BATCH;
+        constexpr int PCT = kHPruneChunkTiles;               // tiles per list chunk: one per lane
         constexpr int kPruneDrainTrigger = MCE_H_PRUNE_TRIGGER;
         static_assert(f16_prune_slice_bytes(KST) >= kBatch * KST * 1024 + 256, "tile slice");
         const int* const mylist = clist + (int64_t)qblk * list_len;
@@ -664,6 +668,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
         const int boot_n = same_order ? 2 * kHPruneBoot + QT : 0;
         int boot_k = 0;
         bool boot_flush = false;
+        // (a wave of padding queries only would never tighten anything and walk the whole list)
+        if (qwave0 >= nq) { boot_k = boot_n; e = list_len; }
         for (;;) {
             // ---- collect: fill the pending list from the current chunk's mask, moving down the list
             while (pend < kBatch) {
@@ -719,7 +725,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
                     const int bsel = (int)__builtin_ctzll(cand);
                     cand &= cand - 1;
                     c = __shfl(win_c, bsel, 64);
-                    const float* cb = tbox_r + (int64_t)c * (2 * D * CT) + (lane < CT ? lane : 0);
+                    const float* cb = tbox_r + (int64_t)c * (2 * D * PCT) + lane;
                     // fp32 is enough for a rigorous bound: a gap fl(a - b) of two floats is within 2^-24
                     // of exact, the sum of <= 13 squares within 2^-19; the comparison gives back 2^-18
                     float acc[QT];
@@ -728,7 +734,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
 #pragma unroll
                     for (int i = 0; i < kPruneDims; ++i) {
                         if (i < D) {
-                            const float rlo = cb[i * CT], rhi = cb[(D + i) * CT];
+                            const float rlo = cb[i * PCT], rhi = cb[(D + i) * PCT];
 #pragma unroll
                             for (int qt = 0; qt < QT; ++qt) {
                                 const float g = fmaxf(0.0f, fmaxf(qb[qt * 2 * D + i] - rhi, rlo - qb[qt * 2 * D + D + i]));
@@ -737,10 +743,10 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
                         }
                     }
                     {
-                        const int tile_id = c * CT + lane;
+                        const int tile_id = c * PCT + lane;
                         const bool booted = tile_id >= boot_lo && tile_id < boot_hi;
 #pragma unroll
-                        for (int qt = 0; qt < QT; ++qt) need |= __ballot(lane < CT && !booted && !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]));
+                        for (int qt = 0; qt < QT; ++qt) need |= __ballot(!booted && !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]));
                     }
                     st_tiles += __builtin_popcountll(need);
                     if (need == 0) continue;
@@ -749,7 +755,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
                 const bool mine = (need >> lane) & 1ull;
                 const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
                 const bool take = mine && rank < kBatch - pend;
-                if (take) wl[pend + rank] = c * CT + lane;
+                if (take) wl[pend + rank] = c * PCT + lane;
                 const unsigned long long taken = __ballot(take);
                 need &= ~taken;
                 pend += __builtin_popcountll(taken);

@@ -47,10 +47,10 @@ hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
         if (dev < kMaxDevices) attr_set[dev] = true;
     }
     // pruned walk: one 64-thread workgroup per wave of a query block
-    const dim3 grid((unsigned)(PRUNE ? a.nqblk * kHWaves : a.nqblk * a.rsplit));
+    const dim3 grid((unsigned)(PRUNE ? (a.nqblk_run ? a.nqblk_run : a.nqblk) * kHWaves : a.nqblk * a.rsplit));
     hipLaunchKernelGGL(kern, grid, dim3(PRUNE ? 64 : kHThreads), LDS, st, static_cast<const _Float16*>(a.Yh), a.nchunk_total, a.rsplit,
                        static_cast<const _Float16*>(a.Xh), a.qinfo, a.params, a.X, a.Y, a.nq, a.nr, a.D, a.nq_pad, a.nqblk,
-                       a.self_exclude, a.self_offset, a.ksel, a.part_d, a.part_i, a.clist, a.cdist, a.list_len, a.rperm, a.qperm, a.tbox_r, a.tbox_q, a.cbox_r);
+                       a.self_exclude, a.self_offset, a.ksel, a.part_d, a.part_i, a.clist, a.cdist, a.list_len, a.rperm, a.qperm, a.tbox_r, a.tbox_q, a.cbox_r, a.qblk0, a.qblk_stride, a.border);
     return hipGetLastError();
 }
 #endif
@@ -83,7 +83,7 @@ extern const KnnF16Variant MCE_CAT(g_knn_f16_kcap, MCE_KCAP)[kMaxKST] = {
 #else
 // device pass: force the kernel instantiations
 #if MCE_KCAP <= 16
-#define MCE_F16_INST(KST, PR) template __global__ void knn_f16_kernel<KST, MCE_KCAP, PR>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*);
+#define MCE_F16_INST(KST, PR) template __global__ void knn_f16_kernel<KST, MCE_KCAP, PR>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*, int, int, const int*);
 MCE_F16_INST(1, false) MCE_F16_INST(2, false) MCE_F16_INST(3, false) MCE_F16_INST(4, false) MCE_F16_INST(1, true)
 #endif
 #define MCE_INST(KS) template __global__ void knn_mfma_kernel<KS, MCE_KCAP>(const double*, int64_t, int, const double*, const double*, int64_t, int, int64_t, int, int, int64_t, int, double*, int*);

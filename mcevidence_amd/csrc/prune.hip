@@ -18,34 +18,46 @@ constexpr int kThreads = 256;
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-int tree_levels(int64_t n_units)
+constexpr int kAlign = 64;        // units (32-row tiles) per aligned group: the list chunk of the pruned walk
+constexpr int kAlignLevels = 6;
+
+int top_tree_levels(int64_t n_units)
 {
+    const int64_t groups = (n_units + kAlign - 1) / kAlign;
     int L = 0;
-    while (((int64_t)1 << L) < n_units) ++L;
+    while (((int64_t)1 << L) < groups) ++L;
     return L;
 }
 
 // key = (node id at `level`) << 32 | order-preserving bits of (float) coordinate; padding rows
 // sort behind everything in their node (which is always the last node).
 __global__ __launch_bounds__(kThreads) void kd_key_kernel(const int* __restrict__ perm_in, int64_t n, int64_t n_pad, int unit_rows,
-                                                          int n_units, int level, const double* __restrict__ P, int d, int dim,
+                                                          int n_units, int top_levels, int level, const double* __restrict__ P, int d, int dim,
                                                           unsigned long long* __restrict__ keys, int* __restrict__ vals)
 {
     const int64_t pos = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (pos >= n_pad) return;
     const int row = perm_in ? perm_in[pos] : (pos < n ? (int)pos : -1);
+    // ALIGNED tree: the top levels split whole groups of kAlign units (2048 rows) between the children, the
+    // last log2(kAlign) levels halve a group bit by bit -- so every aligned run of 2, 16 or 64 units (a
+    // wave's query tiles, a query block, a list chunk) is exactly one subtree: a tight box.  (Splitting at
+    // (lo+hi)/2 units instead lets such runs straddle high-level split planes: their boxes span far-apart
+    // corners and the walk does up to 2x the work.)
     const int u = (int)(pos / unit_rows);
-    int lo = 0, hi = n_units;
+    const int cu = u / kAlign;
+    int clo = 0, chi = (n_units + kAlign - 1) / kAlign;
     unsigned id = 0;
-    for (int l = 0; l < level; ++l) {
-        if (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (u < mid) { hi = mid; id = 2 * id; }
-            else { lo = mid; id = 2 * id + 1; }
+    int l = 0;
+    for (; l < level && l < top_levels; ++l) {
+        if (chi - clo > 1) {
+            const int mid = (clo + chi) >> 1;
+            if (cu < mid) { chi = mid; id = 2 * id; }
+            else { clo = mid; id = 2 * id + 1; }
         } else {
             id = 2 * id;
         }
     }
+    for (int half = kAlign >> 1; l < level; ++l, half >>= 1) id = 2 * id + ((u & half) ? 1u : 0u);
     unsigned b = 0xFFFFFFFFu;
     if (row >= 0) {
         const float c = (float)P[(int64_t)row * d + dim];
@@ -147,6 +159,22 @@ __global__ __launch_bounds__(kThreads) void box_dist_kernel(const float* __restr
     out_c[e] = c;
 }
 
+// dispatch order of the query blocks: largest box first (the sparse corner cells of the k-d order walk ten
+// times farther than the rest: started last they would BE the tail of the launch)
+__global__ __launch_bounds__(kThreads) void block_cost_kernel(const float* __restrict__ qbox, int nqblk, int d, float* __restrict__ keys,
+                                                              int* __restrict__ vals)
+{
+    const int b = blockIdx.x * kThreads + threadIdx.x;
+    if (b >= nqblk) return;
+    float s = 0.0f;
+    for (int i = 0; i < d; ++i) {
+        const float w = qbox[((int64_t)b * 2 + 1) * d + i] - qbox[((int64_t)b * 2) * d + i];
+        s += (w > 0.0f && w < 3.0e38f) ? w * w : 0.0f;
+    }
+    keys[b] = s;
+    vals[b] = b;
+}
+
 struct SegmentOffset {
     unsigned stride;
     __host__ __device__ unsigned operator()(unsigned i) const { return i * stride; }
@@ -180,7 +208,8 @@ size_t segsort_tmp_bytes(int nqblk, int64_t nchunk)
 hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_rows, int n_units, int* perm, unsigned long long* keys_a,
                    unsigned long long* keys_b, int* vals_b, void* tmp, size_t tmp_bytes, hipStream_t st)
 {
-    const int L = tree_levels(n_units);
+    const int Ltop = top_tree_levels(n_units);
+    const int L = Ltop + (n_units > 1 ? kAlignLevels : 0);
     const unsigned blocks = (unsigned)((n_pad + kThreads - 1) / kThreads);
     if (L == 0) {
         hipLaunchKernelGGL(identity_perm_kernel, dim3(blocks), dim3(kThreads), 0, st, n, n_pad, perm);
@@ -188,7 +217,7 @@ hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_ro
     }
     for (int level = 0; level < L; ++level) {
         hipLaunchKernelGGL(kd_key_kernel, dim3(blocks), dim3(kThreads), 0, st, level == 0 ? (const int*)nullptr : perm, n, n_pad, unit_rows,
-                           n_units, level, P, d, level % d, keys_a, vals_b);
+                           n_units, Ltop, level, P, d, level % d, keys_a, vals_b);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         size_t tb = tmp_bytes;
@@ -219,11 +248,18 @@ int prune_layout(int64_t nq, int64_t nq_pad, int nqblk, int64_t nr, int64_t nr_p
     L.tboxT_r = take((size_t)(nr_pad / kPruneTileRows) * 2 * d * 4);
     L.box_r = take((size_t)nchunk * 2 * d * 4);
     L.box_q = take((size_t)nqblk * 2 * d * 4);
+    L.bkey_a = take((size_t)nqblk * 4);
+    L.bkey_b = take((size_t)nqblk * 4);
+    L.bval_a = take((size_t)nqblk * 4);
+    L.border = take((size_t)nqblk * 4);
     L.list_d_a = take((size_t)pairs * 4);
     L.list_c_a = take((size_t)pairs * 4);
     L.list_d_b = take((size_t)pairs * 4);
     L.list_c_b = take((size_t)pairs * 4);
-    L.tmp_bytes = std::max(sort_tmp_bytes(nmax), segsort_tmp_bytes(nqblk, nchunk));
+    size_t border_tmp = 0;
+    (void)rocprim::radix_sort_pairs_desc(nullptr, border_tmp, (const float*)nullptr, (float*)nullptr, (const int*)nullptr, (int*)nullptr,
+                                         (size_t)nqblk, 0u, 32u);
+    L.tmp_bytes = std::max(std::max(sort_tmp_bytes(nmax), segsort_tmp_bytes(nqblk, nchunk)), border_tmp);
     L.tmp = take(L.tmp_bytes);
     L.total = off;
     return 0;
@@ -293,6 +329,18 @@ hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t
     e = rocprim::segmented_radix_sort_pairs(tmp, tb, (const float*)list_d_a, list_d_b, (const int*)list_c_a, list_c_b, (unsigned)pairs,
                                             (unsigned)nqblk, offsets(0, (unsigned)nchunk), offsets(1, (unsigned)nchunk), 0u, 32u, st);
     if (e != hipSuccess) return e;
+    {
+        float* bkey_a = reinterpret_cast<float*>(ws + L.bkey_a);
+        float* bkey_b = reinterpret_cast<float*>(ws + L.bkey_b);
+        int* bval_a = reinterpret_cast<int*>(ws + L.bval_a);
+        int* border = reinterpret_cast<int*>(ws + L.border);
+        hipLaunchKernelGGL(block_cost_kernel, dim3((unsigned)((nqblk + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, box_q, nqblk, d, bkey_a, bval_a);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        size_t tb2 = L.tmp_bytes;
+        e = rocprim::radix_sort_pairs_desc(tmp, tb2, (const float*)bkey_a, bkey_b, (const int*)bval_a, border, (size_t)nqblk, 0u, 32u, st);
+        if (e != hipSuccess) return e;
+        out.border = border;
+    }
     out.Ys = Ys;
     out.rperm = perm_r;
     out.clist = list_c_b;

@@ -36,6 +36,7 @@ struct PruneLayout {
     size_t tbox_r = 0, tbox_q = 0;          // float [tiles][2][d] (lo | hi), rounded outward
     size_t tboxT_r = 0;                     // float [nchunk][2][d][tiles per chunk]: the kernel's layout
     size_t box_r = 0, box_q = 0;            // float [nchunk][2][d], [nqblk][2][d]
+    size_t bkey_a = 0, bkey_b = 0, bval_a = 0, border = 0;   // query blocks by descending box size: [nqblk]
     size_t list_d_a = 0, list_c_a = 0;      // float / int32 [nqblk * nchunk] unsorted
     size_t list_d_b = 0, list_c_b = 0;      // sorted
     size_t tmp = 0, tmp_bytes = 0;          // rocPRIM scratch
@@ -55,6 +56,7 @@ struct PruneOut {
     const float* tbox_r = nullptr;          // reference tile boxes, [chunk][2][d][tiles per chunk]
     const float* tbox_q = nullptr;          // query tile boxes
     const float* cbox_r = nullptr;          // reference chunk boxes [chunk][2][d]
+    const int* border = nullptr;            // dispatch order of the query blocks (largest box first)
 };
 
 // same_set: the queries ARE the reference rows (same pointer, nq == nr): one ordering serves both

@@ -60,10 +60,16 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
     int self_mode, int64_t self_offset,
     double* __restrict__ dist, int64_t* __restrict__ idx, int ld_out,
     int k0, int kmax, const double* __restrict__ w, const double* __restrict__ fs, double lnc,
-    double* __restrict__ partial, const int* __restrict__ qperm)
+    double* __restrict__ partial, const int* __restrict__ qperm, int part, int nparts, int qpb, const int* __restrict__ border, int nqblk)
 {
     __shared__ double red[kRedThreads / 64];
-    const int64_t q = (int64_t)blockIdx.x * kRedThreads + threadIdx.x;
+    // nparts > 1: this launch covers the query blocks part, part + nparts, ... (qpb list columns each) of a
+    // pruned search; the thread index is the compact position among them
+    int64_t q = (int64_t)blockIdx.x * kRedThreads + threadIdx.x;
+    if (nparts > 1) {
+        const int64_t slot = (q / qpb) * nparts + part;          // position in the dispatch order
+        q = slot < nqblk ? (int64_t)border[slot] * qpb + q % qpb : nq;
+    }
     const bool live = q < nq;
     // list column q belongs to caller row qo (pruned search: queries were reordered; the lists
     // already carry caller row numbers for the references)

@@ -40,6 +40,17 @@ def _local_hip(Xs, Y, ws, fss, kmax, k0, self_offset, want_dist):
     return out if want_dist else (out, None)
 
 
+def _reduce_partial(part, group=None):
+    """the single RCCL collective of the path: all-reduce(sum) of kmax doubles"""
+    import torch
+    import torch.distributed as dist
+    backend = dist.get_backend(group)
+    device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    t = torch.as_tensor(np.asarray(part, dtype=np.float64), device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()
+
+
 def sharded_knn_dotp(X, Y, weight, fs, kmax, k0, want_dist=False, group=None, local_fn=None):
     """Query-sharded fused kNN + reduction.  Every rank passes the FULL arrays (they are
     replicated host-side, as the reference set must be anyway) and gets the full
@@ -51,16 +62,19 @@ def sharded_knn_dotp(X, Y, weight, fs, kmax, k0, want_dist=False, group=None, lo
     n = X.shape[0]
     lo, hi = shard_bounds(n, world, rank)
     ref = X if Y is None else Y
+    if Y is None and local_fn is None and not want_dist:
+        # auto evidence: let the library choose the partition (rows for the sweep, k-d cells for the pruned
+        # walk, whose shards must be spatially compact to stay efficient): mce_knn_dotp_part_f64
+        from . import _capi
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        part = _capi.knn_dotp_part(X, weight, fs, kmax, rank, world, device=dev)
+        return _reduce_partial(part, group), None
     fn = local_fn or _local_hip
     if hi > lo:
         part, dpart = fn(np.ascontiguousarray(X[lo:hi]), ref, weight[lo:hi], fs[lo:hi], kmax, k0, lo if k0 == 1 else 0, want_dist)
     else:
         part, dpart = np.zeros(kmax), (np.zeros((0, kmax - k0)) if want_dist else None)
-    backend = dist.get_backend(group)
-    device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    t = torch.as_tensor(np.asarray(part, dtype=np.float64), device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)      # the single RCCL collective of the path
-    dotp = t.cpu().numpy()
+    dotp = _reduce_partial(part, group)
     dist_full = None
     if want_dist:
         # row-concatenation of the shards (debug/verbose path only)

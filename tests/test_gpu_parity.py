@@ -745,3 +745,23 @@ def test_prune_stats_lifetime(prune_modes):
     capi.knn_dev(Y.data_ptr(), n, Y.data_ptr(), n, d, K, capi.SELF_EXCLUDE, 0, dist.data_ptr(), 0, ws.data_ptr(), wsb, 0)
     windows, tiles = capi.last_prune_stats()
     assert 0.0 < tiles < 0.5 and windows > 0.0           # most tile products were never multiplied
+
+
+@pytest.mark.parametrize("n,d,kmax,pruned", [(90000, 6, 5, True), (90000, 6, 5, False), (40000, 27, 10, False), (130001, 3, 3, True)])
+def test_partial_sums_add_up(prune_modes, n, d, kmax, pruned):
+    """mce_knn_dotp_part_f64: the parts (library-chosen: row ranges for the sweep, k-d cells for the pruned
+    walk) are disjoint and complete -- their sums add up to the one-call result -- for any number of parts."""
+    capi = prune_modes
+    capi.set_prune_mode(capi.PRUNE_FORCE if pruned else capi.PRUNE_OFF)
+    rng = np.random.default_rng(n + kmax)
+    Y = rng.standard_normal((n, d))
+    w = rng.integers(1, 5, n).astype(float)
+    fs = -rng.random(n) * 3
+    full = capi.knn_dotp(Y, None, w, fs, kmax, 1)
+    for nparts in (1, 2, 3, 8):
+        parts = [capi.knn_dotp_part(Y, w, fs, kmax, r, nparts) for r in range(nparts)]
+        assert ("pruned" in capi.last_kernel()) == pruned
+        assert np.allclose(np.sum(parts, axis=0), full, rtol=1e-12, atol=0)
+        assert all((p[1:] > 0).all() and p[0] == 0 for p in parts)
+    with pytest.raises(ValueError):
+        capi.knn_dotp_part(Y, w, fs, kmax, 3, 3)

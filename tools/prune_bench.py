@@ -6,6 +6,8 @@ import torch
 from mcevidence_amd import _capi
 
 N, D, K = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+SH = int(sys.argv[sys.argv.index("--shard") + 1]) if "--shard" in sys.argv else 1     # queries = the first 1/SH of the rows
+NQ = N // SH
 rng = np.random.default_rng(0)
 Y = torch.from_numpy(rng.standard_normal((N, D))).cuda()
 out = {}
@@ -13,12 +15,12 @@ for mode, name in ((_capi.PRUNE_FORCE, "pruned"), (_capi.PRUNE_OFF, "exhaustive"
     if name == "exhaustive" and N > 3_000_000 and "--full" not in sys.argv:
         continue
     _capi.set_prune_mode(mode)
-    wsb = _capi.knn_workspace_bytes(N, N, D, K)
+    wsb = _capi.knn_workspace_bytes(NQ, N, D, K)
     ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
-    dist = torch.empty((N, K), dtype=torch.float64, device="cuda")
-    idx = torch.empty((N, K), dtype=torch.int64, device="cuda")
+    dist = torch.empty((NQ, K), dtype=torch.float64, device="cuda")
+    idx = torch.empty((NQ, K), dtype=torch.int64, device="cuda")
     def run():
-        _capi.knn_dev(Y.data_ptr(), N, Y.data_ptr(), N, D, K, _capi.SELF_EXCLUDE, 0, dist.data_ptr(), idx.data_ptr(), ws.data_ptr(), wsb,
+        _capi.knn_dev(Y.data_ptr(), NQ, Y.data_ptr(), N, D, K, _capi.SELF_EXCLUDE, 0, dist.data_ptr(), idx.data_ptr(), ws.data_ptr(), wsb,
                       torch.cuda.current_stream().cuda_stream)
     run(); torch.cuda.synchronize()
     _capi.set_profiling(True)
@@ -33,4 +35,4 @@ for mode, name in ((_capi.PRUNE_FORCE, "pruned"), (_capi.PRUNE_OFF, "exhaustive"
     if name == "pruned":
         run(); out[name]["chunk_fraction"], out[name]["tile_fraction"] = _capi.last_prune_stats()
     del ws
-print(json.dumps({"N": N, "D": D, "K": K, **out}))
+print(json.dumps({"NQ": NQ, "N": N, "D": D, "K": K, **out}))
