@@ -263,14 +263,16 @@ def knn_dotp_part(Y, w, fs, kmax, part, nparts, device=0):
     return out
 
 
-def _rows_f64(a, name, d):
-    """2-D fp64 array whose rows are contiguous in their first d columns (row stride arbitrary)."""
+def _rows_f64(a, name, d, check=True):
+    """2-D fp64 array whose rows are contiguous in their first d columns (row stride arbitrary).
+    ``check=False``: the callee detects NaN / infinity itself (the device covariance turns non-finite and
+    the call fails with ValueError), sparing a host pass over the whole matrix."""
     a = np.asarray(a)
     if a.ndim != 2 or a.shape[1] < d:
         raise ValueError("%s must be 2-D with at least %d columns" % (name, d))
     if a.dtype != np.float64 or a.strides[1] != 8 or a.strides[0] % 8 != 0 or a.strides[0] < 8 * d:
         a = np.ascontiguousarray(a[:, :d], dtype=np.float64)
-    if not np.all(np.isfinite(a[:, :d])):
+    if check and not np.all(np.isfinite(a[:, :d])):
         raise ValueError("%s contains NaN or infinity" % name)
     return a
 
@@ -279,8 +281,8 @@ def evidence_feed(S1, S2, d, cov_mode, kmax, w, fs, device=0):
     """Covariance + whitening + kNN + reduction on the device from ONE upload of the raw parameter
     rows.  Returns (dotp[kmax], jacobian, eigenvalues[d])."""
     lib = load()
-    S1 = _rows_f64(S1, "samples", d)
-    S2 = None if S2 is None else _rows_f64(S2, "samples2", d)
+    S1 = _rows_f64(S1, "samples", d, check=False)
+    S2 = None if S2 is None else _rows_f64(S2, "samples2", d, check=False)
     w = _f64(w, "weight")
     fs = _f64(fs, "fs")
     if w.shape != (S1.shape[0],) or fs.shape != w.shape:
@@ -322,8 +324,8 @@ def evidence_feed_batch(problems, devices=None, return_exceptions=False):
     outs = []
     for i, (S1, S2, d, cov_mode, kmax, w, fs) in enumerate(problems):
         d, kmax = int(d), int(kmax)
-        S1 = _rows_f64(S1, "samples", d)
-        S2 = None if S2 is None else _rows_f64(S2, "samples2", d)
+        S1 = _rows_f64(S1, "samples", d, check=False)
+        S2 = None if S2 is None else _rows_f64(S2, "samples2", d, check=False)
         w = _f64(w, "weight")
         fs = _f64(fs, "fs")
         if w.shape != (S1.shape[0],) or fs.shape != w.shape:

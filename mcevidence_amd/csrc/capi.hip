@@ -1031,8 +1031,10 @@ int feed_stage_b(FeedJob& j)
     for (int sidx = 0; sidx < nsys; ++sidx) {
         std::vector<double> cov(j.h_cov(sidx), j.h_cov(sidx) + (size_t)d * d), lam, V;
         jacobi_eig(cov, d, lam, V);
-        for (int i = 0; i < d; ++i)
+        for (int i = 0; i < d; ++i) {
+            if (lam[i] != lam[i] || std::isinf(lam[i])) return fail(MCE_ERR_INVALID, "samples contain NaN or infinity (non-finite covariance)");
             if (!(lam[i] > 0.0)) return fail(MCE_ERR_INVALID, "math domain error: covariance eigenvalue %d is %g (use fewer parameters, ndim)", i, lam[i]);
+        }
         std::copy(V.begin(), V.end(), j.h_evec(sidx));
         for (int i = 0; i < d; ++i) j.h_scale(sidx)[i] = 1.0 / std::sqrt(lam[i]);
         if (sidx == 0) {
