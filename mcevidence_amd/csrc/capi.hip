@@ -766,15 +766,19 @@ int mce_knn_f64(const double* X, int64_t nq, const double* Y, int64_t nr, int32_
     if (nq == 0) return MCE_OK;
     rc = select_device(device);
     if (rc != MCE_OK) return rc;
+    // queries that ARE rows of the caller's reference buffer (kneighbors(Y) after fit(Y), a shard of it): one
+    // upload, and the search sees one set (shared k-d order in the pruned walk)
+    const bool inside = X >= Y && X + (size_t)nq * d <= Y + (size_t)nr * d && (X - Y) % d == 0;
     DevBuf dX, dY, dD, dI, ws;
-    MCE_HIP(dX.alloc((size_t)nq * d * sizeof(double)));
+    if (!inside) MCE_HIP(dX.alloc((size_t)nq * d * sizeof(double)));
     MCE_HIP(dY.alloc((size_t)nr * d * sizeof(double)));
     MCE_HIP(dD.alloc((size_t)nq * K * sizeof(double)));
     if (idx) MCE_HIP(dI.alloc((size_t)nq * K * sizeof(int64_t)));
     MCE_HIP(ws.alloc(p.total));
-    MCE_HIP(hipMemcpy(dX.p, X, (size_t)nq * d * sizeof(double), hipMemcpyHostToDevice));
+    if (!inside) MCE_HIP(hipMemcpy(dX.p, X, (size_t)nq * d * sizeof(double), hipMemcpyHostToDevice));
     MCE_HIP(hipMemcpy(dY.p, Y, (size_t)nr * d * sizeof(double), hipMemcpyHostToDevice));
-    rc = mce_knn_f64_dev(dX.as<double>(), nq, dY.as<double>(), nr, d, K, self_mode, self_offset, dD.as<double>(),
+    const double* dXp = inside ? dY.as<double>() + (X - Y) : dX.as<double>();
+    rc = mce_knn_f64_dev(dXp, nq, dY.as<double>(), nr, d, K, self_mode, self_offset, dD.as<double>(),
                          idx ? dI.as<int64_t>() : nullptr, ws.p, p.total, nullptr);
     if (rc != MCE_OK) return rc;
     MCE_HIP(hipDeviceSynchronize());
@@ -898,19 +902,22 @@ int fused_on_device(int device, const double* X, int64_t q_lo, int64_t q_hi, con
     rc = make_plan(nq, nr, d, K, k0 == 1 ? MCE_SELF_EXCLUDE : MCE_SELF_NONE, p);
     if (rc != MCE_OK) return rc;
     const size_t wsb = p.total + dotp_ws_bytes(nq, kmax);
+    const double* Xs = X + q_lo * (int64_t)d;
+    const bool inside = Xs >= Y && Xs + (size_t)nq * d <= Y + (size_t)nr * d && (Xs - Y) % d == 0;     // as in mce_knn_f64
     DevBuf dX, dY, dW, dF, dO, dD, ws;
-    MCE_HIP(dX.alloc((size_t)nq * d * sizeof(double)));
+    if (!inside) MCE_HIP(dX.alloc((size_t)nq * d * sizeof(double)));
     MCE_HIP(dY.alloc((size_t)nr * d * sizeof(double)));
     MCE_HIP(dW.alloc((size_t)nq * sizeof(double)));
     MCE_HIP(dF.alloc((size_t)nq * sizeof(double)));
     MCE_HIP(dO.alloc((size_t)kmax * sizeof(double)));
     if (dist_out) MCE_HIP(dD.alloc((size_t)nq * K * sizeof(double)));
     MCE_HIP(ws.alloc(wsb));
-    MCE_HIP(hipMemcpy(dX.p, X + q_lo * (int64_t)d, (size_t)nq * d * sizeof(double), hipMemcpyHostToDevice));
+    if (!inside) MCE_HIP(hipMemcpy(dX.p, Xs, (size_t)nq * d * sizeof(double), hipMemcpyHostToDevice));
     MCE_HIP(hipMemcpy(dY.p, Y, (size_t)nr * d * sizeof(double), hipMemcpyHostToDevice));
+    const double* dXp = inside ? dY.as<double>() + (Xs - Y) : dX.as<double>();
     MCE_HIP(hipMemcpy(dW.p, w + q_lo, (size_t)nq * sizeof(double), hipMemcpyHostToDevice));
     MCE_HIP(hipMemcpy(dF.p, fs + q_lo, (size_t)nq * sizeof(double), hipMemcpyHostToDevice));
-    rc = mce_knn_dotp_f64_dev(dX.as<double>(), nq, dY.as<double>(), nr, d, kmax, k0, self_offset + q_lo,
+    rc = mce_knn_dotp_f64_dev(dXp, nq, dY.as<double>(), nr, d, kmax, k0, self_offset + q_lo,
                               dW.as<double>(), dF.as<double>(), dO.as<double>(), dist_out ? dD.as<double>() : nullptr,
                               ws.p, wsb, nullptr);
     if (rc != MCE_OK) return rc;
