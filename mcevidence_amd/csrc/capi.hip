@@ -63,6 +63,7 @@ std::atomic<int> g_prune_mode{0};
 //   1 M 28 vs 58 ms, 4 M 0.14 vs 0.69 s, 10 M 0.37 vs 3.95 s      d = 7: 1 M 48 vs 59 ms      d = 8: 2 M 197 vs 200,
 //   3 M 342 vs 401, 4 M 504 vs 694 ms      d = 10: 4 M 1.43 vs 0.69 s (the boxes overlap too much)
 // smallest reference set for which the automatic mode takes the pruned walk, by dimension (0: never)
+constexpr int64_t kPruneAutoMinQueries = 32768;
 constexpr int64_t kPruneAutoMinRows[14] = {0, 150000, 150000, 150000, 150000, 300000, 300000, 800000, 2000000, 0, 0, 0, 0, 0};
 
 // Device buffers of the host-pointer entry points.  Small allocations (<= 64 MB) are kept in a
@@ -273,7 +274,10 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     if (f16 && p.KST == 1 && d <= mce::kPruneMaxDim && p.vh->launch_prune && nq > 0 &&
         p.nrow_pad <= ((int64_t)1 << mce::kHRelBits) && (int64_t)p.nqblk * p.nchunk <= mce::kPruneMaxPairs) {
         const int pm = g_prune_mode.load();
-        p.prune = pm == 2 || (pm == 0 && kPruneAutoMinRows[d] > 0 && nr >= kPruneAutoMinRows[d]);
+        // (the k-d ordering costs ~4 ms per million reference rows whatever the number of queries, and sparse
+        // query sets make large query tiles: measured at 2 M x 6, separate sets, the walk wins from nq ~ nr/10)
+        p.prune = pm == 2 || (pm == 0 && kPruneAutoMinRows[d] > 0 && nr >= kPruneAutoMinRows[d] && nq >= kPruneAutoMinQueries &&
+                                           nq >= nr / 8);
     }
     if (p.prune) {
         // no chunk staging in this mode: a "chunk" is just a list entry of 64 tiles (one per lane) = an aligned
