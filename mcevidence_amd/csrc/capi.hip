@@ -1316,9 +1316,13 @@ int mce_knn_dotp_f64(const double* X, int64_t nq, const double* Y, int64_t nr, i
     std::vector<std::vector<double>> parts(n, std::vector<double>(kmax, 0.0));
     std::vector<int> rcs(n, MCE_OK);
     std::vector<std::string> errs(n);
+    // auto evidence over one set: let each device take a library-chosen part (rows for the sweep, blocks of the
+    // shared k-d order for the pruned walk) instead of a row range
+    const bool whole_set = n > 1 && X == Y && nq == nr && k0 == 1 && self_offset == 0 && !dist_out;
     auto work = [&](int i) {
         const int64_t lo = nq * i / n, hi = nq * (i + 1) / n;
-        rcs[i] = fused_on_device(devs[i], X, lo, hi, Y, nr, d, kmax, k0, self_offset, w, fs, parts[i].data(), dist_out);
+        if (whole_set) rcs[i] = mce_knn_dotp_part_f64(Y, nr, d, kmax, i, n, w, fs, parts[i].data(), devs[i]);
+        else rcs[i] = fused_on_device(devs[i], X, lo, hi, Y, nr, d, kmax, k0, self_offset, w, fs, parts[i].data(), dist_out);
         if (rcs[i] != MCE_OK) errs[i] = g_err;   // g_err is thread-local
     };
     if (n == 1) {
