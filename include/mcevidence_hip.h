@@ -46,7 +46,7 @@ extern "C" {
 #define MCE_ERR_DIM_RANGE (-6) /* d larger than MCE_MAX_DIM                  -> ValueError  */
 
 #define MCE_MAX_K 32    /* neighbours per query handled by the MFMA kernels (fp16 filter: 16)  */
-#define MCE_MAX_DIM 63  /* dimensions handled by the MFMA kernels (fp16 filter: 2..61)         */
+#define MCE_MAX_DIM 63  /* dimensions handled by the MFMA kernels                                */
 #define MCE_GENERIC_MAX_K 1024   /* beyond the MFMA limits a plain exact kernel takes over, up to */
 #define MCE_GENERIC_MAX_DIM 1024 /* these sizes; larger -> MCE_ERR_K_RANGE / MCE_ERR_DIM_RANGE    */
 
@@ -175,7 +175,7 @@ const char *mce_last_kernel(void);
 void mce_release_device_memory(void);
 
 /* Search algorithm.  0 (default) / 2: fp16-MFMA filter with exact fp64 refinement where the
- * shape allows it (d <= 61, K <= 16), otherwise the fp64 MFMA sweep; 1: always the
+ * shape allows it (K <= 16), otherwise the fp64 MFMA sweep; 1: always the
  * fp64 MFMA sweep.  Both return the exact fp64 neighbours and distances.  Process-wide. */
 int mce_set_search_mode(int mode);
 int mce_get_search_mode(void);
@@ -184,8 +184,8 @@ int mce_get_search_mode(void);
  * both point sets are put in k-d order on the device (cells of 32 rows) and every wave of 64 queries
  * visits the reference chunks nearest-box-first, multiplies only the 32-row tiles whose box is within
  * reach, and stops once no remaining chunk can hold a neighbour.  Same neighbours, distances and
- * tie-breaks as the exhaustive search.  0 (default): used where it was measured faster -- d <= 4 from
- * 150 k reference rows, d <= 6 from 300 k, d = 7 from 800 k, d = 8 from 2 M; 1: never; 2: whenever the shape allows it (d <= 13, K <= 16).  Process-wide. */
+ * tie-breaks as the exhaustive search.  0 (default): used where it was measured faster -- d <= 2 from
+ * 100 k reference rows, d <= 4 from 150 k, d <= 6 from 300 k, d = 7 from 800 k, d = 8 from 2 M; 1: never; 2: whenever the shape allows it (d <= 15, K <= 16).  Process-wide. */
 int mce_set_prune_mode(int mode);
 int mce_get_prune_mode(void);
 /* Work actually done by the last pruned search launched by this thread through a *_dev entry point

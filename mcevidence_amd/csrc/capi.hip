@@ -59,12 +59,13 @@ std::atomic<int> g_mode{0};
 // spatial pruning (prune.hpp): 0 auto (low d, large reference sets), 1 never, 2 whenever the shape allows it
 std::atomic<int> g_prune_mode{0};
 // measured on MI355X (tools/prune_sweep.sh, tools/prune_sweep_small.sh; search + preparation, K = 10):
+//   d = 1: 0.3 M 3.3 vs 54 ms, 1 M 6.8 vs 474 ms      d = 2: 0.3 M 2.9 vs 11.8 ms
 //   d = 3: 0.1 M 1.3 vs 1.5 ms, 1 M 17 vs 59 ms, 10 M 0.17 vs 4.0 s      d = 6: 0.2 M 4.6 vs 4.0, 0.3 M 8.5 vs 10.8,
 //   1 M 28 vs 58 ms, 4 M 0.14 vs 0.69 s, 10 M 0.37 vs 3.95 s      d = 7: 1 M 48 vs 59 ms      d = 8: 2 M 197 vs 200,
 //   3 M 342 vs 401, 4 M 504 vs 694 ms      d = 10: 4 M 1.43 vs 0.69 s (the boxes overlap too much)
 // smallest reference set for which the automatic mode takes the pruned walk, by dimension (0: never)
 constexpr int64_t kPruneAutoMinQueries = 32768;
-constexpr int64_t kPruneAutoMinRows[14] = {0, 150000, 150000, 150000, 150000, 300000, 300000, 800000, 2000000, 0, 0, 0, 0, 0};
+constexpr int64_t kPruneAutoMinRows[16] = {0, 100000, 100000, 150000, 150000, 300000, 300000, 800000, 2000000, 0, 0, 0, 0, 0, 0, 0};
 
 // Device buffers of the host-pointer entry points.  Small allocations (<= 64 MB) are kept in a
 // per-thread, per-device pool between calls: the reference's typical workload is thousands of

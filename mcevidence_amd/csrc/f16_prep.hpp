@@ -93,9 +93,10 @@ __global__ __launch_bounds__(256) void f16_pack_refs_kernel(const double* __rest
             e_tot += __shfl(err2, m * R + r, 64);
             n_tot += __shfl(n2, m * R + r, 64);
         }
+        const int npieces = f16_norm_pieces(D);
         const _Float16 n_hi = (_Float16)n_tot;
-        const _Float16 n_mid = (_Float16)(n_tot - (double)n_hi);
-        const _Float16 n_lo = (_Float16)(n_tot - (double)n_hi - (double)n_mid);
+        const _Float16 n_mid = npieces > 1 ? (_Float16)(n_tot - (double)n_hi) : (_Float16)0.0f;
+        const _Float16 n_lo = npieces > 2 ? (_Float16)(n_tot - (double)n_hi - (double)n_mid) : (_Float16)0.0f;
         if (inrange) {
             v8h v;
 #pragma unroll
@@ -105,8 +106,8 @@ __global__ __launch_bounds__(256) void f16_pack_refs_kernel(const double* __rest
                 if (live) {
                     if (k < D) x = (_Float16)(-2.0 * th[e]);
                     else if (k == D) x = n_hi;
-                    else if (k == D + 1) x = n_mid;
-                    else if (k == D + 2) x = n_lo;
+                    else if (k == D + 1 && npieces > 1) x = n_mid;
+                    else if (k == D + 2 && npieces > 2) x = n_lo;
                 } else if (k == D) {
                     x = (_Float16)__builtin_huge_valf();      // padding rows: A = +inf, never below a finite gate
                 }
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void f16_pack_queries_kernel(const double* __r
                 xv = (_Float16)t;
                 err2 = fma(t - (double)xv, t - (double)xv, err2);
                 n2 = fma((double)xv, (double)xv, n2);
-            } else if (k < D + 3) {
+            } else if (k < D + f16_norm_pieces(D)) {
                 xv = (_Float16)1.0f;
             }
         }

@@ -87,12 +87,17 @@ constexpr int kHQueue = MCE_H_QUEUE;          // candidate queue entries per wav
 constexpr int kHDrainTrigger = MCE_H_TRIGGER;    // a wave with this many queued candidates asks the workgroup to drain
 constexpr int kHRelBits = MCE_H_GEOM == 1 ? 25 : 26;   // queue entry = query-local (6|7 bits) << kHRelBits | row - first row of the split
 constexpr double kHTargetRadius = 200.0;
-constexpr int kPruneDims = 13;                // pruned walk: largest d (KST = 1)
+constexpr int kPruneDims = 15;                // pruned walk: largest d (KST = 1)
 
 // device-side scalars shared by the f16 kernels (doubles; maxima kept as bit patterns)
 enum { HP_RMAX = 0, HP_SCALE = 1, HP_EY = 2, HP_YHATMAX = 3, HP_RHO = 4, HP_STAT_CHUNKS = 5, HP_STAT_TILES = 6, HP_COUNT = 16 };   // STAT_*: pruned walk, totals over the launch
 
-__host__ __device__ constexpr int f16_ksteps(int D) { return (D + 3 + 15) / 16; }          // 16-wide k-steps
+// |y^|^2 rides in the k dimension as 1..3 fp16 pieces (x' carries matching ones): three pieces (33 bits) when
+// they fit the padding of the last 16-wide k-step, fewer when that saves a whole k-step -- d = 14, 15, 30, 31,
+// 46, 47, 62, 63.  What the pieces miss (<= 2^-11 |y^|^2 <= 20 with one piece; thresholds there are in the
+// thousands) is measured while packing (HP_RHO) and given back to the gate, so the filter stays rigorous.
+__host__ __device__ constexpr int f16_ksteps(int D) { return (D + 1 + 15) / 16; }          // 16-wide k-steps
+__host__ __device__ constexpr int f16_norm_pieces(int D) { return 16 * f16_ksteps(D) - D < 3 ? 16 * f16_ksteps(D) - D : 3; }
 __host__ __device__ constexpr int f16_qt(int) { return kHQT; }
 __host__ __device__ constexpr bool f16_supported(int D, int K) { return D >= 1 && f16_ksteps(D) <= 4 && K <= 16; }
 __host__ __device__ constexpr int f16_qpb(int KCAP) { return kHWaves * f16_qt(KCAP) * 32; }
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
 #define MCE_H_NPASS 3
 #endif
         constexpr int NPASS = MCE_H_NPASS;                         // 8*NPASS pairs, 8*NPASS loads per lane in flight (D <= 32)
-        constexpr int EPL = (16 * KST + 3) / 8 > 4 ? 8 : 4;        // elements per lane: 4 covers D <= 32, 8 covers D <= 61
+        constexpr int EPL = KST > 2 ? 8 : 4;        // elements per lane: 4 covers D <= 32, 8 covers D <= 63
         for (int b0 = 0; b0 < qcount; b0 += NPASS * 8) {
             int qlp[NPASS], ep[NPASS];
             bool okp[NPASS];
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
                 for (int sb = 0; sb < 8; ++sb) {
                     double a0 = 0.0;
 #pragma unroll
-                    for (int v = 0; v < 2; ++v) {                  // D <= 13: at most two elements per partial sum
+                    for (int v = 0; v < 2; ++v) {                  // D <= 15: at most two elements per partial sum
                         const int i = sb + 8 * v;
                         if (i < D) {
                             const double t = xr[i * QPW] - yr[i * 32];
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
         }
     };
     if constexpr (PRUNE) {
-        static_assert(KST == 1, "pruned walk: d <= 13");
+        static_assert(KST == 1, "pruned walk: d <= 15");
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             const int64_t q = qwave0 + qt * 32 + (lane & 31);

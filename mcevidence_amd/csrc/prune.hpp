@@ -25,7 +25,7 @@
 namespace mce {
 
 constexpr int kPruneTileRows = 32;                        // k-d cells = MFMA reference tiles = query tiles
-constexpr int kPruneMaxDim = 13;                          // KST = 1 variants only
+constexpr int kPruneMaxDim = 15;                          // KST = 1 variants only
 constexpr int64_t kPruneMaxPairs = (int64_t)1 << 30;      // nqblk * nchunk list entries
 
 struct PruneLayout {
