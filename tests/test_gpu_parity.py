@@ -29,7 +29,7 @@ def _rel(a, b):
 
 
 # --------------------------------------------------------------------------- kNN
-@pytest.mark.parametrize("d", [1, 2, 3, 6, 7, 8, 15, 16, 27, 33, 63])
+@pytest.mark.parametrize("d", [1, 2, 3, 6, 7, 8, 13, 14, 15, 16, 27, 30, 31, 33, 47, 48, 62, 63])
 def test_knn_matches_oracle_over_dims(capi, d):
     rng = np.random.default_rng(100 + d)
     n = 3001
@@ -122,7 +122,7 @@ ADVERSARIAL = {
 
 
 @pytest.mark.parametrize("kind", sorted(ADVERSARIAL))
-@pytest.mark.parametrize("d", [1, 2, 5, 14])
+@pytest.mark.parametrize("d", [1, 2, 5, 14, 15, 31])
 def test_knn_adversarial_inputs_stay_exact(capi, kind, d):
     """the filter must never drop a true neighbour, whatever the data look like: the result is
     compared with the exact CPU search (distances AND neighbour sets)."""
