@@ -45,7 +45,7 @@ extern "C" {
 #define MCE_ERR_WORKSPACE (-5) /* caller workspace too small                 -> ValueError  */
 #define MCE_ERR_DIM_RANGE (-6) /* d larger than MCE_MAX_DIM                  -> ValueError  */
 
-#define MCE_MAX_K 32    /* neighbours per query handled by the MFMA kernels (fp16 filter: 16)  */
+#define MCE_MAX_K 32    /* neighbours per query handled by the MFMA kernels (fp16 filter: 17..32 in two sweeps) */
 #define MCE_MAX_DIM 63  /* dimensions handled by the MFMA kernels                                */
 #define MCE_GENERIC_MAX_K 1024   /* beyond the MFMA limits a plain exact kernel takes over, up to */
 #define MCE_GENERIC_MAX_DIM 1024 /* these sizes; larger -> MCE_ERR_K_RANGE / MCE_ERR_DIM_RANGE    */
@@ -175,7 +175,7 @@ const char *mce_last_kernel(void);
 void mce_release_device_memory(void);
 
 /* Search algorithm.  0 (default) / 2: fp16-MFMA filter with exact fp64 refinement where the
- * shape allows it (K <= 16), otherwise the fp64 MFMA sweep; 1: always the
+ * shape allows it (all d <= 63, K <= 32), otherwise the fp64 MFMA sweep; 1: always the
  * fp64 MFMA sweep.  Both return the exact fp64 neighbours and distances.  Process-wide. */
 int mce_set_search_mode(int mode);
 int mce_get_search_mode(void);

@@ -189,6 +189,7 @@ struct Plan {
     int rsplit = 1;
     int L = 4;
     size_t off_yf = 0, off_pd = 0, off_pi = 0, off_center = 0, off_msum = 0, total = 0;
+    bool twopass = false;                     // fp16 filter, 16 < K <= 32: two sweeps of 16-entry lists (knn_f16.hpp, LOWER)
     bool prune = false;                       // fp16 filter walking k-d ordered chunk lists (prune.hpp)
     int part = 0, nparts = 1;                 // pruned walk over query blocks part, part + nparts, ... only
     int64_t pl_nr = 0;                        // reference rows the plan was made for
@@ -249,6 +250,11 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     const bool f16 = (g_mode.load() != 1) && mce::f16_supported(d, K);
     int qpb, rows_per_tile;
     if (f16) {
+        if (K > 16) {                          // 16 nearest per reference split first, then the next K - 16 beyond them
+            p.twopass = true;
+            ki = 3;
+            p.KCAP = 16;
+        }
         p.KST = mce::f16_ksteps(d);
         const mce::KnnF16Variant* tab = ki == 0 ? mce::g_knn_f16_kcap4 : ki == 1 ? mce::g_knn_f16_kcap8
                                         : ki == 2 ? mce::g_knn_f16_kcap12 : mce::g_knn_f16_kcap16;
@@ -272,7 +278,7 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     p.nchunk = (nr + rows_per_chunk - 1) / rows_per_chunk;
     p.nrow_pad = p.nchunk * rows_per_chunk;
 
-    if (f16 && p.KST == 1 && d <= mce::kPruneMaxDim && p.vh->launch_prune && nq > 0 &&
+    if (f16 && !p.twopass && p.KST == 1 && d <= mce::kPruneMaxDim && p.vh->launch_prune && nq > 0 &&
         p.nrow_pad <= ((int64_t)1 << mce::kHRelBits) && (int64_t)p.nqblk * p.nchunk <= mce::kPruneMaxPairs) {
         const int pm = g_prune_mode.load();
         // (the k-d ordering costs ~4 ms per million reference rows whatever the number of queries, and sparse
@@ -302,7 +308,7 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     //   total(r)   = ceil(nqblk*r / CUs) * block(r),   n_r = nr/r
     int best_r = 1;
     double best_c = 1e300;
-    const int rmax = (int)std::min<int64_t>(mce::kMaxLists, p.nchunk);
+    const int rmax = (int)std::min<int64_t>(p.twopass ? mce::kMaxLists / 2 : mce::kMaxLists, p.nchunk);
     const int rmin = f16 ? (int)((nr + ((int64_t)1 << mce::kHRelBits) - 1) >> mce::kHRelBits) : 1;   // queue entries hold 26-bit row offsets
     if (rmin > rmax) return fail(MCE_ERR_INVALID, "reference set too large for the fp16-filter path (nr=%lld)", (long long)nr);
     for (int r = std::max(1, rmin); r <= rmax; ++r) {
@@ -316,7 +322,7 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     }
     if (p.prune) best_r = 1;                  // every workgroup walks its own chunk list
     p.rsplit = best_r;
-    p.L = p.rsplit;
+    p.L = p.twopass ? 2 * p.rsplit : p.rsplit;
 
     size_t off = 0;
     p.off_yf = off;
@@ -459,11 +465,24 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
         }
         int rc = prof_begin();
         if (rc != MCE_OK) return rc;
-        MCE_HIP(p.vh->launch(a, st));
+        if (p.twopass) {
+            // lists [2*rsplit][16][nq_pad]: pass 1 fills splits 0..rsplit-1 with each split's 16 nearest, pass 2 the
+            // next K - 16 beyond them into rsplit..2*rsplit-1; the merge takes the K best of all
+            a.ksel = 16;
+            MCE_HIP(p.vh->launch(a, st));
+            a.lo_d = pd;
+            a.lo_i = pi;
+            a.part_d = pd + (size_t)p.rsplit * p.KCAP * (size_t)p.nq_pad;
+            a.part_i = pi + (size_t)p.rsplit * p.KCAP * (size_t)p.nq_pad;
+            a.ksel = K - 16;
+            MCE_HIP(p.vh->launch_lower(a, st));
+        } else {
+            MCE_HIP(p.vh->launch(a, st));
+        }
         rc = prof_end();
         if (rc != MCE_OK) return rc;
-        snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d", p.vh->name,
-                 p.nqblk * p.rsplit, mce::kHThreads, p.vh->lds_bytes, p.QT, p.CT, p.rsplit);
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d%s", p.vh->name,
+                 p.nqblk * p.rsplit, mce::kHThreads, p.vh->lds_bytes, p.QT, p.CT, p.rsplit, p.twopass ? " two passes" : "");
         return MCE_OK;
     }
     // ---- fp64 MFMA sweep ----------------------------------------------------------

@@ -63,6 +63,8 @@ struct KnnF16Args {
     const float* tbox_r = nullptr;
     const float* tbox_q = nullptr;
     const float* cbox_r = nullptr;
+    const double* lo_d = nullptr;  // second pass (K > 16): the first pass's lists
+    const int* lo_i = nullptr;
     const int* border = nullptr;   // pruned walk: dispatch order of the query blocks
     int qblk0 = 0, qblk_stride = 1, nqblk_run = 0;   // pruned walk: nqblk_run query blocks qblk0, qblk0 + stride, ... (0: all)
 };
@@ -70,6 +72,7 @@ typedef hipError_t (*knn_f16_launch_fn)(const KnnF16Args&, hipStream_t);
 struct KnnF16Variant {
     knn_f16_launch_fn launch;
     knn_f16_launch_fn launch_prune;   // PRUNE = true instantiation (KST = 1 only), else null
+    knn_f16_launch_fn launch_lower;   // LOWER = true instantiation (KCAP = 16 only), else null
     int kst, kcap, qt, ct;
     size_t lds_bytes;
     const char* name;

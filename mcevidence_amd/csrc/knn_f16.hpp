@@ -99,7 +99,7 @@ enum { HP_RMAX = 0, HP_SCALE = 1, HP_EY = 2, HP_YHATMAX = 3, HP_RHO = 4, HP_STAT
 __host__ __device__ constexpr int f16_ksteps(int D) { return (D + 1 + 15) / 16; }          // 16-wide k-steps
 __host__ __device__ constexpr int f16_norm_pieces(int D) { return 16 * f16_ksteps(D) - D < 3 ? 16 * f16_ksteps(D) - D : 3; }
 __host__ __device__ constexpr int f16_qt(int) { return kHQT; }
-__host__ __device__ constexpr bool f16_supported(int D, int K) { return D >= 1 && f16_ksteps(D) <= 4 && K <= 16; }
+__host__ __device__ constexpr bool f16_supported(int D, int K) { return D >= 1 && f16_ksteps(D) <= 4 && K <= 32; }   // K > 16: two passes
 __host__ __device__ constexpr int f16_qpb(int KCAP) { return kHWaves * f16_qt(KCAP) * 32; }
 // 32-row reference tiles per LDS chunk (tile = KST KB): MCE_H_STAGE_KB per buffer, even count,
 // and a whole number of 16-byte vectors per thread (CT*KST % 8 == 0)
@@ -143,7 +143,12 @@ __host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST, int D)
 // entries at a time before any tile box is read.  The lists then carry the CALLER's
 // row numbers (rperm), so ties break exactly as without pruning; the own row of query q is
 // rperm-row self_offset + qperm[q].  rsplit must be 1.
-template <int KST, int KCAP, bool PRUNE = false>
+//
+// LOWER = true: second pass of a search for 16 < K <= 32 neighbours.  The lists hold 16 entries, so the
+// first pass finds the 16 nearest per (query, reference split) and the second, identical sweep keeps only
+// candidates beyond that split's 16th (lo_d / lo_i = the first pass's lists) and finds the next K - 16;
+// the merge then sees two sorted lists per split.  Two sweeps at fp16 speed instead of one fp64 sweep.
+template <int KST, int KCAP, bool PRUNE = false, bool LOWER = false>
 __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES : (MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ? 4 : 2))) void knn_f16_kernel(
     const _Float16* __restrict__ Yh, int64_t nchunk_total, int rsplit,
     const _Float16* __restrict__ Xh, const double* __restrict__ qinfo, const double* __restrict__ params,
@@ -152,8 +157,10 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
     double* __restrict__ part_d, int* __restrict__ part_i,
     const int* __restrict__ clist, const float* __restrict__ cdist, int list_len,
     const int* __restrict__ rperm, const int* __restrict__ qperm,
-    const float* __restrict__ tbox_r, const float* __restrict__ tbox_q, const float* __restrict__ cbox_r, int qblk0, int qblk_stride, const int* __restrict__ border)
+    const float* __restrict__ tbox_r, const float* __restrict__ tbox_q, const float* __restrict__ cbox_r, int qblk0, int qblk_stride, const int* __restrict__ border,
+    const double* __restrict__ lo_d, const int* __restrict__ lo_i)
 {
+    static_assert(!(PRUNE && LOWER), "second pass: exhaustive sweep only");
     constexpr int QT = f16_qt(KCAP);
     constexpr int QPW = QT * 32;                         // queries per wave
     constexpr int QPB = kHWaves * QPW;
@@ -354,7 +361,19 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
                 a0 += __shfl_xor(a0, 1, 64);
                 a0 += __shfl_xor(a0, 2, 64);
                 a0 += __shfl_xor(a0, 4, 64);
-                if (okp[u] && sub == 0) {
+                bool ok = okp[u];
+                if constexpr (LOWER) {
+                    // second pass of a K > 16 search: only what lies BEYOND the first pass's 16th neighbour of
+                    // this reference split -- lexicographically in (distance, row), like every tie-break here
+                    if (ok) {
+                        const int64_t o = ((int64_t)split * KCAP + (KCAP - 1)) * nq_pad + qwave0 + qlp[u];
+                        const double ld = lo_d[o];
+                        const int li = lo_i[o];
+                        const int j = jsplit0 + (int)((unsigned)wq[ep[u]] & ((1u << kHRelBits) - 1u));
+                        ok = a0 > ld || (a0 == ld && j > li);       // (list not full: ld = +inf, nothing is left)
+                    }
+                }
+                if (ok && sub == 0) {
                     wqd[ep[u]] = a0;
                     wnx[ep[u]] = atomicExch(&whead[qlp[u]], ep[u]);      // push onto the query's chain
                 }

@@ -31,14 +31,14 @@ hipError_t launch_variant(const KnnArgs& a, hipStream_t st)
 }
 
 #if MCE_KCAP <= 16
-template <int KST, int KCAP, bool PRUNE>
+template <int KST, int KCAP, bool PRUNE, bool LOWER = false>
 hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
 {
     constexpr size_t LDS_MAX = PRUNE ? f16_prune_lds_bytes(KST, 16 * KST - 1) : f16_lds_bytes(KST, KCAP);
     static_assert(LDS_MAX <= 160 * 1024, "LDS budget");
     const size_t LDS = PRUNE ? f16_prune_lds_bytes(KST, a.D) : LDS_MAX;     // pruned walk: sized by the dimension (more waves per CU)
     static bool attr_set[kMaxDevices] = {};
-    auto kern = knn_f16_kernel<KST, KCAP, PRUNE>;
+    auto kern = knn_f16_kernel<KST, KCAP, PRUNE, LOWER>;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= kMaxDevices || !attr_set[dev]) {
@@ -50,7 +50,7 @@ hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
     const dim3 grid((unsigned)(PRUNE ? (a.nqblk_run ? a.nqblk_run : a.nqblk) * kHWaves : a.nqblk * a.rsplit));
     hipLaunchKernelGGL(kern, grid, dim3(PRUNE ? 64 : kHThreads), LDS, st, static_cast<const _Float16*>(a.Yh), a.nchunk_total, a.rsplit,
                        static_cast<const _Float16*>(a.Xh), a.qinfo, a.params, a.X, a.Y, a.nq, a.nr, a.D, a.nq_pad, a.nqblk,
-                       a.self_exclude, a.self_offset, a.ksel, a.part_d, a.part_i, a.clist, a.cdist, a.list_len, a.rperm, a.qperm, a.tbox_r, a.tbox_q, a.cbox_r, a.qblk0, a.qblk_stride, a.border);
+                       a.self_exclude, a.self_offset, a.ksel, a.part_d, a.part_i, a.clist, a.cdist, a.list_len, a.rperm, a.qperm, a.tbox_r, a.tbox_q, a.cbox_r, a.qblk0, a.qblk_stride, a.border, a.lo_d, a.lo_i);
     return hipGetLastError();
 }
 #endif
@@ -72,8 +72,13 @@ extern const KnnVariant MCE_CAT(g_knn_kcap, MCE_KCAP)[kMaxKS] = {
     MCE_VARIANT(13), MCE_VARIANT(14), MCE_VARIANT(15), MCE_VARIANT(16),
 };
 #if MCE_KCAP <= 16
+#if MCE_KCAP == 16
+#define MCE_F16_LOWER(KST) (&launch_f16_variant<KST, MCE_KCAP, false, true>)
+#else
+#define MCE_F16_LOWER(KST) nullptr
+#endif
 #define MCE_F16_VARIANT(KST, PRUNE_FN)                                                                   \
-    {&launch_f16_variant<KST, MCE_KCAP, false>, PRUNE_FN, KST, MCE_KCAP, f16_qt(MCE_KCAP), f16_chunk_tiles(KST), \
+    {&launch_f16_variant<KST, MCE_KCAP, false>, PRUNE_FN, MCE_F16_LOWER(KST), KST, MCE_KCAP, f16_qt(MCE_KCAP), f16_chunk_tiles(KST), \
      f16_lds_bytes(KST, MCE_KCAP), "knn_f16_kernel<KST=" #KST ",KCAP=" MCE_STR(MCE_KCAP) ">"}
 extern const KnnF16Variant MCE_CAT(g_knn_f16_kcap, MCE_KCAP)[kMaxKST] = {
     MCE_F16_VARIANT(1, (&launch_f16_variant<1, MCE_KCAP, true>)), MCE_F16_VARIANT(2, nullptr), MCE_F16_VARIANT(3, nullptr),
@@ -83,8 +88,11 @@ extern const KnnF16Variant MCE_CAT(g_knn_f16_kcap, MCE_KCAP)[kMaxKST] = {
 #else
 // device pass: force the kernel instantiations
 #if MCE_KCAP <= 16
-#define MCE_F16_INST(KST, PR) template __global__ void knn_f16_kernel<KST, MCE_KCAP, PR>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*, int, int, const int*);
-MCE_F16_INST(1, false) MCE_F16_INST(2, false) MCE_F16_INST(3, false) MCE_F16_INST(4, false) MCE_F16_INST(1, true)
+#define MCE_F16_INST(KST, PR, LW) template __global__ void knn_f16_kernel<KST, MCE_KCAP, PR, LW>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*, int, int, const int*, const double*, const int*);
+MCE_F16_INST(1, false, false) MCE_F16_INST(2, false, false) MCE_F16_INST(3, false, false) MCE_F16_INST(4, false, false) MCE_F16_INST(1, true, false)
+#if MCE_KCAP == 16
+MCE_F16_INST(1, false, true) MCE_F16_INST(2, false, true) MCE_F16_INST(3, false, true) MCE_F16_INST(4, false, true)
+#endif
 #endif
 #define MCE_INST(KS) template __global__ void knn_mfma_kernel<KS, MCE_KCAP>(const double*, int64_t, int, const double*, const double*, int64_t, int, int64_t, int, int, int64_t, int, double*, int*);
 MCE_INST(1) MCE_INST(2) MCE_INST(3) MCE_INST(4) MCE_INST(5) MCE_INST(6) MCE_INST(7) MCE_INST(8)
