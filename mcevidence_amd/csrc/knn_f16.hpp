@@ -125,7 +125,7 @@ constexpr int kHPruneQueue = 256;   // pruned walk: queue entries per wave (alre
 __host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST, int D)
 {
     return (size_t)f16_prune_slice_bytes(KST) + (size_t)kHPruneQueue * 16 + (size_t)kHQT * 32 * 4 + 128 +
-           (size_t)(kHQT * 32 + 32) * D * 8 + 128 + (size_t)kHQT * 32 * 8;
+           (size_t)(kHQT * 32 + 32) * D * 8 + 128 + (size_t)kHQT * 32 * 8 + 64 * 8;
 }
 
 // ---------------------------------------------------------------------------
@@ -692,6 +692,14 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
         const int boot_n = same_order ? 2 * kHPruneBoot + QT : 0;
         int boot_k = 0;
         bool boot_flush = false;
+        // Bootstrap for a SEPARATE query set (no shared order to start from): of the first window of the list,
+        // first only the tiles whose box overlaps a query tile's (xb_state 0), then the thresholds settle and
+        // the window is walked again properly, skipping what was done (xb_mask, per window entry, in LDS).
+        int xb_state = same_order ? 2 : 0;
+        bool xb_win0 = false;
+        unsigned long long xb_full = 0;
+        int cur_bsel = 0;
+        unsigned long long* const xb_mask = reinterpret_cast<unsigned long long*>(thrq + QPW);
         // (a wave of padding queries only would never tighten anything and walk the whole list)
         if (qwave0 >= nq) { boot_k = boot_n; e = list_len; }
         for (;;) {
@@ -714,7 +722,15 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
                     continue;
                 }
                 if (need == 0) {
+                    if (xb_state == 0 && xb_win0 && cand == 0) {
+                        // the overlapping tiles of the first window are collected: multiply them, settle the
+                        // thresholds, then walk that window again with the real test
+                        xb_state = 2;
+                        cand = xb_full;
+                        if (pend > 0) { boot_flush = true; break; }
+                    }
                     if (cand == 0) {
+                        xb_win0 = false;
                         if (e >= list_len) break;
                         // next window of 64 list entries, lane l <-> entry e + l: still within this wave's
                         // reach?  chunk box within reach of one of the query tiles?
@@ -744,11 +760,21 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
                         cand = __ballot(in && !far && reach);
                         e = (__ballot(in && far) != 0) ? list_len : e + 64;
                         st_chunks += 1;
+                        if (xb_state == 0) {                           // first window of a separate query set
+                            float amin = acc[0];
+#pragma unroll
+                            for (int qt = 1; qt < QT; ++qt) amin = fminf(amin, acc[qt]);
+                            xb_full = cand;
+                            xb_win0 = true;
+                            xb_mask[lane] = 0;
+                            const unsigned long long ov = __ballot(in && amin == 0.0f) & cand;
+                            cand = ov ? ov : (cand & (0ull - cand));   // (no overlapping chunk box: the nearest one)
+                        }
                         if (cand == 0) continue;
                     }
-                    const int bsel = (int)__builtin_ctzll(cand);
+                    cur_bsel = (int)__builtin_ctzll(cand);
                     cand &= cand - 1;
-                    c = __shfl(win_c, bsel, 64);
+                    c = __shfl(win_c, cur_bsel, 64);
                     const float* cb = tbox_r + (int64_t)c * (2 * D * PCT) + lane;
                     // fp32 is enough for a rigorous bound: a gap fl(a - b) of two floats is within 2^-24
                     // of exact, the sum of <= 13 squares within 2^-19; the comparison gives back 2^-18
@@ -766,9 +792,16 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
                             }
                         }
                     }
-                    {
+                    if (xb_state == 0) {
+                        float amin = acc[0];
+#pragma unroll
+                        for (int qt = 1; qt < QT; ++qt) amin = fminf(amin, acc[qt]);
+                        need = __ballot(amin == 0.0f);
+                        if (need == 0 && xb_full == (1ull << cur_bsel)) need = __ballot(amin < __builtin_huge_valf());   // a lone chunk: all of it
+                        if (lane == 0) xb_mask[cur_bsel] = need;
+                    } else {
                         const int tile_id = c * PCT + lane;
-                        const bool booted = tile_id >= boot_lo && tile_id < boot_hi;
+                        const bool booted = same_order ? (tile_id >= boot_lo && tile_id < boot_hi) : (xb_win0 && ((xb_mask[cur_bsel] >> lane) & 1ull));
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) need |= __ballot(!booted && !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]));
                     }

@@ -10,6 +10,8 @@ SH = int(sys.argv[sys.argv.index("--shard") + 1]) if "--shard" in sys.argv else 
 NQ = N // SH
 rng = np.random.default_rng(0)
 Y = torch.from_numpy(rng.standard_normal((N, D))).cuda()
+CROSS = "--cross" in sys.argv          # queries: an independent draw in its own buffer
+X = torch.from_numpy(rng.standard_normal((NQ, D))).cuda() if CROSS else Y
 out = {}
 for mode, name in ((_capi.PRUNE_FORCE, "pruned"), (_capi.PRUNE_OFF, "exhaustive")):
     if name == "exhaustive" and N > 3_000_000 and "--full" not in sys.argv:
@@ -20,7 +22,7 @@ for mode, name in ((_capi.PRUNE_FORCE, "pruned"), (_capi.PRUNE_OFF, "exhaustive"
     dist = torch.empty((NQ, K), dtype=torch.float64, device="cuda")
     idx = torch.empty((NQ, K), dtype=torch.int64, device="cuda")
     def run():
-        _capi.knn_dev(Y.data_ptr(), NQ, Y.data_ptr(), N, D, K, _capi.SELF_EXCLUDE, 0, dist.data_ptr(), idx.data_ptr(), ws.data_ptr(), wsb,
+        _capi.knn_dev(X.data_ptr(), NQ, Y.data_ptr(), N, D, K, _capi.SELF_NONE if CROSS else _capi.SELF_EXCLUDE, 0, dist.data_ptr(), idx.data_ptr(), ws.data_ptr(), wsb,
                       torch.cuda.current_stream().cuda_stream)
     run(); torch.cuda.synchronize()
     _capi.set_profiling(True)
