@@ -653,7 +653,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
     } else {
         // Sparse walk: no chunk staging and no workgroup barriers -- every wave goes down the block's
         // chunk list (nearest box first) on its own, stops at the first entry whose bound exceeds
-        // the largest K-th distance among ITS 64 queries, tests the 48 tile boxes of a chunk in one
+        // the largest K-th distance among ITS 64 queries, tests the 64 tile boxes of a chunk in one
         // pass (lane t <-> tile t), collects the tiles within reach and multiplies them in batches
         // of kBatch: the batch's A tiles (1 KB each) go through registers into the wave's private
         // slice of the staging area and are swept from there.
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
                     c = __shfl(win_c, cur_bsel, 64);
                     const float* cb = tbox_r + (int64_t)c * (2 * D * PCT) + lane;
                     // fp32 is enough for a rigorous bound: a gap fl(a - b) of two floats is within 2^-24
-                    // of exact, the sum of <= 13 squares within 2^-19; the comparison gives back 2^-18
+                    // of exact, the sum of <= 15 squares within 2^-19; the comparison gives back 2^-18
                     float acc[QT];
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) acc[qt] = 0.0f;
