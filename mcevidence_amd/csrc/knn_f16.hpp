@@ -346,7 +346,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
             for (int u = 0; u < NPASS; ++u)
 #pragma unroll
                 for (int v = 0; v < EPL; ++v) {
-                    const int iv = (sub + 8 * v < D) ? sub + 8 * v : sub;     // clamped load, masked use
+                    const int iv = (sub + 8 * v < D) ? sub + 8 * v : (sub < D ? sub : D - 1);     // clamped INSIDE the row, masked use
                     xv[u][v] = xp[u][iv];
                     yv[u][v] = yp[u][iv];
                 }
