@@ -463,26 +463,41 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
                      p.nqblk * mce::kHWaves, mce::f16_prune_lds_bytes(p.KST, d), p.QT, p.CT, (long long)p.nchunk);
             return MCE_OK;
         }
+        // seed phase: the host picks the group size; MCE_F16_SEED_ROWS / MCE_F16_SEED_SHARE override (tests, tuning)
+        auto seed_cfg = [&](int ksel) {
+            const char* const e_rows = getenv("MCE_F16_SEED_ROWS");
+            const char* const e_share = getenv("MCE_F16_SEED_SHARE");
+            const char* const e_tg = getenv("MCE_F16_SEED_TG");
+            const int64_t cps = (p.nchunk + p.rsplit - 1) / p.rsplit;
+            return mce::f16_seed_cfg(cps, p.CT, ksel + a.self_exclude, e_rows ? atoi(e_rows) : MCE_H_SEED_ROWS,
+                                     e_share ? atoi(e_share) : MCE_H_SEED_SHARE, e_tg ? atoi(e_tg) : MCE_H_SEED_TG);
+        };
         int rc = prof_begin();
         if (rc != MCE_OK) return rc;
         if (p.twopass) {
             // lists [2*rsplit][16][nq_pad]: pass 1 fills splits 0..rsplit-1 with each split's 16 nearest, pass 2 the
             // next K - 16 beyond them into rsplit..2*rsplit-1; the merge takes the K best of all
             a.ksel = 16;
+            a.seed_cfg = seed_cfg(16);
             MCE_HIP(p.vh->launch(a, st));
             a.lo_d = pd;
             a.lo_i = pi;
             a.part_d = pd + (size_t)p.rsplit * p.KCAP * (size_t)p.nq_pad;
             a.part_i = pi + (size_t)p.rsplit * p.KCAP * (size_t)p.nq_pad;
             a.ksel = K - 16;
+            a.seed_cfg = 0;
             MCE_HIP(p.vh->launch_lower(a, st));
         } else {
+            a.seed_cfg = seed_cfg(K);
             MCE_HIP(p.vh->launch(a, st));
         }
         rc = prof_end();
         if (rc != MCE_OK) return rc;
-        snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d%s", p.vh->name,
-                 p.nqblk * p.rsplit, mce::kHThreads, p.vh->lds_bytes, p.QT, p.CT, p.rsplit, p.twopass ? " two passes" : "");
+        const int seed_first = p.twopass ? seed_cfg(16) : a.seed_cfg;
+        char seed_txt[48] = "";
+        if (seed_first) snprintf(seed_txt, sizeof(seed_txt), " seed=%dx%d", seed_first & 0xffff, seed_first >> 16);   // chunks x tiles per group
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d%s%s", p.vh->name,
+                 p.nqblk * p.rsplit, mce::kHThreads, p.vh->lds_bytes, p.QT, p.CT, p.rsplit, p.twopass ? " two passes" : "", seed_txt);
         return MCE_OK;
     }
     // ---- fp64 MFMA sweep ----------------------------------------------------------

@@ -65,6 +65,7 @@ struct KnnF16Args {
     const float* cbox_r = nullptr;
     const double* lo_d = nullptr;  // second pass (K > 16): the first pass's lists
     const int* lo_i = nullptr;
+    int seed_cfg = 0;              // exhaustive sweep: seed phase (f16_seed_cfg: chunks | tiles per group << 16), 0 = none
     const int* border = nullptr;   // pruned walk: dispatch order of the query blocks
     int qblk0 = 0, qblk_stride = 1, nqblk_run = 0;   // pruned walk: nqblk_run query blocks qblk0, qblk0 + stride, ... (0: all)
 };

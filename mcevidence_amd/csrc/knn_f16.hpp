@@ -33,7 +33,7 @@
 #define MCE_STATS 0    // tools/knn_f16_bench.hip only: per-wave clock64/event counters appended to `params`
 #endif
 #ifndef MCE_ABLATE
-#define MCE_ABLATE 0   // tools/knn_f16_bench.hip only: 1 = gate never passes, 3 = also no barriers (results invalid)
+#define MCE_ABLATE 0   // tools/knn_f16_bench.hip only: 1 = gate never passes, 2 = no gate at all, 3 = 1 + no barriers, 5 = 1 + no LDS reads, 6 = 2 + 5 (results invalid)
 #endif
 
 namespace mce {
@@ -55,7 +55,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #ifndef MCE_H_GEOM
 #define MCE_H_GEOM 0
 #endif
-constexpr int kHWaves = MCE_H_GEOM == 1 ? 4 : (MCE_H_GEOM == 2 ? 16 : 8);   // GEOM 2: 16 waves (4 per SIMD, <= 128 VGPRs)
+constexpr int kHWaves = (MCE_H_GEOM == 1 || MCE_H_GEOM == 3) ? 4 : (MCE_H_GEOM == 2 ? 16 : 8);   // GEOM 2: 16 waves (4 per SIMD, <= 128 VGPRs); GEOM 3: 4 waves x 2 tiles, two workgroups per CU
 constexpr int kHQT = MCE_H_GEOM == 1 ? 4 : 2;      // 32-query tiles per wave
 constexpr int kHNL = kHQT / 2;                     // top-K lists per owner lane (64 queries per list set)
 constexpr int kHThreads = kHWaves * 64;
@@ -64,6 +64,15 @@ constexpr int kHThreads = kHWaves * 64;
 #endif
 #ifndef MCE_H_QUEUE
 #define MCE_H_QUEUE 448
+#endif
+#ifndef MCE_H_SEED_ROWS
+#define MCE_H_SEED_ROWS 16384  // seed phase: reference rows swept twice (0 = no seed phase) ...
+#endif
+#ifndef MCE_H_SEED_SHARE
+#define MCE_H_SEED_SHARE 40    // ... at most 1/40 of the split's chunks ...
+#endif
+#ifndef MCE_H_SEED_TG
+#define MCE_H_SEED_TG 8        // ... in groups of 8 tiles (256 rows)
 #endif
 #ifndef MCE_H_TRIGGER
 #define MCE_H_TRIGGER 96
@@ -104,6 +113,18 @@ __host__ __device__ constexpr int f16_qpb(int KCAP) { return kHWaves * f16_qt(KC
 // 32-row reference tiles per LDS chunk (tile = KST KB): MCE_H_STAGE_KB per buffer, even count,
 // and a whole number of 16-byte vectors per thread (CT*KST % 8 == 0)
 __host__ __device__ constexpr int f16_chunk_tiles(int KST) { return MCE_H_STAGE_KB / KST; }   // 48 KB: 48, 24, 16, 12 tiles
+// seed phase of the exhaustive sweep (see the kernel): about `rows` reference rows of the split, at most 1/share of
+// its `cps` chunks, in groups of `tg` 32-row tiles -- and only if that makes at least twice the `kneed` = K (+1 with
+// self-exclusion) groups the bound needs.  Returns chunks | tg << 16, or 0 for no seed phase.
+inline int f16_seed_cfg(int64_t cps, int CT, int kneed, int rows = MCE_H_SEED_ROWS, int share = MCE_H_SEED_SHARE, int tg = MCE_H_SEED_TG)
+{
+    if (rows <= 0 || share <= 0 || tg <= 0 || kneed <= 0) return 0;
+    int64_t chunks = (rows + CT * 32 - 1) / (CT * 32);
+    if (chunks > cps / share) chunks = cps / share;
+    if (chunks > 0xffff) chunks = 0xffff;
+    if (chunks * CT / tg < 2 * (int64_t)kneed) return 0;
+    return (int)chunks | (tg << 16);
+}
 __host__ __device__ constexpr size_t f16_lds_bytes(int KST, int KCAP)
 {
     return (size_t)2 * f16_chunk_tiles(KST) * KST * 1024             // staging
@@ -158,7 +179,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
     const int* __restrict__ clist, const float* __restrict__ cdist, int list_len,
     const int* __restrict__ rperm, const int* __restrict__ qperm,
     const float* __restrict__ tbox_r, const float* __restrict__ tbox_q, const float* __restrict__ cbox_r, int qblk0, int qblk_stride, const int* __restrict__ border,
-    const double* __restrict__ lo_d, const int* __restrict__ lo_i)
+    const double* __restrict__ lo_d, const int* __restrict__ lo_i, int seed_cfg)
 {
     static_assert(!(PRUNE && LOWER), "second pass: exhaustive sweep only");
     constexpr int QT = f16_qt(KCAP);
@@ -230,6 +251,19 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
 #pragma unroll
         for (int k = 0; k < KCAP; ++k) { own_d[nl][k] = INF; own_i[nl][k] = -1; }
 
+    // upper bound on the final K-th squared distance of the owned queries, known before the sweep (seed phase below)
+    double seed_thr[kHNL];
+#pragma unroll
+    for (int nl = 0; nl < kHNL; ++nl) seed_thr[nl] = INF;
+#ifndef MCE_SEED_CHECK
+#define MCE_SEED_CHECK 0
+#endif
+#if MCE_SEED_CHECK
+    double seed_dbg[kHNL];
+#pragma unroll
+    for (int nl = 0; nl < kHNL; ++nl) seed_dbg[nl] = INF;
+#endif
+
     const int64_t qwave0 = (int64_t)qblk * QPB + wave * QPW;     // first query of this wave
 
     // ---- B fragments (fp16 query rows) + per-query gate constants ---------------
@@ -242,7 +276,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks)
             b[qt][ks] = *reinterpret_cast<const v8h*>(Xh + q * (int64_t)(16 * KST) + 16 * ks + 8 * (lane >> 5));
-        G[qt] = (q < nq && MCE_ABLATE != 1 && MCE_ABLATE != 3) ? __builtin_huge_valf() : -__builtin_huge_valf();     // padding queries never pass
+        G[qt] = (q < nq && MCE_ABLATE != 1 && MCE_ABLATE != 3 && MCE_ABLATE != 5) ? __builtin_huge_valf() : -__builtin_huge_valf();     // padding queries never pass
     }
     const int k_last = ksel - 1;
     // gate of query (qt, lane&31) from its current K-th best `thr` (exact squared distance, input
@@ -250,7 +284,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
     // and keeping them in registers would cost 6 VGPRs per query tile in the sweep.
     auto gate_of = [&](double thr, int qt) -> float {
         const int64_t q = qwave0 + qt * 32 + (lane & 31);
-        if (!(q < nq) || MCE_ABLATE == 1 || MCE_ABLATE == 3) return -__builtin_huge_valf();
+        if (!(q < nq) || MCE_ABLATE == 1 || MCE_ABLATE == 3 || MCE_ABLATE == 5) return -__builtin_huge_valf();
         if (!(thr < INF)) return __builtin_huge_valf();
         const double ex = qinfo[2 * q], xn = qinfo[2 * q + 1];
         const double r = sqrt(xn) + params[HP_YHATMAX];
@@ -281,6 +315,10 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
     auto load_a = [&](const char* lp, v8h (&a)[KST]) {
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks) a[ks] = *reinterpret_cast<const v8h*>(lp + ks * 1024);
+#if MCE_ABLATE == 5 || MCE_ABLATE == 6      // ablation: no LDS reads in the sweep (results invalid)
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) a[ks] = b[0][ks];
+#endif
     };
     // one 32-row tile: QT chains of KST MFMAs
     auto mfma_tile = [&](const v8h (&a)[KST], v16f (&acc)[QT]) {
@@ -422,6 +460,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
             thr_own[nl] = own_d[nl][KCAP - 1];
 #pragma unroll
             for (int k = 0; k < KCAP - 1; ++k) thr_own[nl] = (k == k_last) ? own_d[nl][k] : thr_own[nl];
+            thr_own[nl] = fmin(thr_own[nl], seed_thr[nl]);
         }
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) G[qt] = gate_of(__shfl(thr_own[qt >> 1], (qt & 1) * 32 + (lane & 31), 64), qt);
@@ -444,9 +483,11 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
     // gate + enqueue for one finished tile; jb0 = first reference row of the tile.
     // C layout of 32x32 f32: lane l -> query column l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5)
     auto process = [&](const v16f (&acc)[QT], int jb0) {
-#if MCE_ABLATE == 2
+#if MCE_ABLATE == 2 || MCE_ABLATE == 6
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) asm volatile("" ::"v"(acc[qt]));
+#endif
         return;
 #endif
         bool passq[QT];
@@ -605,7 +646,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
 
     // one staged chunk (vote / barrier / prefetch are done around it).  A macro, not a lambda: the
     // accumulators must stay in registers across the two call sites.
-#define MCE_SWEEP_CHUNK(BUF, JCHUNK)                                                                       \
+#define MCE_SWEEP_CHUNK(BUF, JCHUNK, PROC)                                                                 \
     do {                                                                                                   \
         const char* lbuf = stage0 + (BUF) * CHUNK_BYTES + lane * 16;                                       \
         const int jchunk = (JCHUNK);                                                                       \
@@ -616,11 +657,11 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
             load_a(lbuf + ((t + 1) * KST) * 1024, a1);                                                     \
             mfma_tile(a0, accA);                                                                           \
             jbA = jchunk + t * 32;                                                                         \
-            process(accB, jbB);                                                                            \
+            PROC(accB, jbB);                                                                               \
             load_a(lbuf + ((t + 2 < CT ? t + 2 : t) * KST) * 1024, a0); /* last trip: harmless re-read */  \
             mfma_tile(a1, accB);                                                                           \
             jbB = jchunk + (t + 1) * 32;                                                                   \
-            process(accA, jbA);                                                                            \
+            PROC(accA, jbA);                                                                               \
         }                                                                                                  \
     } while (0)
 
@@ -629,6 +670,118 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
     // wave whose queue is filling raises the vote of this chunk's parity; after the barrier
     // everybody reads it.  (process() still drains locally if its queue would overflow.)
     if constexpr (!PRUNE) {
+        // ---- seed: an upper bound on every query's final K-th distance BEFORE anything is queued ----------
+        // A stream of N references in arbitrary order puts ~K ln(N/K) genuine updates per query through the
+        // exact path, half of them within the first ~sqrt(N K) rows while the lists are still loose.  The first
+        // rows of the split are therefore swept twice: once here, only tracking the minimum of A per GROUP of
+        // `tg` tiles and, per query, the K' smallest of those group minima (K' = K, + 1 if the query itself is
+        // among the references).  They belong to K' different rows, at most one of them the query's own, so the
+        // K-th nearest row is no farther than the K'-th smallest group minimum -- turned into a rigorous bound on
+        // the true distance with the same error terms as the gate (true <= sqrt(A + |x^|^2 + eps) + e_x + max e_y).
+        // With many more groups than K' this is close to the K-th distance within the seed rows.  The sweep
+        // proper then starts with that threshold instead of +inf: no flood of early candidates.
+        if constexpr (!LOWER && (MCE_ABLATE == 0)) {
+            const int kneed = ksel + (self_exclude ? 1 : 0);
+            const int tg = seed_cfg >> 16;
+            const int nseed = ((int64_t)(seed_cfg & 0xffff) * 2 <= c_end - c_begin) ? (seed_cfg & 0xffff) : 0;   // chunks (host: f16_seed_cfg)
+            if (nseed > 0 && tg > 0 && kneed <= KCAP + 1) {
+                const float FINF = __builtin_huge_valf();
+                static_assert(QT == 2, "wait-state asm names both accumulator tiles");
+                float gm[QT], sm[QT][KCAP + 1];         // running group minimum; the KCAP + 1 smallest group minima, ascending
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    gm[qt] = FINF;
+#pragma unroll
+                    for (int k = 0; k <= KCAP; ++k) sm[qt][k] = FINF;
+                }
+                int tcnt = 0;
+#define MCE_SEED_GROUP_END()                                                                               \
+                do {                                                                                       \
+                    _Pragma("unroll") for (int qt = 0; qt < QT; ++qt)                                      \
+                    {                                                                                      \
+                        float v_ = fminf(gm[qt], __shfl_xor(gm[qt], 32, 64));     /* both row halves */    \
+                        gm[qt] = FINF;                                                                     \
+                        _Pragma("unroll") for (int k = 0; k <= KCAP; ++k)                                  \
+                        {                                                                                  \
+                            const float lo_ = fminf(sm[qt][k], v_);                                        \
+                            v_ = fmaxf(sm[qt][k], v_);                                                     \
+                            sm[qt][k] = lo_;                                                               \
+                        }                                                                                  \
+                    }                                                                                      \
+                    tcnt = 0;                                                                              \
+                } while (0)
+                // (the minima are inline asm, which the compiler's hazard recogniser does not cover and which -- with
+                //  no branch in this loop to hold them in place -- it schedules right behind the MFMAs that write their
+                //  operands: the wait states are spelled out, tied to the accumulators)
+#define MCE_SEED_TILE(ACC, JB)                                                                             \
+                do {                                                                                       \
+                    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(ACC[0]), "+v"(ACC[1]));                       \
+                    _Pragma("unroll") for (int qt = 0; qt < QT; ++qt)                                      \
+                    {                                                                                      \
+                        const v16f& c_ = ACC[qt];                                                          \
+                        float m0 = min3f(c_[0], c_[1], c_[2]);                                             \
+                        float m1 = min3f(c_[3], c_[4], c_[5]);                                             \
+                        float m2 = min3f(c_[6], c_[7], c_[8]);                                             \
+                        float m3 = min3f(c_[9], c_[10], c_[11]);                                           \
+                        float m4 = min3f(c_[12], c_[13], c_[14]);                                          \
+                        m0 = min3f(m0, m1, m2);                                                            \
+                        m3 = min3f(m3, m4, c_[15]);                                                        \
+                        gm[qt] = min3f(gm[qt], m0, m3);                                                    \
+                    }                                                                                      \
+                    if (++tcnt == tg) MCE_SEED_GROUP_END();                                                \
+                } while (0)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accB[qt][r] = FINF;          // "no pending tile" for a minimum
+                stage_async(c_begin, 0);
+                for (int cc = 0; cc < nseed; ++cc) {
+                    const int buf = cc & 1;
+                    __syncthreads();
+                    if (cc + 1 < nseed) stage_async(c_begin + cc + 1, buf ^ 1);
+                    MCE_SWEEP_CHUNK(buf, 0, MCE_SEED_TILE);
+                }
+                MCE_SEED_TILE(accB, 0);                 // the pending tile
+                if (tcnt > 0) MCE_SEED_GROUP_END();     // a last, smaller group
+#undef MCE_SEED_TILE
+#undef MCE_SEED_GROUP_END
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accB[qt][r] = __builtin_nanf("");
+                // owner lane l holds query nl*64 + l = tile 2 nl + (l >> 5), column l & 31 -- its own column
+#pragma unroll
+                for (int nl = 0; nl < kHNL; ++nl) {
+                    float u0 = sm[2 * nl][KCAP], u1 = sm[2 * nl + 1][KCAP];
+#pragma unroll
+                    for (int k = 0; k < KCAP; ++k) {
+                        u0 = (k == kneed - 1) ? sm[2 * nl][k] : u0;
+                        u1 = (k == kneed - 1) ? sm[2 * nl + 1][k] : u1;
+                    }
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm("" : "+v"(u0), "+v"(u1));       // plain registers: keeps the select from becoming an indexed (scratch) array
+#endif
+                    const float a_up = (lane >> 5) ? u1 : u0;
+                    const int64_t q = qwave0 + nl * 64 + lane;
+                    if (q < nq && a_up < FINF) {
+                        const double ex = qinfo[2 * q], xn = qinfo[2 * q + 1];
+                        const double r = sqrt(xn) + params[HP_YHATMAX];
+                        const double ga = (ex + params[HP_EY]) * (1.0 + 1e-9) + 2.0 * sqrt(16.0 * KST) * 0x1p-14;
+                        const double eps = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 1e-9) + params[HP_RHO] + 1e-30;
+                        const double h2 = fmax((double)a_up + xn + eps, 0.0);
+                        const double dd = sqrt(h2) * (1.0 + 1e-12) + ga;
+#if MCE_SEED_CHECK      // tools/knn_f16_bench.hip: compute the bound, do not use it, compare with the final K-th distance
+                        seed_dbg[nl] = dd * dd * (1.0 + 1e-12) / s2 * (1.0 + 1e-12);
+#else
+                        seed_thr[nl] = dd * dd * (1.0 + 1e-12) / s2 * (1.0 + 1e-12);
+#endif
+                    }
+                }
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) G[qt] = gate_of(__shfl(seed_thr[qt >> 1], (qt & 1) * 32 + (lane & 31), 64), qt);
+                __syncthreads();            // everybody is done with the staging buffers
+            }
+        }
         if (c_begin < c_end) stage_async(c_begin, 0);
         for (int64_t c = c_begin; c < c_end; ++c) {
             const int buf = (int)((c - c_begin) & 1);
@@ -648,7 +801,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
             const bool all_drain = wvote[buf] != 0;
             if (tid == 0) wvote[buf ^ 1] = 0;          // re-arm the other parity (read again only after the next barrier)
             if (all_drain) drain();
-            MCE_SWEEP_CHUNK(buf, (int)(c * (CT * 32)));
+            MCE_SWEEP_CHUNK(buf, (int)(c * (CT * 32)), process);
         }
     } else {
         // Sparse walk: no chunk staging and no workgroup barriers -- every wave goes down the block's
@@ -885,6 +1038,21 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
 #undef MCE_SWEEP_CHUNK
     if constexpr (!PRUNE) process(accB, jbB);
     drain();
+#if MCE_SEED_CHECK
+#pragma unroll
+    for (int nl = 0; nl < kHNL; ++nl) {
+        double fin = own_d[nl][KCAP - 1];
+#pragma unroll
+        for (int k = 0; k < KCAP - 1; ++k) fin = (k == k_last) ? own_d[nl][k] : fin;
+        if (qwave0 + nl * 64 + lane < nq && seed_dbg[nl] < INF) {
+            double* stat = const_cast<double*>(params);
+            unsafeAtomicAdd(stat + 8, 1.0);
+            if (fin > seed_dbg[nl]) unsafeAtomicAdd(stat + 9, 1.0);
+            unsafeAtomicAdd(stat + 10, seed_dbg[nl]);
+            unsafeAtomicAdd(stat + 11, fin);
+        }
+    }
+#endif
 
 #if MCE_STATS
     if (lane == 0) {

@@ -50,7 +50,7 @@ hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
     const dim3 grid((unsigned)(PRUNE ? (a.nqblk_run ? a.nqblk_run : a.nqblk) * kHWaves : a.nqblk * a.rsplit));
     hipLaunchKernelGGL(kern, grid, dim3(PRUNE ? 64 : kHThreads), LDS, st, static_cast<const _Float16*>(a.Yh), a.nchunk_total, a.rsplit,
                        static_cast<const _Float16*>(a.Xh), a.qinfo, a.params, a.X, a.Y, a.nq, a.nr, a.D, a.nq_pad, a.nqblk,
-                       a.self_exclude, a.self_offset, a.ksel, a.part_d, a.part_i, a.clist, a.cdist, a.list_len, a.rperm, a.qperm, a.tbox_r, a.tbox_q, a.cbox_r, a.qblk0, a.qblk_stride, a.border, a.lo_d, a.lo_i);
+                       a.self_exclude, a.self_offset, a.ksel, a.part_d, a.part_i, a.clist, a.cdist, a.list_len, a.rperm, a.qperm, a.tbox_r, a.tbox_q, a.cbox_r, a.qblk0, a.qblk_stride, a.border, a.lo_d, a.lo_i, a.seed_cfg);
     return hipGetLastError();
 }
 #endif
@@ -88,7 +88,7 @@ extern const KnnF16Variant MCE_CAT(g_knn_f16_kcap, MCE_KCAP)[kMaxKST] = {
 #else
 // device pass: force the kernel instantiations
 #if MCE_KCAP <= 16
-#define MCE_F16_INST(KST, PR, LW) template __global__ void knn_f16_kernel<KST, MCE_KCAP, PR, LW>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*, int, int, const int*, const double*, const int*);
+#define MCE_F16_INST(KST, PR, LW) template __global__ void knn_f16_kernel<KST, MCE_KCAP, PR, LW>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*, int, int, const int*, const double*, const int*, int);
 MCE_F16_INST(1, false, false) MCE_F16_INST(2, false, false) MCE_F16_INST(3, false, false) MCE_F16_INST(4, false, false) MCE_F16_INST(1, true, false)
 #if MCE_KCAP == 16
 MCE_F16_INST(1, false, true) MCE_F16_INST(2, false, true) MCE_F16_INST(3, false, true) MCE_F16_INST(4, false, true)

@@ -95,6 +95,50 @@ def test_knn_duplicates_and_ties(capi):
     assert np.allclose(d, od, rtol=0, atol=1e-7) and np.allclose(d ** 2, od ** 2, atol=1e-12)
 
 
+SEED_FORCED = [dict(MCE_F16_SEED_SHARE="2", MCE_F16_SEED_ROWS="4096", MCE_F16_SEED_TG="1"),
+               dict(MCE_F16_SEED_SHARE="3", MCE_F16_SEED_ROWS="20000", MCE_F16_SEED_TG="4"),
+               dict(MCE_F16_SEED_SHARE="2", MCE_F16_SEED_ROWS="100000", MCE_F16_SEED_TG="64")]
+
+
+@pytest.mark.parametrize("shape", [(40000, 40000, 6, 4, True), (60000, 60000, 27, 11, False), (30000, 30000, 16, 16, True),
+                                   (50000, 50000, 20, 20, False), (45000, 45000, 40, 7, False), (50000, 50000, 1, 3, True)])
+def test_seeded_sweep_is_bit_identical(shape, monkeypatch):
+    """The filter kernel's seed phase (an upper bound on every K-th distance before the sweep) only
+    removes work: lists with it forced on at small sizes == lists without it == the oracle."""
+    from mcevidence_amd import _capi
+    nq, nr, d, K, same = shape
+    _capi.set_search_mode(_capi.MODE_AUTO)
+    _capi.set_prune_mode(1)
+    try:
+        rng = np.random.default_rng(nq + nr + d)
+        Y = rng.standard_normal((nr, d))
+        Y[1000:1040] = Y[7]                              # a block of duplicates inside the seed rows
+        Y[nr // 2] = Y[11]
+        X = Y if same else rng.standard_normal((nq, d))
+        if not same:
+            X[:50] = Y[:50]                              # queries that coincide with reference rows
+        sm = _capi.SELF_EXCLUDE if same else 0
+        monkeypatch.setenv("MCE_F16_SEED_ROWS", "0")
+        d0, i0 = _capi.knn(X, Y, K, self_mode=sm)
+        assert _capi.last_kernel().startswith("knn_f16") and " seed=" not in _capi.last_kernel()
+        engaged = 0
+        for env in SEED_FORCED:
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            d1, i1 = _capi.knn(X, Y, K, self_mode=sm)
+            assert np.array_equal(d0, d1) and np.array_equal(i0, i1), env
+            engaged += " seed=" in _capi.last_kernel()
+        assert engaged >= 1, _capi.last_kernel()
+        rows = rng.choice(nq, size=400, replace=False)
+        od, oi = orc.knn_brute(X[rows], Y, K + (1 if same else 0))
+        if same:                                         # drop the own row (by index) from the oracle's lists
+            keep = np.array([[j for j in oi[r] if j != rows[r]][:K] for r in range(len(rows))])
+            od = np.sqrt(((X[rows][:, None, :] - Y[keep]) ** 2).sum(-1))
+        assert _rel(d0[rows], od) < DIST_RTOL
+    finally:
+        _capi.set_prune_mode(0)
+
+
 def test_knn_large_offsets_are_stable(capi):
     """un-whitened data far from the origin: GEMM-form cancellation stays within tolerance."""
     rng = np.random.default_rng(5)

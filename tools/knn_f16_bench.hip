@@ -22,6 +22,8 @@ int main(int argc, char** argv)
     const int64_t n = argc > 1 ? atoll(argv[1]) : 200000;
     const int rsplit = argc > 2 ? atoi(argv[2]) : 1;
     const int reps = argc > 3 ? atoi(argv[3]) : 2;
+    const int seed_rows = argc > 4 ? atoi(argv[4]) : MCE_H_SEED_ROWS;      // seed phase: rows, tiles per group
+    const int seed_tg = argc > 5 ? atoi(argv[5]) : MCE_H_SEED_TG;
     constexpr int D = DIM;
     constexpr int KST = f16_ksteps(D);
     constexpr int CT = f16_chunk_tiles(KST);
@@ -56,12 +58,29 @@ int main(int argc, char** argv)
         CK(hipEventRecord(e0));
         kern<<<nqblk * rsplit, kHThreads, LDS>>>(Yh, nchunk, rsplit, Xh, qinfo, params, X, X, n, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi,
                                                 (const int*)nullptr, (const float*)nullptr, 0, (const int*)nullptr, (const int*)nullptr, (const float*)nullptr,
-                                                (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr);
+                                                (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr,
+                                                f16_seed_cfg((nchunk + rsplit - 1) / rsplit, CT, KSEL + 1, seed_rows, MCE_H_SEED_SHARE, seed_tg));
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("D=%d KST=%d KCAP=%d K=%d CT=%d ablate=%d lds=%zu n=%lld rsplit=%d grid=%d: %.2f ms  %.3f Mq/s  %.1f TF(f16 flops)\n", D, KST, KCAP, KSEL, CT, MCE_ABLATE, LDS,
                (long long)n, rsplit, nqblk * rsplit, ms, n / ms / 1e3, (double)n * n * 32.0 * KST / ms / 1e9);
     }
+    {   // sanity of the lists: K-th entries finite, and a checksum to compare builds / seed settings
+        std::vector<double> hk((size_t)nq_pad);
+        long long bad = 0; double sum = 0.0;
+        for (int sp = 0; sp < rsplit; ++sp) {
+            CK(hipMemcpy(hk.data(), pd + ((size_t)sp * KCAP + (KSEL - 1)) * nq_pad, sizeof(double) * nq_pad, hipMemcpyDeviceToHost));
+            for (int64_t q = 0; q < n; ++q) { if (!(hk[q] < 1e300)) ++bad; else sum += hk[q]; }
+        }
+        printf("K-th entries: %lld not finite, checksum %.17g\n", bad, sum);
+    }
+#if MCE_SEED_CHECK
+    {
+        double hp[16];
+        CK(hipMemcpy(hp, params, sizeof(hp), hipMemcpyDeviceToHost));
+        printf("seed check (all reps): %.0f queries seeded, %.0f violated; mean bound %.6g vs mean final K-th %.6g\n", hp[8], hp[9], hp[10] / hp[8], hp[11] / hp[8]);
+    }
+#endif
 #if MCE_STATS
     {
         const size_t nw = (size_t)nqblk * rsplit * 8;
