@@ -672,8 +672,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
     if constexpr (!PRUNE) {
         // ---- seed: an upper bound on every query's final K-th distance BEFORE anything is queued ----------
         // A stream of N references in arbitrary order puts ~K ln(N/K) genuine updates per query through the
-        // exact path, half of them within the first ~sqrt(N K) rows while the lists are still loose.  The first
-        // rows of the split are therefore swept twice: once here, only tracking the minimum of A per GROUP of
+        // exact path, half of them within the first ~sqrt(N K) rows while the lists are still loose.  A few
+        // chunks of the split are therefore swept twice: once here, only tracking the minimum of A per GROUP of
         // `tg` tiles and, per query, the K' smallest of those group minima (K' = K, + 1 if the query itself is
         // among the references).  They belong to K' different rows, at most one of them the query's own, so the
         // K-th nearest row is no farther than the K'-th smallest group minimum -- turned into a rigorous bound on
@@ -734,11 +734,14 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
                 for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) accB[qt][r] = FINF;          // "no pending tile" for a minimum
+                // the seed chunks are spread evenly over the split: the rows of a Markov chain are correlated in
+                // time, and its first stretch alone would say little about queries elsewhere in the posterior
+                const int64_t sstep = (c_end - c_begin) / nseed;              // >= 2
                 stage_async(c_begin, 0);
                 for (int cc = 0; cc < nseed; ++cc) {
                     const int buf = cc & 1;
                     __syncthreads();
-                    if (cc + 1 < nseed) stage_async(c_begin + cc + 1, buf ^ 1);
+                    if (cc + 1 < nseed) stage_async(c_begin + (cc + 1) * sstep, buf ^ 1);
                     MCE_SWEEP_CHUNK(buf, 0, MCE_SEED_TILE);
                 }
                 MCE_SEED_TILE(accB, 0);                 // the pending tile
