@@ -610,6 +610,53 @@ def test_filter_and_sweep_agree_on_every_row_at_full_size():
     assert np.allclose(d_f, d_s, rtol=1e-14, atol=0)
 
 
+def test_cross_at_full_size_C4():
+    """N1 = N2 = 1M, D = 15, K = 5, separate query set (BASELINE configs[3]): sampled query rows against the exact
+    CPU search; the fp16-filter search (seeded, one norm piece at d = 15) against the fp64 sweep on ALL rows."""
+    from mcevidence_amd import _capi
+    rng = np.random.default_rng(44)
+    X = rng.standard_normal((1_000_000, 15))
+    Y = rng.standard_normal((1_000_000, 15))
+    Y[:3] = X[:3]                                                    # a few queries coincide with reference rows
+    _capi.set_search_mode(_capi.MODE_AUTO)
+    d_f, i_f = _capi.knn(X, Y, 5)
+    assert "knn_f16" in _capi.last_kernel() and " seed=" in _capi.last_kernel()
+    assert np.all(np.diff(d_f, axis=1) >= 0) and np.all(d_f[:3, 0] == 0.0) and i_f.min() >= 0 and i_f.max() < len(Y)
+    rows = np.sort(rng.choice(len(X), 1000, replace=False))
+    od, oi = orc.knn_brute(X[rows], Y, 5)
+    assert _rel(d_f[rows], od) < DIST_RTOL and np.array_equal(i_f[rows], oi)
+    _capi.set_search_mode(_capi.MODE_F64)
+    try:
+        d_s, i_s = _capi.knn(X, Y, 5)
+        assert "knn_mfma" in _capi.last_kernel()
+    finally:
+        _capi.set_search_mode(_capi.MODE_AUTO)
+    assert np.array_equal(i_f, i_s) and np.allclose(d_f, d_s, rtol=1e-14, atol=0)
+
+
+def test_auto_at_full_size_C5(prune_modes):
+    """N = 10M, D = 6, K = 9 (BASELINE configs[4]): the k-d pruned walk (automatic at this shape) against the
+    exhaustive seeded sweep on ALL 90M (query, rank) entries, sampled rows against the exact CPU search, and the
+    nearest-neighbour symmetry property."""
+    capi = prune_modes
+    rng = np.random.default_rng(55)
+    X = rng.standard_normal((10_000_000, 6))
+    K = 9
+    capi.set_prune_mode(0)
+    d_p, i_p = capi.knn(X, X, K, self_mode=capi.SELF_EXCLUDE)
+    assert "pruned" in capi.last_kernel()
+    assert np.all(np.diff(d_p, axis=1) >= 0) and np.all(i_p != np.arange(len(X))[:, None])
+    nn = i_p[:, 0]
+    assert np.all(d_p[nn, 0] <= d_p[:, 0] * (1 + 1e-12))
+    rows = np.sort(rng.choice(len(X), 300, replace=False))
+    od, oi = orc.knn_brute(X[rows], X, K + 1)
+    assert _rel(d_p[rows], od[:, 1:]) < DIST_RTOL and np.array_equal(i_p[rows], oi[:, 1:])
+    capi.set_prune_mode(1)
+    d_e, i_e = capi.knn(X, X, K, self_mode=capi.SELF_EXCLUDE)
+    assert "pruned" not in capi.last_kernel() and " seed=" in capi.last_kernel()
+    assert np.array_equal(i_p, i_e) and np.array_equal(d_p, d_e)
+
+
 def test_neighbors_shim_matches_sklearn_semantics(capi):
     from mcevidence_amd.neighbors import NearestNeighbors
     rng = np.random.default_rng(11)
