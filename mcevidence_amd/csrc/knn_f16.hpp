@@ -355,7 +355,10 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
 #ifndef MCE_H_NPASS
 #define MCE_H_NPASS 3
 #endif
-        constexpr int NPASS = MCE_H_NPASS;                         // 8*NPASS pairs, 8*NPASS loads per lane in flight (D <= 32)
+#ifndef MCE_H_NPASS_WIDE
+#define MCE_H_NPASS_WIDE 1      // D > 31 (16 loads per lane and pass): more in flight spills (3: 160-300 bytes of scratch per lane)
+#endif
+        constexpr int NPASS = KST > 2 ? MCE_H_NPASS_WIDE : MCE_H_NPASS;            // 8*NPASS pairs in flight; 8 (D <= 32) or 16 (D <= 63) loads per lane and pass
         constexpr int EPL = KST > 2 ? 8 : 4;        // elements per lane: 4 covers D <= 32, 8 covers D <= 63
         for (int b0 = 0; b0 < qcount; b0 += NPASS * 8) {
             int qlp[NPASS], ep[NPASS];

@@ -1,4 +1,4 @@
-// knn_inst.hip -- instantiates knn_mfma_kernel<KS, MCE_KCAP, QT> for KS = 1..16.
+// knn_inst.hip -- instantiates knn_mfma_kernel<KS, MCE_KCAP> for KS = 1..16 and knn_f16_kernel<KST, MCE_KCAP, ..> for KST = 1..4.
 // Compile with -DMCE_KCAP=<4|8|12|16|24|32>.
 #include "knn_mfma.hpp"
 #include "knn_f16.hpp"
@@ -7,9 +7,17 @@
 #ifndef MCE_KCAP
 #error "compile with -DMCE_KCAP=n"
 #endif
+// MCE_INST_PART: 1 = the fp16 filter kernels only, 2 = the fp64 sweep kernels only (the Makefile builds them as
+// separate objects: they are compiled with different instruction schedulers), 0 = both
+#ifndef MCE_INST_PART
+#define MCE_INST_PART 0
+#endif
+#define MCE_INST_F16 (MCE_KCAP <= 16 && MCE_INST_PART != 2)
+#define MCE_INST_F64 (MCE_INST_PART != 1)
 
 namespace mce {
 
+#if MCE_INST_F64
 template <int KS, int KCAP>
 hipError_t launch_variant(const KnnArgs& a, hipStream_t st)
 {
@@ -29,8 +37,9 @@ hipError_t launch_variant(const KnnArgs& a, hipStream_t st)
                        a.nq_pad, a.nqblk, a.self_exclude, a.self_offset, a.ksel, a.part_d, a.part_i);
     return hipGetLastError();
 }
+#endif
 
-#if MCE_KCAP <= 16
+#if MCE_INST_F16
 template <int KST, int KCAP, bool PRUNE, bool LOWER = false>
 hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
 {
@@ -66,12 +75,14 @@ hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
 
 // host-only table (a namespace-scope const would otherwise be emitted for the device too)
 #if !defined(__HIP_DEVICE_COMPILE__)
+#if MCE_INST_F64
 extern const KnnVariant MCE_CAT(g_knn_kcap, MCE_KCAP)[kMaxKS] = {
     MCE_VARIANT(1),  MCE_VARIANT(2),  MCE_VARIANT(3),  MCE_VARIANT(4),  MCE_VARIANT(5),  MCE_VARIANT(6),
     MCE_VARIANT(7),  MCE_VARIANT(8),  MCE_VARIANT(9),  MCE_VARIANT(10), MCE_VARIANT(11), MCE_VARIANT(12),
     MCE_VARIANT(13), MCE_VARIANT(14), MCE_VARIANT(15), MCE_VARIANT(16),
 };
-#if MCE_KCAP <= 16
+#endif
+#if MCE_INST_F16
 #if MCE_KCAP == 16
 #define MCE_F16_LOWER(KST) (&launch_f16_variant<KST, MCE_KCAP, false, true>)
 #else
@@ -87,16 +98,18 @@ extern const KnnF16Variant MCE_CAT(g_knn_f16_kcap, MCE_KCAP)[kMaxKST] = {
 #endif
 #else
 // device pass: force the kernel instantiations
-#if MCE_KCAP <= 16
+#if MCE_INST_F16
 #define MCE_F16_INST(KST, PR, LW) template __global__ void knn_f16_kernel<KST, MCE_KCAP, PR, LW>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*, int, int, const int*, const double*, const int*, int);
 MCE_F16_INST(1, false, false) MCE_F16_INST(2, false, false) MCE_F16_INST(3, false, false) MCE_F16_INST(4, false, false) MCE_F16_INST(1, true, false)
 #if MCE_KCAP == 16
 MCE_F16_INST(1, false, true) MCE_F16_INST(2, false, true) MCE_F16_INST(3, false, true) MCE_F16_INST(4, false, true)
 #endif
 #endif
+#if MCE_INST_F64
 #define MCE_INST(KS) template __global__ void knn_mfma_kernel<KS, MCE_KCAP>(const double*, int64_t, int, const double*, const double*, int64_t, int, int64_t, int, int, int64_t, int, double*, int*);
 MCE_INST(1) MCE_INST(2) MCE_INST(3) MCE_INST(4) MCE_INST(5) MCE_INST(6) MCE_INST(7) MCE_INST(8)
 MCE_INST(9) MCE_INST(10) MCE_INST(11) MCE_INST(12) MCE_INST(13) MCE_INST(14) MCE_INST(15) MCE_INST(16)
+#endif
 #endif
 
 }  // namespace mce
