@@ -35,6 +35,9 @@ thread_local char g_last_kernel[256] = "";
 thread_local int g_prof_on = 0;
 thread_local std::vector<std::pair<hipEvent_t, hipEvent_t>> g_ev_pool;   // reused brackets
 thread_local size_t g_ev_used = 0;                                        // brackets since enable
+thread_local size_t g_ev_calls = 0;                                       // searches since enable (a split search: two brackets)
+thread_local bool g_in_tail = false;                                      // inside the tail part of a split search
+thread_local int g_split_depth = 0;                                       // > 0: inside a part of a split search
 thread_local double g_last_prune_geom[3] = {0, 0, 0};                     // blocks, chunks, tiles per chunk
 
 int fail(int code, const char* fmt, ...)
@@ -189,6 +192,7 @@ struct Plan {
     int rsplit = 1;
     int L = 4;
     size_t off_yf = 0, off_pd = 0, off_pi = 0, off_center = 0, off_msum = 0, total = 0;
+    double cost = 0.0;                        // the split model's estimate for this plan (cycles per SIMD; exhaustive kernels)
     bool twopass = false;                     // fp16 filter, 16 < K <= 32: two sweeps of 16-entry lists (knn_f16.hpp, LOWER)
     bool prune = false;                       // fp16 filter walking k-d ordered chunk lists (prune.hpp)
     int part = 0, nparts = 1;                 // pruned walk over query blocks part, part + nparts, ... only
@@ -322,6 +326,7 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     }
     if (p.prune) best_r = 1;                  // every workgroup walks its own chunk list
     p.rsplit = best_r;
+    p.cost = best_c;
     p.L = p.twopass ? 2 * p.rsplit : p.rsplit;
 
     size_t off = 0;
@@ -402,6 +407,7 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
         if (!prof) return MCE_OK;
         MCE_HIP(hipEventRecord(g_ev_pool[g_ev_used].second, st));
         ++g_ev_used;
+        if (!g_in_tail) ++g_ev_calls;
         return MCE_OK;
     };
     const int threads = 256;
@@ -616,7 +622,7 @@ int mce_last_prune_stats(double* chunk_fraction, double* tile_fraction)
 void mce_set_profiling(int on)
 {
     g_prof_on = on ? 1 : 0;
-    if (on) g_ev_used = 0;
+    if (on) { g_ev_used = 0; g_ev_calls = 0; }
 }
 
 double mce_last_kernel_ms(void)
@@ -629,7 +635,7 @@ double mce_last_kernel_ms(void)
         if (hipEventElapsedTime(&ms, g_ev_pool[i].first, g_ev_pool[i].second) != hipSuccess) return -1.0;
         sum += ms;
     }
-    return sum / (double)g_ev_used;
+    return sum / (double)(g_ev_calls ? g_ev_calls : g_ev_used);      // per search (a split search times two launches)
 }
 
 int mce_device_count(void)
@@ -637,6 +643,40 @@ int mce_device_count(void)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+// ---- trailing partial round ------------------------------------------------------------------------
+// The exhaustive kernels run one 512-query workgroup per CU, all of the same length, so a search is a sequence of
+// rounds of 256 workgroups and the last one is as long as the others however few it holds: 782 blocks (N = 400 k)
+// take four rounds for 3.05 rounds of work.  When the last round would fill at most half the chip, the queries are
+// searched as two ranges instead: the full rounds as they are, and the remainder as its own search, whose plan
+// then splits the reference set over the idle CUs (measured, sequential launches: 400 k x 6 13.1 -> 11.0 ms,
+// 400 k x 27 17.0 -> 13.4 ms, 300 k x 15 6.7 -> 5.9 ms, 700 k x 10 22.4 -> 20.6 ms; C3's last round is 63 % full
+// and is left alone: 67.6 vs 67.3 ms).  Rows, lists and partial sums of the two ranges are disjoint and laid
+// out exactly as in one search, so every result is bit-identical.  Returns the rows of the first range, or 0.
+// mce_last_kernel() of a split search: the first range's launch + the geometry of the second
+void note_split(const char* first)
+{
+    char tail[sizeof(g_last_kernel)];
+    snprintf(tail, sizeof(tail), "%s", g_last_kernel);
+    const char* g = strstr(tail, " grid=");
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "%.150s + tail%.80s", first, g ? g : "");
+}
+
+int64_t tail_split_rows(const Plan& p, int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, size_t ws_avail)
+{
+    if (g_split_depth > 0 || !p.vh || p.prune || p.generic || p.rsplit != 1 || p.nqblk <= kAssumedCUs) return 0;
+    const char* const off = getenv("MCE_TAIL_SPLIT");
+    if (off && atoi(off) == 0) return 0;
+    const int tail = p.nqblk % kAssumedCUs;
+    if (tail == 0 || 2 * tail > kAssumedCUs) return 0;
+    const int64_t nq_main = (int64_t)(p.nqblk - tail) * mce::f16_qpb(p.KCAP);
+    static_assert(mce::f16_qpb(4) % mce::kRedThreads == 0, "the merge blocks of the two ranges must tile like one search's");
+    Plan pm, pt;
+    if (make_plan(nq_main, nr, d, K, self_mode, pm) != MCE_OK || make_plan(nq - nq_main, nr, d, K, self_mode, pt) != MCE_OK) return 0;
+    if (!pm.vh || !pt.vh || pm.prune || pt.prune || pm.total > ws_avail || pt.total > ws_avail) return 0;
+    if (pm.cost + pt.cost > 0.97 * p.cost) return 0;
+    return nq_main;
 }
 
 size_t mce_knn_workspace_bytes(int64_t nq, int64_t nr, int32_t d, int32_t K)
@@ -658,6 +698,21 @@ int mce_knn_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t nr, 
     if (rc != MCE_OK) return rc;
     if (ws_bytes < p.total) return fail(MCE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, p.total);
     if (nq == 0) return MCE_OK;
+    if (const int64_t nm = tail_split_rows(p, nq, nr, d, K, self_mode, ws_bytes)) {
+        ++g_split_depth;
+        rc = mce_knn_f64_dev(dX, nm, dY, nr, d, K, self_mode, self_offset, d_dist, d_idx, ws, ws_bytes, stream);
+        char first[sizeof(g_last_kernel)];
+        snprintf(first, sizeof(first), "%s", g_last_kernel);
+        if (rc == MCE_OK) {
+            g_in_tail = true;
+            rc = mce_knn_f64_dev(dX + nm * (int64_t)d, nq - nm, dY, nr, d, K, self_mode, self_offset + nm, d_dist + nm * (int64_t)K,
+                                 d_idx ? d_idx + nm * (int64_t)K : nullptr, ws, ws_bytes, stream);
+            g_in_tail = false;
+        }
+        --g_split_depth;
+        if (rc == MCE_OK) note_split(first);
+        return rc;
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = run_search(p, dX, nq, dY, nr, d, K, self_mode, self_offset, static_cast<char*>(ws), st);
     if (rc != MCE_OK) return rc;
@@ -712,10 +767,40 @@ int mce_knn_dotp_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t
     if (ws_bytes < need) return fail(MCE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* wsc = static_cast<char*>(ws);
-    rc = run_search(p, dX, nq, dY, nr, d, K, self_mode, self_offset, wsc, st);
-    if (rc != MCE_OK) return rc;
     double* partial = reinterpret_cast<double*>(wsc + p.total);
     const unsigned blocks = (unsigned)((nq + mce::kRedThreads - 1) / mce::kRedThreads);
+    if (const int64_t nm = tail_split_rows(p, nq, nr, d, K, self_mode, p.total)) {
+        // two ranges, one reduction: the partial sums of the second range follow those of the first in the
+        // order one search would have produced them
+        Plan pm, pt;
+        if (make_plan(nm, nr, d, K, self_mode, pm) != MCE_OK || make_plan(nq - nm, nr, d, K, self_mode, pt) != MCE_OK)
+            return fail(MCE_ERR_INVALID, "split plan");
+        ++g_split_depth;
+        rc = run_search(pm, dX, nm, dY, nr, d, K, self_mode, self_offset, wsc, st);
+        if (rc == MCE_OK)
+            rc = launch_merge(pm, d_dist_out != nullptr, true, dX, dY, nm, d, K, self_mode, self_offset, d_dist_out, nullptr, (int)k0,
+                              (int)kmax, d_w, d_fs, partial, wsc, st);
+        char first[sizeof(g_last_kernel)];
+        snprintf(first, sizeof(first), "%s", g_last_kernel);
+        if (rc == MCE_OK) {
+            g_in_tail = true;
+            rc = run_search(pt, dX + nm * (int64_t)d, nq - nm, dY, nr, d, K, self_mode, self_offset + nm, wsc, st);
+            g_in_tail = false;
+        }
+        if (rc == MCE_OK)
+            rc = launch_merge(pt, d_dist_out != nullptr, true, dX + nm * (int64_t)d, dY, nq - nm, d, K, self_mode, self_offset + nm,
+                              d_dist_out ? d_dist_out + nm * (int64_t)K : nullptr, nullptr, (int)k0, (int)kmax, d_w + nm, d_fs + nm,
+                              partial + (nm / mce::kRedThreads) * (int64_t)kmax, wsc, st);
+        --g_split_depth;
+        if (rc != MCE_OK) return rc;
+        note_split(first);
+        hipLaunchKernelGGL(mce::dotp_final_kernel, dim3((unsigned)kmax), dim3(mce::kRedThreads), 0, st, partial,
+                           (int64_t)blocks, (int)k0, (int)kmax, d_dotp);
+        MCE_HIP(hipGetLastError());
+        return MCE_OK;
+    }
+    rc = run_search(p, dX, nq, dY, nr, d, K, self_mode, self_offset, wsc, st);
+    if (rc != MCE_OK) return rc;
     if (p.generic) {
         // lists -> distance matrix [nq, K] (caller's buffer or workspace scratch) -> unfused reduction
         double* dd = d_dist_out ? d_dist_out : reinterpret_cast<double*>(wsc + p.off_center);

@@ -139,6 +139,39 @@ def test_seeded_sweep_is_bit_identical(shape, monkeypatch):
         _capi.set_prune_mode(0)
 
 
+@pytest.mark.parametrize("nq,nr,d,K,same", [(140000, 140000, 6, 4, True), (135000, 90000, 27, 9, False), (150000, 150000, 10, 20, True)])
+def test_trailing_round_split_is_bit_identical(nq, nr, d, K, same, monkeypatch):
+    """A search whose last round of workgroups would fill less than half the chip runs as two query ranges
+    (DESIGN.md 3.0): neighbours, distances and the fused sums must equal the single search's to the bit."""
+    from mcevidence_amd import _capi
+    _capi.set_search_mode(_capi.MODE_AUTO)
+    _capi.set_prune_mode(1)
+    try:
+        rng = np.random.default_rng(nq + d)
+        Y = rng.standard_normal((nr, d))
+        X = Y if same else rng.standard_normal((nq, d))
+        w = rng.integers(1, 5, size=nq).astype(float)
+        fs = -rng.random(nq)
+        sm = _capi.SELF_EXCLUDE if same else 0
+        k0 = 1 if same else 0
+        out = {}
+        for flag in ("0", "1"):
+            monkeypatch.setenv("MCE_TAIL_SPLIT", flag)
+            dist, idx = _capi.knn(X, Y, K, self_mode=sm)
+            kern = _capi.last_kernel()
+            dotp = _capi.knn_dotp(X, Y, w, fs, K + k0, k0)
+            out[flag] = (dist, idx, dotp, kern, _capi.last_kernel())
+        assert "+ tail" not in out["0"][3] and "+ tail" in out["1"][3] and "+ tail" in out["1"][4], out["1"][3:]
+        assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
+        assert np.array_equal(out["0"][2], out["1"][2])
+        if not same:
+            rows = np.sort(rng.choice(nq, size=300, replace=False))
+            od, oi = orc.knn_brute(X[rows], Y, K)
+            assert _rel(out["1"][0][rows], od) < DIST_RTOL and np.array_equal(out["1"][1][rows], oi)
+    finally:
+        _capi.set_prune_mode(0)
+
+
 def test_knn_large_offsets_are_stable(capi):
     """un-whitened data far from the origin: GEMM-form cancellation stays within tolerance."""
     rng = np.random.default_rng(5)
