@@ -778,12 +778,19 @@ def test_dev_entry_point_under_graph_capture(capi, pruned):
         capi.set_prune_mode(capi.PRUNE_AUTO)
 
 
-def test_random_shapes_against_oracle(capi):
-    """seeded sweep over ragged shapes, all self modes, pruning forced or off: distances and rows against
-    the exact CPU search."""
+def test_random_shapes_against_oracle(capi, monkeypatch):
+    """seeded sweep over ragged shapes, all self modes, pruning forced or off, the filter's seed phase forced on
+    with random settings in a third of the cases: distances and rows against the exact CPU search."""
     rng = np.random.default_rng(2024)
     try:
-        for case in range(36):
+        for case in range(48):
+            if case % 3 == 1:
+                monkeypatch.setenv("MCE_F16_SEED_SHARE", "2")
+                monkeypatch.setenv("MCE_F16_SEED_ROWS", str(int(rng.integers(64, 8192))))
+                monkeypatch.setenv("MCE_F16_SEED_TG", str(int(rng.integers(1, 17))))
+            else:
+                for k in ("MCE_F16_SEED_SHARE", "MCE_F16_SEED_ROWS", "MCE_F16_SEED_TG"):
+                    monkeypatch.delenv(k, raising=False)
             d = int(rng.choice([1, 2, 3, 5, 6, 8, 13, 14, 27, 40]))
             nr = int(rng.integers(40, 20000))
             K = int(rng.integers(1, min(32, nr - 1) + 1))
