@@ -68,7 +68,7 @@ std::atomic<int> g_prune_mode{0};
 //   3 M 342 vs 401, 4 M 504 vs 694 ms      d = 10: 4 M 1.43 vs 0.69 s (the boxes overlap too much)
 // smallest reference set for which the automatic mode takes the pruned walk, by dimension (0: never)
 constexpr int64_t kPruneAutoMinQueries = 32768;
-constexpr int64_t kPruneAutoMinRows[16] = {0, 100000, 100000, 150000, 150000, 300000, 300000, 800000, 2000000, 0, 0, 0, 0, 0, 0, 0};
+constexpr int64_t kPruneAutoMinRows[16] = {0, 100000, 100000, 100000, 150000, 300000, 300000, 800000, 2000000, 0, 0, 0, 0, 0, 0, 0};
 
 // Device buffers of the host-pointer entry points.  Small allocations (<= 64 MB) are kept in a
 // per-thread, per-device pool between calls: the reference's typical workload is thousands of
