@@ -196,7 +196,9 @@ int mce_last_prune_stats(double *chunk_fraction, double *tile_fraction);
 /* Measurement hook: while enabled, the search-kernel launch of every call on this thread
  * is bracketed by hipEvents recorded on the launch stream (no synchronisation);
  * mce_last_kernel_ms() waits for the brackets recorded since the last enable and returns
- * their MEAN duration in ms (-1 if none).  Used by bench.py for the roofline figure. */
+ * the MEAN search-kernel time per call in ms (-1 if none; a call that searches two query ranges --
+ * DESIGN.md 3.0, trailing round -- counts once, with both launches).  Used by bench.py for the
+ * roofline figure. */
 void mce_set_profiling(int on);
 double mce_last_kernel_ms(void);
 
