@@ -159,7 +159,9 @@ def test_trailing_round_split_is_bit_identical(nq, nr, d, K, same, monkeypatch):
             monkeypatch.setenv("MCE_TAIL_SPLIT", flag)
             dist, idx = _capi.knn(X, Y, K, self_mode=sm)
             kern = _capi.last_kernel()
-            dotp = _capi.knn_dotp(X, Y, w, fs, K + k0, k0)
+            dotp, dd = _capi.knn_dotp(X, Y, w, fs, K + k0, k0, return_dist=True)
+            assert np.array_equal(dd, dist)                      # the fused call's distance matrix = the search's
+            assert np.array_equal(dotp, _capi.knn_dotp(X, Y, w, fs, K + k0, k0))
             out[flag] = (dist, idx, dotp, kern, _capi.last_kernel())
         assert "+ tail" not in out["0"][3] and "+ tail" in out["1"][3] and "+ tail" in out["1"][4], out["1"][3:]
         assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
