@@ -466,7 +466,7 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
             g_last_params = params;
             g_last_prune_geom[0] = p.nqblk; g_last_prune_geom[1] = (double)p.nchunk; g_last_prune_geom[2] = p.CT;
             snprintf(g_last_kernel, sizeof(g_last_kernel), "%s pruned grid=%d block=64 lds=%zu qt=%d ct=%d chunks=%lld", p.vh->name,
-                     p.nqblk * mce::kHWaves, mce::f16_prune_lds_bytes(p.KST, d), p.QT, p.CT, (long long)p.nchunk);
+                     p.nqblk * mce::kHWaves, mce::f16_prune_lds_bytes(p.KST, d, p.KCAP), p.QT, p.CT, (long long)p.nchunk);
             return MCE_OK;
         }
         // seed phase: the host picks the group size; MCE_F16_SEED_ROWS / MCE_F16_SEED_SHARE override (tests, tuning)

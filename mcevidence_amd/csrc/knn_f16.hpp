@@ -83,12 +83,14 @@ constexpr int kHThreads = kHWaves * 64;
 #ifndef MCE_H_PRUNE_WAVES
 #define MCE_H_PRUNE_WAVES 2     // pruned walk: waves per SIMD the register allocation aims for
 #endif
-#ifndef MCE_H_PRUNE_BATCH
-#define MCE_H_PRUNE_BATCH 8     // pruned walk: tiles multiplied per batch (LDS slice = BATCH KB per wave)
-#endif
-#ifndef MCE_H_PRUNE_TRIGGER
-#define MCE_H_PRUNE_TRIGGER 48
-#endif
+// Pruned walk, LDS per wave: tiles multiplied per batch (slice = BATCH KB), queue entries, drain trigger.  Lists of
+// 4 entries leave the kernel at 160 VGPRs -- three waves per SIMD IF a wave's LDS stays under 13.3 KB: with half the
+// batch and half the queue, K <= 4 searches run 10-27 % faster (10 M x 6: 130 -> 100 ms; 4 M x 3: 5.5 -> 4.0 ms);
+// longer lists need 182-253 VGPRs (two waves per SIMD either way), and there the smaller batch only costs
+// (10 M x 6, K = 9: 197 -> 224 ms).
+__host__ __device__ constexpr int f16_prune_batch(int KCAP) { return KCAP <= 4 ? 4 : 8; }
+__host__ __device__ constexpr int f16_prune_queue(int KCAP) { return KCAP <= 4 ? 128 : 256; }   // entries are already exact: only the list insertion is deferred
+__host__ __device__ constexpr int f16_prune_trigger(int KCAP) { return KCAP <= 4 ? 32 : 48; }
 #ifndef MCE_H_STAGE_KB
 #define MCE_H_STAGE_KB 48
 #endif
@@ -132,7 +134,7 @@ __host__ __device__ constexpr size_t f16_lds_bytes(int KST, int KCAP)
            + (size_t)kHWaves * kHQT * 32 * 4 + 128;                    // chain heads + votes + block thresholds (pruned walk)
 }
 
-__host__ __device__ constexpr int f16_prune_slice_bytes(int KST) { return MCE_H_PRUNE_BATCH * KST * 1024 + 256; }   // kBatch tiles + pending ids
+__host__ __device__ constexpr int f16_prune_slice_bytes(int KST, int KCAP) { return f16_prune_batch(KCAP) * KST * 1024 + 256; }   // kBatch tiles + pending ids
 #ifndef MCE_H_PRUNE_BOOT_ORDER
 #define MCE_H_PRUNE_BOOT_ORDER 1   // 1: own tiles first, then outward; 0: ascending tile number
 #endif
@@ -141,11 +143,10 @@ __host__ __device__ constexpr int f16_prune_slice_bytes(int KST) { return MCE_H_
 #endif
 constexpr int kHPruneBoot = MCE_H_PRUNE_BOOT;   // pruned walk: k-d neighbour tiles on either side multiplied before the walk
 constexpr int kHPruneChunkTiles = 64; // pruned walk: tiles per list entry ("chunk" = 2048 rows, an aligned k-d subtree)
-constexpr int kHPruneQueue = 256;   // pruned walk: queue entries per wave (already exact: only the list insertion is deferred)
 // [tile slice + pending ids][queue d2 | row | next][heads][the wave's 64 fp64 query rows][one fp64 reference tile][its caller row numbers]
-__host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST, int D)
+__host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST, int D, int KCAP)
 {
-    return (size_t)f16_prune_slice_bytes(KST) + (size_t)kHPruneQueue * 16 + (size_t)kHQT * 32 * 4 + 128 +
+    return (size_t)f16_prune_slice_bytes(KST, KCAP) + (size_t)f16_prune_queue(KCAP) * 16 + (size_t)kHQT * 32 * 4 + 128 +
            (size_t)(kHQT * 32 + 32) * D * 8 + 128 + (size_t)kHQT * 32 * 8 + 64 * 8;
 }
 
@@ -198,9 +199,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
     // workgroups let the hardware balance their very uneven walks): [tile slice + pending ids]
     // [queue d2][queue packed][queue next][heads]; workgroup g serves wave g%8 of query block g/8.
     constexpr int LW = PRUNE ? 1 : kHWaves;                       // waves sharing this LDS allocation
-    constexpr int STAGE_BYTES = PRUNE ? f16_prune_slice_bytes(KST) : 2 * CT * KST * 1024;
+    constexpr int STAGE_BYTES = PRUNE ? f16_prune_slice_bytes(KST, KCAP) : 2 * CT * KST * 1024;
     char* const stage0 = lds_raw;
-    constexpr int QN = PRUNE ? kHPruneQueue : kHQueue;            // queue entries per wave
+    constexpr int QN = PRUNE ? f16_prune_queue(KCAP) : kHQueue;   // queue entries per wave
     double* const qd2_all = reinterpret_cast<double*>(lds_raw + STAGE_BYTES);
     int* const qpk_all = reinterpret_cast<int*>(qd2_all + LW * QN);
     int* const qnx_all = qpk_all + LW * QN;
@@ -816,10 +817,10 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES :
         // pass (lane t <-> tile t), collects the tiles within reach and multiplies them in batches
         // of kBatch: the batch's A tiles (1 KB each) go through registers into the wave's private
         // slice of the staging area and are swept from there.
-        constexpr int kBatch = MCE_H_PRUNE_BATCH;
+        constexpr int kBatch = f16_prune_batch(KCAP);
         constexpr int PCT = kHPruneChunkTiles;               // tiles per list chunk: one per lane
-        constexpr int kPruneDrainTrigger = MCE_H_PRUNE_TRIGGER;
-        static_assert(f16_prune_slice_bytes(KST) >= kBatch * KST * 1024 + 256, "tile slice");
+        constexpr int kPruneDrainTrigger = f16_prune_trigger(KCAP);
+        static_assert(f16_prune_slice_bytes(KST, KCAP) >= kBatch * KST * 1024 + 256, "tile slice");
         const int* const mylist = clist + (int64_t)qblk * list_len;
         const float* const mydist = cdist + (int64_t)qblk * list_len;
         char* const wbuf = stage0;                                          // [kBatch tiles][pending ids]

@@ -43,9 +43,9 @@ hipError_t launch_variant(const KnnArgs& a, hipStream_t st)
 template <int KST, int KCAP, bool PRUNE, bool LOWER = false>
 hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
 {
-    constexpr size_t LDS_MAX = PRUNE ? f16_prune_lds_bytes(KST, 16 * KST - 1) : f16_lds_bytes(KST, KCAP);
+    constexpr size_t LDS_MAX = PRUNE ? f16_prune_lds_bytes(KST, 16 * KST - 1, KCAP) : f16_lds_bytes(KST, KCAP);
     static_assert(LDS_MAX <= 160 * 1024, "LDS budget");
-    const size_t LDS = PRUNE ? f16_prune_lds_bytes(KST, a.D) : LDS_MAX;     // pruned walk: sized by the dimension (more waves per CU)
+    const size_t LDS = PRUNE ? f16_prune_lds_bytes(KST, a.D, KCAP) : LDS_MAX;     // pruned walk: sized by the dimension (more waves per CU)
     static bool attr_set[kMaxDevices] = {};
     auto kern = knn_f16_kernel<KST, KCAP, PRUNE, LOWER>;
     int dev = 0;
