@@ -83,14 +83,18 @@ constexpr int kHThreads = kHWaves * 64;
 #ifndef MCE_H_PRUNE_WAVES
 #define MCE_H_PRUNE_WAVES 2     // pruned walk: waves per SIMD the register allocation aims for
 #endif
-// Pruned walk, LDS per wave: tiles multiplied per batch (slice = BATCH KB), queue entries, drain trigger.  Lists of
-// 4 entries leave the kernel at 160 VGPRs -- three waves per SIMD IF a wave's LDS stays under 13.3 KB: with half the
-// batch and half the queue, K <= 4 searches run 10-27 % faster (10 M x 6: 130 -> 100 ms; 4 M x 3: 5.5 -> 4.0 ms);
-// longer lists need 182-253 VGPRs (two waves per SIMD either way), and there the smaller batch only costs
-// (10 M x 6, K = 9: 197 -> 224 ms).
-__host__ __device__ constexpr int f16_prune_batch(int KCAP) { return KCAP <= 4 ? 4 : 8; }
-__host__ __device__ constexpr int f16_prune_queue(int KCAP) { return KCAP <= 4 ? 128 : 256; }   // entries are already exact: only the list insertion is deferred
-__host__ __device__ constexpr int f16_prune_trigger(int KCAP) { return KCAP <= 4 ? 32 : 48; }
+// Pruned walk, LDS per wave: tiles multiplied per batch (slice = BATCH KB), queue entries, drain trigger.  The walk
+// is latency-bound and gains from a third wave per SIMD, which needs <= 168 VGPRs AND <= 13.3 KB of LDS per wave.
+// Lists of up to 8 entries get there (144 / 166 VGPRs, no scratch) with half the batch and half the queue:
+// K <= 8 searches run 10-27 % faster (10 M x 6: K = 4 130 -> 100 ms, K = 8 179 -> 142 ms; 4 M x 3, K = 4:
+// 5.5 -> 4.0 ms).  Longer lists need 217-253 VGPRs: forced under 168 they spill (K = 9: 197 -> 366 ms), and at
+// two waves per SIMD the smaller batch only costs (197 -> 224 ms), so they keep the larger footprint.
+#ifndef MCE_H_PRUNE_SMALL
+#define MCE_H_PRUNE_SMALL 8      // largest list capacity on the three-wave configuration
+#endif
+__host__ __device__ constexpr int f16_prune_batch(int KCAP) { return KCAP <= MCE_H_PRUNE_SMALL ? 4 : 8; }
+__host__ __device__ constexpr int f16_prune_queue(int KCAP) { return KCAP <= MCE_H_PRUNE_SMALL ? 128 : 256; }   // entries are already exact: only the list insertion is deferred
+__host__ __device__ constexpr int f16_prune_trigger(int KCAP) { return KCAP <= MCE_H_PRUNE_SMALL ? 32 : 48; }
 #ifndef MCE_H_STAGE_KB
 #define MCE_H_STAGE_KB 48
 #endif
@@ -171,7 +175,7 @@ __host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST, int D, int KCA
 // candidates beyond that split's 16th (lo_d / lo_i = the first pass's lists) and finds the next K - 16;
 // the merge then sees two sorted lists per split.  Two sweeps at fp16 speed instead of one fp64 sweep.
 template <int KST, int KCAP, bool PRUNE = false, bool LOWER = false>
-__global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? MCE_H_PRUNE_WAVES : (MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ? 4 : 2))) void knn_f16_kernel(
+__global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUNE_SMALL ? 3 : MCE_H_PRUNE_WAVES) : (MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ? 4 : 2))) void knn_f16_kernel(
     const _Float16* __restrict__ Yh, int64_t nchunk_total, int rsplit,
     const _Float16* __restrict__ Xh, const double* __restrict__ qinfo, const double* __restrict__ params,
     const double* __restrict__ X, const double* __restrict__ Y, int64_t nq, int64_t nr, int D,
