@@ -184,6 +184,16 @@ def _f64(a, name):
     return a
 
 
+def _f64_fs(a, name="fs"):
+    """fs = logL - max(logL) <= 0 (reference :1062-1064).  -inf is a legitimate entry -- a row with zero
+    likelihood, exp(fs) = 0, a harmless zero term in the reference's sum and in the kernel's -- so only NaN
+    and +inf are refused."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if np.isnan(a).any() or (a == np.inf).any():
+        raise ValueError("%s contains NaN or +infinity" % name)
+    return a
+
+
 # ---------------------------------------------------------------------------
 # host-pointer wrappers (NumPy in, NumPy out)
 # ---------------------------------------------------------------------------
@@ -210,7 +220,7 @@ def dotp(dist, w, fs, d, k0, kmax, device=0):
     lib = load()
     dist = _f64_allow_inf(dist)
     w = _f64(w, "weight")
-    fs = _f64(fs, "fs")
+    fs = _f64_fs(fs)
     if dist.ndim != 2 or w.shape != (dist.shape[0],) or fs.shape != w.shape:
         raise ValueError("shape mismatch: dist %r, w %r, fs %r" % (dist.shape, w.shape, fs.shape))
     out = np.zeros(int(kmax), dtype=np.float64)
@@ -229,7 +239,7 @@ def knn_dotp(X, Y, w, fs, kmax, k0, self_offset=0, return_dist=False, devices=No
     X = _f64(X, "X")
     Y = X if Y is None else _f64(Y, "Y")
     w = _f64(w, "weight")
-    fs = _f64(fs, "fs")
+    fs = _f64_fs(fs)
     if X.ndim != 2 or Y.ndim != 2 or X.shape[1] != Y.shape[1]:
         raise ValueError("X and Y must be 2-D with the same number of columns")
     nq, d = X.shape
@@ -254,7 +264,7 @@ def knn_dotp_part(Y, w, fs, kmax, part, nparts, device=0):
     lib = load()
     Y = _f64(Y, "Y")
     w = _f64(w, "weight")
-    fs = _f64(fs, "fs")
+    fs = _f64_fs(fs)
     if Y.ndim != 2 or w.shape != (Y.shape[0],) or fs.shape != w.shape:
         raise ValueError("Y must be 2-D, weight and fs one entry per row")
     out = np.zeros(int(kmax), dtype=np.float64)
@@ -284,7 +294,7 @@ def evidence_feed(S1, S2, d, cov_mode, kmax, w, fs, device=0):
     S1 = _rows_f64(S1, "samples", d, check=False)
     S2 = None if S2 is None else _rows_f64(S2, "samples2", d, check=False)
     w = _f64(w, "weight")
-    fs = _f64(fs, "fs")
+    fs = _f64_fs(fs)
     if w.shape != (S1.shape[0],) or fs.shape != w.shape:
         raise ValueError("weight and fs must have one entry per s1 row")
     out = np.zeros(int(kmax))
@@ -327,7 +337,7 @@ def evidence_feed_batch(problems, devices=None, return_exceptions=False):
         S1 = _rows_f64(S1, "samples", d, check=False)
         S2 = None if S2 is None else _rows_f64(S2, "samples2", d, check=False)
         w = _f64(w, "weight")
-        fs = _f64(fs, "fs")
+        fs = _f64_fs(fs)
         if w.shape != (S1.shape[0],) or fs.shape != w.shape:
             raise ValueError("problem %d: weight and fs must have one entry per s1 row" % i)
         out = np.zeros(max(kmax, 0))

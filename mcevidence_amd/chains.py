@@ -28,21 +28,55 @@ import numpy as np
 logger = logging.getLogger("mcevidence_amd")
 
 
+def rank0_draw(draw):
+    """Every random decision of the host bookkeeping (the s1/s2 split, Poisson thinning, random batches)
+    comes from the process's own global NumPy RNG, as in the reference (:225, :417-445, :917).  Under
+    ``torchrun`` each rank is its own process with its own unseeded RNG, and the query-sharded hot path
+    (``parallel.sharded_knn_dotp``) needs every rank to hold the SAME rows: rank 0 draws, the others
+    receive its result (one ``broadcast_object_list``; the other ranks' RNGs are not advanced).
+    Outside a process group this is just ``draw()``."""
+    from . import parallel
+    if not parallel.is_distributed():
+        return draw()
+    import torch.distributed as dist
+    box = [draw() if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
 def read_chain_file(path):
     """One chain text file -> fp64 array [rows, columns]: what ``np.loadtxt(f)`` gives the reference
     (:564), read by the native multi-threaded reader (``chain_io`` / ``libmcechains.so``).
     ``MCE_CHAIN_READER=numpy`` selects NumPy's reader instead."""
-    if os.environ.get("MCE_CHAIN_READER", "native") == "numpy":
+    if os.environ.get("MCE_CHAIN_READER", "native") == "numpy" or not _native_reader():
         return np.loadtxt(path, ndmin=2)
     from . import chain_io
     return chain_io.loadtxt(path)
+
+
+_NATIVE_READER = None
+
+
+def _native_reader():
+    """Is libmcechains.so there?  Reading chains is host bookkeeping, not the hot path: without the native
+    reader (an install that lost the library) the files are read by ``np.loadtxt`` -- the reference's own
+    reader (:564), same values, ~10x slower -- with ONE warning.  (The HIP hot path has no such fallback.)"""
+    global _NATIVE_READER
+    if _NATIVE_READER is None:
+        from . import chain_io
+        _NATIVE_READER = os.path.exists(chain_io.LIB_PATH)
+        if not _NATIVE_READER:
+            import warnings
+            warnings.warn("mcevidence_amd: %s not found (build it with `make -C mcevidence_amd/csrc`); "
+                          "reading chain files with numpy.loadtxt instead" % chain_io.LIB_PATH, RuntimeWarning)
+    return _NATIVE_READER
 
 
 def read_chain_files(paths):
     """The chain files of one root, in order.  Small files (a Planck chain is ~3 MB: one reader thread
     each) are parsed concurrently -- the native reader runs outside the GIL."""
     paths = list(paths)
-    if len(paths) < 2 or os.environ.get("MCE_CHAIN_READER", "native") == "numpy":
+    if len(paths) < 2 or os.environ.get("MCE_CHAIN_READER", "native") == "numpy" or not _native_reader():
         return [read_chain_file(f) for f in paths]
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(len(paths), 8)) as pool:
@@ -116,7 +150,7 @@ def poisson_thin(weights, retain_fraction):
     """0 < thinlen < 1: new weight ~ Poisson(w * fraction) drawn row by row from the
     global NumPy RNG; rows with zero draws are dropped (reference :417-445)."""
     w = np.asarray(weights) * retain_fraction
-    draws = np.array([float(np.random.poisson(x)) for x in w])
+    draws = rank0_draw(lambda: np.array([float(np.random.poisson(x)) for x in w]))
     keep = np.where(draws > 0)[0]
     return keep, draws[keep]
 
@@ -242,7 +276,7 @@ class MCSamples(object):
         ascending row order (reference :221-249)."""
         if self.split:
             nrow = len(s)
-            pick = np.random.choice(range(nrow), size=int(nrow * self.s1frac), replace=False)
+            pick = rank0_draw(lambda: np.random.choice(range(nrow), size=int(nrow * self.s1frac), replace=False))
             rest = np.setxor1d(range(nrow), pick)
             self.logger.info("%s chain with nrow=%s split to ns1=%s, ns2=%s" % (self.nchains, nrow, len(pick), len(rest)))
             return self._partitions(s, pick, rest)

@@ -1138,11 +1138,15 @@ int feed_stage_a(FeedJob& j, hipStream_t st)
     const mce_feed_problem& q = *j.q;
     const int d = q.d;
     const size_t row = (size_t)d * sizeof(double);
-    // pageable sources: plain (blocking) copies; the streams used here do not synchronise with them
-    MCE_HIP(hipMemcpy2D(j.dS1(), row, q.S1, (size_t)q.ld1 * sizeof(double), row, (size_t)q.n1, hipMemcpyHostToDevice));
-    if (q.S2) MCE_HIP(hipMemcpy2D(j.dS2(), row, q.S2, (size_t)q.ld2 * sizeof(double), row, (size_t)q.n2, hipMemcpyHostToDevice));
-    MCE_HIP(hipMemcpy(j.dW(), q.w, (size_t)q.n1 * sizeof(double), hipMemcpyHostToDevice));
-    MCE_HIP(hipMemcpy(j.dF(), q.fs, (size_t)q.n1 * sizeof(double), hipMemcpyHostToDevice));
+    // Uploads are issued ON the job's stream, so the covariance kernels behind them are ordered after them by the
+    // stream itself (hipStreamNonBlocking streams do not synchronise with the legacy default stream, and the
+    // contract of a blocking hipMemcpy from pageable memory only promises that the SOURCE has been staged on
+    // return).  From pageable memory these calls still return once the source is consumed: the pipeline's
+    // "host uploads group g+1 while the device searches group g" is unchanged.
+    MCE_HIP(hipMemcpy2DAsync(j.dS1(), row, q.S1, (size_t)q.ld1 * sizeof(double), row, (size_t)q.n1, hipMemcpyHostToDevice, st));
+    if (q.S2) MCE_HIP(hipMemcpy2DAsync(j.dS2(), row, q.S2, (size_t)q.ld2 * sizeof(double), row, (size_t)q.n2, hipMemcpyHostToDevice, st));
+    MCE_HIP(hipMemcpyAsync(j.dW(), q.w, (size_t)q.n1 * sizeof(double), hipMemcpyHostToDevice, st));
+    MCE_HIP(hipMemcpyAsync(j.dF(), q.fs, (size_t)q.n1 * sizeof(double), hipMemcpyHostToDevice, st));
     // "all": one eigen-system from s1 U s2; "single": s1's own, and s2's own for s2 (J stays s1's)
     int rc = launch_covariance(j.dS1(), q.cov_mode == 0 ? j.ntot : q.n1, d, j.d_part(), j.d_mean3(), j.d_cov(), st);
     if (rc != MCE_OK) return rc;
@@ -1272,6 +1276,12 @@ int feed_run_on_device(int device, std::vector<FeedJob*>& jobs)
             ++hi;
         }
         DevBuf arena;
+        // destroyed BEFORE the arena: an early return (a failing HIP call in the loops below) must not hand the
+        // arena back to the pool while kernels of other jobs are still running on the other streams
+        struct Quiesce {
+            bool armed = true;
+            ~Quiesce() { if (armed) (void)hipDeviceSynchronize(); }
+        } quiesce;
         PinnedArena& pinned = g_pinned;
         MCE_HIP(arena.alloc(dev_bytes));
         MCE_HIP(pinned.reserve(host_bytes));
@@ -1289,8 +1299,9 @@ int feed_run_on_device(int device, std::vector<FeedJob*>& jobs)
                 if (r == MCE_OK) { MCE_HIP(hipStreamSynchronize(nullptr)); r = feed_stage_b(j); }
                 if (r == MCE_OK) r = feed_stage_c(j, nullptr);
                 if (r == MCE_OK) { MCE_HIP(hipStreamSynchronize(nullptr)); feed_stage_d(j); }
-                else j.set_error(r);
+                else { j.set_error(r); (void)hipStreamSynchronize(nullptr); }
             }
+            quiesce.armed = false;
             lo = hi;
             continue;
         }
@@ -1325,6 +1336,8 @@ int feed_run_on_device(int device, std::vector<FeedJob*>& jobs)
             }
         }
         for (hipStream_t st : sc) MCE_HIP(hipStreamSynchronize(st));
+        for (hipStream_t st : sa) MCE_HIP(hipStreamSynchronize(st));     // (jobs that failed after stage A left work there)
+        quiesce.armed = false;
         for (size_t i = lo; i < hi; ++i)
             if (jobs[i]->rc == MCE_OK) feed_stage_d(*jobs[i]);
         lo = hi;

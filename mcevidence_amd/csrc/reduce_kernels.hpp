@@ -2,7 +2,10 @@
 // reduction of the evidence estimator (reference MCEvidence.py:1107-1117).
 //
 //   dotp[k] = sum_j  pi^(D/2) r_jk^D / Gamma(1+D/2) / w_j * exp(fs_j)
-//           = sum_j  exp( lnC_D + (D/2) ln r_jk^2 - ln w_j + fs_j )          (log domain)
+//           = sum_j  sign(w_j) exp( lnC_D + (D/2) ln r_jk^2 - ln |w_j| + fs_j )     (log domain)
+//
+// The sign keeps the reference's value for a negative weight (volume / weight is a finite signed term there);
+// fs_j = -inf (a row whose likelihood is 0) contributes exp(-inf) = 0, r = 0 likewise.
 //
 // Deterministic: per-workgroup partial sums in a fixed tree, then one fixed-order
 // pass over the partials (no floating-point atomics), so results are run-to-run
@@ -82,8 +85,12 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
 
     if (live) {
         const int selfj = (self_mode == 1) ? (int)(self_offset + qo) : -1;
-        double base = 0.0;
-        if (FUSE_DOTP) base = lnc - log(w[qo]) + fs[qo];
+        double base = 0.0, sgn = 1.0;
+        if (FUSE_DOTP) {
+            const double wq = w[qo];
+            base = lnc - log(fabs(wq)) + fs[qo];
+            sgn = wq < 0.0 ? -1.0 : 1.0;
+        }
 
         unsigned char head[kMaxLists];
         for (int l = 0; l < L; ++l) head[l] = 0;
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
             }
             if (FUSE_DOTP) {
                 // column k of the K = kmax-k0 true neighbours <-> reference column k0+k
-                const double t = exp(base + 0.5 * (double)D * log(d2));
+                const double t = sgn * exp(base + 0.5 * (double)D * log(d2));
 #pragma unroll
                 for (int kk = 0; kk < kMaxK; ++kk)
                     if (kk == k) term[kk] = t;
@@ -170,13 +177,17 @@ __global__ __launch_bounds__(kRedThreads) void dotp_partial_kernel(
     __shared__ double red[kRedThreads / 64];
     const int64_t q = (int64_t)blockIdx.x * kRedThreads + threadIdx.x;
     const bool live = q < nq;
-    double base = 0.0;
-    if (live) base = lnc - log(w[q]) + fs[q];
+    double base = 0.0, sgn = 1.0;
+    if (live) {
+        const double wq = w[q];
+        base = lnc - log(fabs(wq)) + fs[q];
+        sgn = wq < 0.0 ? -1.0 : 1.0;
+    }
     for (int k = k0; k < kmax; ++k) {
         double t = 0.0;
         if (live) {
             const double r = dist[q * (int64_t)ld + k];
-            t = exp(base + (double)D * log(r));
+            t = sgn * exp(base + (double)D * log(r));
         }
         const double s = block_sum(t, red);
         if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * kmax + k] = s;

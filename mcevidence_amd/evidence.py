@@ -26,7 +26,7 @@ from collections import namedtuple
 
 import numpy as np
 
-from .chains import MCSamples
+from .chains import MCSamples, rank0_draw
 
 FORMAT = "%(levelname)s:%(filename)s.%(funcName)s():%(lineno)-8s %(message)s"
 logger = logging.getLogger("mcevidence_amd")
@@ -142,7 +142,15 @@ class MCEvidence(object):
         self.info["Nsamples_read"] = self.gd.get_shape()[0]
         self.info["Nparams_read"] = self.gd.get_shape()[1]
         self.nsample = [self.gd.get_shape(name=s)[0] for s in self.snames]
-        self.ndim = self.gd.nparamMC if ndim is None else ndim
+        # the reference cuts s[:, 0:ndim] wherever it uses ndim (:893, :857): a slice, so an ndim beyond the
+        # parameter columns silently means "all of them".  Clamped ONCE here, so the host route and the
+        # device-feeder route (which passes ndim to the library) see the same number.
+        self.ndim = self.gd.nparamMC if ndim is None else int(ndim)
+        if self.ndim < 1:
+            raise ValueError("ndim must be >= 1 (got %r)" % (ndim,))
+        if self.ndim > self.gd.nparamMC:
+            self.logger.warning("ndim=%s exceeds the %s parameter columns of the chain; using all of them" % (ndim, self.gd.nparamMC))
+            self.ndim = self.gd.nparamMC
         self.info["NparamsCosmo"] = self.ndim
         self.info["Nsamples"] = ", ".join(str(x) for x in self.nsample)
         self.logger.info("chain array dimensions: %s x %s =" % (self.nsample, self.ndim))
@@ -217,7 +225,7 @@ class MCEvidence(object):
             if rand and self.brange is not None:
                 if nsamples > ntot:
                     raise ValueError("partition %s nsamples=%s, ntotal_chain=%s" % (name, nsamples, ntot))
-                idx = np.random.randint(0, high=ntot, size=nsamples)
+                idx = rank0_draw(lambda: np.random.randint(0, high=ntot, size=nsamples))
             else:
                 idx = np.arange(istart, nsamples + istart)
             s, lnp, w = s[idx, :], lnp[idx], w[idx]

@@ -51,14 +51,56 @@ def _reduce_partial(part, group=None):
     return t.cpu().numpy()
 
 
-def sharded_knn_dotp(X, Y, weight, fs, kmax, k0, want_dist=False, group=None, local_fn=None):
+def replica_fingerprint(*arrays):
+    """63-bit fingerprint of the replicated inputs: shapes, every value of vectors, and for matrices
+    ~4096 evenly spaced rows plus the column sums (one pass; ~10 ms per 200 MB).  Not cryptographic --
+    it is there to catch ranks that hold DIFFERENT partitions (an unsynchronised random split)."""
+    import zlib
+    h = 0
+    for a in arrays:
+        if a is None:
+            h = zlib.crc32(b"none", h)
+            continue
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        h = zlib.crc32(np.asarray(a.shape, dtype=np.int64).tobytes(), h)
+        if a.ndim < 2 or a.shape[0] <= 4096:
+            h = zlib.crc32(a.tobytes(), h)
+        else:
+            h = zlib.crc32(np.ascontiguousarray(a[:: a.shape[0] // 4096]).tobytes(), h)
+            h = zlib.crc32(a.sum(axis=0).tobytes(), h)
+    return int(h)
+
+
+def check_replicas(X, Y, weight, fs, group=None):
+    """The sharded sum is only meaningful if every rank holds the same X, Y, weight and fs (each rank
+    reduces its own row range of them).  One all-reduce(MAX) of [h, -h] compares the fingerprints;
+    a mismatch raises on every rank instead of returning a silently wrong, rank-dependent ln E."""
+    import torch
+    import torch.distributed as dist
+    h = replica_fingerprint(X, Y, weight, fs)
+    backend = dist.get_backend(group)
+    device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([h, -h], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    hi, lo = int(t[0]), -int(t[1])
+    if hi != lo:
+        raise RuntimeError(
+            "mcevidence_amd: the ranks of this process group hold different samples/weights (fingerprints differ). "
+            "Construct MCEvidence on every rank AFTER init_process_group (random splits and thinning are then "
+            "drawn on rank 0 and broadcast), from the same chains.")
+
+
+def sharded_knn_dotp(X, Y, weight, fs, kmax, k0, want_dist=False, group=None, local_fn=None, verify=True):
     """Query-sharded fused kNN + reduction.  Every rank passes the FULL arrays (they are
     replicated host-side, as the reference set must be anyway) and gets the full
-    ``dotp`` back.  ``local_fn`` lets the CPU tests substitute the per-shard compute."""
+    ``dotp`` back.  ``local_fn`` lets the CPU tests substitute the per-shard compute.
+    ``verify``: compare a fingerprint of the inputs across the ranks first (``check_replicas``)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if verify:
+        check_replicas(X, Y, weight, fs, group)
     n = X.shape[0]
     lo, hi = shard_bounds(n, world, rank)
     ref = X if Y is None else Y

@@ -57,7 +57,8 @@ int oracle_knn_f64(const double *X, int64_t nq, const double *Y, int64_t nr, int
     return 0;
 }
 
-/* dotp[k] = sum_j exp(lnC_D + D ln r_jk - ln w_j + fs_j), k in [k0,kmax); serial, row order. */
+/* dotp[k] = sum_j sign(w_j) exp(lnC_D + D ln r_jk - ln |w_j| + fs_j), k in [k0,kmax); serial, row order
+   (= volume/weight * exp(fs) of MCEvidence.py:1107-1117, also for a negative weight). */
 int oracle_dotp_f64(const double *dist, int64_t nq, int32_t ld, int32_t k0, int32_t kmax, int32_t d,
                     const double *w, const double *fs, double *dotp)
 {
@@ -67,7 +68,7 @@ int oracle_dotp_f64(const double *dist, int64_t nq, int32_t ld, int32_t k0, int3
         double s = 0.0;
         for (int64_t j = 0; j < nq; ++j) {
             double r = dist[j * ld + k];
-            s += exp(lnc + d * log(r) - log(w[j]) + fs[j]);
+            s += (w[j] < 0 ? -1.0 : 1.0) * exp(lnc + d * log(r) - log(fabs(w[j])) + fs[j]);
         }
         dotp[k] = s;
     }

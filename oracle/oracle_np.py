@@ -140,13 +140,16 @@ def ln_unit_ball(ndim):
 
 def dotp_logdomain(DkNN, weight, fs, ndim, k0, kmax):
     """Same sum in the log domain -- the form the HIP reduction kernel uses:
-    dotp_k = sum_j exp(lnC_D + D ln r_jk - ln w_j + fs_j)."""
+    dotp_k = sum_j sign(w_j) exp(lnC_D + D ln r_jk - ln |w_j| + fs_j)  (the sign keeps the reference's
+    volume/weight for a negative weight; fs = -inf and r = 0 give zero terms)."""
     out = np.zeros(kmax)
     lnc = ln_unit_ball(ndim)
-    base = fs - np.log(weight)
+    weight = np.asarray(weight, dtype=np.float64)
     with np.errstate(divide="ignore"):
+        base = fs - np.log(np.abs(weight))
+        sgn = np.where(weight < 0, -1.0, 1.0)
         for k in range(k0, kmax):
-            out[k] = np.sum(np.exp(lnc + ndim * np.log(DkNN[:, k]) + base))
+            out[k] = np.sum(sgn * np.exp(lnc + ndim * np.log(DkNN[:, k]) + base))
     return out
 
 

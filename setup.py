@@ -22,7 +22,8 @@ setup(
     description="MI355X-native kNN Bayesian-evidence estimator (drop-in for MCEvidence)",
     packages=["mcevidence_amd"],
     py_modules=["MCEvidence"],
-    package_data={"mcevidence_amd": ["libmcevidence_hip.so"]},
+    # both libraries the Makefile builds: the HIP hot path and the host chain reader (chains.read_chain_file)
+    package_data={"mcevidence_amd": ["libmcevidence_hip.so", "libmcechains.so"]},
     install_requires=["numpy"],
     cmdclass={"build_py": BuildWithHip},
     license="MIT",

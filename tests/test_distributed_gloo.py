@@ -164,3 +164,69 @@ def test_two_rank_problem_farm_matches_single_process():
     assert sorted(set(owner)) == [0, 1]
     loads = [sum((500 + 130 * i) ** 2 for i in range(7) if owner[i] == r) for r in (0, 1)]
     assert max(loads) < 1.35 * min(loads)
+
+
+def _split_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import logging
+    import tempfile
+    logging.disable(logging.CRITICAL)
+    import mcevidence_amd as pkg
+    from mcevidence_amd import parallel
+    from mcevidence_amd.synth import gaussian_chain
+
+    class Be(object):
+        def knn_dotp(self, X, Y, weight, fs, kmax, k0, want_dist=False):
+            return parallel.sharded_knn_dotp(X, Y, weight, fs, kmax, k0, want_dist=want_dist, local_fn=_local_oracle)
+    # every rank has its OWN global RNG state, as separate torchrun processes have
+    np.random.seed(1000 + 17 * rank)
+    chain = gaussian_chain(5, 1400, 4, weights="int")
+    m = pkg.MCEvidence([chain], kmax=4, split=True, s1frac=0.4, verbose=0, backend=Be())
+    rows1 = np.asarray(m.gd.data["s1"].ichain)
+    lnE = m.evidence(covtype="all")
+    # Poisson thinning of a file-read chain draws from the global RNG too
+    tmp = tempfile.mkdtemp()
+    np.savetxt(os.path.join(tmp, "c_1.txt"), chain)
+    mt = pkg.MCEvidence(os.path.join(tmp, "c"), kmax=3, thinlen=0.5, verbose=0, backend=Be())
+    wthin = np.asarray(mt.gd.data["s1"].weights)
+    lnEt = mt.evidence()
+    # ranks that do hold different rows are refused, on every rank
+    refused = None
+    X = np.random.default_rng(rank).standard_normal((300, 3))
+    try:
+        parallel.sharded_knn_dotp(X, None, np.ones(300), np.zeros(300), 3, 1, local_fn=_local_oracle)
+    except RuntimeError as exc:
+        refused = "different samples" in str(exc)
+    q.put((rank, rows1, lnE, wthin, lnEt, refused))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_random_split_and_thinning_agree_across_ranks():
+    """split=True / 0<thinlen<1 under a process group: the draws come from rank 0 (each process has its own
+    global RNG), so every rank reduces shards of the SAME partition; ranks with different inputs raise."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, rows_a, lnE_a, w_a, lnEt_a, ref_a), (_, rows_b, lnE_b, w_b, lnEt_b, ref_b) = got
+    assert np.array_equal(rows_a, rows_b) and np.array_equal(w_a, w_b)
+    assert np.array_equal(lnE_a, lnE_b) and np.array_equal(lnEt_a, lnEt_b)
+    assert ref_a is True and ref_b is True
+    # and it is rank 0's split: the single-process class under rank 0's seed gives the same numbers
+    import mcevidence_amd as pkg
+    from mcevidence_amd.synth import gaussian_chain
+    from helpers import OracleBackend
+    np.random.seed(1000)
+    one = pkg.MCEvidence([gaussian_chain(5, 1400, 4, weights="int")], kmax=4, split=True, s1frac=0.4, verbose=0, backend=OracleBackend())
+    assert np.array_equal(np.asarray(one.gd.data["s1"].ichain), rows_a)
+    assert np.allclose(one.evidence(covtype="all"), lnE_a, atol=1e-12)

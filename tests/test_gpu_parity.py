@@ -309,6 +309,28 @@ def test_dotp_zero_distance_terms(capi):
     assert np.all(np.isfinite(out)) and np.allclose(out[1:], ref[1:], rtol=1e-12)
 
 
+def test_dotp_signed_weights_and_zero_likelihood_rows(capi):
+    """negative weights keep the reference's signed term; fs = -inf rows contribute zero (fused and unfused)"""
+    rng = np.random.default_rng(12)
+    n, d, k0, kmax = 3000, 5, 1, 4
+    X = rng.standard_normal((n, d))
+    w = rng.integers(1, 5, n).astype(float)
+    w[[3, 77, 2000]] = [-2.0, -1.0, -0.5]
+    fs = -rng.random(n)
+    fs[[9, 77, 1500]] = -np.inf
+    od, _ = orc.knn_brute(X, X, kmax - k0, self_mode=2)
+    full = np.zeros((n, kmax))
+    full[:, k0:] = od
+    ref = orc.dotp_literal(full, w, fs, d, k0, kmax)
+    dp = capi.knn_dotp(X, None, w, fs, kmax, k0)
+    un = capi.dotp(full, w, fs, d, k0, kmax)
+    assert np.all(np.isfinite(dp)) and np.allclose(dp[k0:], ref[k0:], rtol=1e-11) and np.allclose(un[k0:], ref[k0:], rtol=1e-12)
+    with pytest.raises(ValueError):
+        capi.knn_dotp(X, None, w, np.where(np.arange(n) == 4, np.inf, fs), kmax, k0)
+    with pytest.raises(ValueError):
+        capi.knn_dotp(X, None, w, np.where(np.arange(n) == 4, np.nan, fs), kmax, k0)
+
+
 def test_query_sharding_sums_to_full(capi):
     """shard the queries, add the partial sums."""
     rng = np.random.default_rng(9)

@@ -230,3 +230,35 @@ def test_cli_runs_cross(planck_root, monkeypatch, capsys):
     out = cli.main([root, "-k", "3", "--cross", "-vb", "0"])
     assert out.shape == (2,) and np.all(np.isfinite(out))
     assert "Using file" in capsys.readouterr().out
+
+
+def test_ndim_is_clamped_once_and_both_routes_agree():
+    """ndim beyond the parameter columns means "all of them" (the reference slices s[:, 0:ndim]); ndim below them
+    cuts the leading columns.  The device-feeder route (ndim goes to the library) and the host route (NumPy
+    whitening, then the hot path) must see the same number and give the same ln E."""
+    ch = gaussian_chain(seed=4, n=3000, d=5, cov="corr")
+    for ndim, used in ((3, 3), (5, 5), (9, 5)):
+        feed = pkg.MCEvidence([ch], ndim=ndim, kmax=4, verbose=0, backend=OracleFeedBackend())
+        host = pkg.MCEvidence([ch], ndim=ndim, kmax=4, verbose=0, backend=OracleBackend())
+        assert feed.ndim == host.ndim == used and feed.info["NparamsCosmo"] == used
+        a, b = feed.evidence(), host.evidence()
+        assert feed.backend.calls[0]["d"] == host.backend.calls[0]["d"] == used
+        assert np.allclose(a, b, rtol=0, atol=LNE_TOL)
+    with pytest.raises(ValueError):
+        pkg.MCEvidence([ch], ndim=0, verbose=0, backend=OracleBackend())
+
+
+def test_missing_native_reader_falls_back_to_loadtxt(tmp_path, monkeypatch):
+    """an install without libmcechains.so still reads chain files (np.loadtxt, the reference's reader), with a warning"""
+    from mcevidence_amd import chain_io, chains
+    ch = gaussian_chain(seed=2, n=300, d=3)
+    root = str(tmp_path / "c")
+    np.savetxt(root + "_1.txt", ch[:150])
+    np.savetxt(root + "_2.txt", ch[150:])
+    want = pkg.MCEvidence(root, kmax=3, verbose=0, backend=OracleBackend()).evidence()
+    monkeypatch.setattr(chain_io, "LIB_PATH", str(tmp_path / "nowhere.so"))
+    monkeypatch.setattr(chains, "_NATIVE_READER", None)
+    with pytest.warns(RuntimeWarning, match="libmcechains|nowhere"):
+        got = pkg.MCEvidence(root, kmax=3, verbose=0, backend=OracleBackend()).evidence()
+    assert np.array_equal(want, got)
+    monkeypatch.setattr(chains, "_NATIVE_READER", None)

@@ -65,6 +65,27 @@ def test_dotp_forms_agree(name):
     assert np.allclose(cc[k0:], lit[k0:], rtol=1e-12)
 
 
+def test_dotp_signed_weights_and_zero_likelihood_rows():
+    """a negative weight gives the reference's signed term volume/weight*exp(fs); fs = -inf (likelihood 0) and
+    r = 0 give zero terms -- in the literal form and in both log-domain restatements"""
+    rng = np.random.default_rng(11)
+    n, ndim, k0, kmax = 400, 5, 1, 4
+    dist = np.abs(rng.standard_normal((n, kmax))) + 0.1
+    dist[5, 2] = 0.0
+    w = rng.integers(1, 5, n).astype(float)
+    w[[3, 77, 200]] = [-2.0, -1.0, -0.5]
+    fs = -rng.random(n)
+    fs[[9, 77]] = -np.inf
+    with np.errstate(divide="ignore"):
+        lit = orc.dotp_literal(dist, w, fs, ndim, k0, kmax)
+    logd = orc.dotp_logdomain(dist, w, fs, ndim, k0, kmax)
+    cc = orc.dotp_c(dist, w, fs, ndim, k0, kmax)
+    assert np.all(np.isfinite(lit[k0:]))
+    assert np.allclose(logd[k0:], lit[k0:], rtol=1e-12) and np.allclose(cc[k0:], lit[k0:], rtol=1e-12)
+    pos = orc.dotp_literal(dist, np.abs(w), fs, ndim, k0, kmax)
+    assert np.all(lit[k0:] < pos[k0:])
+
+
 def test_knn_brute_modes_and_numpy_agree():
     rng = np.random.default_rng(5)
     X = rng.standard_normal((700, 5))
