@@ -188,6 +188,18 @@ int mce_get_search_mode(void);
  * 100 k reference rows, d <= 4 from 150 k, d <= 6 from 300 k, d = 7 from 800 k, d = 8 from 2 M; 1: never; 2: whenever the shape allows it (d <= 15, K <= 16).  Process-wide. */
 int mce_set_prune_mode(int mode);
 int mce_get_prune_mode(void);
+
+/* Symmetric sweep of an auto-evidence search (X and Y are ONE buffer, nq == nr: reference
+ * MCEvidence.py:1100-1104, `nbrs.fit(samples); nbrs.kneighbors(samples)`).  d(i,j) = d(j,i), so every
+ * 32x32 tile of the exhaustive fp16 filter sweep is needed by both of its sides; here it is multiplied once:
+ * the rows are sorted by distance from the mean, a prepass bounds every row's K-th distance, every block of
+ * 512 rows sweeps only the blocks before it, and each tile is gated for the streamed rows
+ * too; their candidates are merged into the lists afterwards.  Same neighbours, distances and tie-breaks as
+ * the exhaustive search.  0 (default): from 512 blocks (262 144 rows) where pruning does not apply;
+ * 1: never; 2: whenever the shape allows it (fp16-filter shapes with K <= 16, at least 1024 rows).
+ * Process-wide; the environment variable MCE_SYM sets the initial value. */
+int mce_set_sym_mode(int mode);
+int mce_get_sym_mode(void);
 /* Work actually done by the last pruned search launched by this thread through a *_dev entry point
  * (its workspace must still be alive): fraction of (query block, reference chunk) pairs staged, and
  * fraction of (wave, 32-row tile) products multiplied.  Synchronises the device. */

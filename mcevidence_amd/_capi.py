@@ -44,6 +44,8 @@ SIGNATURES = {
     "mce_get_search_mode": (_c.c_int, []),
     "mce_set_prune_mode": (_c.c_int, [_c.c_int]),
     "mce_get_prune_mode": (_c.c_int, []),
+    "mce_set_sym_mode": (_c.c_int, [_c.c_int]),
+    "mce_get_sym_mode": (_c.c_int, []),
     "mce_last_prune_stats": (_c.c_int, [_c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "mce_set_profiling": (None, [_c.c_int]),
     "mce_last_kernel_ms": (_c.c_double, []),
@@ -135,6 +137,18 @@ def set_prune_mode(mode):
 
 def get_prune_mode():
     return int(load().mce_get_prune_mode())
+
+
+SYM_AUTO, SYM_OFF, SYM_FORCE = 0, 1, 2
+
+
+def set_sym_mode(mode):
+    """symmetric sweep of auto-evidence searches (each pair of rows multiplied once): 0 auto, 1 never, 2 whenever possible"""
+    check(load().mce_set_sym_mode(int(mode)))
+
+
+def get_sym_mode():
+    return int(load().mce_get_sym_mode())
 
 
 def last_prune_stats():

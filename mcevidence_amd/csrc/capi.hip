@@ -61,6 +61,28 @@ int fail(int code, const char* fmt, ...)
 std::atomic<int> g_mode{0};
 // spatial pruning (prune.hpp): 0 auto (low d, large reference sets), 1 never, 2 whenever the shape allows it
 std::atomic<int> g_prune_mode{0};
+// symmetric sweep of an auto-evidence search (knn_f16.hpp): 0 auto (large sets), 1 never, 2 whenever the shape allows it.
+// MCE_SYM in the environment sets the initial value.
+std::atomic<int> g_sym_mode{-1};
+int sym_mode()
+{
+    int m = g_sym_mode.load();
+    if (m < 0) {
+        const char* e = getenv("MCE_SYM");
+        m = e ? atoi(e) : 0;
+        if (m < 0 || m > 2) m = 0;
+        g_sym_mode.store(m);
+    }
+    return m;
+}
+constexpr int kSymAutoMinBlocks = 512;        // query blocks (512 rows each) from which the automatic mode takes it
+// bucket entries per row: a row receives ~K ln(N/2 / seed rows) + K row-side candidates; MCE_SYM_BUCKET overrides (tests)
+int sym_bucket_per_row(int K)
+{
+    const char* e = getenv("MCE_SYM_BUCKET");
+    if (e && atoi(e) > 0) return atoi(e);
+    return 6 * K + 24;
+}
 // measured on MI355X (tools/prune_sweep.sh, tools/prune_sweep_small.sh; search + preparation, K = 10):
 //   d = 1: 0.3 M 3.3 vs 54 ms, 1 M 6.8 vs 474 ms      d = 2: 0.3 M 2.9 vs 11.8 ms
 //   d = 3: 0.1 M 1.3 vs 1.5 ms, 1 M 17 vs 59 ms, 10 M 0.17 vs 4.0 s      d = 6: 0.2 M 4.6 vs 4.0, 0.3 M 8.5 vs 10.8,
@@ -199,6 +221,10 @@ struct Plan {
     int64_t pl_nr = 0;                        // reference rows the plan was made for
     mce::PruneLayout pl;
     size_t off_prune = 0;
+    bool sym = false;                         // workspace holds the symmetric sweep's scratch (run_search decides: X and Y must be one buffer)
+    bool sym_active = false;                  // set by run_search: the lists are in sorted-row order, one split
+    mce::SymLayout sl;
+    size_t off_sym = 0;
 };
 
 const mce::KnnVariant* variant_for(int KS, int kcap_idx)
@@ -343,10 +369,16 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     } else {
         off = align_up(off + (size_t)p.nrow_pad * (size_t)(4 * p.KS) * sizeof(double), 256);
     }
+    // symmetric sweep: auto-evidence searches (the caller passes ONE buffer as X and Y; only the sizes are known here)
+    if (f16 && !p.twopass && !p.prune && nq == nr && p.vh->launch_sym && p.nqblk >= 2 && p.nrow_pad <= ((int64_t)1 << mce::kHRelBits)) {
+        const int sm = sym_mode();
+        p.sym = sm == 2 || (sm == 0 && p.nqblk >= kSymAutoMinBlocks);
+    }
+    const int l_alloc = p.L;
     p.off_pd = off;
-    off = align_up(off + (size_t)p.L * p.KCAP * (size_t)p.nq_pad * sizeof(double), 256);
+    off = align_up(off + (size_t)l_alloc * p.KCAP * (size_t)p.nq_pad * sizeof(double), 256);
     p.off_pi = off;
-    off = align_up(off + (size_t)p.L * p.KCAP * (size_t)p.nq_pad * sizeof(int), 256);
+    off = align_up(off + (size_t)l_alloc * p.KCAP * (size_t)p.nq_pad * sizeof(int), 256);
     p.off_center = off;
     off = align_up(off + (size_t)3 * mce::kMaxDimPad * sizeof(double), 256);      // centre | box(Y) | box(X)
     p.off_msum = off;
@@ -356,6 +388,11 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
         p.pl_nr = nr;
         p.off_prune = off;
         off = align_up(off + p.pl.total, 256);
+    }
+    if (p.sym) {
+        mce::sym_layout(nr, p.nq_pad, p.nqblk, d, p.KCAP, mce::f16_qpb(p.KCAP), sym_bucket_per_row(K), p.sl);
+        p.off_sym = off;
+        off = align_up(off + p.sl.total, 256);
     }
     p.total = off;
     return MCE_OK;
@@ -370,9 +407,10 @@ size_t dotp_ws_bytes(int64_t nq, int32_t kmax)
 double ln_unit_ball(int d) { return 0.5 * d * std::log(M_PI) - std::lgamma(1.0 + 0.5 * d); }
 
 // pack + search; leaves the lane/split lists in the workspace
-int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, int64_t nr, int32_t d, int32_t K,
+int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t nr, int32_t d, int32_t K,
                int32_t self_mode, int64_t self_offset, char* ws, hipStream_t st)
 {
+    p.sym_active = false;
     double* pd = reinterpret_cast<double*>(ws + p.off_pd);
     int* pi = reinterpret_cast<int*>(ws + p.off_pi);
     if (p.generic) {
@@ -423,6 +461,13 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
         const double* sX = dX;     // the rows the search reads: the caller's, or their k-d ordered copies
         const double* sY = dY;
         mce::PruneOut po;
+        const bool use_sym = p.sym && dX == dY && nq == nr && self_offset == 0 && g_split_depth == 0;
+        if (use_sym) {
+            // rows by distance from the mean: a 32-row tile then holds rows of nearly equal K-th neighbour distance
+            MCE_HIP(mce::sym_prepare(dY, nr, (int)d, center, p.nq_pad, ws + p.off_sym, p.sl, st));
+            sX = sY = reinterpret_cast<const double*>(ws + p.off_sym + p.sl.Ys);
+            separate_queries = false;
+        }
         if (p.prune) {
             const bool same_set = (dX == dY && nq == nr);
             MCE_HIP(mce::prune_prepare(dX, nq, dY, nr, (int)d, same_set, mce::f16_qpb(p.KCAP), p.CT * 32, p.nq_pad, p.nqblk, p.nrow_pad,
@@ -478,6 +523,52 @@ int run_search(const Plan& p, const double* dX, int64_t nq, const double* dY, in
             return mce::f16_seed_cfg(cps, p.CT, ksel + a.self_exclude, e_rows ? atoi(e_rows) : MCE_H_SEED_ROWS,
                                      e_share ? atoi(e_share) : MCE_H_SEED_SHARE, e_tg ? atoi(e_tg) : MCE_H_SEED_TG);
         };
+        if (use_sym) {
+            char* const sw = ws + p.off_sym;
+            a.rsplit = 1;
+            a.rperm = reinterpret_cast<const int*>(sw + p.sl.perm);
+            a.sym.thr = reinterpret_cast<unsigned long long*>(sw + p.sl.thr);
+            a.sym.rrow = reinterpret_cast<unsigned*>(sw + p.sl.rrow);
+            a.sym.rtile = reinterpret_cast<float*>(sw + p.sl.rtile);
+            a.sym.slots = reinterpret_cast<unsigned long long*>(sw + p.sl.slots);
+            a.sym.bucket_cnt = reinterpret_cast<int*>(sw + p.sl.bucket_cnt);
+            a.sym.bucket_flag = reinterpret_cast<int*>(sw + p.sl.bucket_flag);
+            a.sym.bucket = reinterpret_cast<mce::SymEntry*>(sw + p.sl.bucket);
+            a.sym.cap = p.sl.cap;
+            // prepass: every row's bound before any block runs (the seed phase as its own launch)
+            const char* const e_rows = getenv("MCE_SYM_SEED_ROWS");
+            const char* const e_share = getenv("MCE_SYM_SEED_SHARE");
+            a.seed_cfg = mce::f16_seed_cfg(p.nchunk, p.CT, K + a.self_exclude, e_rows ? atoi(e_rows) : 2 * MCE_H_SEED_ROWS,
+                                           e_share ? atoi(e_share) : 8, MCE_H_SEED_TG);
+            int rc = prof_begin();
+            if (rc != MCE_OK) return rc;
+            a.sym.mode = 1;
+            MCE_HIP(p.vh->launch_sym_pre(a, st));
+            const int seed_used = a.seed_cfg;
+            a.seed_cfg = 0;
+            a.sym.mode = 2;
+            MCE_HIP(p.vh->launch_sym(a, st));
+            a.sym.mode = 3;                    // repair: blocks whose bucket overflowed (normally none: they exit at once)
+            MCE_HIP(p.vh->launch_sym(a, st));
+            {
+                const dim3 g((unsigned)p.nqblk), b(mce::kSymMergeThreads);
+                static_assert(mce::kSymMergeThreads == mce::f16_qpb(4), "one merge block per query block");
+                switch (p.KCAP) {
+                    case 4: hipLaunchKernelGGL(mce::sym_merge_kernel<4>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap); break;
+                    case 8: hipLaunchKernelGGL(mce::sym_merge_kernel<8>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap); break;
+                    case 12: hipLaunchKernelGGL(mce::sym_merge_kernel<12>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap); break;
+                    default: hipLaunchKernelGGL(mce::sym_merge_kernel<16>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap); break;
+                }
+                MCE_HIP(hipGetLastError());
+            }
+            rc = prof_end();
+            if (rc != MCE_OK) return rc;
+            p.sym_active = true;
+            p.L = 1;
+            snprintf(g_last_kernel, sizeof(g_last_kernel), "%s symmetric grid=%d block=%d lds=%zu qt=%d ct=%d seed=%dx%d bucket=%d", p.vh->name,
+                     p.nqblk, mce::kHThreads, p.vh->lds_bytes_sym, p.QT, p.CT, seed_used & 0xffff, seed_used >> 16, p.sl.cap);
+            return MCE_OK;
+        }
         int rc = prof_begin();
         if (rc != MCE_OK) return rc;
         if (p.twopass) {
@@ -555,6 +646,7 @@ int launch_merge(const Plan& p, bool write_dist, bool fuse, const double* dX, co
     // pruned search: list column q is the q-th query in k-d order; its caller row is qperm[q]
     const int* qperm = nullptr;
     if (p.prune) qperm = reinterpret_cast<const int*>(ws + p.off_prune + (same_set ? p.pl.perm_r : p.pl.perm_q));
+    if (p.sym_active) qperm = reinterpret_cast<const int*>(ws + p.off_sym + p.sl.perm);     // list column = sorted position
     const int* border = p.prune ? reinterpret_cast<const int*>(ws + p.off_prune + p.pl.border) : nullptr;
 #define MCE_MERGE(W, F, R)                                                                                          \
     hipLaunchKernelGGL((mce::merge_lists_kernel<W, F, R>), dim3(blocks), dim3(mce::kRedThreads), 0, st, pd, pi, p.L,  \
@@ -601,6 +693,15 @@ int mce_set_prune_mode(int mode)
 }
 
 int mce_get_prune_mode(void) { return g_prune_mode.load(); }
+
+int mce_set_sym_mode(int mode)
+{
+    if (mode < 0 || mode > 2) return fail(MCE_ERR_INVALID, "symmetric-sweep mode must be 0 (auto), 1 (never) or 2 (whenever the shape allows it)");
+    g_sym_mode.store(mode);
+    return MCE_OK;
+}
+
+int mce_get_sym_mode(void) { return sym_mode(); }
 
 int mce_last_prune_stats(double* chunk_fraction, double* tile_fraction)
 {
@@ -663,9 +764,10 @@ void note_split(const char* first)
     snprintf(g_last_kernel, sizeof(g_last_kernel), "%.150s + tail%.80s", first, g ? g : "");
 }
 
-int64_t tail_split_rows(const Plan& p, int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, size_t ws_avail)
+int64_t tail_split_rows(const Plan& p, int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, size_t ws_avail, bool same_set)
 {
     if (g_split_depth > 0 || !p.vh || p.prune || p.generic || p.rsplit != 1 || p.nqblk <= kAssumedCUs) return 0;
+    if (p.sym && same_set) return 0;          // symmetric sweep: one launch over the whole set
     const char* const off = getenv("MCE_TAIL_SPLIT");
     if (off && atoi(off) == 0) return 0;
     const int tail = p.nqblk % kAssumedCUs;
@@ -698,7 +800,7 @@ int mce_knn_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t nr, 
     if (rc != MCE_OK) return rc;
     if (ws_bytes < p.total) return fail(MCE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, p.total);
     if (nq == 0) return MCE_OK;
-    if (const int64_t nm = tail_split_rows(p, nq, nr, d, K, self_mode, ws_bytes)) {
+    if (const int64_t nm = tail_split_rows(p, nq, nr, d, K, self_mode, ws_bytes, dX == dY && self_offset == 0)) {
         ++g_split_depth;
         rc = mce_knn_f64_dev(dX, nm, dY, nr, d, K, self_mode, self_offset, d_dist, d_idx, ws, ws_bytes, stream);
         char first[sizeof(g_last_kernel)];
@@ -769,7 +871,7 @@ int mce_knn_dotp_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t
     char* wsc = static_cast<char*>(ws);
     double* partial = reinterpret_cast<double*>(wsc + p.total);
     const unsigned blocks = (unsigned)((nq + mce::kRedThreads - 1) / mce::kRedThreads);
-    if (const int64_t nm = tail_split_rows(p, nq, nr, d, K, self_mode, p.total)) {
+    if (const int64_t nm = tail_split_rows(p, nq, nr, d, K, self_mode, p.total, dX == dY && self_offset == 0)) {
         // two ranges, one reduction: the partial sums of the second range follow those of the first in the
         // order one search would have produced them
         Plan pm, pt;

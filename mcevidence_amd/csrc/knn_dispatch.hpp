@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "sym_types.hpp"
+
 namespace mce {
 
 constexpr int kMaxDevices = 64;   // per-device one-time kernel attributes
@@ -68,12 +70,16 @@ struct KnnF16Args {
     int seed_cfg = 0;              // exhaustive sweep: seed phase (f16_seed_cfg: chunks | tiles per group << 16), 0 = none
     const int* border = nullptr;   // pruned walk: dispatch order of the query blocks
     int qblk0 = 0, qblk_stride = 1, nqblk_run = 0;   // pruned walk: nqblk_run query blocks qblk0, qblk0 + stride, ... (0: all)
+    SymParams sym;                 // symmetric sweep (launch_sym_pre / launch_sym); rperm = sorted position -> caller's row
 };
 typedef hipError_t (*knn_f16_launch_fn)(const KnnF16Args&, hipStream_t);
 struct KnnF16Variant {
     knn_f16_launch_fn launch;
     knn_f16_launch_fn launch_prune;   // PRUNE = true instantiation (KST = 1 only), else null
     knn_f16_launch_fn launch_lower;   // LOWER = true instantiation (KCAP = 16 only), else null
+    knn_f16_launch_fn launch_sym_pre; // SYM = 1: prepass of the symmetric sweep
+    knn_f16_launch_fn launch_sym;     // SYM = 2: symmetric sweep / repair (a.sym.mode)
+    size_t lds_bytes_sym;
     int kst, kcap, qt, ct;
     size_t lds_bytes;
     const char* name;

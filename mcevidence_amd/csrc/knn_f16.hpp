@@ -29,6 +29,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "sym_types.hpp"
+
 #ifndef MCE_STATS
 #define MCE_STATS 0    // tools/knn_f16_bench.hip only: per-wave clock64/event counters appended to `params`
 #endif
@@ -131,11 +133,55 @@ inline int f16_seed_cfg(int64_t cps, int CT, int kneed, int rows = MCE_H_SEED_RO
     if (chunks * CT / tg < 2 * (int64_t)kneed) return 0;
     return (int)chunks | (tg << 16);
 }
-__host__ __device__ constexpr size_t f16_lds_bytes(int KST, int KCAP)
+__host__ __device__ constexpr size_t f16_lds_bytes(int KST, int KCAP, bool sym = false)
 {
     return (size_t)2 * f16_chunk_tiles(KST) * KST * 1024             // staging
            + (size_t)kHWaves * kHQueue * 16                            // queues: packed(4) + next(4) + d2(8)
-           + (size_t)kHWaves * kHQT * 32 * 4 + 128;                    // chain heads + votes + block thresholds (pruned walk)
+           + (size_t)kHWaves * kHQT * 32 * 4 + 128                     // chain heads + votes + block thresholds (pruned walk)
+           + (sym ? (size_t)kHWaves * kHQT * 32 * 8 : 0);              // symmetric sweep: K-th bound per query as of the last drain
+}
+
+// ---------------------------------------------------------------------------
+// Symmetric sweep (auto evidence: the queries ARE the reference rows, one buffer).
+// d(i,j) = d(j,i): every 32x32 MFMA tile of the exhaustive sweep is computed twice, once with i as the query and
+// once with j.  Here it is computed ONCE and gated for both sides:
+//   * the rows are sorted by distance from the mean (sym_prepare), so the 32 rows of a tile have nearly the same
+//     K-th neighbour distance; a prepass (SYM = 1: the seed phase of the exhaustive kernel as its own launch) gives
+//     EVERY row an upper bound on its K-th distance before any block runs;
+//   * query block a (512 rows) sweeps only the rows of the blocks 0..a: the pair of blocks {a, b}, b < a, is handled by
+//     a alone.  Blocks are dispatched in index order, so every row a block meets belongs to a block that has started
+//     before it -- usually finished -- and has published tight bounds.  (Measured and dropped: a RING, every block
+//     handling the n/2 blocks behind it, wrapping around -- equal work per block, but the first blocks to run then
+//     meet rows nobody has bounded yet: 362 exact evaluations per query there instead of 45, 88 ms instead of 48.
+//     The triangle's price is blocks of unequal length: the last round of workgroups is the longest, ~13 % of tail.
+//     Cutting the long blocks into parts with their own lists balances that but every part re-discovers the
+//     bounds within its share of the rows: 22 evaluations per query and part, no net gain.)
+//   * column side (lane = query i): as before, min of the lane's 16 accumulators <= G_i;
+//     row side (the 32 streamed rows j): a pair can be among j's K nearest only if A[i,j] <= R_j + c_i with
+//     R_j = (s sqrt(thr_j) + e_j + max e)^2 and c_i = eps_i - |x^_i|^2; the gate tests the lane's minimum against
+//     the TILE's largest R_j (rtile, fetched one chunk ahead, wave-uniform): + 2 VALU per tile and query tile;
+//   * a pair that passes either gate is evaluated exactly once (phase A).  For the column side it joins query i's
+//     chain as before.  For the row side (phase R, one lane per queued pair) it must beat thr[j], then goes through
+//     j's K global SLOTS (the K smallest row-side distances so far, lock-free: replace-the-maximum by
+//     compare-and-swap) -- whose K-th tightens thr[j] / rrow[j] / rtile for everybody who meets the row later -- and
+//     is appended to the BUCKET of j's block.  sym_merge_kernel folds the buckets into the
+//     lists afterwards.  A bucket that overflows flags its block; a repair launch (mode 3) then searches the flagged
+//     blocks exhaustively, so the result never depends on the bucket size.
+// Everything published is a valid upper bound at all times and only ever shrinks, so stale reads merely let more
+// candidates through.  Lists carry the caller's row numbers and ties break on them: results are bit-identical to
+// the exhaustive sweep's.
+// ---------------------------------------------------------------------------
+// R_j from the bound thr on row j's K-th squared distance and its conversion error ex (same error terms as the
+// column gate, see gate_of); inflated by what the gate's fp32 addition R + c can lose
+__device__ __forceinline__ float sym_row_gate(double thr, double ex, const double* __restrict__ params, int KST)
+{
+    if (!(thr < __builtin_huge_val())) return __builtin_huge_valf();
+    const double s2 = params[HP_SCALE] * params[HP_SCALE];
+    const double ga = (ex + params[HP_EY]) * (1.0 + 1e-9) + 2.0 * sqrt(16.0 * KST) * 0x1p-14;
+    const double rr = sqrt(thr * s2) * (1.0 + 1e-12) + ga;
+    const double g = rr * rr * (1.0 + 1e-12);
+    const double ym = params[HP_YHATMAX];
+    return __double2float_ru(g * (1.0 + 0x1p-22) + 0x1p-22 * (ym * ym + 1.0) + 1e-30);
 }
 
 __host__ __device__ constexpr int f16_prune_slice_bytes(int KST, int KCAP) { return f16_prune_batch(KCAP) * KST * 1024 + 256; }   // kBatch tiles + pending ids
@@ -174,7 +220,7 @@ __host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST, int D, int KCA
 // first pass finds the 16 nearest per (query, reference split) and the second, identical sweep keeps only
 // candidates beyond that split's 16th (lo_d / lo_i = the first pass's lists) and finds the next K - 16;
 // the merge then sees two sorted lists per split.  Two sweeps at fp16 speed instead of one fp64 sweep.
-template <int KST, int KCAP, bool PRUNE = false, bool LOWER = false>
+template <int KST, int KCAP, bool PRUNE = false, bool LOWER = false, int SYM = 0>
 __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUNE_SMALL ? 3 : MCE_H_PRUNE_WAVES) : (MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ? 4 : 2))) void knn_f16_kernel(
     const _Float16* __restrict__ Yh, int64_t nchunk_total, int rsplit,
     const _Float16* __restrict__ Xh, const double* __restrict__ qinfo, const double* __restrict__ params,
@@ -184,9 +230,11 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
     const int* __restrict__ clist, const float* __restrict__ cdist, int list_len,
     const int* __restrict__ rperm, const int* __restrict__ qperm,
     const float* __restrict__ tbox_r, const float* __restrict__ tbox_q, const float* __restrict__ cbox_r, int qblk0, int qblk_stride, const int* __restrict__ border,
-    const double* __restrict__ lo_d, const int* __restrict__ lo_i, int seed_cfg)
+    const double* __restrict__ lo_d, const int* __restrict__ lo_i, int seed_cfg, SymParams sym)
 {
     static_assert(!(PRUNE && LOWER), "second pass: exhaustive sweep only");
+    static_assert(SYM == 0 || (!PRUNE && !LOWER), "symmetric sweep: exhaustive, single pass");
+    static_assert(SYM == 0 || kHNL == 1, "symmetric sweep: one list per owner lane");
     constexpr int QT = f16_qt(KCAP);
     constexpr int QPW = QT * 32;                         // queries per wave
     constexpr int QPB = kHWaves * QPW;
@@ -214,6 +262,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
 #if MCE_STATS
     const long long t_kernel0 = clock64();
     long long st_drains = 0, st_enq = 0, st_steps = 0, st_events = 0, st_tA = 0, st_tD = 0, st_tB = 0;
+    long long st_tR = 0, st_tE = 0, st_rtest = 0, st_rapp = 0, st_cas = 0, st_linked = 0, st_tP = 0;      // SYM: phase R / event cycles, row-side tested / appended / slot replacements, chain links, publish cycles
 #endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -224,6 +273,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
     const int qblk = PRUNE ? border[qblk0 + (int)(blockIdx.x / kHWaves) * qblk_stride] : (int)(blockIdx.x % nqblk);
     const int split = PRUNE ? 0 : (int)(blockIdx.x / nqblk);
 
+    if constexpr (SYM == 2) {
+        if (sym.mode == 3 && sym.bucket_flag[qblk] == 0) return;      // repair launch: only the blocks whose bucket overflowed
+    }
     const int64_t cps = (nchunk_total + rsplit - 1) / rsplit;
     const int64_t c_begin = (int64_t)split * cps;
     int64_t c_end = c_begin + cps;
@@ -240,11 +292,12 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
     double* const ytile = xq + QPW * D;
     int* const yorig = reinterpret_cast<int*>(ytile + 32 * D);
     double* const thrq = reinterpret_cast<double*>(yorig + 32);      // current exact K-th squared distance per wave-local query
+    double* const sthr = xq + lwave * QPW;                      // SYM: K-th bound of every wave-local query as of the last drain (same LDS region as xq; never both)
     float mythr = __builtin_huge_valf();                        // PRUNE: largest K-th squared distance among this wave's queries (rounded up)
     float Tq[kHQT];                                             // PRUNE: the same per 32-query tile (wave-uniform)
 #pragma unroll
     for (int qt = 0; qt < kHQT; ++qt) Tq[qt] = __builtin_huge_valf();
-    const int jsplit0 = (int)(c_begin * (CT * 32));             // first reference row of this split
+    const int jsplit0 = SYM ? 0 : (int)(c_begin * (CT * 32));   // first reference row of this split (SYM: queue entries hold absolute rows)
 #pragma unroll
     for (int nl = 0; nl < kHNL; ++nl) whead[nl * 64 + lane] = -1;
 
@@ -283,11 +336,27 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
             b[qt][ks] = *reinterpret_cast<const v8h*>(Xh + q * (int64_t)(16 * KST) + 16 * ks + 8 * (lane >> 5));
         G[qt] = (q < nq && MCE_ABLATE != 1 && MCE_ABLATE != 3 && MCE_ABLATE != 5) ? __builtin_huge_valf() : -__builtin_huge_valf();     // padding queries never pass
     }
+    // SYM: c_i = eps_i - |x^_i|^2 of the lane's query (rounded up): the row-side gate is  min A <= R_tile + c_i
+    float cR[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) cR[qt] = -__builtin_huge_valf();
+    if constexpr (SYM == 2) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const int64_t q = qwave0 + qt * 32 + (lane & 31);
+            if (q < nq) {
+                const double xn = qinfo[2 * q + 1];
+                const double r = sqrt(xn) + params[HP_YHATMAX];
+                const double eps = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 1e-9) + params[HP_RHO] + 1e-30;
+                cR[qt] = __double2float_ru(eps - xn);
+            }
+        }
+    }
     const int k_last = ksel - 1;
     // gate of query (qt, lane&31) from its current K-th best `thr` (exact squared distance, input
     // units).  The per-query constants are re-read from qinfo (L2) here -- this runs once per drain,
     // and keeping them in registers would cost 6 VGPRs per query tile in the sweep.
-    auto gate_of = [&](double thr, int qt) -> float {
+    auto gate_of = [&](double thr, int qt) __attribute__((always_inline)) -> float {
         const int64_t q = qwave0 + qt * 32 + (lane & 31);
         if (!(q < nq) || MCE_ABLATE == 1 || MCE_ABLATE == 3 || MCE_ABLATE == 5) return -__builtin_huge_valf();
         if (!(thr < INF)) return __builtin_huge_valf();
@@ -346,7 +415,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
 
     int qcount = 0;   // wave-uniform number of queued candidates
 
-    auto drain = [&]() {
+    auto drain = [&]() __attribute__((always_inline)) {
 #if MCE_STATS
         const long long t_d0 = clock64();
         st_drains += 1; st_enq += qcount;
@@ -419,11 +488,119 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                         ok = a0 > ld || (a0 == ld && j > li);       // (list not full: ld = +inf, nothing is left)
                     }
                 }
-                if (ok && sub == 0) {
+                if constexpr (SYM == 2) {
+                    // every entry gets its distance (-1: no pair behind it) for phase R; only what can still enter
+                    // the query's list (K-th bound of the last drain) joins its chain
+                    if (sub == 0 && ep[u] < qcount) {
+                        wqd[ep[u]] = ok ? a0 : -1.0;
+                        if (ok && !(a0 > sthr[qlp[u]])) {
+                            wnx[ep[u]] = atomicExch(&whead[qlp[u]], ep[u]);
+#if MCE_STATS
+                            st_linked += 1;
+#endif
+                        }
+                    }
+                } else if (ok && sub == 0) {
                     wqd[ep[u]] = a0;
                     wnx[ep[u]] = atomicExch(&whead[qlp[u]], ep[u]);      // push onto the query's chain
                 }
             }
+        }
+        if constexpr (SYM == 2) {
+            // ---- phase R: the ROW side of every evaluated pair, one lane per queue entry ----------------------
+            // Pair (i, j): j is a row of another block (behind this one on the ring).  If the distance can still be
+            // among j's K smallest (thr[j]) it goes through j's slots -- replace the largest of the K smallest
+            // row-side distances so far, by compare-and-swap; once they are all finite their maximum is a new bound
+            // on j's K-th distance, published for everybody -- and into the bucket of j's block.  Then the entry's
+            // packed word is replaced by the caller's row number of j, which is what the lists carry.
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#if MCE_STATS
+            const long long t_r0 = clock64();
+#endif
+            // one candidate distance d2 for sorted row `row`: replace the largest of the row's K slots if d2 is
+            // smaller (compare-and-swap; lock-free, any number of writers) and publish the new K-th as the row's
+            // bound.  Returns false if K slots hold strictly smaller distances (the candidate cannot be among the K).
+            auto slot_insert = [&](int row, double d2) __attribute__((always_inline)) -> bool {
+                unsigned long long* const sl = sym.slots + (int64_t)row * KCAP;
+                for (;;) {
+                    double vmax = -1.0, v2 = -1.0;
+                    int imax = 0;
+#pragma unroll
+                    for (int k = 0; k < KCAP; ++k) {
+                        if (k < ksel) {
+                            const double v = __longlong_as_double((long long)__hip_atomic_load(sl + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            if (v > vmax) { v2 = vmax; vmax = v; imax = k; }
+                            else if (v > v2) v2 = v;
+                        }
+                    }
+                    if (d2 > vmax) return false;
+                    if (d2 == vmax) return true;                     // a tie: the merge decides by row number
+                    unsigned long long expect = (unsigned long long)__double_as_longlong(vmax);
+                    if (__hip_atomic_compare_exchange_strong(sl + imax, &expect, (unsigned long long)__double_as_longlong(d2), __ATOMIC_RELAXED,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+#if MCE_STATS
+                        st_cas += 1;
+#endif
+                        const double nk = fmax(v2, d2);              // the K-th smallest after the replacement, from a snapshot: an upper bound
+                        if (nk < INF) {
+                            const unsigned long long nb = (unsigned long long)__double_as_longlong(nk);
+                            const unsigned long long ob = __hip_atomic_fetch_min(sym.thr + row, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (nb < ob) {
+                                const unsigned rb = __float_as_uint(sym_row_gate(nk, qinfo[2 * (int64_t)row], params, KST));
+                                const unsigned orb = __hip_atomic_fetch_min(sym.rrow + row, rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (rb < orb) {
+                                    // the tile's largest R_j, from a snapshot (each value >= its current one): safe to store
+                                    const unsigned* const rt = sym.rrow + (int64_t)(row >> 5) * 32;
+                                    unsigned m = 0;
+                                    for (int k = 0; k < 32; ++k) {
+                                        const unsigned v = __hip_atomic_load(rt + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        m = v > m ? v : m;
+                                    }
+                                    __hip_atomic_store(sym.rtile + (row >> 5), __uint_as_float(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                            }
+                        }
+                        return true;
+                    }
+                }
+            };
+            for (int e0 = 0; e0 < qcount; e0 += 64) {
+                const int e = e0 + lane;
+                const bool valid = e < qcount;
+                const unsigned ent = valid ? (unsigned)wq[e] : 0u;
+                const int ql = (int)(ent >> kHRelBits);
+                const int j = jsplit0 + (int)(ent & ((1u << kHRelBits) - 1u));
+                const double d2 = valid ? wqd[e] : -1.0;
+                const bool ok = valid && d2 >= 0.0;
+                const int oj = ok ? rperm[j] : -1;
+                const int jb = j / QPB;
+                bool rs = ok && sym.mode == 2 && jb != qblk;
+#if MCE_STATS
+                st_rtest += __builtin_popcountll(__ballot(rs));
+#endif
+                if (rs) rs = d2 <= __longlong_as_double((long long)__hip_atomic_load(sym.thr + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (rs) rs = slot_insert(j, d2);
+                if (rs) {
+                    const int slot = atomicAdd(sym.bucket_cnt + jb, 1);
+                    if (slot < sym.cap) {
+                        SymEntry en;
+                        en.d2 = d2;
+                        en.src = rperm[qwave0 + ql];
+                        en.row = j;
+                        sym.bucket[(int64_t)jb * sym.cap + slot] = en;
+                    } else {
+                        sym.bucket_flag[jb] = 1;
+                    }
+                }
+                if (valid) wq[e] = oj;
+#if MCE_STATS
+                st_rapp += __builtin_popcountll(__ballot(rs));
+#endif
+            }
+#if MCE_STATS
+            st_tR += clock64() - t_r0;
+#endif
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         }
 #if MCE_STATS
@@ -441,7 +618,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                 const bool on = cur >= 0;
                 const int ce = on ? cur : 0;
                 const double d2 = on ? wqd[ce] : INF;
-                const int j = PRUNE ? wq[ce] : jsplit0 + (int)((unsigned)wq[ce] & ((1u << kHRelBits) - 1u));
+                const int j = (PRUNE || SYM == 2) ? wq[ce] : jsplit0 + (int)((unsigned)wq[ce] & ((1u << kHRelBits) - 1u));
                 cur = on ? wnx[ce] : -1;
                 // ascending list, ties by row; d2 = +inf (idle lane) changes nothing
                 bool c_hi = (d2 < own_d[nl][KCAP - 1]) || (d2 == own_d[nl][KCAP - 1] && j < own_i[nl][KCAP - 1] && d2 < INF);
@@ -470,6 +647,38 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
             for (int k = 0; k < KCAP - 1; ++k) thr_own[nl] = (k == k_last) ? own_d[nl][k] : thr_own[nl];
             thr_own[nl] = fmin(thr_own[nl], seed_thr[nl]);
         }
+#if MCE_STATS
+        const long long t_p0 = clock64();
+#endif
+        if constexpr (SYM == 2) {
+            // publish: thr[q] takes this list's K-th bound and gives back what the row side knows (the K-th of q's
+            // slots); the row-side gate constants follow, and the maximum over each 32-row tile (= half a wave)
+            const int64_t q = qwave0 + lane;
+            double t = thr_own[0];
+            float R = 0.0f;
+            if (q < nq) {
+                if (t < INF) {
+                    const unsigned long long mb = (unsigned long long)__double_as_longlong(t);
+                    const unsigned long long ob = __hip_atomic_fetch_min(sym.thr + q, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    t = fmin(t, __longlong_as_double((long long)ob));
+                } else {
+                    t = __longlong_as_double((long long)__hip_atomic_load(sym.thr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                }
+                const unsigned rb = __float_as_uint(sym_row_gate(t, qinfo[2 * q], params, KST));
+                const unsigned orb = __hip_atomic_fetch_min(sym.rrow + q, rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                R = __uint_as_float(rb < orb ? rb : orb);
+            }
+            thr_own[0] = t;
+            seed_thr[0] = t;
+            sthr[lane] = t;
+            float m = R;
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            if ((lane & 31) == 0 && sym.mode == 2) __hip_atomic_store(sym.rtile + ((qwave0 + lane) >> 5), m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#if MCE_STATS
+        st_tP += clock64() - t_p0;
+#endif
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) G[qt] = gate_of(__shfl(thr_own[qt >> 1], (qt & 1) * 32 + (lane & 31), 64), qt);
         if constexpr (PRUNE) {
@@ -490,7 +699,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
 
     // gate + enqueue for one finished tile; jb0 = first reference row of the tile.
     // C layout of 32x32 f32: lane l -> query column l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5)
-    auto process = [&](const v16f (&acc)[QT], int jb0) {
+    // SYM: Rt = the tile's row-side gate constant (wave-uniform; -inf: column side only)
+    auto process = [&](const v16f (&acc)[QT], int jb0, float Rt) __attribute__((always_inline)) {
 #if MCE_ABLATE == 2 || MCE_ABLATE == 6
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -510,12 +720,14 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
             float m4 = min3f(c[12], c[13], c[14]);
             m0 = min3f(m0, m1, m2);
             m3 = min3f(m3, m4, c[15]);
-            passq[qt] = min3f(m0, m3, m3) <= G[qt];
+            if constexpr (SYM == 2) passq[qt] = min3f(m0, m3, m3) <= fmaxf(G[qt], Rt + cR[qt]);      // either side
+            else passq[qt] = min3f(m0, m3, m3) <= G[qt];
             pass |= passq[qt];
         }
         if (__any(pass)) {
 #if MCE_STATS
             st_events += 1;
+            const long long t_e0 = clock64();
 #endif
             const int jrel0 = jb0 - jsplit0 + 4 * (lane >> 5);
 #pragma unroll
@@ -523,8 +735,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                 if (!__any(passq[qt])) continue;
                 // per-lane bit mask of the accumulators under the gate (branch-free) ...
                 unsigned pm = 0;
+                const float gq = (SYM == 2) ? fmaxf(G[qt], Rt + cR[qt]) : G[qt];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) pm |= (acc[qt][r] <= G[qt]) ? (1u << r) : 0u;
+                for (int r = 0; r < 16; ++r) pm |= (acc[qt][r] <= gq) ? (1u << r) : 0u;
                 // ... then one queue entry per lane and trip (usually a single trip)
                 unsigned long long m = __ballot(pm != 0);
                 while (m) {
@@ -540,6 +753,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                     m = __ballot(pm != 0);
                 }
             }
+#if MCE_STATS
+            st_tE += clock64() - t_e0;
+#endif
         }
     };
 
@@ -654,22 +870,28 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
 
     // one staged chunk (vote / barrier / prefetch are done around it).  A macro, not a lambda: the
     // accumulators must stay in registers across the two call sites.
-#define MCE_SWEEP_CHUNK(BUF, JCHUNK, PROC)                                                                 \
+    // (TLO, THI: the chunk's tiles [TLO, THI), both even -- the whole chunk except at the ends of a symmetric
+    //  sweep's ranges; RTL: lane t holds the row-side gate constant of the chunk's tile t, SYM only)
+    float rA = -__builtin_huge_valf(), rB = -__builtin_huge_valf();
+#define MCE_SWEEP_CHUNK(BUF, JCHUNK, PROC, TLO, THI, RTL)                                                  \
     do {                                                                                                   \
         const char* lbuf = stage0 + (BUF) * CHUNK_BYTES + lane * 16;                                       \
         const int jchunk = (JCHUNK);                                                                       \
+        const int thi_ = (THI);                                                                            \
         v8h a0[KST], a1[KST];                                                                              \
-        load_a(lbuf, a0);                                                                                  \
-        _Pragma("unroll 1") for (int t = 0; t < CT; t += 2)                                                \
+        load_a(lbuf + ((TLO) * KST) * 1024, a0);                                                           \
+        _Pragma("unroll 1") for (int t = (TLO); t < thi_; t += 2)                                          \
         {                                                                                                  \
             load_a(lbuf + ((t + 1) * KST) * 1024, a1);                                                     \
             mfma_tile(a0, accA);                                                                           \
             jbA = jchunk + t * 32;                                                                         \
-            PROC(accB, jbB);                                                                               \
-            load_a(lbuf + ((t + 2 < CT ? t + 2 : t) * KST) * 1024, a0); /* last trip: harmless re-read */  \
+            PROC(accB, jbB, rB);                                                                           \
+            if constexpr (SYM == 2) rA = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(RTL), t));       \
+            load_a(lbuf + ((t + 2 < thi_ ? t + 2 : t) * KST) * 1024, a0); /* last trip: harmless re-read */ \
             mfma_tile(a1, accB);                                                                           \
             jbB = jchunk + (t + 1) * 32;                                                                   \
-            PROC(accA, jbA);                                                                               \
+            PROC(accA, jbA, rA);                                                                           \
+            if constexpr (SYM == 2) rB = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(RTL), t + 1));   \
         }                                                                                                  \
     } while (0)
 
@@ -688,7 +910,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
         // the true distance with the same error terms as the gate (true <= sqrt(A + |x^|^2 + eps) + e_x + max e_y).
         // With many more groups than K' this is close to the K-th distance within the seed rows.  The sweep
         // proper then starts with that threshold instead of +inf: no flood of early candidates.
-        if constexpr (!LOWER && (MCE_ABLATE == 0)) {
+        if constexpr (!LOWER && (MCE_ABLATE == 0) && SYM != 2) {
             const int kneed = ksel + (self_exclude ? 1 : 0);
             const int tg = seed_cfg >> 16;
             const int nseed = ((int64_t)(seed_cfg & 0xffff) * 2 <= c_end - c_begin) ? (seed_cfg & 0xffff) : 0;   // chunks (host: f16_seed_cfg)
@@ -721,7 +943,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                 // (the minima are inline asm, which the compiler's hazard recogniser does not cover and which -- with
                 //  no branch in this loop to hold them in place -- it schedules right behind the MFMAs that write their
                 //  operands: the wait states are spelled out, tied to the accumulators)
-#define MCE_SEED_TILE(ACC, JB)                                                                             \
+#define MCE_SEED_TILE(ACC, JB, RR)                                                                         \
                 do {                                                                                       \
                     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(ACC[0]), "+v"(ACC[1]));                       \
                     _Pragma("unroll") for (int qt = 0; qt < QT; ++qt)                                      \
@@ -750,9 +972,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                     const int buf = cc & 1;
                     __syncthreads();
                     if (cc + 1 < nseed) stage_async(c_begin + (cc + 1) * sstep, buf ^ 1);
-                    MCE_SWEEP_CHUNK(buf, 0, MCE_SEED_TILE);
+                    MCE_SWEEP_CHUNK(buf, 0, MCE_SEED_TILE, 0, CT, 0.0f);
                 }
-                MCE_SEED_TILE(accB, 0);                 // the pending tile
+                MCE_SEED_TILE(accB, 0, 0.0f);           // the pending tile
                 if (tcnt > 0) MCE_SEED_GROUP_END();     // a last, smaller group
 #undef MCE_SEED_TILE
 #undef MCE_SEED_GROUP_END
@@ -793,6 +1015,91 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                 __syncthreads();            // everybody is done with the staging buffers
             }
         }
+        if constexpr (SYM == 1) {
+            // ---- prepass of the symmetric sweep: publish every row's bound and its row-side gate constants,
+            // empty its slots; nothing else happens in this launch
+            const int64_t q = qwave0 + lane;
+            float R = 0.0f;
+            if (q < nq) {
+                sym.thr[q] = (unsigned long long)__double_as_longlong(seed_thr[0]);
+                R = sym_row_gate(seed_thr[0], qinfo[2 * q], params, KST);
+                sym.rrow[q] = __float_as_uint(R);
+                for (int k = 0; k < KCAP; ++k) sym.slots[q * KCAP + k] = 0x7FF0000000000000ull;
+            } else {
+                sym.thr[q] = 0x7FF0000000000000ull;
+                sym.rrow[q] = 0u;
+            }
+            float m = R;
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            if ((lane & 31) == 0) sym.rtile[q >> 5] = m;
+            return;
+        } else if constexpr (SYM == 2) {
+            // ---- symmetric sweep: the blocks 0..a (mode 3: everything, column side only)
+            {
+                const int64_t q = qwave0 + lane;
+                const double t0 = __longlong_as_double((long long)__hip_atomic_load(sym.thr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                seed_thr[0] = t0;
+                sthr[lane] = t0;
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) G[qt] = gate_of(__shfl(t0, (qt & 1) * 32 + (lane & 31), 64), qt);
+            }
+            constexpr int TPB = QPB / 32;                          // tiles per query block
+            const int Tr = (int)((nr + 31) / 32);
+            const int Tre = Tr + (Tr & 1);                         // (the tile loop takes tiles in pairs; Yh is padded to whole chunks)
+            // tiles [0, hi): the blocks 0..a, swept upwards (the block's own rows last).  Upwards, not from the own rows down:
+            // the rows met first then belong to the blocks that finished longest ago (tightest bounds: fewest row-side
+            // candidates), and blocks running at the same time stream the same chunks through L2 (measured at 1M x 27:
+            // 47.6 ms vs 50.0 downwards, 48.5 from a per-block offset).
+            const int hi = sym.mode == 2 ? (TPB * (qblk + 1) < Tre ? TPB * (qblk + 1) : Tre) : Tre;
+            const int ntot = hi > 0 ? (hi - 1) / CT + 1 : 0;
+            // k-th chunk of the sequence: its number and its tiles [tlo, thi)
+            auto seq_at = [&](int k, int& c, int& tlo, int& thi) {
+                c = k;
+                tlo = 0;
+                thi = hi - c * CT < CT ? hi - c * CT : CT;
+            };
+            // lane t <- the row-side gate constant of tile t of chunk c (own rows and tiles outside the range: none)
+            auto rt_load = [&](int c, int tlo, int thi) -> float {
+                const int t = c * CT + lane;
+                const bool en = sym.mode == 2 && lane >= tlo && lane < thi && t / TPB != qblk;
+#ifndef MCE_SYM_ABL
+#define MCE_SYM_ABL 0      // tools/knn_sym_bench.hip only: 1 = no row side at all (results invalid), 2 = plain (L2-cached) load of the tile constants
+#endif
+#if MCE_SYM_ABL == 1
+                return -__builtin_huge_valf();
+#elif MCE_SYM_ABL == 2
+                return en ? sym.rtile[t] : -__builtin_huge_valf();
+#else
+                return en ? __hip_atomic_load(sym.rtile + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -__builtin_huge_valf();
+#endif
+            };
+            float rt_cur = -__builtin_huge_valf(), rt_next = -__builtin_huge_valf();
+            int c0 = 0, tlo0 = 0, thi0 = 0;
+            if (ntot > 0) {
+                seq_at(0, c0, tlo0, thi0);
+                stage_async(c0, 0);
+                rt_next = rt_load(c0, tlo0, thi0);
+            }
+            for (int k = 0; k < ntot; ++k) {
+                const int buf = k & 1;
+                if (qcount >= kHDrainTrigger && lane == 0) wvote[buf] = 1;
+                __syncthreads();
+                int c, tlo, thi;
+                seq_at(k, c, tlo, thi);
+                rt_cur = rt_next;
+                if (k + 1 < ntot) {
+                    int cn, tlon, thin;
+                    seq_at(k + 1, cn, tlon, thin);
+                    stage_async(cn, buf ^ 1);
+                    rt_next = rt_load(cn, tlon, thin);
+                }
+                const bool all_drain = wvote[buf] != 0;
+                if (tid == 0) wvote[buf ^ 1] = 0;
+                if (all_drain) drain();
+                MCE_SWEEP_CHUNK(buf, c * (CT * 32), process, tlo, thi, rt_cur);
+            }
+        } else {
         if (c_begin < c_end) stage_async(c_begin, 0);
         for (int64_t c = c_begin; c < c_end; ++c) {
             const int buf = (int)((c - c_begin) & 1);
@@ -812,7 +1119,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
             const bool all_drain = wvote[buf] != 0;
             if (tid == 0) wvote[buf ^ 1] = 0;          // re-arm the other parity (read again only after the next barrier)
             if (all_drain) drain();
-            MCE_SWEEP_CHUNK(buf, (int)(c * (CT * 32)), process);
+            MCE_SWEEP_CHUNK(buf, (int)(c * (CT * 32)), process, 0, CT, 0.0f);
+        }
         }
     } else {
         // Sparse walk: no chunk staging and no workgroup barriers -- every wave goes down the block's
@@ -1047,8 +1355,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
         }
     }
 #undef MCE_SWEEP_CHUNK
-    if constexpr (!PRUNE) process(accB, jbB);
-    drain();
+    if constexpr (!PRUNE && SYM != 1) process(accB, jbB, rB);
+    if constexpr (SYM != 1) drain();
 #if MCE_SEED_CHECK
 #pragma unroll
     for (int nl = 0; nl < kHNL; ++nl) {
@@ -1066,10 +1374,18 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
 #endif
 
 #if MCE_STATS
+    for (int o_ = 32; o_ >= 1; o_ >>= 1) {         // per-lane counters -> wave totals
+        st_cas += __shfl_xor((int)st_cas, o_, 64);
+        st_linked += __shfl_xor((int)st_linked, o_, 64);
+    }
     if (lane == 0) {
         double* o = const_cast<double*>(params) + 16 + ((int64_t)blockIdx.x * kHWaves + wave) * 8;
         o[0] = (double)st_drains; o[1] = (double)st_enq; o[2] = (double)st_steps; o[3] = (double)st_events;
         o[4] = (double)st_tA; o[5] = (double)st_tD; o[6] = (double)(clock64() - t_kernel0); o[7] = (double)st_tB;
+        if constexpr (SYM == 2) {      // (the harness sizes `params` for 16 values per wave)
+            double* o2 = const_cast<double*>(params) + 16 + ((int64_t)gridDim.x * kHWaves) * 8 + ((int64_t)blockIdx.x * kHWaves + wave) * 8;
+            o2[0] = (double)st_tR; o2[1] = (double)st_tE; o2[2] = (double)st_rtest; o2[3] = (double)st_rapp; o2[4] = (double)st_cas; o2[5] = (double)st_linked; o2[6] = (double)st_tP; o2[7] = 0.0;
+        }
     }
 #endif
     // ---- write the lists: lane l owns wave-local queries nl*64 + l (coalesced over lanes) ----

@@ -348,4 +348,78 @@ hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t
     return hipSuccess;
 }
 
+// ---------------------------------------------------------------------------
+// symmetric sweep: order by distance from the mean
+// ---------------------------------------------------------------------------
+namespace {
+
+// key = order-preserving bits of (float)|y - c|^2 (non-negative: the bit pattern itself); padding sorts last
+__global__ __launch_bounds__(kThreads) void norm_key_kernel(const double* __restrict__ Y, int64_t n, int64_t n_pad, int d,
+                                                            const double* __restrict__ center, unsigned* __restrict__ keys,
+                                                            int* __restrict__ vals)
+{
+    const int64_t pos = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (pos >= n_pad) return;
+    unsigned k = 0xFFFFFFFFu;
+    if (pos < n) {
+        double s = 0.0;
+        for (int i = 0; i < d; ++i) {
+            const double t = Y[pos * d + i] - center[i];
+            s = fma(t, t, s);
+        }
+        k = __float_as_uint((float)s);
+        if (k > 0xFFFFFFFEu || s != s) k = 0xFFFFFFFEu;      // (NaN rows: anywhere, the search rejects them elsewhere)
+    }
+    keys[pos] = k;
+    vals[pos] = pos < n ? (int)pos : -1;
+}
+
+}  // namespace
+
+int sym_layout(int64_t n, int64_t n_pad, int nqblk, int d, int kcap, int qpb, int per_row, SymLayout& L)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L.perm = take((size_t)n_pad * 4);
+    L.keys_a = take((size_t)n_pad * 4);
+    L.keys_b = take((size_t)n_pad * 4);
+    L.vals_a = take((size_t)n_pad * 4);
+    L.Ys = take((size_t)n * d * 8);
+    L.thr = take((size_t)n_pad * 8);
+    L.rrow = take((size_t)n_pad * 4);
+    L.rtile = take((size_t)(n_pad / 32) * 4);
+    L.slots = take((size_t)n_pad * kcap * 8);
+    L.bucket_cnt = take((size_t)nqblk * 4 * 2);
+    L.bucket_flag = L.bucket_cnt + (size_t)nqblk * 4;
+    L.cap = per_row * qpb;
+    L.bucket = take((size_t)nqblk * L.cap * 16);
+    size_t tb = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, tb, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, (size_t)n_pad, 0u, 32u);
+    L.tmp_bytes = tb;
+    L.tmp = take(tb);
+    L.total = off;
+    return 0;
+}
+
+hipError_t sym_prepare(const double* dY, int64_t n, int d, const double* center, int64_t n_pad, char* ws, const SymLayout& L, hipStream_t st)
+{
+    int* perm = reinterpret_cast<int*>(ws + L.perm);
+    unsigned* keys_a = reinterpret_cast<unsigned*>(ws + L.keys_a);
+    unsigned* keys_b = reinterpret_cast<unsigned*>(ws + L.keys_b);
+    int* vals_a = reinterpret_cast<int*>(ws + L.vals_a);
+    double* Ys = reinterpret_cast<double*>(ws + L.Ys);
+    const unsigned blocks = (unsigned)((n_pad + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(norm_key_kernel, dim3(blocks), dim3(kThreads), 0, st, dY, n, n_pad, d, center, keys_a, vals_a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    size_t tb = L.tmp_bytes;
+    // (stable: rows at the same distance keep the caller's order -- the permutation is deterministic)
+    e = rocprim::radix_sort_pairs(ws + L.tmp, tb, (const unsigned*)keys_a, keys_b, (const int*)vals_a, perm, (size_t)n_pad, 0u, 32u, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n * d + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, dY, perm, n, d, Ys);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    e = hipMemsetAsync(ws + L.bucket_cnt, 0, (size_t)2 * 4 * ((L.bucket_flag - L.bucket_cnt) / 4), st);
+    return e;
+}
+
 }  // namespace mce

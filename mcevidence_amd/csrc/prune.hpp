@@ -64,4 +64,27 @@ hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t
                          int chunk_rows, int64_t nq_pad, int nqblk, int64_t nr_pad, int64_t nchunk, char* ws,
                          const PruneLayout& L, hipStream_t st, PruneOut& out);
 
+// ---- symmetric sweep (knn_f16.hpp, "Symmetric sweep"): rows sorted by distance from the mean + its scratch ----
+struct SymLayout {
+    size_t perm = 0;                        // int32 [n_pad]: sorted position -> caller's row (-1: padding)
+    size_t keys_a = 0, keys_b = 0;          // uint32 [n_pad] sort keys (ping-pong)
+    size_t vals_a = 0;                      // int32 [n_pad]
+    size_t Ys = 0;                          // double [n * d] sorted rows (queries and references)
+    size_t thr = 0;                         // uint64 [n_pad]
+    size_t rrow = 0;                        // uint32 [n_pad]
+    size_t rtile = 0;                       // float [n_pad / 32]
+    size_t slots = 0;                       // uint64 [n_pad][kcap]
+    size_t bucket_cnt = 0, bucket_flag = 0; // int32 [nqblk] each (contiguous: one memset)
+    size_t bucket = 0;                      // SymEntry [nqblk][cap]
+    size_t tmp = 0, tmp_bytes = 0;          // rocPRIM scratch
+    size_t total = 0;
+    int cap = 0;                            // bucket entries per query block
+};
+// pure function of its arguments.  per_row: bucket entries per row (cap = per_row * qpb)
+int sym_layout(int64_t n, int64_t n_pad, int nqblk, int d, int kcap, int qpb, int per_row, SymLayout& L);
+// sorts the rows of Y[n, d] by their distance from `center` (device pointer, d doubles), writes the sorted copy and the
+// permutation; stream-ordered, no host synchronisation
+hipError_t sym_prepare(const double* dY, int64_t n, int d, const double* center, int64_t n_pad, char* ws, const SymLayout& L,
+                       hipStream_t st);
+
 }  // namespace mce

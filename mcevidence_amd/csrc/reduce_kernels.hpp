@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "sym_types.hpp"
+
 namespace mce {
 
 constexpr int kRedThreads = 256;
@@ -164,6 +166,75 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
                 if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * kmax + k0 + kk] = s;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// symmetric sweep (knn_f16.hpp): fold the row-side candidates of one query block -- its bucket -- into the
+// block's lists.  One thread per query keeps its list in registers; the bucket is taken in batches through LDS:
+// every entry is linked onto its row's chain (atomic exchange on the chain head), then every thread walks its
+// chain with the same insertion network as the sweep (ascending distance, ties by caller row: the result does not
+// depend on the order in which candidates arrived).  Blocks whose bucket overflowed were searched again
+// exhaustively (their lists are complete) and are skipped.
+//   part_d / part_i : [KCAP][nq_pad], updated in place
+// ---------------------------------------------------------------------------
+constexpr int kSymMergeThreads = 512;      // == queries per block of the filter kernels
+constexpr int kSymMergeBatch = 2048;
+template <int KCAP>
+__global__ __launch_bounds__(kSymMergeThreads) void sym_merge_kernel(double* __restrict__ part_d, int* __restrict__ part_i, int64_t nq_pad,
+                                                                     const int* __restrict__ bucket_cnt, const int* __restrict__ bucket_flag,
+                                                                     const SymEntry* __restrict__ bucket, int cap)
+{
+    __shared__ double e_d[kSymMergeBatch];
+    __shared__ int e_i[kSymMergeBatch];
+    __shared__ int e_nx[kSymMergeBatch];
+    __shared__ int head[kSymMergeThreads];
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (bucket_flag[b]) return;
+    int n = bucket_cnt[b];
+    if (n <= 0) return;
+    if (n > cap) n = cap;
+    const double INF = __builtin_huge_val();
+    const int64_t q = (int64_t)b * kSymMergeThreads + t;
+    double own_d[KCAP];
+    int own_i[KCAP];
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) {
+        own_d[k] = part_d[(int64_t)k * nq_pad + q];
+        own_i[k] = part_i[(int64_t)k * nq_pad + q];
+    }
+    const SymEntry* const mine = bucket + (int64_t)b * cap;
+    for (int e0 = 0; e0 < n; e0 += kSymMergeBatch) {
+        const int m = n - e0 < kSymMergeBatch ? n - e0 : kSymMergeBatch;
+        head[t] = -1;
+        __syncthreads();
+        for (int e = t; e < m; e += kSymMergeThreads) {
+            const SymEntry en = mine[e0 + e];
+            e_d[e] = en.d2;
+            e_i[e] = en.src;
+            e_nx[e] = atomicExch(&head[en.row - b * kSymMergeThreads], e);
+        }
+        __syncthreads();
+        for (int cur = head[t]; cur >= 0; cur = e_nx[cur]) {
+            const double d2 = e_d[cur];
+            const int j = e_i[cur];
+            bool c_hi = (d2 < own_d[KCAP - 1]) || (d2 == own_d[KCAP - 1] && j < own_i[KCAP - 1] && d2 < INF);
+#pragma unroll
+            for (int k = KCAP - 1; k >= 1; --k) {
+                const bool c_lo = (d2 < own_d[k - 1]) || (d2 == own_d[k - 1] && j < own_i[k - 1] && d2 < INF);
+                own_d[k] = c_lo ? own_d[k - 1] : (c_hi ? d2 : own_d[k]);
+                own_i[k] = c_lo ? own_i[k - 1] : (c_hi ? j : own_i[k]);
+                c_hi = c_lo;
+            }
+            own_d[0] = c_hi ? d2 : own_d[0];
+            own_i[0] = c_hi ? j : own_i[0];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) {
+        part_d[(int64_t)k * nq_pad + q] = own_d[k];
+        part_i[(int64_t)k * nq_pad + q] = own_i[k];
     }
 }
 

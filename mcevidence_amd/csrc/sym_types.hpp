@@ -1,0 +1,21 @@
+// sym_types.hpp -- argument block of the symmetric sweep (knn_f16.hpp, "Symmetric sweep"), shared by the kernel
+// header, the dispatch table and the host code.
+#pragma once
+#include <stdint.h>
+
+namespace mce {
+
+struct SymEntry { double d2; int src; int row; };      // row-side candidate: caller row `src` at squared distance d2 from sorted row `row`
+struct SymParams {
+    unsigned long long* thr = nullptr;     // [nq_pad] bit pattern of the published bound on the K-th squared distance (input units)
+    unsigned* rrow = nullptr;              // [nq_pad] bit pattern of the row-side gate constant R_j (float > 0; padding rows 0)
+    float* rtile = nullptr;                // [nq_pad / 32] max of rrow over a tile
+    unsigned long long* slots = nullptr;   // [nq_pad][KCAP] bit patterns of the K smallest row-side squared distances
+    int* bucket_cnt = nullptr;             // [nqblk]
+    int* bucket_flag = nullptr;            // [nqblk] 1: the bucket overflowed, the block is searched again exhaustively
+    SymEntry* bucket = nullptr;            // [nqblk][cap]
+    int cap = 0;
+    int mode = 0;                          // 2: symmetric sweep, 3: repair (flagged blocks only, exhaustive, column side only)
+};
+
+}  // namespace mce

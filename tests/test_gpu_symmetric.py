@@ -1,0 +1,149 @@
+"""Symmetric sweep of auto-evidence searches (knn_f16.hpp, "Symmetric sweep": every pair of rows multiplied
+once, gated for both of its sides) against the exhaustive sweep and the CPU oracle: same distances, same
+neighbour rows, same order -- bit for bit.  Needs a real MI355X: run with -m gpu."""
+import logging
+
+import numpy as np
+import pytest
+
+from helpers import DIST_RTOL, LNE_TOL, chain_of, load_golden, orc
+
+pytestmark = pytest.mark.gpu
+logging.disable(logging.CRITICAL)
+G = load_golden()
+
+
+@pytest.fixture()
+def sym():
+    from mcevidence_amd import _capi
+    assert _capi.device_count() >= 1, "no GPU visible: the HIP path cannot be tested"
+    _capi.set_search_mode(_capi.MODE_AUTO)
+    _capi.set_prune_mode(_capi.PRUNE_OFF)          # the pruned walk has priority where it applies
+    yield _capi
+    _capi.set_sym_mode(_capi.SYM_AUTO)
+    _capi.set_prune_mode(_capi.PRUNE_AUTO)
+
+
+def _both(capi, fn):
+    capi.set_sym_mode(capi.SYM_OFF)
+    a = fn()
+    ka = capi.last_kernel()
+    capi.set_sym_mode(capi.SYM_FORCE)
+    b = fn()
+    kb = capi.last_kernel()
+    assert "symmetric" in kb and "symmetric" not in ka, (ka, kb)
+    return a, b
+
+
+def _data(n, d, seed):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((n, d)) @ (np.eye(d) + 0.3 * rng.standard_normal((d, d))) + 3.0
+
+
+@pytest.mark.parametrize("n,d,K", [(1025, 3, 2), (2048, 6, 4), (5000, 1, 3), (7777, 27, 9), (20000, 6, 10), (33333, 15, 16), (25000, 16, 4),
+                                   (12345, 31, 12), (9000, 40, 5), (6000, 63, 8), (70001, 27, 10), (150000, 6, 4)])
+def test_symmetric_sweep_is_bit_identical(sym, n, d, K):
+    """all three self modes; sizes that are not whole blocks, whole chunks or even tile counts; every k-step count"""
+    capi = sym
+    Y = _data(n, d, n + d)
+    for sm in (capi.SELF_EXCLUDE, capi.SELF_INCLUDE, capi.SELF_NONE):
+        (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(Y, Y, K, self_mode=sm))
+        assert np.array_equal(d0, d1) and np.array_equal(i0, i1), (sm, np.argwhere(d0 != d1)[:5], np.argwhere(i0 != i1)[:5])
+    m = min(n, 2000)
+    od, oi = orc.knn_brute(Y[-m:], Y, K, self_mode=2, self_offset=n - m)
+    g, gi = capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE)
+    assert _rel(g[-m:], od) < DIST_RTOL and np.mean(gi[-m:] == oi) > 0.999
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300) * (b != 0)) if a.size else 0.0
+
+
+def test_symmetric_sweep_duplicates_clusters_and_ties(sym):
+    """exact ties break on the caller's row numbers although the rows are searched in sorted order and candidates
+    reach a row from two sides; tight far-apart clusters; a constant column; a lattice (massive ties at the K-th distance)"""
+    capi = sym
+    rng = np.random.default_rng(9)
+    base = rng.standard_normal((3000, 4))
+    Y = np.concatenate([base, base, base[:1500], rng.standard_normal((2000, 4)) * 1e-3 + 50.0, base[::-1]])
+    Y[:, 3] = 1.25
+    Y = np.ascontiguousarray(Y[rng.permutation(len(Y))])
+    for K in (1, 4, 9):
+        (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE))
+        assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+    od, oi = orc.knn_brute(Y[:1500], Y, 4, self_mode=2)
+    g, gi = capi.knn(Y, Y, 4, self_mode=capi.SELF_EXCLUDE)
+    assert np.array_equal(g[:1500], od) and np.array_equal(gi[:1500], oi)
+    grid = np.stack(np.meshgrid(*[np.arange(12.0)] * 4), -1).reshape(-1, 4)     # 20736 lattice points
+    (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(grid, grid, 9, self_mode=capi.SELF_EXCLUDE))
+    assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+    same = np.tile(rng.standard_normal((1, 5)), (3000, 1))                      # every row identical: all distances 0
+    (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(same, same, 6, self_mode=capi.SELF_EXCLUDE))
+    assert np.array_equal(d0, d1) and np.array_equal(i0, i1) and np.all(d1 == 0)
+
+
+@pytest.mark.parametrize("per_row", [1, 3])
+def test_bucket_overflow_is_repaired(sym, per_row, monkeypatch):
+    """buckets far too small for the row-side candidates: the overflowing blocks are searched again exhaustively
+    inside the same call, and nothing changes in the result"""
+    capi = sym
+    Y = _data(30000, 8, 5)
+    capi.set_sym_mode(capi.SYM_OFF)
+    d0, i0 = capi.knn(Y, Y, 7, self_mode=capi.SELF_EXCLUDE)
+    monkeypatch.setenv("MCE_SYM_BUCKET", str(per_row))
+    capi.set_sym_mode(capi.SYM_FORCE)
+    d1, i1 = capi.knn(Y, Y, 7, self_mode=capi.SELF_EXCLUDE)
+    assert "symmetric" in capi.last_kernel() and "bucket=%d" % (per_row * 512) in capi.last_kernel()
+    assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+
+
+@pytest.mark.parametrize("n,d,kmax", [(40000, 27, 10), (30001, 6, 5), (5000, 15, 3)])
+def test_fused_reduction_and_class_with_symmetric_sweep(sym, n, d, kmax):
+    capi = sym
+    import mcevidence_amd as pkg
+    from mcevidence_amd.synth import gaussian_chain
+    chain = gaussian_chain(seed=n, n=n, d=d, weights="int", cov="corr")
+    X = _data(n, d, 77)
+    w = np.random.default_rng(1).integers(1, 5, n).astype(float)
+    fs = -np.random.default_rng(2).random(n)
+    (p0, q0), (p1, q1) = _both(capi, lambda: capi.knn_dotp(X, None, w, fs, kmax, 1, return_dist=True))
+    assert np.array_equal(q0, q1)                          # the distances that entered the sums
+    assert np.allclose(p0, p1, rtol=1e-13, atol=0)         # sums: same terms, different association (list columns are in sorted-row order)
+    assert np.array_equal(p1, capi.knn_dotp(X, None, w, fs, kmax, 1))       # and reproducible run to run, whatever order the candidates arrive in
+    a, b = _both(capi, lambda: pkg.MCEvidence([chain], kmax=kmax, verbose=0).evidence())
+    assert np.max(np.abs(a - b)) < 1e-12
+    ref = orc.evidence_from_chain(chain, kmax=kmax, knn="brute")
+    assert np.allclose(b, ref["lnE"], rtol=0, atol=LNE_TOL)
+
+
+def test_symmetric_sweep_needs_one_buffer(sym):
+    """separate query and reference sets of equal size, shards and cross evidence take the exhaustive sweep"""
+    capi = sym
+    capi.set_sym_mode(capi.SYM_FORCE)
+    X, Y = _data(6000, 5, 1), _data(6000, 5, 2)
+    d1, i1 = capi.knn(X, Y, 4)
+    assert "symmetric" not in capi.last_kernel()
+    od, oi = orc.knn_brute(X, Y, 4)
+    assert _rel(d1, od) < DIST_RTOL and np.array_equal(i1, oi)
+    d2, i2 = capi.knn(Y[1000:3000], Y, 4, self_mode=capi.SELF_EXCLUDE, self_offset=1000)
+    assert "symmetric" not in capi.last_kernel()
+    full, fi = capi.knn(Y, Y, 4, self_mode=capi.SELF_EXCLUDE)
+    assert "symmetric" in capi.last_kernel()
+    assert np.array_equal(full[1000:3000], d2) and np.array_equal(fi[1000:3000], i2)
+
+
+def test_symmetric_sweep_golden_lnE(sym):
+    """the reference's own ln E (golden vectors recorded from /root/reference) with the symmetric sweep forced on"""
+    capi = sym
+    import mcevidence_amd as pkg
+    capi.set_sym_mode(capi.SYM_FORCE)
+    done = 0
+    for name in sorted(G):
+        case = G[name]
+        if case["tag"] == "big" or case["mce"].get("split") or case["S"] < 2000:
+            continue
+        mce = pkg.MCEvidence([chain_of(case)], verbose=0, **case["mce"])
+        lnE = mce.evidence(**case["ev"])
+        assert np.allclose(lnE, case["lnE"], rtol=0, atol=LNE_TOL), name
+        done += "symmetric" in capi.last_kernel()
+    assert done >= 3

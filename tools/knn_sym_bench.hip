@@ -1,0 +1,127 @@
+// knn_sym_bench.hip -- developer microbench for the symmetric sweep (knn_f16_kernel<.., SYM>): prepass + sweep with the
+// per-wave statistics on; not part of the product.  Rows are sorted by distance from the mean on the host.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DMCE_STATS=1 -mllvm -amdgpu-sched-strategy=max-ilp tools/knn_sym_bench.hip -o tools/knn_bench_sym
+#include "../mcevidence_amd/csrc/f16_prep.hpp"
+#include "../mcevidence_amd/csrc/pack_refs.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include <numeric>
+#include <random>
+#ifndef DIM
+#define DIM 27
+#endif
+#ifndef KCAP
+#define KCAP 12
+#endif
+#ifndef KSEL
+#define KSEL 9
+#endif
+using namespace mce;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+int main(int argc, char** argv)
+{
+    const int64_t n = argc > 1 ? atoll(argv[1]) : 200000;
+    const int reps = argc > 2 ? atoi(argv[2]) : 2;
+    const int seed_rows = argc > 3 ? atoi(argv[3]) : 2 * MCE_H_SEED_ROWS;
+    const int per_row = argc > 4 ? atoi(argv[4]) : 6 * KSEL + 24;
+    const int sorted = argc > 5 ? atoi(argv[5]) : 1;
+    const int parts = 1;
+    constexpr int D = DIM;
+    constexpr int KST = f16_ksteps(D);
+    constexpr int CT = f16_chunk_tiles(KST);
+    const int qpb = f16_qpb(KCAP);
+    const int nqblk = (int)((n + qpb - 1) / qpb);
+    const int64_t nq_pad = (int64_t)nqblk * qpb;
+    const int64_t nchunk = (n + CT * 32 - 1) / (CT * 32);
+    const int64_t nrow_pad = nchunk * CT * 32;
+    std::vector<double> h((size_t)n * D), hsorted((size_t)n * D);
+    std::mt19937_64 g(1); std::normal_distribution<double> nd;
+    for (auto& v : h) v = nd(g);
+    std::vector<int> perm(nq_pad, -1);
+    {
+        std::vector<double> nrm(n);
+        for (int64_t i = 0; i < n; ++i) { double s = 0; for (int k = 0; k < D; ++k) s += h[i * D + k] * h[i * D + k]; nrm[i] = s; }
+        std::vector<int> idx(n); std::iota(idx.begin(), idx.end(), 0);
+        if (sorted) std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return nrm[a] < nrm[b]; });
+        for (int64_t i = 0; i < n; ++i) { perm[i] = idx[i]; std::copy(&h[(size_t)idx[i] * D], &h[(size_t)idx[i] * D] + D, &hsorted[(size_t)i * D]); }
+    }
+    double *X, *pd, *center, *msum, *params, *qinfo; int *pi, *dperm; _Float16 *Yh, *Xh;
+    CK(hipMalloc(&X, sizeof(double) * n * D));
+    CK(hipMalloc(&Yh, 2 * nrow_pad * 16 * KST)); CK(hipMalloc(&Xh, 2 * nq_pad * 16 * KST));
+    CK(hipMalloc(&qinfo, 16 * nq_pad)); const size_t pbytes = 256 + (size_t)nqblk * 5 * 16 * 64; CK(hipMalloc(&params, pbytes)); CK(hipMalloc(&center, 3 * 512)); CK(hipMalloc(&msum, 8 * kStatStride * 256));
+    CK(hipMalloc(&dperm, 4 * nq_pad));
+    const size_t nl = (size_t)parts * KCAP * nq_pad;
+    CK(hipMalloc(&pd, sizeof(double) * nl)); CK(hipMalloc(&pi, sizeof(int) * nl));
+    CK(hipMemcpy(X, hsorted.data(), sizeof(double) * n * D, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dperm, perm.data(), 4 * nq_pad, hipMemcpyHostToDevice));
+    SymParams sp;
+    const int cap = per_row * qpb;
+    CK(hipMalloc(&sp.thr, 8 * nq_pad)); CK(hipMalloc(&sp.rrow, 4 * nq_pad)); CK(hipMalloc(&sp.rtile, 4 * (nq_pad / 32)));
+    CK(hipMalloc(&sp.slots, 8 * nq_pad * KCAP)); CK(hipMalloc(&sp.bucket_cnt, 8 * nqblk)); sp.bucket_flag = sp.bucket_cnt + nqblk;
+    CK(hipMalloc(&sp.bucket, (size_t)16 * nqblk * cap)); sp.cap = cap;
+    col_stats_partial_kernel<<<kMeanBlocks, kMeanThreads>>>(X, n, D, msum);
+    col_stats_final_kernel<<<1, 64>>>(msum, n, D, center, center + 64);
+    CK(hipMemset(params, 0, pbytes));
+    f16_scale_kernel<<<1, 64>>>(center + 64, nullptr, params);
+    const int64_t rpb = 4 * (64 / (2 * KST));
+    f16_pack_refs_kernel<<<(unsigned)std::min<int64_t>((nrow_pad + rpb - 1) / rpb, 2048), 256>>>(X, n, D, KST, nrow_pad, center, params, Yh);
+    f16_pack_queries_kernel<<<(unsigned)((nq_pad + rpb - 1) / rpb), 256>>>(X, n, nq_pad, D, KST, center, params, Xh, qinfo);
+    CK(hipDeviceSynchronize());
+    constexpr size_t LDS = f16_lds_bytes(KST, KCAP, true);
+    auto kpre = knn_f16_kernel<KST, KCAP, false, false, 1>;
+    auto kern = knn_f16_kernel<KST, KCAP, false, false, 2>;
+    CK(hipFuncSetAttribute((const void*)kpre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+    const int seed_cfg = f16_seed_cfg(nchunk, CT, KSEL + 1, seed_rows, 8, MCE_H_SEED_TG);
+    for (int r = 0; r < reps; ++r) {
+        CK(hipMemset(sp.bucket_cnt, 0, 8 * nqblk));
+        CK(hipMemset((char*)params + 128, 0, pbytes - 128));
+        CK(hipEventRecord(e0));
+        sp.mode = 1;
+        kpre<<<nqblk, kHThreads, LDS>>>(Yh, nchunk, 1, Xh, qinfo, params, X, X, n, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi,
+                                        (const int*)nullptr, (const float*)nullptr, 0, dperm, (const int*)nullptr, (const float*)nullptr,
+                                        (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr, seed_cfg, sp);
+        CK(hipEventRecord(e1));
+        sp.mode = 2;
+        kern<<<nqblk, kHThreads, LDS>>>(Yh, nchunk, 1, Xh, qinfo, params, X, X, n, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi,
+                                        (const int*)nullptr, (const float*)nullptr, 0, dperm, (const int*)nullptr, (const float*)nullptr,
+                                        (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr, 0, sp);
+        CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
+        float ms1, ms2; CK(hipEventElapsedTime(&ms1, e0, e1)); CK(hipEventElapsedTime(&ms2, e1, e2));
+         printf("D=%d KST=%d KCAP=%d K=%d n=%lld grid=%d seed=%dx%d sorted=%d: prepass %.2f ms  sweep %.2f ms\n", D, KST, KCAP, KSEL, (long long)n, nqblk,
+               seed_cfg & 0xffff, seed_cfg >> 16, sorted, ms1, ms2);
+    }
+    {
+        std::vector<int> cnt(2 * nqblk);
+        CK(hipMemcpy(cnt.data(), sp.bucket_cnt, 8 * nqblk, hipMemcpyDeviceToHost));
+        long long tot = 0, mx = 0, fl = 0;
+        for (int b = 0; b < nqblk; ++b) { tot += cnt[b]; mx = std::max<long long>(mx, cnt[b]); fl += cnt[nqblk + b]; }
+        printf("buckets: %.1f entries per row on average, fullest %.1f per row (cap %d), %lld overflowed\n", (double)tot / n, (double)mx / qpb, per_row, fl);
+    }
+#if MCE_STATS
+    {
+        const size_t nw = (size_t)nqblk * 8;
+        std::vector<double> hs(nw * 16);
+        CK(hipMemcpy(hs.data(), (char*)params + 128, nw * 128, hipMemcpyDeviceToHost));
+        double m[16] = {0};
+        for (size_t w = 0; w < nw; ++w) for (int k = 0; k < 8; ++k) { m[k] += hs[w * 8 + k] / nw; m[8 + k] += hs[nw * 8 + w * 8 + k] / nw; }
+        printf("per wave (mean): drains %.1f  enq %.0f (per query %.1f)  chain-steps %.1f  event_tiles %.0f | cycles: phaseA %.3g  drain(all) %.3g  barrier-wait %.3g  kernel %.3g\n",
+               m[0], m[1], m[1] / 64, m[2], m[3], m[4], m[5], m[7], m[6]);
+        printf("   sym: phaseR %.3g  events %.3g  publish %.3g cycles | row-side tested %.0f (per query %.1f)  appended %.0f (%.1f)  slot replacements %.0f (%.1f)  chain links %.0f (%.1f)\n",
+               m[8], m[9], m[14], m[10], m[10] / 64, m[11], m[11] / 64, m[12], m[12] / 64, m[13], m[13] / 64);
+        // by dispatch position: tenths of the blocks
+        for (int part = 0; part < 10; part += 1) {
+            const size_t b0 = (nw / 8) * part / 10, b1 = (nw / 8) * (part + 1) / 10;
+            double a[16] = {0}; size_t c = 0;
+            for (size_t b = b0; b < b1; ++b) for (int w = 0; w < 8; ++w) { for (int k = 0; k < 8; ++k) { a[k] += hs[(b * 8 + w) * 8 + k]; a[8 + k] += hs[nw * 8 + (b * 8 + w) * 8 + k]; } ++c; }
+            for (int k = 0; k < 16; ++k) a[k] /= c;
+            printf("   blocks %4zu..%4zu: kernel %.3g cyc | drains %.1f enq/q %.1f events %.0f | phaseA+R %.3g (R %.3g) drain(all) %.3g events %.3g publish %.3g | row tested/q %.1f appended/q %.1f links/q %.1f\n",
+                   b0, b1, a[6], a[0], a[1] / 64, a[3], a[4], a[8], a[5], a[9], a[14], a[10] / 64, a[11] / 64, a[13] / 64);
+        }
+    }
+#endif
+    return 0;
+}
