@@ -15,7 +15,9 @@ Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel, its laun
 measured with HIP events on the launch stream.  Default (--mode 0): knn_f16_kernel, the fp16-MFMA
 all-pairs filter + exact fp64 refine -- algorithmic flops per launch = nq * nr * 2 * 16*KST (the
 augmented product |y^|^2 - 2 x^.y^ the MFMA evaluates) against the 2.5 PFLOP/s dense
-fp16 peak.  --mode 1: knn_mfma_kernel, the pure fp64 MFMA sweep -- nq * nr * 2 * 4*KS flops against
+fp16 peak.  At N = 1 (queries and references are one resident buffer) the library takes the symmetric
+sweep: each pair of rows is multiplied once and gated for both of its sides, so the
+kernel executes about half of those flops; `roofline.note` states the executed figure.  --mode 1: knn_mfma_kernel, the pure fp64 MFMA sweep -- nq * nr * 2 * 4*KS flops against
 78.6 TFLOP/s (tools/mfma_f64_peak.hip reaches 72-74 on this part).  `traffic` = HBM bytes per launch
 from the committed rocprofv3 PMC passes (profiles/).
 `cpu_baseline` = the reference's own CPU path (scikit-learn NearestNeighbors with its
@@ -47,7 +49,12 @@ def hbm_traffic_from_profile(kernel_desc):
     if not m:
         return None
     name, p1, p2 = m.groups()
-    wants = ("%s<%s, %s>" % (name, p1, p2), "%sILi%sELi%sE" % (name, p1, p2))     # demangled / mangled spelling
+    if name == "knn_f16_kernel":
+        # <KST, KCAP, PRUNE, LOWER, SYM>: the symmetric sweep is the SYM = 2 instantiation (round-1 profiles: no SYM parameter)
+        sy = "2" if " symmetric" in kernel_desc else "0"
+        wants = ("%sILi%sELi%sELb0ELb0ELi%sE" % (name, p1, p2, sy),) + (("%sILi%sELi%sELb0ELb0EE" % (name, p1, p2),) if sy == "0" else ())
+    else:
+        wants = ("%s<%s, %s>" % (name, p1, p2), "%sILi%sELi%sE" % (name, p1, p2))     # demangled / mangled spelling
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*", "pmc_summary.csv")), reverse=True):
         fetch = write = None
         for ln in open(f):
@@ -176,6 +183,16 @@ def main():
             kst = (d + 3 + 15) // 16
             flops = float(nq) * n * 2.0 * 16 * kst
             peak, note = F16_PEAK_TFLOPS, "fp16 MFMA pre-filter over all pairs (2*16*KST flop/pair) + exact fp64 refine of the survivors"
+            if " symmetric" in kdesc:
+                # d(i,j) = d(j,i): block a (512 rows) multiplies only the tiles of blocks 0..a, each tile gated for both
+                # of its sides.  `achieved` stays the ALGORITHMIC all-pairs figure over the sweep kernel's duration (the
+                # contract's definition); what the matrix cores execute is about half of it:
+                nb = (n + 511) // 512
+                executed = float(512) * 512 * nb * (nb + 1) / 2.0 * 2.0 * 16 * kst
+                note = ("symmetric sweep: every pair of rows multiplied once (blocks 0..a per block a of 512 rows) and gated for both sides; "
+                        "algorithmic flops = all pairs (2*16*KST flop/pair), executed MFMA flops in the sweep kernel = %.3g "
+                        "(%.1f TFLOP/s); the prepass, repair and merge kernels of the same search are in ms_per_step, not in kernel_ms" %
+                        (executed, executed / (kern_ms * 1e-3) / 1e12))
         else:
             KS = (d + 1 + 3) // 4
             flops = float(nq) * n * 2.0 * 4 * KS

@@ -75,7 +75,14 @@ int sym_mode()
     }
     return m;
 }
-constexpr int kSymAutoMinBlocks = 512;        // query blocks (512 rows each) from which the automatic mode takes it
+// query blocks (512 rows each) from which the automatic mode takes it, by 16-wide k-steps of the filter.  Measured
+// (tools/sym_crossover.py, fused search + reduction, exhaustive -> symmetric): d = 6 / 10 / 15 (1 k-step) 12.1 -> 13.2 /
+// 12.1 -> 12.5 / 12.3 -> 12.4 ms at 524 k rows, 40.1 -> 37.2 / 40.5 -> 36.2 / 41.3 -> 35.7 ms at 1 M; d = 27 (2)
+// 19.9 -> 19.2 ms at 524 k, 66.4 -> 52.6 at 1 M, 237 -> 167 at 2 M; d = 45 (3) 7.6 -> 6.5 ms at 197 k, 28.3 -> 23.4 at
+// 524 k, 94.8 -> 65.5 at 1 M.  (The more of a search is MFMA work and the more rounds of workgroups it has -- the
+// triangle's last round is its tail -- the more halving the products pays.)
+constexpr int kSymAutoMinBlocks[5] = {0, 1536, 1024, 384, 384};
+constexpr int kSymPanelChunks = 96;           // 48 KB chunks per panel of reference rows (knn_f16.hpp, units): 1M x 27: 24 -> 52.5 ms, 48 -> 46.5, 96 -> 45.7, 192 -> 46.2
 // bucket entries per row: a row receives ~K ln(N/2 / seed rows) + K row-side candidates; MCE_SYM_BUCKET overrides (tests)
 int sym_bucket_per_row(int K)
 {
@@ -372,7 +379,7 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     // symmetric sweep: auto-evidence searches (the caller passes ONE buffer as X and Y; only the sizes are known here)
     if (f16 && !p.twopass && !p.prune && nq == nr && p.vh->launch_sym && p.nqblk >= 2 && p.nrow_pad <= ((int64_t)1 << mce::kHRelBits)) {
         const int sm = sym_mode();
-        p.sym = sm == 2 || (sm == 0 && p.nqblk >= kSymAutoMinBlocks);
+        p.sym = sm == 2 || (sm == 0 && p.nqblk >= kSymAutoMinBlocks[p.KST]);
     }
     const int l_alloc = p.L;
     p.off_pd = off;
@@ -535,21 +542,24 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             a.sym.bucket_flag = reinterpret_cast<int*>(sw + p.sl.bucket_flag);
             a.sym.bucket = reinterpret_cast<mce::SymEntry*>(sw + p.sl.bucket);
             a.sym.cap = p.sl.cap;
+            a.sym.done = reinterpret_cast<int*>(sw + p.sl.done);
+            // panel = the packed rows one L2 (4 MB per XCD) serves to the units running at the same time; MCE_SYM_PANEL: chunks (tuning)
+            const char* const e_panel = getenv("MCE_SYM_PANEL");
+            a.sym.panel = e_panel && atoi(e_panel) > 0 ? atoi(e_panel) : kSymPanelChunks;
             // prepass: every row's bound before any block runs (the seed phase as its own launch)
             const char* const e_rows = getenv("MCE_SYM_SEED_ROWS");
             const char* const e_share = getenv("MCE_SYM_SEED_SHARE");
             a.seed_cfg = mce::f16_seed_cfg(p.nchunk, p.CT, K + a.self_exclude, e_rows ? atoi(e_rows) : 2 * MCE_H_SEED_ROWS,
                                            e_share ? atoi(e_share) : 8, MCE_H_SEED_TG);
-            int rc = prof_begin();
-            if (rc != MCE_OK) return rc;
-            a.sym.mode = 1;
             MCE_HIP(p.vh->launch_sym_pre(a, st));
             const int seed_used = a.seed_cfg;
             a.seed_cfg = 0;
-            a.sym.mode = 2;
+            int rc = prof_begin();             // (the bracket of mce_last_kernel_ms(): the dominant kernel, as for the other searches)
+            if (rc != MCE_OK) return rc;
             MCE_HIP(p.vh->launch_sym(a, st));
-            a.sym.mode = 3;                    // repair: blocks whose bucket overflowed (normally none: they exit at once)
-            MCE_HIP(p.vh->launch_sym(a, st));
+            rc = prof_end();
+            if (rc != MCE_OK) return rc;
+            MCE_HIP(p.vh->launch_sym_repair(a, st));      // blocks whose bucket overflowed (normally none: every workgroup exits at once)
             {
                 const dim3 g((unsigned)p.nqblk), b(mce::kSymMergeThreads);
                 static_assert(mce::kSymMergeThreads == mce::f16_qpb(4), "one merge block per query block");
@@ -561,12 +571,11 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
                 }
                 MCE_HIP(hipGetLastError());
             }
-            rc = prof_end();
-            if (rc != MCE_OK) return rc;
             p.sym_active = true;
             p.L = 1;
-            snprintf(g_last_kernel, sizeof(g_last_kernel), "%s symmetric grid=%d block=%d lds=%zu qt=%d ct=%d seed=%dx%d bucket=%d", p.vh->name,
-                     p.nqblk, mce::kHThreads, p.vh->lds_bytes_sym, p.QT, p.CT, seed_used & 0xffff, seed_used >> 16, p.sl.cap);
+            snprintf(g_last_kernel, sizeof(g_last_kernel), "%s symmetric grid=%d block=%d lds=%zu qt=%d ct=%d panel=%d seed=%dx%d bucket=%d", p.vh->name,
+                     mce::sym_unit_count(p.nqblk, mce::kHWaves * mce::kHQT, a.sym.panel * p.CT, (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1)),
+                     mce::kHThreads, p.vh->lds_bytes_sym, p.QT, p.CT, a.sym.panel, seed_used & 0xffff, seed_used >> 16, p.sl.cap);
             return MCE_OK;
         }
         int rc = prof_begin();

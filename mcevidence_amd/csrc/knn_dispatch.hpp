@@ -78,7 +78,8 @@ struct KnnF16Variant {
     knn_f16_launch_fn launch_prune;   // PRUNE = true instantiation (KST = 1 only), else null
     knn_f16_launch_fn launch_lower;   // LOWER = true instantiation (KCAP = 16 only), else null
     knn_f16_launch_fn launch_sym_pre; // SYM = 1: prepass of the symmetric sweep
-    knn_f16_launch_fn launch_sym;     // SYM = 2: symmetric sweep / repair (a.sym.mode)
+    knn_f16_launch_fn launch_sym;     // SYM = 2: symmetric sweep
+    knn_f16_launch_fn launch_sym_repair;   // SYM = 3: exhaustive search of the blocks whose bucket overflowed
     size_t lds_bytes_sym;
     int kst, kcap, qt, ct;
     size_t lds_bytes;

@@ -165,7 +165,7 @@ __host__ __device__ constexpr size_t f16_lds_bytes(int KST, int KCAP, bool sym =
 //     j's K global SLOTS (the K smallest row-side distances so far, lock-free: replace-the-maximum by
 //     compare-and-swap) -- whose K-th tightens thr[j] / rrow[j] / rtile for everybody who meets the row later -- and
 //     is appended to the BUCKET of j's block.  sym_merge_kernel folds the buckets into the
-//     lists afterwards.  A bucket that overflows flags its block; a repair launch (mode 3) then searches the flagged
+//     lists afterwards.  A bucket that overflows flags its block; a repair launch (SYM = 3) then searches the flagged
 //     blocks exhaustively, so the result never depends on the bucket size.
 // Everything published is a valid upper bound at all times and only ever shrinks, so stale reads merely let more
 // candidates through.  Lists carry the caller's row numbers and ties break on them: results are bit-identical to
@@ -270,11 +270,25 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
     const int wave = PRUNE ? (int)(blockIdx.x % kHWaves) : lwave;                            // position inside the query block
     // PRUNE: the launch's (or part's) blocks are border[qblk0], border[qblk0 + stride], ...: the dispatch
     // order puts the largest boxes -- the longest walks -- first
-    const int qblk = PRUNE ? border[qblk0 + (int)(blockIdx.x / kHWaves) * qblk_stride] : (int)(blockIdx.x % nqblk);
-    const int split = PRUNE ? 0 : (int)(blockIdx.x / nqblk);
-
+    // SYM == 2: workgroup = UNIT (panel p of the reference rows, query block a), numbered panel by panel
+    // (sym_unit_count): the units running at the same time stream the same few MB of packed rows through L2
+    int sym_a = 0, sym_p = 0;
     if constexpr (SYM == 2) {
-        if (sym.mode == 3 && sym.bucket_flag[qblk] == 0) return;      // repair launch: only the blocks whose bucket overflowed
+        constexpr int TPB_ = kHWaves * kHQT;                        // 32-row tiles per query block
+        const int tpp = sym.panel * f16_chunk_tiles(KST);          // tiles per panel
+        int u = (int)blockIdx.x;
+        for (;; ++sym_p) {
+            const int amin = (int)(((int64_t)sym_p * tpp) / TPB_);  // blocks a >= amin reach into panel p
+            const int cnt = nqblk - amin;
+            if (u < cnt) { sym_a = amin + u; break; }
+            u -= cnt;
+        }
+    }
+    const int qblk = PRUNE ? border[qblk0 + (int)(blockIdx.x / kHWaves) * qblk_stride] : (SYM == 2 ? sym_a : (int)(blockIdx.x % nqblk));
+    const int split = PRUNE ? 0 : (SYM >= 2 ? 0 : (int)(blockIdx.x / nqblk));
+
+    if constexpr (SYM >= 2) {
+        if (SYM == 3 && sym.bucket_flag[qblk] == 0) return;      // repair launch: only the blocks whose bucket overflowed
     }
     const int64_t cps = (nchunk_total + rsplit - 1) / rsplit;
     const int64_t c_begin = (int64_t)split * cps;
@@ -309,6 +323,22 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
 #pragma unroll
         for (int k = 0; k < KCAP; ++k) { own_d[nl][k] = INF; own_i[nl][k] = -1; }
 
+    if constexpr (SYM == 2) {
+        // A block's lists travel from its unit p - 1 to its unit p through the list arrays.  Units are dispatched in
+        // number order, panel by panel -- the previous unit of this block started a whole panel's worth of units ago --
+        // so the wait below practically never spins; it is there for the ordering guarantee (the earlier unit is
+        // resident or done, never waiting for this one).
+        if (sym_p > 0) {
+            while (__hip_atomic_load(sym.done + qblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sym_p) __builtin_amdgcn_s_sleep(32);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const int64_t q = (int64_t)qblk * QPB + wave * QPW + lane;
+#pragma unroll
+            for (int k = 0; k < KCAP; ++k) {
+                own_d[0][k] = part_d[(int64_t)k * nq_pad + q];
+                own_i[0][k] = part_i[(int64_t)k * nq_pad + q];
+            }
+        }
+    }
     // upper bound on the final K-th squared distance of the owned queries, known before the sweep (seed phase below)
     double seed_thr[kHNL];
 #pragma unroll
@@ -340,7 +370,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
     float cR[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) cR[qt] = -__builtin_huge_valf();
-    if constexpr (SYM == 2) {
+    if constexpr (SYM >= 2) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             const int64_t q = qwave0 + qt * 32 + (lane & 31);
@@ -488,7 +518,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                         ok = a0 > ld || (a0 == ld && j > li);       // (list not full: ld = +inf, nothing is left)
                     }
                 }
-                if constexpr (SYM == 2) {
+                if constexpr (SYM >= 2) {
                     // every entry gets its distance (-1: no pair behind it) for phase R; only what can still enter
                     // the query's list (K-th bound of the last drain) joins its chain
                     if (sub == 0 && ep[u] < qcount) {
@@ -506,7 +536,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                 }
             }
         }
-        if constexpr (SYM == 2) {
+        if constexpr (SYM >= 2) {
             // ---- phase R: the ROW side of every evaluated pair, one lane per queue entry ----------------------
             // Pair (i, j): j is a row of another block (behind this one on the ring).  If the distance can still be
             // among j's K smallest (thr[j]) it goes through j's slots -- replace the largest of the K smallest
@@ -574,7 +604,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                 const bool ok = valid && d2 >= 0.0;
                 const int oj = ok ? rperm[j] : -1;
                 const int jb = j / QPB;
-                bool rs = ok && sym.mode == 2 && jb != qblk;
+                bool rs = ok && SYM == 2 && jb != qblk;
 #if MCE_STATS
                 st_rtest += __builtin_popcountll(__ballot(rs));
 #endif
@@ -618,7 +648,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                 const bool on = cur >= 0;
                 const int ce = on ? cur : 0;
                 const double d2 = on ? wqd[ce] : INF;
-                const int j = (PRUNE || SYM == 2) ? wq[ce] : jsplit0 + (int)((unsigned)wq[ce] & ((1u << kHRelBits) - 1u));
+                const int j = (PRUNE || SYM >= 2) ? wq[ce] : jsplit0 + (int)((unsigned)wq[ce] & ((1u << kHRelBits) - 1u));
                 cur = on ? wnx[ce] : -1;
                 // ascending list, ties by row; d2 = +inf (idle lane) changes nothing
                 bool c_hi = (d2 < own_d[nl][KCAP - 1]) || (d2 == own_d[nl][KCAP - 1] && j < own_i[nl][KCAP - 1] && d2 < INF);
@@ -650,7 +680,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
 #if MCE_STATS
         const long long t_p0 = clock64();
 #endif
-        if constexpr (SYM == 2) {
+        if constexpr (SYM >= 2) {
             // publish: thr[q] takes this list's K-th bound and gives back what the row side knows (the K-th of q's
             // slots); the row-side gate constants follow, and the maximum over each 32-row tile (= half a wave)
             const int64_t q = qwave0 + lane;
@@ -674,7 +704,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
             float m = R;
 #pragma unroll
             for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-            if ((lane & 31) == 0 && sym.mode == 2) __hip_atomic_store(sym.rtile + ((qwave0 + lane) >> 5), m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((lane & 31) == 0 && SYM == 2) __hip_atomic_store(sym.rtile + ((qwave0 + lane) >> 5), m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #if MCE_STATS
         st_tP += clock64() - t_p0;
@@ -910,7 +940,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
         // the true distance with the same error terms as the gate (true <= sqrt(A + |x^|^2 + eps) + e_x + max e_y).
         // With many more groups than K' this is close to the K-th distance within the seed rows.  The sweep
         // proper then starts with that threshold instead of +inf: no flood of early candidates.
-        if constexpr (!LOWER && (MCE_ABLATE == 0) && SYM != 2) {
+        if constexpr (!LOWER && (MCE_ABLATE == 0) && SYM < 2) {
             const int kneed = ksel + (self_exclude ? 1 : 0);
             const int tg = seed_cfg >> 16;
             const int nseed = ((int64_t)(seed_cfg & 0xffff) * 2 <= c_end - c_begin) ? (seed_cfg & 0xffff) : 0;   // chunks (host: f16_seed_cfg)
@@ -966,7 +996,10 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                     for (int r = 0; r < 16; ++r) accB[qt][r] = FINF;          // "no pending tile" for a minimum
                 // the seed chunks are spread evenly over the split: the rows of a Markov chain are correlated in
                 // time, and its first stretch alone would say little about queries elsewhere in the posterior
-                const int64_t sstep = (c_end - c_begin) / nseed;              // >= 2
+                // (SYM = 1: the rows are sorted by distance from the mean, and the seed rows are the FIRST chunks -- the rows
+                //  nearest the mean are near every query, most of every row's neighbours are among them: at 1M x 27 the
+                //  sweep that follows takes 41.4 ms instead of 45.7 with the same number of seed rows spread evenly)
+                const int64_t sstep = SYM == 1 ? 1 : (c_end - c_begin) / nseed;              // >= 2
                 stage_async(c_begin, 0);
                 for (int cc = 0; cc < nseed; ++cc) {
                     const int buf = cc & 1;
@@ -1034,8 +1067,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
             for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
             if ((lane & 31) == 0) sym.rtile[q >> 5] = m;
             return;
-        } else if constexpr (SYM == 2) {
-            // ---- symmetric sweep: the blocks 0..a (mode 3: everything, column side only)
+        } else if constexpr (SYM >= 2) {
+            // ---- symmetric sweep: the blocks 0..a (SYM = 3, repair: everything, column side only)
             {
                 const int64_t q = qwave0 + lane;
                 const double t0 = __longlong_as_double((long long)__hip_atomic_load(sym.thr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -1051,18 +1084,27 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
             // the rows met first then belong to the blocks that finished longest ago (tightest bounds: fewest row-side
             // candidates), and blocks running at the same time stream the same chunks through L2 (measured at 1M x 27:
             // 47.6 ms vs 50.0 downwards, 48.5 from a per-block offset).
-            const int hi = sym.mode == 2 ? (TPB * (qblk + 1) < Tre ? TPB * (qblk + 1) : Tre) : Tre;
-            const int ntot = hi > 0 ? (hi - 1) / CT + 1 : 0;
+            //
+            // A block's range is worked off PANEL by panel (sym.panel chunks: a few MB of packed rows), one unit each,
+            // and the units are numbered panel-major: at any time the chip is on one panel (L2 serves 31 of the 32 CUs
+            // of an XCD), and the units are of equal length, so the launch ends with at most one unit of tail instead
+            // of the longest block's.  (One workgroup per block, 0..a in one go: blocks of different length drift apart,
+            // 79 GB through the fabric per search at 1M x 27 instead of 17, and ~13 % of tail.)
+            const int hi_a = TPB * (qblk + 1) < Tre ? TPB * (qblk + 1) : Tre;
+            const int lo = SYM == 2 ? sym_p * sym.panel * CT : 0;
+            const int hi = SYM == 2 ? ((sym_p + 1) * sym.panel * CT < hi_a ? (sym_p + 1) * sym.panel * CT : hi_a) : Tre;
+            const int cfirst = lo / CT;
+            const int ntot = hi > lo ? (hi - 1) / CT - cfirst + 1 : 0;
             // k-th chunk of the sequence: its number and its tiles [tlo, thi)
             auto seq_at = [&](int k, int& c, int& tlo, int& thi) {
-                c = k;
+                c = cfirst + k;
                 tlo = 0;
                 thi = hi - c * CT < CT ? hi - c * CT : CT;
             };
             // lane t <- the row-side gate constant of tile t of chunk c (own rows and tiles outside the range: none)
             auto rt_load = [&](int c, int tlo, int thi) -> float {
                 const int t = c * CT + lane;
-                const bool en = sym.mode == 2 && lane >= tlo && lane < thi && t / TPB != qblk;
+                const bool en = SYM == 2 && lane >= tlo && lane < thi && t / TPB != qblk;
 #ifndef MCE_SYM_ABL
 #define MCE_SYM_ABL 0      // tools/knn_sym_bench.hip only: 1 = no row side at all (results invalid), 2 = plain (L2-cached) load of the tile constants
 #endif
@@ -1382,7 +1424,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
         double* o = const_cast<double*>(params) + 16 + ((int64_t)blockIdx.x * kHWaves + wave) * 8;
         o[0] = (double)st_drains; o[1] = (double)st_enq; o[2] = (double)st_steps; o[3] = (double)st_events;
         o[4] = (double)st_tA; o[5] = (double)st_tD; o[6] = (double)(clock64() - t_kernel0); o[7] = (double)st_tB;
-        if constexpr (SYM == 2) {      // (the harness sizes `params` for 16 values per wave)
+        if constexpr (SYM >= 2) {      // (the harness sizes `params` for 16 values per wave)
             double* o2 = const_cast<double*>(params) + 16 + ((int64_t)gridDim.x * kHWaves) * 8 + ((int64_t)blockIdx.x * kHWaves + wave) * 8;
             o2[0] = (double)st_tR; o2[1] = (double)st_tE; o2[2] = (double)st_rtest; o2[3] = (double)st_rapp; o2[4] = (double)st_cas; o2[5] = (double)st_linked; o2[6] = (double)st_tP; o2[7] = 0.0;
         }
@@ -1398,6 +1440,12 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
             part_d[o] = own_d[nl][k];
             part_i[o] = own_i[nl][k];
         }
+    }
+    if constexpr (SYM == 2) {
+        // hand the lists to the block's next unit
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(sym.done + qblk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

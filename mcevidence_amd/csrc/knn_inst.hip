@@ -43,7 +43,7 @@ hipError_t launch_variant(const KnnArgs& a, hipStream_t st)
 template <int KST, int KCAP, bool PRUNE, bool LOWER = false, int SYM = 0>
 hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
 {
-    constexpr size_t LDS_MAX = PRUNE ? f16_prune_lds_bytes(KST, 16 * KST - 1, KCAP) : f16_lds_bytes(KST, KCAP, SYM == 2);
+    constexpr size_t LDS_MAX = PRUNE ? f16_prune_lds_bytes(KST, 16 * KST - 1, KCAP) : f16_lds_bytes(KST, KCAP, SYM >= 2);
     static_assert(LDS_MAX <= 160 * 1024, "LDS budget");
     const size_t LDS = PRUNE ? f16_prune_lds_bytes(KST, a.D, KCAP) : LDS_MAX;     // pruned walk: sized by the dimension (more waves per CU)
     static bool attr_set[kMaxDevices] = {};
@@ -56,7 +56,10 @@ hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
         if (dev < kMaxDevices) attr_set[dev] = true;
     }
     // pruned walk: one 64-thread workgroup per wave of a query block
-    const dim3 grid((unsigned)(PRUNE ? (a.nqblk_run ? a.nqblk_run : a.nqblk) * kHWaves : a.nqblk * a.rsplit));
+    // symmetric sweep: one workgroup per unit (sym_types.hpp); its prepass and repair launches: one per query block
+    const int ntiles_even = (int)((a.nr + 31) / 32) + (int)(((a.nr + 31) / 32) & 1);
+    const dim3 grid((unsigned)(PRUNE ? (a.nqblk_run ? a.nqblk_run : a.nqblk) * kHWaves
+                               : SYM == 2 ? sym_unit_count(a.nqblk, kHWaves * kHQT, a.sym.panel * f16_chunk_tiles(KST), ntiles_even) : a.nqblk * a.rsplit));
     hipLaunchKernelGGL(kern, grid, dim3(PRUNE ? 64 : kHThreads), LDS, st, static_cast<const _Float16*>(a.Yh), a.nchunk_total, a.rsplit,
                        static_cast<const _Float16*>(a.Xh), a.qinfo, a.params, a.X, a.Y, a.nq, a.nr, a.D, a.nq_pad, a.nqblk,
                        a.self_exclude, a.self_offset, a.ksel, a.part_d, a.part_i, a.clist, a.cdist, a.list_len, a.rperm, a.qperm, a.tbox_r, a.tbox_q, a.cbox_r, a.qblk0, a.qblk_stride, a.border, a.lo_d, a.lo_i, a.seed_cfg, a.sym);
@@ -90,7 +93,7 @@ extern const KnnVariant MCE_CAT(g_knn_kcap, MCE_KCAP)[kMaxKS] = {
 #endif
 #define MCE_F16_VARIANT(KST, PRUNE_FN)                                                                   \
     {&launch_f16_variant<KST, MCE_KCAP, false>, PRUNE_FN, MCE_F16_LOWER(KST), &launch_f16_variant<KST, MCE_KCAP, false, false, 1>, \
-     &launch_f16_variant<KST, MCE_KCAP, false, false, 2>, f16_lds_bytes(KST, MCE_KCAP, true), KST, MCE_KCAP, f16_qt(MCE_KCAP), f16_chunk_tiles(KST), \
+     &launch_f16_variant<KST, MCE_KCAP, false, false, 2>, &launch_f16_variant<KST, MCE_KCAP, false, false, 3>, f16_lds_bytes(KST, MCE_KCAP, true), KST, MCE_KCAP, f16_qt(MCE_KCAP), f16_chunk_tiles(KST), \
      f16_lds_bytes(KST, MCE_KCAP), "knn_f16_kernel<KST=" #KST ",KCAP=" MCE_STR(MCE_KCAP) ">"}
 extern const KnnF16Variant MCE_CAT(g_knn_f16_kcap, MCE_KCAP)[kMaxKST] = {
     MCE_F16_VARIANT(1, (&launch_f16_variant<1, MCE_KCAP, true>)), MCE_F16_VARIANT(2, nullptr), MCE_F16_VARIANT(3, nullptr),
@@ -104,6 +107,7 @@ extern const KnnF16Variant MCE_CAT(g_knn_f16_kcap, MCE_KCAP)[kMaxKST] = {
 MCE_F16_INST(1, false, false, 0) MCE_F16_INST(2, false, false, 0) MCE_F16_INST(3, false, false, 0) MCE_F16_INST(4, false, false, 0) MCE_F16_INST(1, true, false, 0)
 MCE_F16_INST(1, false, false, 1) MCE_F16_INST(2, false, false, 1) MCE_F16_INST(3, false, false, 1) MCE_F16_INST(4, false, false, 1)
 MCE_F16_INST(1, false, false, 2) MCE_F16_INST(2, false, false, 2) MCE_F16_INST(3, false, false, 2) MCE_F16_INST(4, false, false, 2)
+MCE_F16_INST(1, false, false, 3) MCE_F16_INST(2, false, false, 3) MCE_F16_INST(3, false, false, 3) MCE_F16_INST(4, false, false, 3)
 #if MCE_KCAP == 16
 MCE_F16_INST(1, false, true, 0) MCE_F16_INST(2, false, true, 0) MCE_F16_INST(3, false, true, 0) MCE_F16_INST(4, false, true, 0)
 #endif

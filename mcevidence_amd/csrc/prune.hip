@@ -389,8 +389,9 @@ int sym_layout(int64_t n, int64_t n_pad, int nqblk, int d, int kcap, int qpb, in
     L.rrow = take((size_t)n_pad * 4);
     L.rtile = take((size_t)(n_pad / 32) * 4);
     L.slots = take((size_t)n_pad * kcap * 8);
-    L.bucket_cnt = take((size_t)nqblk * 4 * 2);
+    L.bucket_cnt = take((size_t)nqblk * 4 * 3);
     L.bucket_flag = L.bucket_cnt + (size_t)nqblk * 4;
+    L.done = L.bucket_flag + (size_t)nqblk * 4;
     L.cap = per_row * qpb;
     L.bucket = take((size_t)nqblk * L.cap * 16);
     size_t tb = 0;
@@ -418,7 +419,7 @@ hipError_t sym_prepare(const double* dY, int64_t n, int d, const double* center,
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n * d + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, dY, perm, n, d, Ys);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    e = hipMemsetAsync(ws + L.bucket_cnt, 0, (size_t)2 * 4 * ((L.bucket_flag - L.bucket_cnt) / 4), st);
+    e = hipMemsetAsync(ws + L.bucket_cnt, 0, (size_t)3 * (L.bucket_flag - L.bucket_cnt), st);      // counts | flags | done
     return e;
 }
 

@@ -74,7 +74,7 @@ struct SymLayout {
     size_t rrow = 0;                        // uint32 [n_pad]
     size_t rtile = 0;                       // float [n_pad / 32]
     size_t slots = 0;                       // uint64 [n_pad][kcap]
-    size_t bucket_cnt = 0, bucket_flag = 0; // int32 [nqblk] each (contiguous: one memset)
+    size_t bucket_cnt = 0, bucket_flag = 0, done = 0; // int32 [nqblk] each (contiguous: one memset)
     size_t bucket = 0;                      // SymEntry [nqblk][cap]
     size_t tmp = 0, tmp_bytes = 0;          // rocPRIM scratch
     size_t total = 0;

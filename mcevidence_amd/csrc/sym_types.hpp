@@ -15,7 +15,18 @@ struct SymParams {
     int* bucket_flag = nullptr;            // [nqblk] 1: the bucket overflowed, the block is searched again exhaustively
     SymEntry* bucket = nullptr;            // [nqblk][cap]
     int cap = 0;
-    int mode = 0;                          // 2: symmetric sweep, 3: repair (flagged blocks only, exhaustive, column side only)
+    int* done = nullptr;                   // [nqblk] units of the block finished so far (its lists are handed from unit to unit)
+    int panel = 0;                         // chunks per panel of reference rows (a unit = one block's queries x one panel)
 };
+
+// Units of the symmetric sweep: unit = (panel p, block a) for every block whose range of tiles [0, tpb (a + 1)) reaches into
+// panel p = tiles [p tpp, (p + 1) tpp), numbered panel by panel, blocks ascending (the kernel decodes with the same loop).
+// ntiles: 32-row tiles that hold reference rows.
+inline int sym_unit_count(int nqblk, int tpb, int tpp, int ntiles)
+{
+    int total = 0;
+    for (int p = 0; (int64_t)p * tpp < ntiles; ++p) total += nqblk - (int)(((int64_t)p * tpp) / tpb);
+    return total;
+}
 
 }  // namespace mce

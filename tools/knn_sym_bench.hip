@@ -27,7 +27,7 @@ int main(int argc, char** argv)
     const int seed_rows = argc > 3 ? atoi(argv[3]) : 2 * MCE_H_SEED_ROWS;
     const int per_row = argc > 4 ? atoi(argv[4]) : 6 * KSEL + 24;
     const int sorted = argc > 5 ? atoi(argv[5]) : 1;
-    const int parts = 1;
+    const int panel = argc > 6 ? atoi(argv[6]) : 48;
     constexpr int D = DIM;
     constexpr int KST = f16_ksteps(D);
     constexpr int CT = f16_chunk_tiles(KST);
@@ -50,16 +50,17 @@ int main(int argc, char** argv)
     double *X, *pd, *center, *msum, *params, *qinfo; int *pi, *dperm; _Float16 *Yh, *Xh;
     CK(hipMalloc(&X, sizeof(double) * n * D));
     CK(hipMalloc(&Yh, 2 * nrow_pad * 16 * KST)); CK(hipMalloc(&Xh, 2 * nq_pad * 16 * KST));
-    CK(hipMalloc(&qinfo, 16 * nq_pad)); const size_t pbytes = 256 + (size_t)nqblk * 5 * 16 * 64; CK(hipMalloc(&params, pbytes)); CK(hipMalloc(&center, 3 * 512)); CK(hipMalloc(&msum, 8 * kStatStride * 256));
+    CK(hipMalloc(&qinfo, 16 * nq_pad)); const size_t pbytes = 256 + (size_t)nqblk * 40 * 16 * 64; CK(hipMalloc(&params, pbytes)); CK(hipMalloc(&center, 3 * 512)); CK(hipMalloc(&msum, 8 * kStatStride * 256));
     CK(hipMalloc(&dperm, 4 * nq_pad));
-    const size_t nl = (size_t)parts * KCAP * nq_pad;
+    const size_t nl = (size_t)KCAP * nq_pad;
     CK(hipMalloc(&pd, sizeof(double) * nl)); CK(hipMalloc(&pi, sizeof(int) * nl));
     CK(hipMemcpy(X, hsorted.data(), sizeof(double) * n * D, hipMemcpyHostToDevice));
     CK(hipMemcpy(dperm, perm.data(), 4 * nq_pad, hipMemcpyHostToDevice));
     SymParams sp;
     const int cap = per_row * qpb;
     CK(hipMalloc(&sp.thr, 8 * nq_pad)); CK(hipMalloc(&sp.rrow, 4 * nq_pad)); CK(hipMalloc(&sp.rtile, 4 * (nq_pad / 32)));
-    CK(hipMalloc(&sp.slots, 8 * nq_pad * KCAP)); CK(hipMalloc(&sp.bucket_cnt, 8 * nqblk)); sp.bucket_flag = sp.bucket_cnt + nqblk;
+    CK(hipMalloc(&sp.slots, 8 * nq_pad * KCAP)); CK(hipMalloc(&sp.bucket_cnt, 12 * nqblk)); sp.bucket_flag = sp.bucket_cnt + nqblk; sp.done = sp.bucket_cnt + 2 * nqblk; sp.panel = panel;
+    const int nunits = sym_unit_count(nqblk, kHWaves * kHQT, panel * CT, (int)((n + 31) / 32) + (int)(((n + 31) / 32) & 1));
     CK(hipMalloc(&sp.bucket, (size_t)16 * nqblk * cap)); sp.cap = cap;
     col_stats_partial_kernel<<<kMeanBlocks, kMeanThreads>>>(X, n, D, msum);
     col_stats_final_kernel<<<1, 64>>>(msum, n, D, center, center + 64);
@@ -77,21 +78,19 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
     const int seed_cfg = f16_seed_cfg(nchunk, CT, KSEL + 1, seed_rows, 8, MCE_H_SEED_TG);
     for (int r = 0; r < reps; ++r) {
-        CK(hipMemset(sp.bucket_cnt, 0, 8 * nqblk));
+        CK(hipMemset(sp.bucket_cnt, 0, 12 * nqblk));
         CK(hipMemset((char*)params + 128, 0, pbytes - 128));
         CK(hipEventRecord(e0));
-        sp.mode = 1;
         kpre<<<nqblk, kHThreads, LDS>>>(Yh, nchunk, 1, Xh, qinfo, params, X, X, n, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi,
                                         (const int*)nullptr, (const float*)nullptr, 0, dperm, (const int*)nullptr, (const float*)nullptr,
                                         (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr, seed_cfg, sp);
         CK(hipEventRecord(e1));
-        sp.mode = 2;
-        kern<<<nqblk, kHThreads, LDS>>>(Yh, nchunk, 1, Xh, qinfo, params, X, X, n, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi,
+        kern<<<nunits, kHThreads, LDS>>>(Yh, nchunk, 1, Xh, qinfo, params, X, X, n, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi,
                                         (const int*)nullptr, (const float*)nullptr, 0, dperm, (const int*)nullptr, (const float*)nullptr,
                                         (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr, 0, sp);
         CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
         float ms1, ms2; CK(hipEventElapsedTime(&ms1, e0, e1)); CK(hipEventElapsedTime(&ms2, e1, e2));
-         printf("D=%d KST=%d KCAP=%d K=%d n=%lld grid=%d seed=%dx%d sorted=%d: prepass %.2f ms  sweep %.2f ms\n", D, KST, KCAP, KSEL, (long long)n, nqblk,
+         printf("panel=%d units=%d ", panel, nunits); printf("D=%d KST=%d KCAP=%d K=%d n=%lld grid=%d seed=%dx%d sorted=%d: prepass %.2f ms  sweep %.2f ms\n", D, KST, KCAP, KSEL, (long long)n, nqblk,
                seed_cfg & 0xffff, seed_cfg >> 16, sorted, ms1, ms2);
     }
     {
@@ -103,7 +102,7 @@ int main(int argc, char** argv)
     }
 #if MCE_STATS
     {
-        const size_t nw = (size_t)nqblk * 8;
+        const size_t nw = (size_t)nunits * 8;
         std::vector<double> hs(nw * 16);
         CK(hipMemcpy(hs.data(), (char*)params + 128, nw * 128, hipMemcpyDeviceToHost));
         double m[16] = {0};

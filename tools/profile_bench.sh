@@ -21,7 +21,7 @@ for name, d in (("FETCH_SIZE","/tmp/pf_"+tag),("WRITE_SIZE","/tmp/pw_"+tag),("SQ
         agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.defaultdict(int)
         seen=set()
         for r in csv.DictReader(open(f)):
-            k=r['Kernel_Name'].split('(')[0][:60]
+            k=r['Kernel_Name'].split('(')[0][:72]
             agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
             seen.add((k, r['Dispatch_Id']))
         for k in agg:
