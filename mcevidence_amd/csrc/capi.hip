@@ -76,12 +76,16 @@ int sym_mode()
     return m;
 }
 // query blocks (512 rows each) from which the automatic mode takes it, by 16-wide k-steps of the filter.  Measured
-// (tools/sym_crossover.py, fused search + reduction, exhaustive -> symmetric): d = 6 / 10 / 15 (1 k-step) 12.1 -> 13.2 /
-// 12.1 -> 12.5 / 12.3 -> 12.4 ms at 524 k rows, 40.1 -> 37.2 / 40.5 -> 36.2 / 41.3 -> 35.7 ms at 1 M; d = 27 (2)
-// 19.9 -> 19.2 ms at 524 k, 66.4 -> 52.6 at 1 M, 237 -> 167 at 2 M; d = 45 (3) 7.6 -> 6.5 ms at 197 k, 28.3 -> 23.4 at
-// 524 k, 94.8 -> 65.5 at 1 M.  (The more of a search is MFMA work and the more rounds of workgroups it has -- the
-// triangle's last round is its tail -- the more halving the products pays.)
-constexpr int kSymAutoMinBlocks[5] = {0, 1536, 1024, 384, 384};
+// (tools/sym_crossover.py, fused search + reduction, exhaustive -> symmetric, ms): d = 45 (3 k-steps) 2.3 -> 1.9 at 65 k rows,
+// 8.3 -> 5.1 at 197 k, 33.1 -> 19.5 at 524 k, 97.8 -> 56.1 at 1 M; d = 27 (2) 1.8 -> 1.8 at 65 k, 3.4 -> 2.8 at 131 k,
+// 15.5 -> 10.5 at 393 k, 26.2 -> 16.1 at 524 k, 67.5 -> 45.4 at 1 M, 254 -> 157 at 2 M; d = 15 / 10 / 6 (1 k-step)
+// 5.4 -> 4.6 / 5.3 -> 4.8 / 5.4 -> 5.3 at 262 k, 41.3 -> 33.8 / 40.4 -> 34.4 / 40.3 -> 36.1 at 1 M (where the pruned walk
+// does not take over).  The more of a search is MFMA work, the more halving the products pays.
+constexpr int kSymAutoMinBlocks[5] = {0, 1024, 256, 128, 128};
+// prepass rows by k-steps: 0 spread over the sorted rows, 1 the rows nearest the mean, 2 half and half.  Fused call, ms,
+// spread / nearest / half: 1M x 3 42.6 / 152.6 / 45.2; 1M x 6 36.1 / 50.1 / 37.1; 1M x 10 34.4 / 36.8 / 34.8; 1M x 15
+// 33.8 / 33.4 / 33.2; 1M x 20 50.2 / 45.9 / 46.8; 1M x 27 48.8 / 44.4 / 45.5 (tools/sym_seedmode.py)
+constexpr int kSymSeedMode[5] = {0, 0, 1, 1, 1};
 constexpr int kSymPanelChunks = 96;           // 48 KB chunks per panel of reference rows (knn_f16.hpp, units): 1M x 27: 24 -> 52.5 ms, 48 -> 46.5, 96 -> 45.7, 192 -> 46.2
 // bucket entries per row: a row receives ~K ln(N/2 / seed rows) + K row-side candidates; MCE_SYM_BUCKET overrides (tests)
 int sym_bucket_per_row(int K)
@@ -551,6 +555,10 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             const char* const e_share = getenv("MCE_SYM_SEED_SHARE");
             a.seed_cfg = mce::f16_seed_cfg(p.nchunk, p.CT, K + a.self_exclude, e_rows ? atoi(e_rows) : 2 * MCE_H_SEED_ROWS,
                                            e_share ? atoi(e_share) : 8, MCE_H_SEED_TG);
+            if (a.seed_cfg) {
+                const char* const e_mode = getenv("MCE_SYM_SEED_MODE");
+                a.seed_cfg |= ((e_mode ? atoi(e_mode) : kSymSeedMode[p.KST]) & 3) << 28;
+            }
             MCE_HIP(p.vh->launch_sym_pre(a, st));
             const int seed_used = a.seed_cfg;
             a.seed_cfg = 0;

@@ -131,7 +131,7 @@ inline int f16_seed_cfg(int64_t cps, int CT, int kneed, int rows = MCE_H_SEED_RO
     if (chunks > cps / share) chunks = cps / share;
     if (chunks > 0xffff) chunks = 0xffff;
     if (chunks * CT / tg < 2 * (int64_t)kneed) return 0;
-    return (int)chunks | (tg << 16);
+    return (int)chunks | (tg << 16);       // (bits 28-29: where the chunks are, set by the caller -- see the seed phase)
 }
 __host__ __device__ constexpr size_t f16_lds_bytes(int KST, int KCAP, bool sym = false)
 {
@@ -942,7 +942,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
         // proper then starts with that threshold instead of +inf: no flood of early candidates.
         if constexpr (!LOWER && (MCE_ABLATE == 0) && SYM < 2) {
             const int kneed = ksel + (self_exclude ? 1 : 0);
-            const int tg = seed_cfg >> 16;
+            const int tg = (seed_cfg >> 16) & 0xfff;
+            const int smode = (seed_cfg >> 28) & 3;       // where the seed chunks are: 0 spread evenly, 1 the first ones, 2 half and half
             const int nseed = ((int64_t)(seed_cfg & 0xffff) * 2 <= c_end - c_begin) ? (seed_cfg & 0xffff) : 0;   // chunks (host: f16_seed_cfg)
             if (nseed > 0 && tg > 0 && kneed <= KCAP + 1) {
                 const float FINF = __builtin_huge_valf();
@@ -996,15 +997,23 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                     for (int r = 0; r < 16; ++r) accB[qt][r] = FINF;          // "no pending tile" for a minimum
                 // the seed chunks are spread evenly over the split: the rows of a Markov chain are correlated in
                 // time, and its first stretch alone would say little about queries elsewhere in the posterior
-                // (SYM = 1: the rows are sorted by distance from the mean, and the seed rows are the FIRST chunks -- the rows
-                //  nearest the mean are near every query, most of every row's neighbours are among them: at 1M x 27 the
-                //  sweep that follows takes 41.4 ms instead of 45.7 with the same number of seed rows spread evenly)
-                const int64_t sstep = SYM == 1 ? 1 : (c_end - c_begin) / nseed;              // >= 2
-                stage_async(c_begin, 0);
+                // Which chunks: spread evenly (rows in the caller's order: a Markov chain's first stretch alone says little
+                // about queries elsewhere in the posterior).  Rows sorted by distance from the mean (symmetric sweep): in
+                // high dimensions the rows NEAREST the mean are near every query and hold most of every row's neighbours --
+                // 1M x 27: the sweep that follows takes 41.4 ms after the first 32 k rows, 45.7 after 32 k spread evenly --
+                // in low dimensions they are not (1M x 6: 50 vs 37 ms); half and half serves both (kSeed* in capi.hip).
+                const int64_t srange = c_end - c_begin;
+                const int nfirst = smode == 1 ? nseed : (smode == 2 ? nseed / 2 : 0);
+                auto seed_chunk = [&](int cc) -> int64_t {
+                    if (cc < nfirst) return c_begin + cc;
+                    const int ns = nseed - nfirst;
+                    return c_begin + nfirst + (int64_t)(cc - nfirst) * ((srange - nfirst) / ns);
+                };
+                stage_async(seed_chunk(0), 0);
                 for (int cc = 0; cc < nseed; ++cc) {
                     const int buf = cc & 1;
                     __syncthreads();
-                    if (cc + 1 < nseed) stage_async(c_begin + (cc + 1) * sstep, buf ^ 1);
+                    if (cc + 1 < nseed) stage_async(seed_chunk(cc + 1), buf ^ 1);
                     MCE_SWEEP_CHUNK(buf, 0, MCE_SEED_TILE, 0, CT, 0.0f);
                 }
                 MCE_SEED_TILE(accB, 0, 0.0f);           // the pending tile

@@ -101,22 +101,26 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
         double sel_d[kMaxK];
         int sel_i[kMaxK];
         int nsel = 0;
-        for (int k = 0; k < K; ++k) {
+        // SELF_INCLUDE: the own row is a reference row by contract; it is reported first, at distance 0, whether or not
+        // it made it into a list (K or more exact duplicates with lower row numbers push it out of one) -- so the result
+        // does not depend on how many lists the plan happened to use
+        if (selfj >= 0) { sel_d[0] = -1.0; sel_i[0] = selfj; nsel = 1; }     // (-1: sentinel, sorts first, reported as 0)
+        for (int k = nsel; k < K; ++k) {
             double bv = INF;
             int bi = 0x7fffffff, bl = -1;
             for (int l = 0; l < L; ++l) {
+                if (head[l] < KCAP && part_i[((int64_t)l * KCAP + head[l]) * nq_pad + q] == selfj && selfj >= 0) head[l]++;      // already taken
                 const int h = head[l];
                 if (h >= KCAP) continue;
                 const int64_t o = ((int64_t)l * KCAP + h) * nq_pad + q;
                 const int i = part_i[o];
                 if (i < 0) continue;                       // list exhausted
-                double v = part_d[o];
-                if (i == selfj) v = -INF;                  // SELF_INCLUDE: own row sorts first
+                const double v = part_d[o];
                 if (v < bv || (v == bv && i < bi)) { bv = v; bi = i; bl = l; }
             }
             if (bl < 0) break;
             head[bl]++;
-            sel_d[nsel] = (bi == selfj) ? -1.0 : bv;     // own row: sentinel, sorts first, reported as 0
+            sel_d[nsel] = bv;
             sel_i[nsel++] = bi;
         }
         // ---- refine: exact direct-difference distances of the selected pairs ----

@@ -147,3 +147,74 @@ def test_symmetric_sweep_golden_lnE(sym):
         assert np.allclose(lnE, case["lnE"], rtol=0, atol=LNE_TOL), name
         done += "symmetric" in capi.last_kernel()
     assert done >= 3
+
+
+def test_symmetric_sweep_under_graph_capture(sym):
+    """the *_dev entry points only enqueue -- sort, prepass, units, repair and merge included -- so the call can be
+    captured into a HIP graph and replayed on new data in the same buffers"""
+    import torch
+    capi = sym
+    capi.set_sym_mode(capi.SYM_FORCE)
+    rng = np.random.default_rng(21)
+    n, d, kmax = 30000, 9, 4
+    K = kmax - 1
+    X = torch.empty((n, d), dtype=torch.float64, device="cuda")
+    w = torch.ones(n, dtype=torch.float64, device="cuda")
+    fs = torch.zeros(n, dtype=torch.float64, device="cuda")
+    wsb = capi.knn_workspace_bytes(n, n, d, K) + capi.dotp_workspace_bytes(n, kmax)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(kmax, dtype=torch.float64, device="cuda")
+    dd = torch.zeros((n, K), dtype=torch.float64, device="cuda")
+
+    def call(stream):
+        capi.knn_dotp_dev(X.data_ptr(), n, X.data_ptr(), n, d, kmax, 1, 0, w.data_ptr(), fs.data_ptr(), out.data_ptr(),
+                          dd.data_ptr(), ws.data_ptr(), wsb, stream)
+    data = [rng.standard_normal((n, d)) for _ in range(3)]
+    X.copy_(torch.from_numpy(data[0]))
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                       # warm-up outside capture (one-time kernel attributes)
+        call(side.cuda_stream)
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call(torch.cuda.current_stream().cuda_stream)
+    assert "symmetric" in capi.last_kernel()
+    capi.set_sym_mode(capi.SYM_OFF)
+    for h in data[1:]:
+        X.copy_(torch.from_numpy(h))
+        graph.replay()
+        torch.cuda.synchronize()
+        want_dotp, want_dist = capi.knn_dotp(h, None, np.ones(n), np.zeros(n), kmax, 1, return_dist=True)
+        assert "symmetric" not in capi.last_kernel()
+        assert np.array_equal(dd.cpu().numpy(), want_dist)
+        assert np.allclose(out.cpu().numpy(), want_dotp, rtol=1e-13, atol=0)
+
+
+def test_random_shapes_with_random_settings(sym, monkeypatch):
+    """seeded sweep over ragged shapes and every self mode with random prepass sizes and layouts, panel sizes (units per
+    block) and bucket sizes (overflow + repair in some cases): distances and rows identical to the exhaustive sweep's,
+    and equal to the exact CPU search on a sample"""
+    capi = sym
+    rng = np.random.default_rng(4242)
+    for case in range(40):
+        d = int(rng.choice([1, 2, 3, 5, 6, 8, 13, 14, 16, 27, 31, 33, 40, 50]))
+        n = int(rng.integers(1025, 40000))
+        K = int(rng.integers(1, 17))
+        sm = [capi.SELF_EXCLUDE, capi.SELF_INCLUDE, capi.SELF_NONE][case % 3]
+        Y = rng.standard_normal((n, d)) * rng.uniform(0.1, 30.0) + rng.standard_normal(d) * rng.uniform(0, 50.0)
+        if case % 5 == 0:
+            Y[rng.integers(0, n, n // 3)] = Y[rng.integers(0, n, n // 3)]          # exact duplicates
+        if case % 7 == 3:
+            Y = np.round(Y)                                                         # a lattice: ties at every distance
+        monkeypatch.setenv("MCE_SYM_SEED_ROWS", str(int(rng.integers(64, 16384))))
+        monkeypatch.setenv("MCE_SYM_SEED_SHARE", "2")
+        monkeypatch.setenv("MCE_SYM_SEED_MODE", str(int(rng.integers(0, 3))))
+        monkeypatch.setenv("MCE_SYM_PANEL", str(int(rng.choice([1, 2, 3, 7, 96]))))
+        monkeypatch.setenv("MCE_SYM_BUCKET", str(int(rng.choice([1, 2, 8, 200]))))
+        (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(Y, Y, K, self_mode=sm))
+        tag = (case, d, n, K, sm, capi.last_kernel())
+        assert np.array_equal(d0, d1) and np.array_equal(i0, i1), tag
+        pick = np.sort(rng.choice(n, 300, replace=False))
+        od, oi = orc.knn_brute(Y[pick], Y, K, self_mode=0)        # (self modes differ only in the own row's handling: check values)
+        if sm == capi.SELF_NONE:
+            assert np.allclose(d1[pick], od, rtol=DIST_RTOL, atol=0), tag

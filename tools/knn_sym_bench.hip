@@ -85,10 +85,24 @@ int main(int argc, char** argv)
                                         (const int*)nullptr, (const float*)nullptr, 0, dperm, (const int*)nullptr, (const float*)nullptr,
                                         (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr, seed_cfg, sp);
         CK(hipEventRecord(e1));
-        kern<<<nunits, kHThreads, LDS>>>(Yh, nchunk, 1, Xh, qinfo, params, X, X, n, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi,
+        if (!getenv("SYM_REPAIR_ALL")) kern<<<nunits, kHThreads, LDS>>>(Yh, nchunk, 1, Xh, qinfo, params, X, X, n, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi,
                                         (const int*)nullptr, (const float*)nullptr, 0, dperm, (const int*)nullptr, (const float*)nullptr,
                                         (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr, 0, sp);
         CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
+        if (getenv("SYM_REPAIR_ALL")) {      // experiment: the exhaustive column-only sweep over the sorted rows (every block "repaired")
+            std::vector<int> ones(nqblk, 1);
+            CK(hipMemcpy(sp.bucket_flag, ones.data(), 4 * nqblk, hipMemcpyHostToDevice));
+            auto krep = knn_f16_kernel<KST, KCAP, false, false, 3>;
+            CK(hipFuncSetAttribute((const void*)krep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+            hipEvent_t e3; CK(hipEventCreate(&e3));
+            CK(hipEventRecord(e2));
+            krep<<<nqblk, kHThreads, LDS>>>(Yh, nchunk, 1, Xh, qinfo, params, X, X, n, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi,
+                                            (const int*)nullptr, (const float*)nullptr, 0, dperm, (const int*)nullptr, (const float*)nullptr,
+                                            (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr, 0, sp);
+            CK(hipEventRecord(e3)); CK(hipEventSynchronize(e3));
+            float ms3; CK(hipEventElapsedTime(&ms3, e2, e3));
+            printf("exhaustive column-only sweep over the sorted rows, thresholds from the prepass: %.2f ms\n", ms3);
+        }
         float ms1, ms2; CK(hipEventElapsedTime(&ms1, e0, e1)); CK(hipEventElapsedTime(&ms2, e1, e2));
          printf("panel=%d units=%d ", panel, nunits); printf("D=%d KST=%d KCAP=%d K=%d n=%lld grid=%d seed=%dx%d sorted=%d: prepass %.2f ms  sweep %.2f ms\n", D, KST, KCAP, KSEL, (long long)n, nqblk,
                seed_cfg & 0xffff, seed_cfg >> 16, sorted, ms1, ms2);
