@@ -581,9 +581,9 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             }
             p.sym_active = true;
             p.L = 1;
-            snprintf(g_last_kernel, sizeof(g_last_kernel), "%s symmetric grid=%d block=%d lds=%zu qt=%d ct=%d panel=%d seed=%dx%d bucket=%d", p.vh->name,
+            snprintf(g_last_kernel, sizeof(g_last_kernel), "%s symmetric grid=%d block=%d lds=%zu qt=%d ct=%d panel=%d seed=%dx%d/%d bucket=%d", p.vh->name,
                      mce::sym_unit_count(p.nqblk, mce::kHWaves * mce::kHQT, a.sym.panel * p.CT, (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1)),
-                     mce::kHThreads, p.vh->lds_bytes_sym, p.QT, p.CT, a.sym.panel, seed_used & 0xffff, seed_used >> 16, p.sl.cap);
+                     mce::kHThreads, p.vh->lds_bytes_sym, p.QT, p.CT, a.sym.panel, seed_used & 0xffff, (seed_used >> 16) & 0xfff, (seed_used >> 28) & 3, p.sl.cap);
             return MCE_OK;
         }
         int rc = prof_begin();
