@@ -262,7 +262,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
 #if MCE_STATS
     const long long t_kernel0 = clock64();
     long long st_drains = 0, st_enq = 0, st_steps = 0, st_events = 0, st_tA = 0, st_tD = 0, st_tB = 0;
-    long long st_tR = 0, st_tE = 0, st_rtest = 0, st_rapp = 0, st_cas = 0, st_linked = 0, st_tP = 0;      // SYM: phase R / event cycles, row-side tested / appended / slot replacements, chain links, publish cycles
+    long long st_tR = 0, st_tE = 0, st_rtest = 0, st_rapp = 0, st_cas = 0, st_linked = 0, st_tP = 0, st_tPro = 0;      // SYM: phase R / event cycles, row-side tested / appended / slot replacements, chain links, publish cycles
 #endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1132,6 +1132,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                 stage_async(c0, 0);
                 rt_next = rt_load(c0, tlo0, thi0);
             }
+#if MCE_STATS
+            st_tPro = clock64() - t_kernel0;
+#endif
             for (int k = 0; k < ntot; ++k) {
                 const int buf = k & 1;
                 if (qcount >= kHDrainTrigger && lane == 0) wvote[buf] = 1;
@@ -1406,8 +1409,14 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
         }
     }
 #undef MCE_SWEEP_CHUNK
+#if MCE_STATS
+    const long long t_epi0 = clock64();
+#endif
     if constexpr (!PRUNE && SYM != 1) process(accB, jbB, rB);
     if constexpr (SYM != 1) drain();
+#if MCE_STATS
+    const long long t_epi1 = clock64();
+#endif
 #if MCE_SEED_CHECK
 #pragma unroll
     for (int nl = 0; nl < kHNL; ++nl) {
@@ -1435,7 +1444,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
         o[4] = (double)st_tA; o[5] = (double)st_tD; o[6] = (double)(clock64() - t_kernel0); o[7] = (double)st_tB;
         if constexpr (SYM >= 2) {      // (the harness sizes `params` for 16 values per wave)
             double* o2 = const_cast<double*>(params) + 16 + ((int64_t)gridDim.x * kHWaves) * 8 + ((int64_t)blockIdx.x * kHWaves + wave) * 8;
-            o2[0] = (double)st_tR; o2[1] = (double)st_tE; o2[2] = (double)st_rtest; o2[3] = (double)st_rapp; o2[4] = (double)st_cas; o2[5] = (double)st_linked; o2[6] = (double)st_tP; o2[7] = 0.0;
+            o2[0] = (double)st_tR; o2[1] = (double)st_tE; o2[2] = (double)st_rtest; o2[3] = (double)st_rapp; o2[4] = (double)st_cas; o2[5] = (double)st_linked; o2[6] = (double)st_tP; o2[7] = (double)st_tPro;
+            o[7] = (double)(t_epi1 - t_epi0);      // (no barrier-wait timer in this mode: the final process + drain instead)
         }
     }
 #endif

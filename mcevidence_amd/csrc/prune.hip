@@ -353,18 +353,30 @@ hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t
 // ---------------------------------------------------------------------------
 namespace {
 
-// key = order-preserving bits of (float)|y - c|^2 (non-negative: the bit pattern itself); padding sorts last
-__global__ __launch_bounds__(kThreads) void norm_key_kernel(const double* __restrict__ Y, int64_t n, int64_t n_pad, int d,
-                                                            const double* __restrict__ center, unsigned* __restrict__ keys,
-                                                            int* __restrict__ vals)
+// key = order-preserving bits of (float)|y - c|^2 (non-negative: the bit pattern itself); padding sorts last.
+// One row per thread, the block's rows staged through LDS: the global reads are contiguous (a thread reading its own
+// row straight from memory strides by D doubles: 0.40 ms at 1M x 27, this 0.1).
+constexpr int kNormRows = 256;
+__global__ __launch_bounds__(kNormRows) void norm_key_kernel(const double* __restrict__ Y, int64_t n, int64_t n_pad, int d,
+                                                             const double* __restrict__ center, unsigned* __restrict__ keys,
+                                                             int* __restrict__ vals)
 {
-    const int64_t pos = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    extern __shared__ double tile[];                 // [kNormRows][d + 1]: the odd stride keeps the row-wise reads off one bank
+    const int64_t r0 = (int64_t)blockIdx.x * kNormRows;
+    const int64_t rows = n - r0 < kNormRows ? (n - r0 > 0 ? n - r0 : 0) : kNormRows;
+    const int ld = d + 1;
+    for (int64_t e = threadIdx.x; e < rows * d; e += kNormRows) {
+        const int r = (int)(e / d), c = (int)(e - (int64_t)r * d);
+        tile[r * ld + c] = Y[r0 * d + e] - center[c];
+    }
+    __syncthreads();
+    const int64_t pos = r0 + threadIdx.x;
     if (pos >= n_pad) return;
     unsigned k = 0xFFFFFFFFu;
     if (pos < n) {
         double s = 0.0;
         for (int i = 0; i < d; ++i) {
-            const double t = Y[pos * d + i] - center[i];
+            const double t = tile[threadIdx.x * ld + i];
             s = fma(t, t, s);
         }
         k = __float_as_uint((float)s);
@@ -409,8 +421,9 @@ hipError_t sym_prepare(const double* dY, int64_t n, int d, const double* center,
     unsigned* keys_b = reinterpret_cast<unsigned*>(ws + L.keys_b);
     int* vals_a = reinterpret_cast<int*>(ws + L.vals_a);
     double* Ys = reinterpret_cast<double*>(ws + L.Ys);
-    const unsigned blocks = (unsigned)((n_pad + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL(norm_key_kernel, dim3(blocks), dim3(kThreads), 0, st, dY, n, n_pad, d, center, keys_a, vals_a);
+    const unsigned blocks = (unsigned)((n_pad + kNormRows - 1) / kNormRows);
+    hipLaunchKernelGGL(norm_key_kernel, dim3(blocks), dim3(kNormRows), (size_t)kNormRows * (d + 1) * sizeof(double), st, dY, n, n_pad, d, center,
+                       keys_a, vals_a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     size_t tb = L.tmp_bytes;

@@ -131,8 +131,8 @@ int main(int argc, char** argv)
             double a[16] = {0}; size_t c = 0;
             for (size_t b = b0; b < b1; ++b) for (int w = 0; w < 8; ++w) { for (int k = 0; k < 8; ++k) { a[k] += hs[(b * 8 + w) * 8 + k]; a[8 + k] += hs[nw * 8 + (b * 8 + w) * 8 + k]; } ++c; }
             for (int k = 0; k < 16; ++k) a[k] /= c;
-            printf("   blocks %4zu..%4zu: kernel %.3g cyc | drains %.1f enq/q %.1f events %.0f | phaseA+R %.3g (R %.3g) drain(all) %.3g events %.3g publish %.3g | row tested/q %.1f appended/q %.1f links/q %.1f\n",
-                   b0, b1, a[6], a[0], a[1] / 64, a[3], a[4], a[8], a[5], a[9], a[14], a[10] / 64, a[11] / 64, a[13] / 64);
+            printf("   units %5zu..%5zu: kernel %.3g cyc (prologue %.3g, final drain %.3g) | drains %.1f enq/q %.1f events %.0f | phaseA+R %.3g (R %.3g) drain(all) %.3g events %.3g publish %.3g | row tested/q %.1f appended/q %.1f links/q %.1f\n",
+                   b0, b1, a[6], a[15], a[7], a[0], a[1] / 64, a[3], a[4], a[8], a[5], a[9], a[14], a[10] / 64, a[11] / 64, a[13] / 64);
         }
     }
 #endif
