@@ -109,6 +109,8 @@ def test_seeded_sweep_is_bit_identical(shape, monkeypatch):
     nq, nr, d, K, same = shape
     _capi.set_search_mode(_capi.MODE_AUTO)
     _capi.set_prune_mode(1)
+    sym_before = _capi.get_sym_mode()
+    _capi.set_sym_mode(_capi.SYM_OFF)                    # (this is about the exhaustive sweep's own seed phase)
     try:
         rng = np.random.default_rng(nq + nr + d)
         Y = rng.standard_normal((nr, d))
@@ -136,6 +138,7 @@ def test_seeded_sweep_is_bit_identical(shape, monkeypatch):
             od = np.sqrt(((X[rows][:, None, :] - Y[keep]) ** 2).sum(-1))
         assert _rel(d0[rows], od) < DIST_RTOL
     finally:
+        _capi.set_sym_mode(sym_before)
         _capi.set_prune_mode(0)
 
 
@@ -146,6 +149,8 @@ def test_trailing_round_split_is_bit_identical(nq, nr, d, K, same, monkeypatch):
     from mcevidence_amd import _capi
     _capi.set_search_mode(_capi.MODE_AUTO)
     _capi.set_prune_mode(1)
+    sym_before = _capi.get_sym_mode()
+    _capi.set_sym_mode(_capi.SYM_OFF)                    # (the exhaustive sweep's trailing round; the symmetric sweep has none)
     try:
         rng = np.random.default_rng(nq + d)
         Y = rng.standard_normal((nr, d))
@@ -171,6 +176,7 @@ def test_trailing_round_split_is_bit_identical(nq, nr, d, K, same, monkeypatch):
             od, oi = orc.knn_brute(X[rows], Y, K)
             assert _rel(out["1"][0][rows], od) < DIST_RTOL and np.array_equal(out["1"][1][rows], oi)
     finally:
+        _capi.set_sym_mode(sym_before)
         _capi.set_prune_mode(0)
 
 
