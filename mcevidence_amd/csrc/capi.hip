@@ -1200,6 +1200,11 @@ struct FeedJob {
     double jac = 0.0;
     std::vector<double> lam;  // eigenvalues of the system that defines J (s1's in 'single' mode)
     std::string err;
+    hipEvent_t upload_ev = nullptr;   // orders the job's stream behind its blocking uploads
+    ~FeedJob() { if (upload_ev) (void)hipEventDestroy(upload_ev); }
+    FeedJob() = default;
+    FeedJob(const FeedJob&) = delete;
+    FeedJob& operator=(const FeedJob&) = delete;
 
     int d() const { return q->d; }
     double* dS1() const { return reinterpret_cast<double*>(dbase + o_S); }
@@ -1257,15 +1262,28 @@ int feed_stage_a(FeedJob& j, hipStream_t st)
     const mce_feed_problem& q = *j.q;
     const int d = q.d;
     const size_t row = (size_t)d * sizeof(double);
-    // Uploads are issued ON the job's stream, so the covariance kernels behind them are ordered after them by the
-    // stream itself (hipStreamNonBlocking streams do not synchronise with the legacy default stream, and the
-    // contract of a blocking hipMemcpy from pageable memory only promises that the SOURCE has been staged on
-    // return).  From pageable memory these calls still return once the source is consumed: the pipeline's
-    // "host uploads group g+1 while the device searches group g" is unchanged.
-    MCE_HIP(hipMemcpy2DAsync(j.dS1(), row, q.S1, (size_t)q.ld1 * sizeof(double), row, (size_t)q.n1, hipMemcpyHostToDevice, st));
-    if (q.S2) MCE_HIP(hipMemcpy2DAsync(j.dS2(), row, q.S2, (size_t)q.ld2 * sizeof(double), row, (size_t)q.n2, hipMemcpyHostToDevice, st));
-    MCE_HIP(hipMemcpyAsync(j.dW(), q.w, (size_t)q.n1 * sizeof(double), hipMemcpyHostToDevice, st));
-    MCE_HIP(hipMemcpyAsync(j.dF(), q.fs, (size_t)q.n1 * sizeof(double), hipMemcpyHostToDevice, st));
+    // Uploads: blocking copies from the caller's pageable arrays (measured faster than hipMemcpyAsync on the job's
+    // non-blocking stream: 300 Planck-sized chains 0.142 vs 0.155 s), followed by an EXPLICIT dependency -- an event
+    // recorded on the stream the copies ran on, waited for by the job's stream -- so the covariance kernels behind them
+    // are ordered after the uploads by the API's rules, not by how this runtime happens to implement a pageable copy
+    // (a blocking hipMemcpy from pageable memory only promises that the SOURCE has been consumed on return, and
+    // hipStreamNonBlocking streams do not synchronise with the legacy default stream).  MCE_FEED_UPLOAD=async: the
+    // copies themselves on the job's stream.
+    static const bool async_upload = [] { const char* e = getenv("MCE_FEED_UPLOAD"); return e && !strcmp(e, "async"); }();
+    if (async_upload || st == nullptr) {
+        MCE_HIP(hipMemcpy2DAsync(j.dS1(), row, q.S1, (size_t)q.ld1 * sizeof(double), row, (size_t)q.n1, hipMemcpyHostToDevice, st));
+        if (q.S2) MCE_HIP(hipMemcpy2DAsync(j.dS2(), row, q.S2, (size_t)q.ld2 * sizeof(double), row, (size_t)q.n2, hipMemcpyHostToDevice, st));
+        MCE_HIP(hipMemcpyAsync(j.dW(), q.w, (size_t)q.n1 * sizeof(double), hipMemcpyHostToDevice, st));
+        MCE_HIP(hipMemcpyAsync(j.dF(), q.fs, (size_t)q.n1 * sizeof(double), hipMemcpyHostToDevice, st));
+    } else {
+        MCE_HIP(hipMemcpy2D(j.dS1(), row, q.S1, (size_t)q.ld1 * sizeof(double), row, (size_t)q.n1, hipMemcpyHostToDevice));
+        if (q.S2) MCE_HIP(hipMemcpy2D(j.dS2(), row, q.S2, (size_t)q.ld2 * sizeof(double), row, (size_t)q.n2, hipMemcpyHostToDevice));
+        MCE_HIP(hipMemcpy(j.dW(), q.w, (size_t)q.n1 * sizeof(double), hipMemcpyHostToDevice));
+        MCE_HIP(hipMemcpy(j.dF(), q.fs, (size_t)q.n1 * sizeof(double), hipMemcpyHostToDevice));
+        if (!j.upload_ev) MCE_HIP(hipEventCreateWithFlags(&j.upload_ev, hipEventDisableTiming));
+        MCE_HIP(hipEventRecord(j.upload_ev, nullptr));
+        MCE_HIP(hipStreamWaitEvent(st, j.upload_ev, 0));
+    }
     // "all": one eigen-system from s1 U s2; "single": s1's own, and s2's own for s2 (J stays s1's)
     int rc = launch_covariance(j.dS1(), q.cov_mode == 0 ? j.ntot : q.n1, d, j.d_part(), j.d_mean3(), j.d_cov(), st);
     if (rc != MCE_OK) return rc;
