@@ -273,17 +273,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
     // SYM == 2: workgroup = UNIT (panel p of the reference rows, query block a), numbered panel by panel
     // (sym_unit_count): the units running at the same time stream the same few MB of packed rows through L2
     int sym_a = 0, sym_p = 0;
-    if constexpr (SYM == 2) {
-        constexpr int TPB_ = kHWaves * kHQT;                        // 32-row tiles per query block
-        const int tpp = sym.panel * f16_chunk_tiles(KST);          // tiles per panel
-        int u = (int)blockIdx.x;
-        for (;; ++sym_p) {
-            const int amin = (int)(((int64_t)sym_p * tpp) / TPB_);  // blocks a >= amin reach into panel p
-            const int cnt = nqblk - amin;
-            if (u < cnt) { sym_a = amin + u; break; }
-            u -= cnt;
-        }
-    }
+    if constexpr (SYM == 2) sym_unit_decode((int)blockIdx.x, nqblk, kHWaves * kHQT, sym.panel * f16_chunk_tiles(KST), sym_p, sym_a);
     const int qblk = PRUNE ? border[qblk0 + (int)(blockIdx.x / kHWaves) * qblk_stride] : (SYM == 2 ? sym_a : (int)(blockIdx.x % nqblk));
     const int split = PRUNE ? 0 : (SYM >= 2 ? 0 : (int)(blockIdx.x / nqblk));
 
@@ -1099,9 +1089,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
             // of an XCD), and the units are of equal length, so the launch ends with at most one unit of tail instead
             // of the longest block's.  (One workgroup per block, 0..a in one go: blocks of different length drift apart,
             // 79 GB through the fabric per search at 1M x 27 instead of 17, and ~13 % of tail.)
-            const int hi_a = TPB * (qblk + 1) < Tre ? TPB * (qblk + 1) : Tre;
-            const int lo = SYM == 2 ? sym_p * sym.panel * CT : 0;
-            const int hi = SYM == 2 ? ((sym_p + 1) * sym.panel * CT < hi_a ? (sym_p + 1) * sym.panel * CT : hi_a) : Tre;
+            int lo = 0, hi = Tre;
+            if constexpr (SYM == 2) sym_unit_tiles(sym_p, qblk, TPB, sym.panel * CT, Tre, lo, hi);
             const int cfirst = lo / CT;
             const int ntot = hi > lo ? (hi - 1) / CT - cfirst + 1 : 0;
             // k-th chunk of the sequence: its number and its tiles [tlo, thi)

@@ -19,14 +19,37 @@ struct SymParams {
     int panel = 0;                         // chunks per panel of reference rows (a unit = one block's queries x one panel)
 };
 
+#if defined(__HIPCC__)
+#define MCE_HD __host__ __device__
+#else
+#define MCE_HD
+#endif
+
 // Units of the symmetric sweep: unit = (panel p, block a) for every block whose range of tiles [0, tpb (a + 1)) reaches into
-// panel p = tiles [p tpp, (p + 1) tpp), numbered panel by panel, blocks ascending (the kernel decodes with the same loop).
-// ntiles: 32-row tiles that hold reference rows.
-inline int sym_unit_count(int nqblk, int tpb, int tpp, int ntiles)
+// panel p = tiles [p tpp, (p + 1) tpp), numbered panel by panel, blocks ascending.  ntiles: 32-row tiles that hold
+// reference rows (the ranges are clipped there).  tests/native/sym_units_check.cpp checks the pair of functions.
+MCE_HD inline int sym_unit_count(int nqblk, int tpb, int tpp, int ntiles)
 {
     int total = 0;
     for (int p = 0; (int64_t)p * tpp < ntiles; ++p) total += nqblk - (int)(((int64_t)p * tpp) / tpb);
     return total;
+}
+// unit number -> (panel, block)
+MCE_HD inline void sym_unit_decode(int u, int nqblk, int tpb, int tpp, int& p, int& a)
+{
+    for (p = 0;; ++p) {
+        const int amin = (int)(((int64_t)p * tpp) / tpb);      // blocks a >= amin reach into panel p
+        const int cnt = nqblk - amin;
+        if (u < cnt) { a = amin + u; return; }
+        u -= cnt;
+    }
+}
+// tiles [lo, hi) of unit (p, a)
+MCE_HD inline void sym_unit_tiles(int p, int a, int tpb, int tpp, int ntiles, int& lo, int& hi)
+{
+    const int hi_a = tpb * (a + 1) < ntiles ? tpb * (a + 1) : ntiles;
+    lo = p * tpp;
+    hi = (p + 1) * tpp < hi_a ? (p + 1) * tpp : hi_a;
 }
 
 }  // namespace mce

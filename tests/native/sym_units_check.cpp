@@ -1,0 +1,45 @@
+// sym_units_check.cpp -- CPU check of the symmetric sweep's unit enumeration (mcevidence_amd/csrc/sym_types.hpp):
+// every (panel, block) whose ranges intersect appears exactly once, in panel-major order; the tile ranges of a
+// block's units tile its range [0, min(tpb (a+1), ntiles)) without gaps or overlaps; the count is the grid size.
+// Build + run: g++ -std=c++17 -O1 -I mcevidence_amd/csrc tests/native/sym_units_check.cpp -o /tmp/sym_units_check && /tmp/sym_units_check
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "sym_types.hpp"
+
+int main()
+{
+    long checked = 0;
+    const int tpbs[] = {16};
+    for (int tpb : tpbs)
+        for (int nqblk = 1; nqblk <= 70; nqblk += (nqblk < 12 ? 1 : 7))
+            for (int tpp : {12, 16, 24, 48, 96, 100, 2304})
+                for (int cut = 0; cut < 3; ++cut) {
+                    // rows end somewhere inside the last block (even tile count, as the kernel rounds it)
+                    int ntiles = tpb * nqblk - (cut == 0 ? 0 : cut == 1 ? 2 : tpb - 2);
+                    if (ntiles <= tpb * (nqblk - 1)) ntiles = tpb * (nqblk - 1) + 2;
+                    const int n = mce::sym_unit_count(nqblk, tpb, tpp, ntiles);
+                    std::vector<int> next_lo(nqblk, 0), units_of(nqblk, 0);
+                    int last_p = 0, last_a = -1;
+                    for (int u = 0; u < n; ++u) {
+                        int p, a, lo, hi;
+                        mce::sym_unit_decode(u, nqblk, tpb, tpp, p, a);
+                        mce::sym_unit_tiles(p, a, tpb, tpp, ntiles, lo, hi);
+                        if (a < 0 || a >= nqblk || p < 0) { printf("bad unit %d -> (%d,%d)\n", u, p, a); return 1; }
+                        if (p < last_p || (p == last_p && a <= last_a)) { printf("order broken at unit %d\n", u); return 1; }
+                        last_p = p; last_a = a;
+                        if (hi <= lo) { printf("empty unit %d (%d,%d) [%d,%d) nqblk=%d tpp=%d ntiles=%d\n", u, p, a, lo, hi, nqblk, tpp, ntiles); return 1; }
+                        if (lo != next_lo[a]) { printf("gap/overlap: block %d expects lo %d, unit %d has %d\n", a, next_lo[a], u, lo); return 1; }
+                        if (units_of[a] != p) { printf("block %d: unit number %d is panel %d\n", a, units_of[a], p); return 1; }   // the hand-over counter
+                        next_lo[a] = hi; units_of[a] += 1;
+                        ++checked;
+                    }
+                    for (int a = 0; a < nqblk; ++a) {
+                        const int want = tpb * (a + 1) < ntiles ? tpb * (a + 1) : ntiles;
+                        if (next_lo[a] != want) { printf("block %d covered to %d, expected %d (nqblk=%d tpp=%d ntiles=%d)\n", a, next_lo[a], want, nqblk, tpp, ntiles); return 1; }
+                    }
+                }
+    printf("ok %ld units\n", checked);
+    return 0;
+}

@@ -114,3 +114,16 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 txt = open(os.path.join(root, f)).read()
                 assert "oracle" not in txt.lower(), "%s mentions the oracle" % f
+
+
+def test_symmetric_sweep_unit_enumeration(tmp_path):
+    """the symmetric sweep's workgroups are numbered panel by panel (mcevidence_amd/csrc/sym_types.hpp); host and
+    kernel share the decode: every (panel, block) once, a block's units tile its rows without gaps, its p-th unit is
+    panel p (the list hand-over counter), the count is the grid size -- checked on the CPU, with UBSan"""
+    import subprocess
+    exe = str(tmp_path / "sym_units_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fsanitize=undefined", "-fno-sanitize-recover=all",
+                           "-I", os.path.join(REPO, "mcevidence_amd", "csrc"),
+                           os.path.join(REPO, "tests", "native", "sym_units_check.cpp"), "-o", exe])
+    out = subprocess.check_output([exe]).decode()
+    assert out.startswith("ok ")
