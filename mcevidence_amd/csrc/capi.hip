@@ -1263,7 +1263,7 @@ int feed_stage_a(FeedJob& j, hipStream_t st)
     const int d = q.d;
     const size_t row = (size_t)d * sizeof(double);
     // Uploads: blocking copies from the caller's pageable arrays (measured faster than hipMemcpyAsync on the job's
-    // non-blocking stream: 300 Planck-sized chains 0.142 vs 0.155 s), followed by an EXPLICIT dependency -- an event
+    // non-blocking stream: 300 Planck-sized chains 0.131 vs 0.153 s), followed by an EXPLICIT dependency -- an event
     // recorded on the stream the copies ran on, waited for by the job's stream -- so the covariance kernels behind them
     // are ordered after the uploads by the API's rules, not by how this runtime happens to implement a pageable copy
     // (a blocking hipMemcpy from pageable memory only promises that the SOURCE has been consumed on return, and
