@@ -595,6 +595,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                 const int oj = ok ? rperm[j] : -1;
                 const int jb = j / QPB;
                 bool rs = ok && SYM == 2 && jb != qblk;
+#if defined(MCE_SYM_ABL) && (MCE_SYM_ABL == 3 || MCE_SYM_ABL == 5)
+                rs = false;                  // ablation: no row-side bookkeeping at all (results invalid)
+#endif
 #if MCE_STATS
                 st_rtest += __builtin_popcountll(__ballot(rs));
 #endif
@@ -670,7 +673,12 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
 #if MCE_STATS
         const long long t_p0 = clock64();
 #endif
+#if defined(MCE_SYM_ABL) && (MCE_SYM_ABL == 4 || MCE_SYM_ABL == 5)
+        if constexpr (SYM >= 2) { sthr[lane] = thr_own[0]; seed_thr[0] = thr_own[0]; }      // ablation: nothing published (results invalid)
+        if constexpr (false) {
+#else
         if constexpr (SYM >= 2) {
+#endif
             // publish: thr[q] takes this list's K-th bound and gives back what the row side knows (the K-th of q's
             // slots); the row-side gate constants follow, and the maximum over each 32-row tile (= half a wave)
             const int64_t q = qwave0 + lane;

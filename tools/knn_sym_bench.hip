@@ -76,7 +76,9 @@ int main(int argc, char** argv)
     CK(hipFuncSetAttribute((const void*)kpre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
     hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
-    const int seed_cfg = f16_seed_cfg(nchunk, CT, KSEL + 1, seed_rows, 8, MCE_H_SEED_TG);
+    const int seed_mode = getenv("SEED_MODE") ? atoi(getenv("SEED_MODE")) : (KST >= 2 ? 1 : 0);      // as capi.hip: kSymSeedMode
+    const int seed_cfg0 = f16_seed_cfg(nchunk, CT, KSEL + 1, seed_rows, 8, MCE_H_SEED_TG);
+    const int seed_cfg = seed_cfg0 ? (seed_cfg0 | (seed_mode << 28)) : 0;
     for (int r = 0; r < reps; ++r) {
         CK(hipMemset(sp.bucket_cnt, 0, 12 * nqblk));
         CK(hipMemset((char*)params + 128, 0, pbytes - 128));
@@ -105,7 +107,7 @@ int main(int argc, char** argv)
         }
         float ms1, ms2; CK(hipEventElapsedTime(&ms1, e0, e1)); CK(hipEventElapsedTime(&ms2, e1, e2));
          printf("panel=%d units=%d ", panel, nunits); printf("D=%d KST=%d KCAP=%d K=%d n=%lld grid=%d seed=%dx%d sorted=%d: prepass %.2f ms  sweep %.2f ms\n", D, KST, KCAP, KSEL, (long long)n, nqblk,
-               seed_cfg & 0xffff, seed_cfg >> 16, sorted, ms1, ms2);
+               seed_cfg & 0xffff, (seed_cfg >> 16) & 0xfff, sorted, ms1, ms2);
     }
     {
         std::vector<int> cnt(2 * nqblk);
