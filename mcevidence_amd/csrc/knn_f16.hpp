@@ -103,6 +103,7 @@ __host__ __device__ constexpr int f16_prune_trigger(int KCAP) { return KCAP <= M
 constexpr int kHQueue = MCE_H_QUEUE;          // candidate queue entries per wave (16 B each in LDS)
 constexpr int kHDrainTrigger = MCE_H_TRIGGER;    // a wave with this many queued candidates asks the workgroup to drain
 constexpr int kHRelBits = MCE_H_GEOM == 1 ? 25 : 26;   // queue entry = query-local (6|7 bits) << kHRelBits | row - first row of the split
+constexpr int kHSymRowBits = kHRelBits - 1;            // symmetric sweep: the row field's top bit says "this lane passed the ROW gate"
 constexpr double kHTargetRadius = 200.0;
 constexpr int kPruneDims = 15;                // pruned walk: largest d (KST = 1)
 
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                 if (valid) {
                     const unsigned ent = (unsigned)wq[e];
                     ql = (int)(ent >> kHRelBits);
-                    j = jsplit0 + (int)(ent & ((1u << kHRelBits) - 1u));
+                    j = jsplit0 + (int)(ent & ((1u << (SYM >= 2 ? kHSymRowBits : kHRelBits)) - 1u));
                 }
                 qlp[u] = ql;
                 const int64_t q = qwave0 + ql;
@@ -568,7 +569,11 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                             if (nb < ob) {
                                 const unsigned rb = __float_as_uint(sym_row_gate(nk, qinfo[2 * (int64_t)row], params, KST));
                                 const unsigned orb = __hip_atomic_fetch_min(sym.rrow + row, rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(MCE_SYM_ABL) && MCE_SYM_ABL == 6
+                                if (false) {
+#else
                                 if (rb < orb) {
+#endif
                                     // the tile's largest R_j, from a snapshot (each value >= its current one): safe to store
                                     const unsigned* const rt = sym.rrow + (int64_t)(row >> 5) * 32;
                                     unsigned m = 0;
@@ -589,12 +594,13 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                 const bool valid = e < qcount;
                 const unsigned ent = valid ? (unsigned)wq[e] : 0u;
                 const int ql = (int)(ent >> kHRelBits);
-                const int j = jsplit0 + (int)(ent & ((1u << kHRelBits) - 1u));
+                const int j = jsplit0 + (int)(ent & ((1u << kHSymRowBits) - 1u));
+                const bool rowflag = (ent >> kHSymRowBits) & 1u;        // the lane passed the row gate on this tile: only then can the pair matter to row j
                 const double d2 = valid ? wqd[e] : -1.0;
                 const bool ok = valid && d2 >= 0.0;
                 const int oj = ok ? rperm[j] : -1;
                 const int jb = j / QPB;
-                bool rs = ok && SYM == 2 && jb != qblk;
+                bool rs = ok && SYM == 2 && jb != qblk && rowflag;
 #if defined(MCE_SYM_ABL) && (MCE_SYM_ABL == 3 || MCE_SYM_ABL == 5)
                 rs = false;                  // ablation: no row-side bookkeeping at all (results invalid)
 #endif
@@ -738,6 +744,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
 #endif
         bool passq[QT];
         bool pass = false;
+        float mm[QT];                          // the lane's smallest accumulator (SYM: read again in the event path)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             const v16f& c = acc[qt];
@@ -748,8 +755,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
             float m4 = min3f(c[12], c[13], c[14]);
             m0 = min3f(m0, m1, m2);
             m3 = min3f(m3, m4, c[15]);
-            if constexpr (SYM == 2) passq[qt] = min3f(m0, m3, m3) <= fmaxf(G[qt], Rt + cR[qt]);      // either side
-            else passq[qt] = min3f(m0, m3, m3) <= G[qt];
+            mm[qt] = min3f(m0, m3, m3);
+            if constexpr (SYM == 2) passq[qt] = mm[qt] <= fmaxf(G[qt], Rt + cR[qt]);      // either side
+            else passq[qt] = mm[qt] <= G[qt];
             pass |= passq[qt];
         }
         if (__any(pass)) {
@@ -774,7 +782,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                         const int r = __builtin_ctz(pm);
                         pm &= pm - 1;
                         const int slot = qcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                        const unsigned rel = (unsigned)(jrel0 + (r & 3) + 8 * (r >> 2));
+                        unsigned rel = (unsigned)(jrel0 + (r & 3) + 8 * (r >> 2));
+                        if constexpr (SYM == 2) rel |= (mm[qt] <= Rt + cR[qt]) ? (1u << kHSymRowBits) : 0u;      // (lane-level: most events are column-side only)
                         wq[slot] = (int)(((unsigned)(qt * 32 + (lane & 31)) << kHRelBits) | rel);
                     }
                     qcount += __builtin_popcountll(m);
