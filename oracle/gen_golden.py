@@ -15,7 +15,7 @@ SURVEY.md section 8c) and records, for seeded synthetic chains made by
   * a few sampled rows of the whitened samples and of DkNN.
 
 Outputs are data only (JSON/NPZ under tests/golden/).  No reference source is
-copied.  Usage:  python oracle/gen_golden.py [--big] [--only NAME]
+copied.  Usage:  python oracle/gen_golden.py [--small] [--medium] [--big] [--sym] [--host]
 """
 from __future__ import annotations
 
@@ -179,6 +179,15 @@ BIG_CASES = [
 ]
 
 
+# medium sizes at which the symmetric sweep is the automatic choice: from 131 k rows at two 16-wide
+# k-steps (d = 16..31), from 65 k at three (d = 32..47)
+SYM_CASES = [
+    ("auto_n135000_d27_k10_corr", dict(seed=21, n=135_000, d=27, cov="corr"), dict(kmax=10), {}, None),
+    ("auto_n70000_d45_k6", dict(seed=22, n=70_000, d=45), dict(kmax=6), {}, None),
+    ("auto_n140000_d20_k5_corr_intw", dict(seed=23, n=140_000, d=20, cov="corr", weights="int"), dict(kmax=5), {}, None),
+]
+
+
 def gen_inmemory(ref, cases, tag):
     out_js, out_npz = [], {}
     for name, ckw, mkw, ekw, sseed in cases:
@@ -301,6 +310,7 @@ def main():
     ap.add_argument("--small", action="store_true")
     ap.add_argument("--medium", action="store_true")
     ap.add_argument("--big", action="store_true")
+    ap.add_argument("--sym", action="store_true")
     ap.add_argument("--host", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
@@ -313,6 +323,8 @@ def main():
         gen_inmemory(ref, MEDIUM_CASES, "medium")
     if a.big:
         gen_inmemory(ref, BIG_CASES, "big")
+    if a.sym:
+        gen_inmemory(ref, SYM_CASES, "sym")
     if a.host:
         gen_host_pins(ref)
 

@@ -25,7 +25,7 @@ DIST_RTOL = 1e-10
 
 def load_golden():
     out = {}
-    for tag in ("small", "medium", "big"):
+    for tag in ("small", "medium", "big", "sym"):
         jp = os.path.join(GOLD, "evidence_%s.json" % tag)
         if not os.path.exists(jp):
             continue

@@ -218,3 +218,34 @@ def test_random_shapes_with_random_settings(sym, monkeypatch):
         od, oi = orc.knn_brute(Y[pick], Y, K, self_mode=0)        # (self modes differ only in the own row's handling: check values)
         if sm == capi.SELF_NONE:
             assert np.allclose(d1[pick], od, rtol=DIST_RTOL, atol=0), tag
+
+
+SYM_GOLD = [n for n in sorted(G) if G[n]["tag"] == "sym"]
+
+
+@pytest.mark.parametrize("name", SYM_GOLD)
+def test_reference_goldens_in_the_automatic_range(name):
+    """golden vectors recorded from the reference itself (oracle/gen_golden.py --sym) at sizes where the symmetric
+    sweep is the AUTOMATIC choice: the class reproduces the reference's ln E, and the search the reference's
+    sampled DkNN rows (what sklearn returned inside the reference's evidence())"""
+    from mcevidence_amd import _capi as capi
+    import mcevidence_amd as pkg
+    capi.set_search_mode(capi.MODE_AUTO)
+    capi.set_prune_mode(capi.PRUNE_AUTO)
+    capi.set_sym_mode(capi.SYM_AUTO)
+    case = G[name]
+    chain = chain_of(case)
+    mce = pkg.MCEvidence([chain], verbose=0, **case["mce"])
+    lnE = mce.evidence(**case["ev"])
+    assert "symmetric" in capi.last_kernel(), capi.last_kernel()
+    assert np.allclose(lnE, case["lnE"], rtol=0, atol=LNE_TOL), (lnE, case["lnE"])
+    # the reference's whitened rows and neighbour distances at the sampled rows
+    a = case["arrays"]
+    theta = chain[:, 2:2 + case["ndim"]]
+    cs = orc.covariance_eig(theta)
+    X = np.ascontiguousarray(orc.whiten(theta, cs["eVec"], cs["eVal"]))
+    assert np.allclose(X[a["rows"]], a["X_rows"], rtol=1e-11, atol=1e-12)
+    kmax = case["kmax"]
+    d, _ = capi.knn(X, X, kmax, self_mode=capi.SELF_EXCLUDE)
+    assert "symmetric" in capi.last_kernel()
+    assert np.allclose(d[a["rows"]][:, :kmax - 1], a["DkNN_rows"][:, 1:kmax], rtol=DIST_RTOL, atol=0)
