@@ -40,7 +40,7 @@ def _data(n, d, seed):
     return rng.standard_normal((n, d)) @ (np.eye(d) + 0.3 * rng.standard_normal((d, d))) + 3.0
 
 
-@pytest.mark.parametrize("n,d,K", [(1025, 3, 2), (2048, 6, 4), (5000, 1, 3), (7777, 27, 9), (20000, 6, 10), (33333, 15, 16), (25000, 16, 4),
+@pytest.mark.parametrize("n,d,K", [(513, 4, 3), (700, 27, 9), (1024, 2, 1), (1025, 3, 2), (2048, 6, 4), (5000, 1, 3), (7777, 27, 9), (20000, 6, 10), (33333, 15, 16), (25000, 16, 4),
                                    (12345, 31, 12), (9000, 40, 5), (6000, 63, 8), (70001, 27, 10), (150000, 6, 4)])
 def test_symmetric_sweep_is_bit_identical(sym, n, d, K):
     """all three self modes; sizes that are not whole blocks, whole chunks or even tile counts; every k-step count"""
