@@ -86,6 +86,15 @@ constexpr int kSymAutoMinBlocks[5] = {0, 512, 256, 128, 128};
 // spread / nearest / half: 1M x 3 42.6 / 152.6 / 45.2; 1M x 6 36.1 / 50.1 / 37.1; 1M x 10 34.4 / 36.8 / 34.8; 1M x 15
 // 33.8 / 33.4 / 33.2; 1M x 20 50.2 / 45.9 / 46.8; 1M x 27 48.8 / 44.4 / 45.5 (tools/sym_seedmode.py)
 constexpr int kSymSeedMode[5] = {0, 0, 1, 1, 1};
+// The planner sees sizes only; the host-pointer entry points see the pointers.  They say here whether queries and
+// references are one buffer, so that cross evidence with equal halves (split = True, s1frac = 0.5: nq == nr) does not
+// reserve ~1 GB of scratch it can never use.  -1: unknown (the *_dev entry points: the workspace query must cover both).
+thread_local int g_same_set_hint = -1;
+struct SameSetHint {
+    int prev;
+    explicit SameSetHint(bool same) : prev(g_same_set_hint) { g_same_set_hint = same ? 1 : 0; }
+    ~SameSetHint() { g_same_set_hint = prev; }
+};
 constexpr int kSymPanelChunks = 96;           // 48 KB chunks per panel of reference rows (knn_f16.hpp, units): 1M x 27: 24 -> 52.5 ms, 48 -> 46.5, 96 -> 45.7, 192 -> 46.2
 // bucket entries per row: a row receives ~K ln(N/2 / seed rows) + K row-side candidates; MCE_SYM_BUCKET overrides (tests)
 int sym_bucket_per_row(int K)
@@ -384,6 +393,7 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     if (f16 && !p.twopass && !p.prune && nq == nr && p.vh->launch_sym && p.nqblk >= 2 && p.nrow_pad <= ((int64_t)1 << mce::kHSymRowBits)) {
         const int sm = sym_mode();
         p.sym = sm == 2 || (sm == 0 && p.nqblk >= kSymAutoMinBlocks[p.KST] * ((p.KST == 1 && p.KCAP == 16) ? 2 : 1));     // (1M x 15, K = 16: 62.3 vs 62.7 ms)
+        if (g_same_set_hint == 0) p.sym = false;
     }
     const int l_alloc = p.L;
     p.off_pd = off;
@@ -1003,6 +1013,7 @@ int mce_knn_f64(const double* X, int64_t nq, const double* Y, int64_t nr, int32_
                 int32_t self_mode, int64_t self_offset, double* dist, int64_t* idx, int32_t device)
 {
     if (!X || !Y || !dist) return fail(MCE_ERR_INVALID, "null pointer argument");
+    SameSetHint hint(X == Y && nq == nr && self_offset == 0);
     Plan p;
     int rc = make_plan(nq, nr, d, K, self_mode, p);
     if (rc != MCE_OK) return rc;
@@ -1141,11 +1152,12 @@ int fused_on_device(int device, const double* X, int64_t q_lo, int64_t q_hi, con
     const int K = kmax - k0;
     int rc = select_device(device);
     if (rc != MCE_OK) return rc;
+    const double* Xs = X + q_lo * (int64_t)d;
+    SameSetHint hint(Xs == Y && nq == nr && self_offset + q_lo == 0);
     Plan p;
     rc = make_plan(nq, nr, d, K, k0 == 1 ? MCE_SELF_EXCLUDE : MCE_SELF_NONE, p);
     if (rc != MCE_OK) return rc;
     const size_t wsb = p.total + dotp_ws_bytes(nq, kmax);
-    const double* Xs = X + q_lo * (int64_t)d;
     const bool inside = Xs >= Y && Xs + (size_t)nq * d <= Y + (size_t)nr * d && (Xs - Y) % d == 0;     // as in mce_knn_f64
     DevBuf dX, dY, dW, dF, dO, dD, ws;
     if (!inside) MCE_HIP(dX.alloc((size_t)nq * d * sizeof(double)));
@@ -1240,6 +1252,7 @@ int feed_plan(FeedJob& j)
     if (q.kmax <= j.k0) return fail(MCE_ERR_INVALID, "kmax=%d must exceed k0=%d", q.kmax, j.k0);
     j.nr = q.S2 ? q.n2 : q.n1;
     j.ntot = q.n1 + (q.S2 ? q.n2 : 0);
+    SameSetHint hint(q.S2 == nullptr);          // auto evidence: one set; cross evidence: never the symmetric sweep
     int rc = make_plan(q.n1, j.nr, q.d, j.K, j.k0 == 1 ? MCE_SELF_EXCLUDE : MCE_SELF_NONE, j.plan);
     if (rc != MCE_OK) return rc;
     j.wsb = j.plan.total + dotp_ws_bytes(q.n1, q.kmax);
@@ -1351,6 +1364,7 @@ int feed_stage_c(FeedJob& j, hipStream_t st)
         rc = feed_whiten(j, 0, j.dS1(), q.cov_mode == 0 ? j.ntot : q.n1, st);
     }
     if (rc != MCE_OK) return rc;
+    SameSetHint hint(q.S2 == nullptr);          // as in feed_plan: the workspace was sized with it
     rc = mce_knn_dotp_f64_dev(j.dS1(), q.n1, q.S2 ? j.dS2() : j.dS1(), j.nr, q.d, q.kmax, j.k0, 0, j.dW(), j.dF(), j.dO(), nullptr,
                               j.ws(), j.wsb, st);
     if (rc != MCE_OK) return rc;

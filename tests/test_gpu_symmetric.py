@@ -249,3 +249,4 @@ def test_reference_goldens_in_the_automatic_range(name):
     d, _ = capi.knn(X, X, kmax, self_mode=capi.SELF_EXCLUDE)
     assert "symmetric" in capi.last_kernel()
     assert np.allclose(d[a["rows"]][:, :kmax - 1], a["DkNN_rows"][:, 1:kmax], rtol=DIST_RTOL, atol=0)
+
