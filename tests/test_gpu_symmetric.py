@@ -250,3 +250,34 @@ def test_reference_goldens_in_the_automatic_range(name):
     assert "symmetric" in capi.last_kernel()
     assert np.allclose(d[a["rows"]][:, :kmax - 1], a["DkNN_rows"][:, 1:kmax], rtol=DIST_RTOL, atol=0)
 
+
+
+@pytest.mark.parametrize("d", [5, 20])
+def test_neighbours_that_only_the_row_side_can_deliver(sym, d):
+    """isolated points near the mean come first in the sorted order; their K nearest all lie in tight clusters far
+    out, which later blocks handle -- and those blocks' own bounds are tiny (their neighbours are inside the cluster),
+    so the pairs survive only because the streamed rows' (large) bounds are honoured: checked against the exact CPU search"""
+    capi = sym
+    rng = np.random.default_rng(77 + d)
+    nclu, per = 60, 400
+    centres = rng.standard_normal((nclu, d))
+    centres *= (8.0 + 4.0 * rng.random((nclu, 1))) / np.linalg.norm(centres, axis=1, keepdims=True)     # shell of radius 8..12
+    clusters = (centres[:, None, :] + 1e-3 * rng.standard_normal((nclu, per, d))).reshape(-1, d)
+    lonely = 0.5 * rng.standard_normal((600, d))                                                       # near the mean, far from every cluster
+    Y = np.concatenate([clusters, lonely])
+    Y = np.ascontiguousarray(Y[rng.permutation(len(Y))])
+    K = 6
+    (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE))
+    assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+    od, oi = orc.knn_brute(Y, Y, K, self_mode=2)
+    assert np.allclose(d1, od, rtol=DIST_RTOL, atol=0) and np.mean(i1 == oi) > 0.999
+    # and the other way round: one tight cluster at the mean, isolated points far out
+    core = 1e-3 * rng.standard_normal((20000, d))
+    far = rng.standard_normal((300, d))
+    far *= (20.0 + 10.0 * rng.random((300, 1))) / np.linalg.norm(far, axis=1, keepdims=True)
+    Z = np.concatenate([core, far])
+    Z = np.ascontiguousarray(Z[rng.permutation(len(Z))])
+    (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(Z, Z, K, self_mode=capi.SELF_EXCLUDE))
+    assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+    od, oi = orc.knn_brute(Z[-2000:], Z, K, self_mode=2, self_offset=len(Z) - 2000)
+    assert np.allclose(d1[-2000:], od, rtol=DIST_RTOL, atol=0)
