@@ -195,7 +195,7 @@ int mce_get_prune_mode(void);
  * the rows are sorted by distance from the mean, a prepass bounds every row's K-th distance, every block of
  * 512 rows sweeps only the blocks before it, and each tile is gated for the streamed rows
  * too; their candidates are merged into the lists afterwards.  Same neighbours, distances and tie-breaks as
- * the exhaustive search.  0 (default): where it was measured faster and pruning does not apply -- from 262 k rows
+ * the exhaustive search.  0 (default): where it was measured faster and pruning does not apply -- from 786 k rows
  * at d <= 15, 131 k at d <= 31, 65 k beyond;
  * 1: never; 2: whenever the shape allows it (fp16-filter shapes with K <= 16, at least 1024 rows).
  * Process-wide; the environment variable MCE_SYM sets the initial value. */

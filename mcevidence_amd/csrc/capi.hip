@@ -76,12 +76,12 @@ int sym_mode()
     return m;
 }
 // query blocks (512 rows each) from which the automatic mode takes it, by 16-wide k-steps of the filter.  Measured
-// (tools/sym_crossover.py, fused search + reduction, exhaustive -> symmetric, ms): d = 45 (3 k-steps) 2.3 -> 1.9 at 65 k rows,
-// 8.3 -> 5.1 at 197 k, 33.1 -> 19.5 at 524 k, 97.8 -> 56.1 at 1 M; d = 27 (2) 1.8 -> 1.8 at 65 k, 3.4 -> 2.8 at 131 k,
-// 15.5 -> 10.5 at 393 k, 26.2 -> 16.1 at 524 k, 67.5 -> 45.4 at 1 M, 254 -> 157 at 2 M; d = 15 / 10 / 6 (1 k-step)
-// 5.4 -> 4.6 / 5.3 -> 4.8 / 5.4 -> 5.3 at 262 k (spread prepass), 41.3 -> 33.8 / 40.4 -> 34.4 / 40.3 -> 36.1 at 1 M (where the pruned walk
-// does not take over).  The more of a search is MFMA work, the more halving the products pays.
-constexpr int kSymAutoMinBlocks[5] = {0, 512, 256, 128, 128};
+// (tools/sym_crossover.py -> profiles/r02_symmetric/crossover.json; fused search + reduction, exhaustive -> symmetric, ms):
+// d = 45 (3 k-steps) 2.1 -> 1.9 at 65 k rows, 7.4 -> 5.0 at 197 k, 27.8 -> 18.8 at 524 k, 95.2 -> 55.1 at 1 M; d = 27 (2)
+// 1.7 -> 1.8 at 65 k, 2.9 -> 2.8 at 131 k, 5.8 -> 4.9 at 197 k, 19.7 -> 15.6 at 524 k, 65.9 -> 44.8 at 1 M, 236 -> 155 at 2 M;
+// d = 15 / 10 / 6 (1 k-step) 12.2 -> 11.9 / 11.9 -> 12.3 / 11.8 -> 13.3 at 524 k, 40.8 -> 33.4 / 39.6 -> 34.1 / 39.2 -> 36.1 at
+// 1 M (where the pruned walk does not take over).  The more of a search is MFMA work, the more halving the products pays.
+constexpr int kSymAutoMinBlocks[5] = {0, 1536, 256, 128, 128};
 // prepass rows by k-steps: 0 spread over the sorted rows, 1 the rows nearest the mean, 2 half and half.  Fused call, ms,
 // spread / nearest / half: 1M x 3 42.6 / 152.6 / 45.2; 1M x 6 36.1 / 50.1 / 37.1; 1M x 10 34.4 / 36.8 / 34.8; 1M x 15
 // 33.8 / 33.4 / 33.2; 1M x 20 50.2 / 45.9 / 46.8; 1M x 27 48.8 / 44.4 / 45.5 (tools/sym_seedmode.py)
