@@ -281,3 +281,28 @@ def test_neighbours_that_only_the_row_side_can_deliver(sym, d):
     assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
     od, oi = orc.knn_brute(Z[-2000:], Z, K, self_mode=2, self_offset=len(Z) - 2000)
     assert np.allclose(d1[-2000:], od, rtol=DIST_RTOL, atol=0)
+
+
+def test_sampled_rows_at_2M_rows():
+    """beyond BASELINE's largest high-dimensional size: 2M x 27 through the automatic symmetric sweep (7631 units of
+    per panel at most, 28 panels); 300 sampled rows against the exact CPU search, and size-independent properties of the
+    whole result: ascending rows, no own row, mutual consistency of nearest neighbours"""
+    from mcevidence_amd import _capi as capi
+    capi.set_search_mode(capi.MODE_AUTO)
+    capi.set_prune_mode(capi.PRUNE_AUTO)
+    capi.set_sym_mode(capi.SYM_AUTO)
+    rng = np.random.default_rng(2027)
+    n, d, K = 2_000_000, 27, 9
+    X = rng.standard_normal((n, d))
+    dist, idx = capi.knn(X, X, K, self_mode=capi.SELF_EXCLUDE)
+    assert "symmetric" in capi.last_kernel(), capi.last_kernel()
+    assert np.all(np.diff(dist, axis=1) >= 0) and np.all(idx != np.arange(n)[:, None]) and np.all(dist > 0)
+    # mutual consistency (what a symmetric search must get right): if j is i's nearest neighbour, then i is in j's
+    # list, or all K of j's neighbours are at most as far from j as i is
+    j = idx[:, 0]
+    assert np.all((idx[j] == np.arange(n)[:, None]).any(axis=1) | (dist[j, K - 1] <= dist[:, 0]))
+    rows = np.sort(rng.choice(n, 300, replace=False))
+    od, oi = orc.knn_brute(X[rows], X, K + 1)
+    keep = np.array([[c for c in oi[r] if c != rows[r]][:K] for r in range(len(rows))])
+    want = np.sqrt(((X[rows][:, None, :] - X[keep]) ** 2).sum(-1))
+    assert np.allclose(dist[rows], want, rtol=DIST_RTOL, atol=0) and np.array_equal(idx[rows], keep)
