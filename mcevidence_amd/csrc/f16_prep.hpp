@@ -130,7 +130,15 @@ __global__ __launch_bounds__(256) void f16_pack_refs_kernel(const double* __rest
         yn = fmax(yn, __shfl_xor(yn, o, 64));
         rho = fmax(rho, __shfl_xor(rho, o, 64));
     }
-    if (lane == 0) {
+    // one set of atomics per BLOCK (the waves' maxima meet in LDS first): the three addresses are shared by the whole launch
+    __shared__ double blk_max[3][4];
+    const int wv = threadIdx.x >> 6;
+    if (lane == 0) { blk_max[0][wv] = ey; blk_max[1][wv] = yn; blk_max[2][wv] = rho; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ey = fmax(fmax(blk_max[0][0], blk_max[0][1]), fmax(blk_max[0][2], blk_max[0][3]));
+        yn = fmax(fmax(blk_max[1][0], blk_max[1][1]), fmax(blk_max[1][2], blk_max[1][3]));
+        rho = fmax(fmax(blk_max[2][0], blk_max[2][1]), fmax(blk_max[2][2], blk_max[2][3]));
         atomic_max_pos(params + HP_EY, ey);
         atomic_max_pos(params + HP_YHATMAX, yn);
         atomic_max_pos(params + HP_RHO, rho);
