@@ -26,6 +26,7 @@
 #include "feeders.hpp"
 #include "reduce_kernels.hpp"
 #include "prune.hpp"
+#include "zero_fill.hpp"
 
 namespace {
 
@@ -476,7 +477,7 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
         _Float16* xh = reinterpret_cast<_Float16*>(ws + p.off_xh);
         double* qinfo = reinterpret_cast<double*>(ws + p.off_qinfo);
         double* params = reinterpret_cast<double*>(ws + p.off_params);
-        MCE_HIP(hipMemsetAsync(params, 0, mce::HP_COUNT * sizeof(double), st));
+        MCE_HIP(mce::zero_async(params, mce::HP_COUNT * sizeof(double), st));
         // queries that are literally rows of the reference buffer are inside its bounding box already
         bool separate_queries = !(dX >= dY && dX + (size_t)nq * d <= dY + (size_t)nr * d);
         const double* sX = dX;     // the rows the search reads: the caller's, or their k-d ordered copies
@@ -968,12 +969,12 @@ int mce_knn_dotp_part_f64_dev(const double* dY, int64_t nr, int32_t d, int32_t k
     if (!p.prune) {
         // contiguous rows: exactly the query shard of SURVEY.md section 8e
         const int64_t lo = nr * part / nparts, hi = nr * (int64_t)(part + 1) / nparts;
-        if (hi == lo) { MCE_HIP(hipMemsetAsync(d_dotp, 0, (size_t)kmax * sizeof(double), st)); return MCE_OK; }
+        if (hi == lo) { MCE_HIP(mce::zero_async(d_dotp, (size_t)kmax * sizeof(double), st)); return MCE_OK; }
         return mce_knn_dotp_f64_dev(dY + lo * (int64_t)d, hi - lo, dY, nr, d, kmax, 1, lo, d_w + lo, d_fs + lo, d_dotp, nullptr, ws, ws_bytes, stream);
     }
     // pruned walk: every nparts-th query block of the k-d order -- spatially compact work units, one shared
     // ordering, and statistically equal shares (contiguous ranges of the order differ 2x in cost)
-    if (part >= p.nqblk) { MCE_HIP(hipMemsetAsync(d_dotp, 0, (size_t)kmax * sizeof(double), st)); return MCE_OK; }
+    if (part >= p.nqblk) { MCE_HIP(mce::zero_async(d_dotp, (size_t)kmax * sizeof(double), st)); return MCE_OK; }
     p.part = part;
     p.nparts = nparts;
     char* wsc = static_cast<char*>(ws);

@@ -31,6 +31,14 @@
 
 #include "sym_types.hpp"
 
+#ifndef MCE_SYM_CHECK
+#define MCE_SYM_CHECK 0    // debugging aid: range checks (device printf) on the indices of the symmetric sweep's global stores
+#endif
+#if MCE_SYM_CHECK
+#define MCE_CHK(cond, code, a, b, c) do { if (!(cond)) { printf("SYMCHK %d blk %d tid %d: %lld %lld %lld\n", code, (int)blockIdx.x, (int)threadIdx.x, (long long)(a), (long long)(b), (long long)(c)); } } while (0)
+#else
+#define MCE_CHK(cond, code, a, b, c) do {} while (0)
+#endif
 #ifndef MCE_STATS
 #define MCE_STATS 0    // tools/knn_f16_bench.hip only: per-wave clock64/event counters appended to `params`
 #endif
@@ -275,6 +283,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
     // (sym_unit_count): the units running at the same time stream the same few MB of packed rows through L2
     int sym_a = 0, sym_p = 0;
     if constexpr (SYM == 2) sym_unit_decode((int)blockIdx.x, nqblk, kHWaves * kHQT, sym.panel * f16_chunk_tiles(KST), sym_p, sym_a);
+    if constexpr (SYM == 2) MCE_CHK(sym_a >= 0 && sym_a < nqblk && sym_p >= 0, 5, sym_a, sym_p, nqblk);
     const int qblk = PRUNE ? border[qblk0 + (int)(blockIdx.x / kHWaves) * qblk_stride] : (SYM == 2 ? sym_a : (int)(blockIdx.x % nqblk));
     const int split = PRUNE ? 0 : (SYM >= 2 ? 0 : (int)(blockIdx.x / nqblk));
 
@@ -543,6 +552,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
             // bound.  Returns false if K slots hold strictly smaller distances (the candidate cannot be among the K).
             auto slot_insert = [&](int row, double d2) __attribute__((always_inline)) -> bool {
                 unsigned long long* const sl = sym.slots + (int64_t)row * KCAP;
+                MCE_CHK(row >= 0 && row < nr, 1, row, nr, 0);
                 for (;;) {
                     double vmax = -1.0, v2 = -1.0;
                     int imax = 0;
@@ -611,7 +621,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                 if (rs) rs = slot_insert(j, d2);
                 if (rs) {
                     const int slot = atomicAdd(sym.bucket_cnt + jb, 1);
-                    if (slot < sym.cap) {
+                    MCE_CHK(slot >= 0 && jb >= 0 && jb < nqblk && j >= 0 && j < nr, 2, slot, jb, j);
+                    if ((unsigned)slot < (unsigned)sym.cap) {      // (unsigned: a count that is not a count ends in the repair pass, not in a wild store)
                         SymEntry en;
                         en.d2 = d2;
                         en.src = rperm[qwave0 + ql];
@@ -688,6 +699,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
             // publish: thr[q] takes this list's K-th bound and gives back what the row side knows (the K-th of q's
             // slots); the row-side gate constants follow, and the maximum over each 32-row tile (= half a wave)
             const int64_t q = qwave0 + lane;
+            MCE_CHK(q >= 0 && q < nq_pad, 3, q, nq_pad, qblk);
             double t = thr_own[0];
             float R = 0.0f;
             if (q < nq) {
@@ -1462,6 +1474,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
 #pragma unroll
         for (int k = 0; k < KCAP; ++k) {
             const int64_t o = ((int64_t)split * KCAP + k) * nq_pad + q;
+            MCE_CHK(q >= 0 && q < nq_pad && split >= 0 && qblk >= 0 && qblk < nqblk, 4, q, split, qblk);
             part_d[o] = own_d[nl][k];
             part_i[o] = own_i[nl][k];
         }

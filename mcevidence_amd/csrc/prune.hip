@@ -1,5 +1,6 @@
 // prune.hip -- k-d ordering, boxes and sorted chunk lists for the pruned search (see prune.hpp).
 #include "prune.hpp"
+#include "zero_fill.hpp"
 
 #include <cstring>
 
@@ -187,13 +188,36 @@ OffsetIt offsets(unsigned first, unsigned stride)
     return rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned>(first), SegmentOffset{stride});
 }
 
-size_t sort_tmp_bytes(int64_t n)
+// rocPRIM's radix sort of (key, row) pairs.  Above ~1 M keys it takes its "onesweep" path, which clears its histogram and
+// look-back states with hipMemsetAsync -- and a memset NODE of a captured graph does not survive replay on this stack
+// (zero_fill.hpp).  While the stream is being captured the merge-sort path is forced instead (no memset, same stable
+// order: the result is the same permutation, only slower for very large inputs); eager calls keep rocPRIM's choice.
+using MergeOnlySort = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, (size_t)-1>;
+
+template <class Key>
+size_t sort_pairs_tmp_bytes(int64_t n, unsigned end_bit)
 {
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr,
-                                    (int*)nullptr, (size_t)n, 0u, 64u);
-    return bytes;
+    size_t a = 0, b = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, a, (const Key*)nullptr, (Key*)nullptr, (const int*)nullptr, (int*)nullptr, (size_t)n, 0u, end_bit);
+    (void)rocprim::radix_sort_pairs<MergeOnlySort>(nullptr, b, (const Key*)nullptr, (Key*)nullptr, (const int*)nullptr, (int*)nullptr, (size_t)n, 0u, end_bit);
+    return std::max(a, b);
 }
+
+template <class Key>
+hipError_t sort_pairs(void* tmp, size_t tmp_bytes, const Key* keys_in, Key* keys_out, const int* vals_in, int* vals_out, int64_t n, unsigned end_bit,
+                      hipStream_t st)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (st) {                   // (the legacy stream cannot be captured)
+        const hipError_t e = hipStreamIsCapturing(st, &cs);
+        if (e != hipSuccess) return e;
+    }
+    size_t tb = tmp_bytes;
+    if (cs != hipStreamCaptureStatusNone) return rocprim::radix_sort_pairs<MergeOnlySort>(tmp, tb, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit, st);
+    return rocprim::radix_sort_pairs(tmp, tb, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit, st);
+}
+
+size_t sort_tmp_bytes(int64_t n) { return sort_pairs_tmp_bytes<unsigned long long>(n, 64u); }
 
 size_t segsort_tmp_bytes(int nqblk, int64_t nchunk)
 {
@@ -220,9 +244,7 @@ hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_ro
                            n_units, Ltop, level, P, d, level % d, keys_a, vals_b);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        size_t tb = tmp_bytes;
-        e = rocprim::radix_sort_pairs(tmp, tb, (const unsigned long long*)keys_a, keys_b, (const int*)vals_b, perm, (size_t)n_pad, 0u,
-                                      (unsigned)(32 + level), st);
+        e = sort_pairs(tmp, tmp_bytes, (const unsigned long long*)keys_a, keys_b, (const int*)vals_b, perm, n_pad, (unsigned)(32 + level), st);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -406,10 +428,8 @@ int sym_layout(int64_t n, int64_t n_pad, int nqblk, int d, int kcap, int qpb, in
     L.done = L.bucket_flag + (size_t)nqblk * 4;
     L.cap = per_row * qpb;
     L.bucket = take((size_t)nqblk * L.cap * 16);
-    size_t tb = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, tb, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, (size_t)n_pad, 0u, 32u);
-    L.tmp_bytes = tb;
-    L.tmp = take(tb);
+    L.tmp_bytes = sort_pairs_tmp_bytes<unsigned>(n_pad, 32u);
+    L.tmp = take(L.tmp_bytes);
     L.total = off;
     return 0;
 }
@@ -426,13 +446,12 @@ hipError_t sym_prepare(const double* dY, int64_t n, int d, const double* center,
                        keys_a, vals_a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    size_t tb = L.tmp_bytes;
     // (stable: rows at the same distance keep the caller's order -- the permutation is deterministic)
-    e = rocprim::radix_sort_pairs(ws + L.tmp, tb, (const unsigned*)keys_a, keys_b, (const int*)vals_a, perm, (size_t)n_pad, 0u, 32u, st);
+    e = sort_pairs(ws + L.tmp, L.tmp_bytes, (const unsigned*)keys_a, keys_b, (const int*)vals_a, perm, n_pad, 32u, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n * d + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, dY, perm, n, d, Ys);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    e = hipMemsetAsync(ws + L.bucket_cnt, 0, (size_t)3 * (L.bucket_flag - L.bucket_cnt), st);      // counts | flags | done
+    e = zero_async(ws + L.bucket_cnt, (size_t)3 * (L.bucket_flag - L.bucket_cnt), st);      // counts | flags | done
     return e;
 }
 

@@ -190,6 +190,104 @@ def test_symmetric_sweep_under_graph_capture(sym):
         assert np.allclose(out.cpu().numpy(), want_dotp, rtol=1e-13, atol=0)
 
 
+@pytest.mark.parametrize("per_row", [None, 3000])
+def test_replays_interleaved_with_eager_symmetric_calls(sym, per_row, monkeypatch):
+    """a replayed graph must clear its own counters: with eager symmetric searches of this library between the replays
+    (their own buffers, their own clears) a memset NODE was seen to leave the bucket counts of the captured call as
+    they were -- garbage counts, stores far outside the workspace (zero_fill.hpp).  No seed phase at this size: every
+    pair goes through the row side, the regime with the most bucket traffic."""
+    import torch
+    capi = sym
+    if per_row:
+        monkeypatch.setenv("MCE_SYM_BUCKET", str(per_row))
+    capi.set_sym_mode(capi.SYM_FORCE)
+    rng = np.random.default_rng(12)
+    kmax = 4
+    K = kmax - 1
+
+    def buffers(n, d):
+        wsb = capi.knn_workspace_bytes(n, n, d, K) + capi.dotp_workspace_bytes(n, kmax)
+        return (torch.empty((n, d), dtype=torch.float64, device="cuda"), torch.ones(n, dtype=torch.float64, device="cuda"),
+                torch.zeros(n, dtype=torch.float64, device="cuda"), torch.empty(wsb, dtype=torch.uint8, device="cuda"),
+                torch.zeros(kmax, dtype=torch.float64, device="cuda"), torch.zeros((n, K), dtype=torch.float64, device="cuda"), wsb)
+    side = torch.cuda.Stream()
+    n, d = 30000, 6                                     # an earlier, larger call whose buffers go back to the allocator
+    X, w, fs, ws, out, dd, wsb = buffers(n, d)
+    X.copy_(torch.from_numpy(rng.standard_normal((n, d))))
+    with torch.cuda.stream(side):
+        capi.knn_dotp_dev(X.data_ptr(), n, X.data_ptr(), n, d, kmax, 1, 0, w.data_ptr(), fs.data_ptr(), out.data_ptr(),
+                          dd.data_ptr(), ws.data_ptr(), wsb, side.cuda_stream)
+    side.synchronize()
+    del X, w, fs, ws, out, dd
+    n, d = 20000, 5
+    X, w, fs, ws, out, dd, wsb = buffers(n, d)
+
+    def call(stream):
+        capi.knn_dotp_dev(X.data_ptr(), n, X.data_ptr(), n, d, kmax, 1, 0, w.data_ptr(), fs.data_ptr(), out.data_ptr(),
+                          dd.data_ptr(), ws.data_ptr(), wsb, stream)
+    X.copy_(torch.from_numpy(rng.standard_normal((n, d))))
+    with torch.cuda.stream(side):
+        call(side.cuda_stream)
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call(torch.cuda.current_stream().cuda_stream)
+    for it in range(5):
+        h = rng.standard_normal((n, d))
+        X.copy_(torch.from_numpy(h))
+        graph.replay()
+        torch.cuda.synchronize()
+        hs = h if it % 2 == 0 else h[:3000]
+        want_dotp, want_dist = capi.knn_dotp(hs, None, np.ones(len(hs)), np.zeros(len(hs)), kmax, 1, return_dist=True)
+        assert "symmetric" in capi.last_kernel()
+        if it % 2 == 0:
+            assert np.array_equal(dd.cpu().numpy(), want_dist)
+            assert np.allclose(out.cpu().numpy(), want_dotp, rtol=1e-13, atol=0)
+
+
+@pytest.mark.parametrize("mode", ["symmetric", "pruned"])
+def test_graph_capture_above_one_million_rows(sym, mode):
+    """past ~1 M keys rocPRIM's radix sort clears its scratch with memset calls, which do not survive graph replay on this
+    stack: a captured call sorts through the merge-sort path instead (prune.hip, sort_pairs) -- same permutation, same
+    results on every replay"""
+    import torch
+    capi = sym
+    capi.set_sym_mode(capi.SYM_FORCE if mode == "symmetric" else capi.SYM_OFF)
+    capi.set_prune_mode(capi.PRUNE_OFF if mode == "symmetric" else capi.PRUNE_FORCE)
+    rng = np.random.default_rng(77)
+    n, d, kmax = 1_200_000, 3, 3
+    K = kmax - 1
+    X = torch.empty((n, d), dtype=torch.float64, device="cuda")
+    w = torch.ones(n, dtype=torch.float64, device="cuda")
+    fs = torch.zeros(n, dtype=torch.float64, device="cuda")
+    wsb = capi.knn_workspace_bytes(n, n, d, K) + capi.dotp_workspace_bytes(n, kmax)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(kmax, dtype=torch.float64, device="cuda")
+    dd = torch.zeros((n, K), dtype=torch.float64, device="cuda")
+
+    def call(stream):
+        capi.knn_dotp_dev(X.data_ptr(), n, X.data_ptr(), n, d, kmax, 1, 0, w.data_ptr(), fs.data_ptr(), out.data_ptr(),
+                          dd.data_ptr(), ws.data_ptr(), wsb, stream)
+    X.copy_(torch.from_numpy(rng.standard_normal((n, d))))
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        call(side.cuda_stream)
+    side.synchronize()
+    assert mode in capi.last_kernel()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call(torch.cuda.current_stream().cuda_stream)
+    for it in range(3):
+        h = rng.standard_normal((n, d)) * (1.0 + it)
+        X.copy_(torch.from_numpy(h))
+        graph.replay()
+        torch.cuda.synchronize()
+        want_dotp, want_dist = capi.knn_dotp(h, None, np.ones(n), np.zeros(n), kmax, 1, return_dist=True)
+        assert mode in capi.last_kernel()
+        assert np.array_equal(dd.cpu().numpy(), want_dist)
+        assert np.allclose(out.cpu().numpy(), want_dotp, rtol=1e-12, atol=0)
+
+
 def test_random_shapes_with_random_settings(sym, monkeypatch):
     """seeded sweep over ragged shapes and every self mode with random prepass sizes and layouts, panel sizes (units per
     block) and bucket sizes (overflow + repair in some cases): distances and rows identical to the exhaustive sweep's,
