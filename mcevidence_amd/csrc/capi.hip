@@ -77,12 +77,15 @@ int sym_mode()
     return m;
 }
 // query blocks (512 rows each) from which the automatic mode takes it, by 16-wide k-steps of the filter.  Measured
-// (tools/sym_crossover.py -> profiles/r02_symmetric/crossover.json; fused search + reduction, exhaustive -> symmetric, ms):
-// d = 45 (3 k-steps) 2.1 -> 1.9 at 65 k rows, 7.4 -> 5.0 at 197 k, 27.8 -> 18.8 at 524 k, 95.2 -> 55.1 at 1 M; d = 27 (2)
-// 1.7 -> 1.8 at 65 k, 2.9 -> 2.8 at 131 k, 5.8 -> 4.9 at 197 k, 19.7 -> 15.6 at 524 k, 65.9 -> 44.8 at 1 M, 236 -> 155 at 2 M;
-// d = 15 / 10 / 6 (1 k-step) 12.2 -> 11.9 / 11.9 -> 12.3 / 11.8 -> 13.3 at 524 k, 40.8 -> 33.4 / 39.6 -> 34.1 / 39.2 -> 36.1 at
-// 1 M (where the pruned walk does not take over).  The more of a search is MFMA work, the more halving the products pays.
-constexpr int kSymAutoMinBlocks[5] = {0, 1536, 256, 128, 128};
+// (tools/sym_crossover.py -> profiles/r02_symmetric/crossover.json; fused search + reduction, exhaustive -> symmetric, ms).
+// Up to 256 blocks -- one round of workgroups -- the seeded exhaustive sweep with its reference splits is as fast or
+// faster (d = 27: 0.49 vs 0.78 at 16 k rows, 1.01 vs 1.53 at 65 k, 2.0 vs 2.5 at 131 k; d = 45: 2.6 vs 2.6 at 131 k); past
+// that the symmetric sweep wins at once where the filter takes two k-steps or more (d = 27: 3.05 -> 2.86 at 147 k, 4.1 -> 3.4
+// at 197 k, 19.1 -> 14.5 at 524 k, 65.0 -> 42.8 at 1 M, 232 -> 148 at 2 M; d = 45: 3.7 -> 3.1 at 147 k, 27.1 -> 16.6 at 524 k,
+// 94.3 -> 52.0 at 1 M) and from ~0.5 M rows with one k-step (d = 15 / 10 / 6: 7.0 -> 6.9 / 6.9 -> 7.1 / 6.9 -> 8.3 at 393 k,
+// 11.7 -> 11.2 / 11.5 -> 11.3 / 11.5 -> 12.4 at 524 k, 39.9 -> 32.9 / 39.1 -> 33.3 / 38.7 -> 35.3 at 1 M; d <= 8: the pruned walk
+// takes over before that).  The more of a search is MFMA work, the more halving the products pays.
+constexpr int kSymAutoMinBlocks[5] = {0, 1024, 257, 257, 257};
 // prepass rows by k-steps: 0 spread over the sorted rows, 1 the rows nearest the mean, 2 half and half.  Fused call, ms,
 // spread / nearest / half: 1M x 3 42.6 / 152.6 / 45.2; 1M x 6 36.1 / 50.1 / 37.1; 1M x 10 34.4 / 36.8 / 34.8; 1M x 15
 // 33.8 / 33.4 / 33.2; 1M x 20 50.2 / 45.9 / 46.8; 1M x 27 48.8 / 44.4 / 45.5 (tools/sym_seedmode.py)
@@ -96,7 +99,11 @@ struct SameSetHint {
     explicit SameSetHint(bool same) : prev(g_same_set_hint) { g_same_set_hint = same ? 1 : 0; }
     ~SameSetHint() { g_same_set_hint = prev; }
 };
-constexpr int kSymPanelChunks = 96;           // 48 KB chunks per panel of reference rows (knn_f16.hpp, units): 1M x 27: 24 -> 52.5 ms, 48 -> 46.5, 96 -> 45.7, 192 -> 46.2
+// 48 KB chunks per panel of reference rows (sym_types.hpp, units), by k-steps.  With the blocks of a panel dispatched from
+// the last one down the length hardly matters above ~150 chunks at d = 27 (1 M rows: 64 -> 41.6 ms, 96 -> 40.8, 160 -> 40.1,
+// 256 -> 39.9, 512 -> 40.1, one panel 41.1; 200 k rows: 96 -> 2.95, 384 -> 2.85); one k-step (d <= 16): 96 -> 32.5 ms,
+// 256 -> 33.6 at 1 M x 15, the other way round at 262 k (4.16 vs 3.84)
+constexpr int kSymPanelChunks[5] = {0, 96, 256, 256, 256};
 // bucket entries per row: a row receives ~K ln(N/2 / seed rows) + K row-side candidates; MCE_SYM_BUCKET overrides (tests)
 int sym_bucket_per_row(int K)
 {
@@ -262,6 +269,26 @@ const mce::KnnVariant* variant_for(int KS, int kcap_idx)
 
 // Validates (nq, nr, d, K, self_mode) and lays out the workspace.  Pure function of its
 // arguments so mce_knn_workspace_bytes() and the launcher always agree.
+// Seed phase of the exhaustive fp16 sweep for splits of (at least) `cps` chunks: chunks | group tiles << 16, 0 = none
+// (knn_f16.hpp: f16_seed_cfg).  MCE_F16_SEED_ROWS / MCE_F16_SEED_SHARE / MCE_F16_SEED_TG override (tests, tuning).
+// Small splits: a quarter of the chunks (then half) in smaller groups, as long as they hold twice the K groups a bound
+// needs.  Without a seed phase a query accepts ~K ln(n/K) candidates before its list settles; measured (fused call, none ->
+// seeded): 32 k x 6, K = 3: 0.61 -> 0.33 ms; 100 k x 6 (C2): 1.23 -> 0.90; 65 k x 27, K = 9: 1.51 -> 0.96; 131 k x 27: 2.60 ->
+// 1.93; 197 k x 27: 5.35 -> 4.10; from ~400 k rows the row budget binds as before.
+int sweep_seed_cfg(int64_t cps, int CT, int kneed)
+{
+    const char* const e_rows = getenv("MCE_F16_SEED_ROWS");
+    const char* const e_share = getenv("MCE_F16_SEED_SHARE");
+    const char* const e_tg = getenv("MCE_F16_SEED_TG");
+    if (e_rows || e_share || e_tg)
+        return mce::f16_seed_cfg(cps, CT, kneed, e_rows ? atoi(e_rows) : MCE_H_SEED_ROWS, e_share ? atoi(e_share) : MCE_H_SEED_SHARE,
+                                 e_tg ? atoi(e_tg) : MCE_H_SEED_TG);
+    for (int share = MCE_H_SEED_SHARE; share >= 2; share /= 2)
+        for (int tg = MCE_H_SEED_TG; tg >= 2; tg /= 2)
+            if (const int cfg = mce::f16_seed_cfg(cps, CT, kneed, MCE_H_SEED_ROWS, share, tg)) return cfg;
+    return 0;
+}
+
 int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, Plan& p)
 {
     if (nq < 0 || nr < 1 || d < 1 || K < 1) return fail(MCE_ERR_INVALID, "invalid sizes nq=%lld nr=%lld d=%d K=%d", (long long)nq, (long long)nr, d, K);
@@ -370,6 +397,20 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
         const double rounds = std::ceil((double)p.nqblk * r / kAssumedCUs);
         const double c = rounds * block;
         if (c < best_c * 0.98) { best_c = c; best_r = r; }   // need >2% gain to take a bigger split
+    }
+    // Searches of at most one round of workgroups (up to ~130 k queries): the sweep of such a set is mostly candidate
+    // handling, which a seed phase cuts by half or more and which parallelises over the splits -- take the largest split
+    // count that still fits one round AND leaves every split enough chunks for a seed phase (tools/_tmp scans, fused call,
+    // model's choice -> this: 8 k x 6, K = 3: 0.41 -> 0.20 ms; 16 k x 6: 0.47 -> 0.23; 12 k x 27, K = 9: 0.75 -> 0.41; 16 k x 45:
+    // 1.04 -> 0.47; from 24 k rows both agree).  Nothing seeded: the model's choice.
+    if (f16 && !p.twopass && p.nqblk <= kAssumedCUs) {
+        const int kneed = K + 1;      // (whatever the self mode: the workspace query does not know it, and the layout depends on r)
+        for (int r = std::min(rmax, kAssumedCUs / p.nqblk); r >= std::max(1, rmin); --r)
+            if (sweep_seed_cfg(p.nchunk / r, p.CT, kneed)) { best_r = r; break; }
+    }
+    if (const char* e = getenv("MCE_RSPLIT")) {          // tuning
+        const int r = atoi(e);
+        if (r >= std::max(1, rmin) && r <= rmax) best_r = r;
     }
     if (p.prune) best_r = 1;                  // every workgroup walks its own chunk list
     p.rsplit = best_r;
@@ -537,14 +578,8 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             return MCE_OK;
         }
         // seed phase: the host picks the group size; MCE_F16_SEED_ROWS / MCE_F16_SEED_SHARE override (tests, tuning)
-        auto seed_cfg = [&](int ksel) {
-            const char* const e_rows = getenv("MCE_F16_SEED_ROWS");
-            const char* const e_share = getenv("MCE_F16_SEED_SHARE");
-            const char* const e_tg = getenv("MCE_F16_SEED_TG");
-            const int64_t cps = (p.nchunk + p.rsplit - 1) / p.rsplit;
-            return mce::f16_seed_cfg(cps, p.CT, ksel + a.self_exclude, e_rows ? atoi(e_rows) : MCE_H_SEED_ROWS,
-                                     e_share ? atoi(e_share) : MCE_H_SEED_SHARE, e_tg ? atoi(e_tg) : MCE_H_SEED_TG);
-        };
+        // (the kernel balances the splits to within one chunk: size the seed phase for the smallest)
+        auto seed_cfg = [&](int ksel) { return sweep_seed_cfg(p.nchunk / p.rsplit, p.CT, ksel + a.self_exclude); };
         if (use_sym) {
             char* const sw = ws + p.off_sym;
             a.rsplit = 1;
@@ -560,12 +595,19 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             a.sym.done = reinterpret_cast<int*>(sw + p.sl.done);
             // panel = the packed rows one L2 (4 MB per XCD) serves to the units running at the same time; MCE_SYM_PANEL: chunks (tuning)
             const char* const e_panel = getenv("MCE_SYM_PANEL");
-            a.sym.panel = e_panel && atoi(e_panel) > 0 ? atoi(e_panel) : kSymPanelChunks;
+            a.sym.panel = e_panel && atoi(e_panel) > 0 ? atoi(e_panel) : kSymPanelChunks[p.KST];
             // prepass: every row's bound before any block runs (the seed phase as its own launch)
             const char* const e_rows = getenv("MCE_SYM_SEED_ROWS");
             const char* const e_share = getenv("MCE_SYM_SEED_SHARE");
-            a.seed_cfg = mce::f16_seed_cfg(p.nchunk, p.CT, K + a.self_exclude, e_rows ? atoi(e_rows) : 2 * MCE_H_SEED_ROWS,
-                                           e_share ? atoi(e_share) : 8, MCE_H_SEED_TG);
+            // about 32 k rows (one k-step: 64 k), at most half of the chunks (tools/_tmp-style scans, fused call, share 8 -> 2:
+            // 49 k x 27 1.51 -> 1.32 ms, 98 k 2.18 -> 2.03, 131 k 2.58 -> 2.47, from 197 k rows the same; 393 k x 15 7.04 -> 6.88)
+            const int seed_rows = e_rows ? atoi(e_rows) : (p.KST == 1 ? 4 : 2) * MCE_H_SEED_ROWS;
+            const int seed_share = e_share ? atoi(e_share) : 2;
+            a.seed_cfg = mce::f16_seed_cfg(p.nchunk, p.CT, K + a.self_exclude, seed_rows, seed_share, MCE_H_SEED_TG);
+            // tiny sets (forced mode): smaller groups, so that half of the chunks still hold twice the K groups a bound needs --
+            // without any bound every pair would go through the row side (20 k x 27: 10.8 ms instead of 0.8)
+            for (int tg = MCE_H_SEED_TG / 2; a.seed_cfg == 0 && tg >= 1; tg /= 2)
+                a.seed_cfg = mce::f16_seed_cfg(p.nchunk, p.CT, K + a.self_exclude, seed_rows, seed_share, tg);
             if (a.seed_cfg) {
                 const char* const e_mode = getenv("MCE_SYM_SEED_MODE");
                 a.seed_cfg |= ((e_mode ? atoi(e_mode) : kSymSeedMode[p.KST]) & 3) << 28;

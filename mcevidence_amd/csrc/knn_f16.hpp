@@ -79,7 +79,7 @@ constexpr int kHThreads = kHWaves * 64;
 #define MCE_H_SEED_ROWS 16384  // seed phase: reference rows swept twice (0 = no seed phase) ...
 #endif
 #ifndef MCE_H_SEED_SHARE
-#define MCE_H_SEED_SHARE 40    // ... at most 1/40 of the split's chunks ...
+#define MCE_H_SEED_SHARE 4     // ... at most 1/4 of the split's chunks (binds below ~65 k rows per split; capi.hip: seed_cfg) ...
 #endif
 #ifndef MCE_H_SEED_TG
 #define MCE_H_SEED_TG 8        // ... in groups of 8 tiles (256 rows)
@@ -290,10 +290,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
     if constexpr (SYM >= 2) {
         if (SYM == 3 && sym.bucket_flag[qblk] == 0) return;      // repair launch: only the blocks whose bucket overflowed
     }
-    const int64_t cps = (nchunk_total + rsplit - 1) / rsplit;
-    const int64_t c_begin = (int64_t)split * cps;
-    int64_t c_end = c_begin + cps;
-    if (c_end > nchunk_total) c_end = nchunk_total;
+    // balanced splits (sizes differ by at most one chunk: the host sizes the seed phase for the smallest, capi.hip: seed_cfg)
+    const int64_t c_begin = (int64_t)split * nchunk_total / rsplit;
+    const int64_t c_end = (int64_t)(split + 1) * nchunk_total / rsplit;
 
     const double INF = __builtin_huge_val();
     double* const wqd = qd2_all + lwave * QN;                   // exact distance of a queued entry (phase A)

@@ -1,5 +1,5 @@
 // sym_units_check.cpp -- CPU check of the symmetric sweep's unit enumeration (mcevidence_amd/csrc/sym_types.hpp):
-// every (panel, block) whose ranges intersect appears exactly once, in panel-major order; the tile ranges of a
+// every (panel, block) whose ranges intersect appears exactly once, panel by panel, blocks descending; the tile ranges of a
 // block's units tile its range [0, min(tpb (a+1), ntiles)) without gaps or overlaps; the count is the grid size.
 // Build + run: g++ -std=c++17 -O1 -I mcevidence_amd/csrc tests/native/sym_units_check.cpp -o /tmp/sym_units_check && /tmp/sym_units_check
 #include <cstdio>
@@ -21,13 +21,15 @@ int main()
                     if (ntiles <= tpb * (nqblk - 1)) ntiles = tpb * (nqblk - 1) + 2;
                     const int n = mce::sym_unit_count(nqblk, tpb, tpp, ntiles);
                     std::vector<int> next_lo(nqblk, 0), units_of(nqblk, 0);
-                    int last_p = 0, last_a = -1;
+                    int last_p = 0, last_a = nqblk;
                     for (int u = 0; u < n; ++u) {
                         int p, a, lo, hi;
                         mce::sym_unit_decode(u, nqblk, tpb, tpp, p, a);
                         mce::sym_unit_tiles(p, a, tpb, tpp, ntiles, lo, hi);
                         if (a < 0 || a >= nqblk || p < 0) { printf("bad unit %d -> (%d,%d)\n", u, p, a); return 1; }
-                        if (p < last_p || (p == last_p && a <= last_a)) { printf("order broken at unit %d\n", u); return 1; }
+                        if (p < last_p || (p == last_p && a >= last_a)) { printf("order broken at unit %d\n", u); return 1; }
+                        if (p != last_p) last_a = nqblk;
+                        if (a >= last_a) { printf("order broken at unit %d\n", u); return 1; }
                         last_p = p; last_a = a;
                         if (hi <= lo) { printf("empty unit %d (%d,%d) [%d,%d) nqblk=%d tpp=%d ntiles=%d\n", u, p, a, lo, hi, nqblk, tpp, ntiles); return 1; }
                         if (lo != next_lo[a]) { printf("gap/overlap: block %d expects lo %d, unit %d has %d\n", a, next_lo[a], u, lo); return 1; }

@@ -323,9 +323,10 @@ SYM_GOLD = [n for n in sorted(G) if G[n]["tag"] == "sym"]
 
 @pytest.mark.parametrize("name", SYM_GOLD)
 def test_reference_goldens_in_the_automatic_range(name):
-    """golden vectors recorded from the reference itself (oracle/gen_golden.py --sym) at sizes where the symmetric
-    sweep is the AUTOMATIC choice: the class reproduces the reference's ln E, and the search the reference's
-    sampled DkNN rows (what sklearn returned inside the reference's evidence())"""
+    """golden vectors recorded from the reference itself (oracle/gen_golden.py --sym) in the size range where the
+    automatic mode switches to the symmetric sweep (more than one round of query blocks: 135 k x 27 and 140 k x 20
+    take it, 70 k x 45 stays with the seeded exhaustive sweep -- and is run again forced): the class reproduces the
+    reference's ln E, and the search the reference's sampled DkNN rows (what sklearn returned inside evidence())"""
     from mcevidence_amd import _capi as capi
     import mcevidence_amd as pkg
     capi.set_search_mode(capi.MODE_AUTO)
@@ -335,8 +336,17 @@ def test_reference_goldens_in_the_automatic_range(name):
     chain = chain_of(case)
     mce = pkg.MCEvidence([chain], verbose=0, **case["mce"])
     lnE = mce.evidence(**case["ev"])
-    assert "symmetric" in capi.last_kernel(), capi.last_kernel()
+    blocks = (len(chain) + 511) // 512
+    assert ("symmetric" in capi.last_kernel()) == (blocks > 256), capi.last_kernel()
     assert np.allclose(lnE, case["lnE"], rtol=0, atol=LNE_TOL), (lnE, case["lnE"])
+    if blocks <= 256:
+        capi.set_sym_mode(capi.SYM_FORCE)
+        try:
+            lnE = mce.evidence(**case["ev"])
+            assert "symmetric" in capi.last_kernel(), capi.last_kernel()
+            assert np.allclose(lnE, case["lnE"], rtol=0, atol=LNE_TOL), (lnE, case["lnE"])
+        finally:
+            capi.set_sym_mode(capi.SYM_AUTO)
     # the reference's whitened rows and neighbour distances at the sampled rows
     a = case["arrays"]
     theta = chain[:, 2:2 + case["ndim"]]
@@ -344,7 +354,11 @@ def test_reference_goldens_in_the_automatic_range(name):
     X = np.ascontiguousarray(orc.whiten(theta, cs["eVec"], cs["eVal"]))
     assert np.allclose(X[a["rows"]], a["X_rows"], rtol=1e-11, atol=1e-12)
     kmax = case["kmax"]
-    d, _ = capi.knn(X, X, kmax, self_mode=capi.SELF_EXCLUDE)
+    capi.set_sym_mode(capi.SYM_FORCE)
+    try:
+        d, _ = capi.knn(X, X, kmax, self_mode=capi.SELF_EXCLUDE)
+    finally:
+        capi.set_sym_mode(capi.SYM_AUTO)
     assert "symmetric" in capi.last_kernel()
     assert np.allclose(d[a["rows"]][:, :kmax - 1], a["DkNN_rows"][:, 1:kmax], rtol=DIST_RTOL, atol=0)
 

@@ -14,7 +14,7 @@ _capi.set_prune_mode(_capi.PRUNE_OFF)
 dev = torch.device("cuda")
 rows = []
 for d, kmax in ((27, 10), (15, 5), (10, 5), (6, 5), (45, 10)):
-    for n in (65536, 131072, 196608, 262144, 393216, 524288, 1000000, 2000000):
+    for n in [int(x) for x in os.environ.get("SIZES", "16384,24576,32768,49152,65536,98304,131072,196608,262144,393216,524288,786432,1000000,2000000").split(",")]:
         if n > 1000000 and d != 27:
             continue
         X = torch.randn((n, d), dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(n + d))
