@@ -49,6 +49,18 @@
 namespace mce {
 
 // v_min3_f32 without the NaN-canonicalising v_max the compiler adds around fminf()
+// Barrier that publishes a chunk staged by LDS-DMA (global_load_lds).  The landing of a DMA is ordered for OTHER waves only
+// by the issuing wave's vmcnt wait FOLLOWED by the workgroup barrier -- and __syncthreads() by itself waits for LDS
+// traffic (lgkmcnt) only: the compiler emits vmcnt(0) before a barrier just when other code around it happens to need it.
+// The seed loop's barrier had none (ISA: "s_waitcnt lgkmcnt(0); s_barrier"): with several searches sharing the chip -- the
+// batched entry point -- a wave could read a buffer another wave's DMA was still filling, and a seed bound computed from
+// half-landed rows cut off true neighbours (300 small chains: ~2 wrong sums per batch call; none since).
+__device__ __forceinline__ void dma_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 __device__ __forceinline__ float min3f(float a, float b, float c)
 {
     float r;
@@ -1030,7 +1042,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                 stage_async(seed_chunk(0), 0);
                 for (int cc = 0; cc < nseed; ++cc) {
                     const int buf = cc & 1;
-                    __syncthreads();
+                    dma_barrier();
                     if (cc + 1 < nseed) stage_async(seed_chunk(cc + 1), buf ^ 1);
                     MCE_SWEEP_CHUNK(buf, 0, MCE_SEED_TILE, 0, CT, 0.0f);
                 }
@@ -1155,7 +1167,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
             for (int k = 0; k < ntot; ++k) {
                 const int buf = k & 1;
                 if (qcount >= kHDrainTrigger && lane == 0) wvote[buf] = 1;
-                __syncthreads();
+                dma_barrier();
                 int c, tlo, thi;
                 seq_at(k, c, tlo, thi);
                 rt_cur = rt_next;
@@ -1179,7 +1191,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
             const long long t_b0 = clock64();
 #endif
 #if MCE_ABLATE != 3
-            __syncthreads();
+            dma_barrier();
 #else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ablation: no barrier (results invalid)
 #endif

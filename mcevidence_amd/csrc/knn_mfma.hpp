@@ -248,7 +248,8 @@ __global__ __launch_bounds__(kThreads, 2) void knn_mfma_kernel(
 
     for (int64_t c = c_begin; c < c_end; ++c) {
         const int buf = (int)((c - c_begin) & 1);
-        __syncthreads();                                  // chunk c landed; chunk c-1's buffer is free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the DMA has landed (knn_f16.hpp: dma_barrier) ...
+        __syncthreads();                                  // ... everybody's has: chunk c is in LDS; chunk c-1's buffer is free
         if ((c + 1) < c_end) stage_async(c + 1, buf ^ 1);   // DMA in flight under the MFMAs
 
         const double* lbuf = lds + buf * LDS_CHUNK_DOUBLES + lane;

@@ -435,6 +435,26 @@ def _feed_problems(rng, count):
     return probs
 
 
+def test_batched_feed_of_planck_sized_chains_under_load(capi):
+    """The Planck driver pattern (reference planck_mcevidence.py:306-348): hundreds of chains of 6 k - 100 k rows, d = 6-8,
+    kmax = 2, searched concurrently on many streams.  Every problem must come out exactly as from a call of its own, every
+    time: with several searches sharing the chip a wave once read a staging buffer that another wave's LDS-DMA was still
+    filling (knn_f16.hpp: dma_barrier) -- a seed bound from half-landed rows, ~2 wrong sums per batch of 300."""
+    rng = np.random.default_rng(0)
+    probs = []
+    for i in range(300):
+        d = int(rng.integers(6, 9))
+        n = int(np.exp(rng.uniform(np.log(6000), np.log(100000))))
+        A = rng.standard_normal((d, d)) + 2 * np.eye(d)
+        probs.append((rng.standard_normal((n, d)) @ A, None, d, 0, 2, rng.integers(1, 5, n).astype(float), -rng.random(n)))
+    singles = [capi.evidence_feed(*p) for p in probs]
+    assert all(np.all(np.isfinite(s[0])) for s in singles)
+    for rep in range(4):
+        batch = capi.evidence_feed_batch(probs)
+        bad = [i for i, (a, b) in enumerate(zip(singles, batch)) if not (np.array_equal(a[0], b[0]) and a[1] == b[1])]
+        assert not bad, (rep, bad[:5], [(singles[i][0], batch[i][0]) for i in bad[:2]])
+
+
 def test_batched_feed_is_bit_identical_to_single_calls(capi, monkeypatch):
     """mce_evidence_feed_batch_f64: same dotp / J / eigenvalues as one
     mce_evidence_feed_f64 call per problem -- bit for bit -- in one wave and in several."""
