@@ -601,7 +601,7 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             const char* const e_share = getenv("MCE_SYM_SEED_SHARE");
             // about 32 k rows (one k-step: 64 k), at most half of the chunks (tools/_tmp-style scans, fused call, share 8 -> 2:
             // 49 k x 27 1.51 -> 1.32 ms, 98 k 2.18 -> 2.03, 131 k 2.58 -> 2.47, from 197 k rows the same; 393 k x 15 7.04 -> 6.88)
-            const int seed_rows = e_rows ? atoi(e_rows) : (p.KST == 1 ? 4 : 2) * MCE_H_SEED_ROWS;
+            const int seed_rows = e_rows ? atoi(e_rows) : (p.KST == 1 ? 65536 : 32768);
             const int seed_share = e_share ? atoi(e_share) : 2;
             a.seed_cfg = mce::f16_seed_cfg(p.nchunk, p.CT, K + a.self_exclude, seed_rows, seed_share, MCE_H_SEED_TG);
             // tiny sets (forced mode): smaller groups, so that half of the chunks still hold twice the K groups a bound needs --

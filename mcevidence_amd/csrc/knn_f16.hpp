@@ -88,7 +88,7 @@ constexpr int kHThreads = kHWaves * 64;
 #define MCE_H_QUEUE 448
 #endif
 #ifndef MCE_H_SEED_ROWS
-#define MCE_H_SEED_ROWS 16384  // seed phase: reference rows swept twice (0 = no seed phase) ...
+#define MCE_H_SEED_ROWS 24576  // seed phase: reference rows swept twice (0 = no seed phase; 16 k - 48 k rows: within 1 % at 0.1 - 1 M rows) ...
 #endif
 #ifndef MCE_H_SEED_SHARE
 #define MCE_H_SEED_SHARE 4     // ... at most 1/4 of the split's chunks (binds below ~65 k rows per split; capi.hip: seed_cfg) ...

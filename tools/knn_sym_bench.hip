@@ -24,7 +24,7 @@ int main(int argc, char** argv)
 {
     const int64_t n = argc > 1 ? atoll(argv[1]) : 200000;
     const int reps = argc > 2 ? atoi(argv[2]) : 2;
-    const int seed_rows = argc > 3 ? atoi(argv[3]) : 2 * MCE_H_SEED_ROWS;
+    const int seed_rows = argc > 3 ? atoi(argv[3]) : 32768;
     const int per_row = argc > 4 ? atoi(argv[4]) : 6 * KSEL + 24;
     const int sorted = argc > 5 ? atoi(argv[5]) : 1;
     const int panel = argc > 6 ? atoi(argv[6]) : 48;
