@@ -142,6 +142,42 @@ def test_seeded_sweep_is_bit_identical(shape, monkeypatch):
         _capi.set_prune_mode(0)
 
 
+@pytest.mark.parametrize("n,d,K", [(2500, 6, 1), (4096, 6, 3), (6144, 15, 4), (8192, 6, 9), (12288, 27, 9), (16384, 6, 3), (20000, 45, 9),
+                                   (26862, 6, 1), (33000, 27, 4), (49152, 8, 1), (70000, 7, 2), (100000, 6, 3)])
+def test_small_searches_are_split_and_seeded_by_default(n, d, K, monkeypatch):
+    """DESIGN.md 3.0, small searches: up to one round of workgroups the plan takes the largest number of reference splits that
+    leaves every split a seed phase (splits balanced to within one chunk, seed sized for the smallest) -- same neighbours,
+    distances and rows as one unseeded sweep over the whole set, and as the oracle"""
+    from mcevidence_amd import _capi
+    _capi.set_search_mode(_capi.MODE_AUTO)
+    _capi.set_prune_mode(1)
+    sym_before = _capi.get_sym_mode()
+    _capi.set_sym_mode(_capi.SYM_OFF)
+    try:
+        rng = np.random.default_rng(n + d + K)
+        Y = rng.standard_normal((n, d)) @ (np.eye(d) + 0.2 * rng.standard_normal((d, d)))
+        Y[n // 3:n // 3 + 20] = Y[5]                       # duplicates
+        d1, i1 = _capi.knn(Y, Y, K, self_mode=_capi.SELF_EXCLUDE)
+        k1 = _capi.last_kernel()
+        assert " seed=" in k1, k1
+        r1 = int(k1.split("rsplit=")[1].split()[0])
+        assert r1 * ((n + 511) // 512) <= 256 or r1 == 1, k1
+        monkeypatch.setenv("MCE_F16_SEED_ROWS", "0")
+        monkeypatch.setenv("MCE_RSPLIT", "1")
+        d0, i0 = _capi.knn(Y, Y, K, self_mode=_capi.SELF_EXCLUDE)
+        k0 = _capi.last_kernel()
+        assert " seed=" not in k0 and "rsplit=1" in k0, k0
+        assert np.array_equal(d0, d1) and np.array_equal(i0, i1), (k0, k1)
+        rows = rng.choice(n, size=300, replace=False)
+        od, oi = orc.knn_brute(Y[rows], Y, K + 1)
+        keep = np.array([[j for j in oi[r] if j != rows[r]][:K] for r in range(len(rows))])
+        od = np.sqrt(((Y[rows][:, None, :] - Y[keep]) ** 2).sum(-1))
+        assert _rel(d1[rows], od) < DIST_RTOL
+    finally:
+        _capi.set_sym_mode(sym_before)
+        _capi.set_prune_mode(0)
+
+
 @pytest.mark.parametrize("nq,nr,d,K,same", [(140000, 140000, 6, 4, True), (135000, 90000, 27, 9, False), (150000, 150000, 10, 20, True)])
 def test_trailing_round_split_is_bit_identical(nq, nr, d, K, same, monkeypatch):
     """A search whose last round of workgroups would fill less than half the chip runs as two query ranges
