@@ -795,12 +795,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                 // per-lane bit mask of the accumulators under the gate (branch-free) ...
                 unsigned pm = 0;
                 const float gq = (SYM == 2) ? fmaxf(G[qt], Rt + cR[qt]) : G[qt];
-#if defined(MCE_EVT_ABL) && MCE_EVT_ABL == 1
-                pm = (mm[qt] <= gq) ? 1u : 0u;      // ablation: no per-accumulator mask (results invalid)
-#else
 #pragma unroll
                 for (int r = 0; r < 16; ++r) pm |= (acc[qt][r] <= gq) ? (1u << r) : 0u;
-#endif
                 // ... then one queue entry per lane and trip (usually a single trip)
                 unsigned long long m = __ballot(pm != 0);
                 while (m) {
