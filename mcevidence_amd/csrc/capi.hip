@@ -20,6 +20,7 @@
 
 #include "knn_dispatch.hpp"
 #include "knn_mfma.hpp"
+#include "knn_panel.hpp"
 #include "pack_refs.hpp"
 #include "f16_prep.hpp"
 #include "knn_generic.hpp"
@@ -75,6 +76,19 @@ int sym_mode()
         g_sym_mode.store(m);
     }
     return m;
+}
+// which kernel sweeps: knn_panel_kernel (default) or the SYM = 2 instantiation of knn_f16_kernel (MCE_SYM_KERNEL=f16: kept
+// for comparisons).  A unit of the panel kernel waits for its block's previous unit at most this many ~1 us sleeps
+// (MCE_SYM_SPIN_LIMIT; 0 in the tests: every wait that is not already satisfied gives up, and the repair launch takes over)
+bool sym_use_panel_kernel()
+{
+    const char* e = getenv("MCE_SYM_KERNEL");
+    return !(e && strcmp(e, "f16") == 0);
+}
+int sym_spin_limit()
+{
+    const char* e = getenv("MCE_SYM_SPIN_LIMIT");
+    return e ? atoi(e) : (1 << 21);
 }
 // query blocks (512 rows each) from which the automatic mode takes it, by 16-wide k-steps of the filter.  Measured
 // (tools/sym_crossover.py -> profiles/r02_symmetric/crossover.json; fused search + reduction, exhaustive -> symmetric, ms).
@@ -617,7 +631,21 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             a.seed_cfg = 0;
             int rc = prof_begin();             // (the bracket of mce_last_kernel_ms(): the dominant kernel, as for the other searches)
             if (rc != MCE_OK) return rc;
-            MCE_HIP(p.vh->launch_sym(a, st));
+            const bool panel_kernel = sym_use_panel_kernel();
+            if (panel_kernel) {
+                mce::PanelArgs pa;
+                pa.Yh = yh; pa.Xh = xh; pa.qinfo = qinfo; pa.params = params; pa.X = sX; pa.Y = sY; pa.rperm = a.rperm;
+                pa.part_d = pd; pa.part_i = pi; pa.nq = nq; pa.nr = nr; pa.nq_pad = p.nq_pad; pa.self_offset = 0;
+                pa.D = d; pa.ksel = K; pa.self_exclude = a.self_exclude; pa.spin_limit = sym_spin_limit();
+                pa.sym = a.sym;
+                pa.debug = getenv("MCE_PANEL_DEBUG") ? atoi(getenv("MCE_PANEL_DEBUG")) : 0;
+                pa.geom.qb_lo = 0; pa.geom.qb_hi = p.nqblk; pa.geom.tpb = mce::kHWaves * mce::kHQT; pa.geom.ct = p.CT;
+                pa.geom.tpp = a.sym.panel * p.CT; pa.geom.sym_on = getenv("MCE_PANEL_NOSYM") ? 0 : 1;      // (debugging: every block sweeps every tile, column side only)
+                pa.geom.ntiles = (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1);
+                MCE_HIP(p.vh->launch_panel(pa, st));
+            } else {
+                MCE_HIP(p.vh->launch_sym(a, st));
+            }
             rc = prof_end();
             if (rc != MCE_OK) return rc;
             MCE_HIP(p.vh->launch_sym_repair(a, st));      // blocks whose bucket overflowed (normally none: every workgroup exits at once)
@@ -634,9 +662,9 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             }
             p.sym_active = true;
             p.L = 1;
-            snprintf(g_last_kernel, sizeof(g_last_kernel), "%s symmetric grid=%d block=%d lds=%zu qt=%d ct=%d panel=%d seed=%dx%d/%d bucket=%d", p.vh->name,
+            snprintf(g_last_kernel, sizeof(g_last_kernel), "%s symmetric%s grid=%d block=%d lds=%zu qt=%d ct=%d panel=%d seed=%dx%d/%d bucket=%d", p.vh->name, panel_kernel ? " panel-kernel" : "",
                      mce::sym_unit_count(p.nqblk, mce::kHWaves * mce::kHQT, a.sym.panel * p.CT, (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1)),
-                     mce::kHThreads, p.vh->lds_bytes_sym, p.QT, p.CT, a.sym.panel, seed_used & 0xffff, (seed_used >> 16) & 0xfff, (seed_used >> 28) & 3, p.sl.cap);
+                     mce::kHThreads, panel_kernel ? p.vh->lds_bytes_panel : p.vh->lds_bytes_sym, p.QT, p.CT, a.sym.panel, seed_used & 0xffff, (seed_used >> 16) & 0xfff, (seed_used >> 28) & 3, p.sl.cap);
             return MCE_OK;
         }
         int rc = prof_begin();

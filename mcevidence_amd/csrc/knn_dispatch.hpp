@@ -73,6 +73,8 @@ struct KnnF16Args {
     SymParams sym;                 // symmetric sweep (launch_sym_pre / launch_sym); rperm = sorted position -> caller's row
 };
 typedef hipError_t (*knn_f16_launch_fn)(const KnnF16Args&, hipStream_t);
+struct PanelArgs;                  // knn_panel.hpp
+typedef hipError_t (*knn_panel_launch_fn)(const PanelArgs&, hipStream_t);
 struct KnnF16Variant {
     knn_f16_launch_fn launch;
     knn_f16_launch_fn launch_prune;   // PRUNE = true instantiation (KST = 1 only), else null
@@ -80,6 +82,8 @@ struct KnnF16Variant {
     knn_f16_launch_fn launch_sym_pre; // SYM = 1: prepass of the symmetric sweep
     knn_f16_launch_fn launch_sym;     // SYM = 2: symmetric sweep
     knn_f16_launch_fn launch_sym_repair;   // SYM = 3: exhaustive search of the blocks whose bucket overflowed
+    knn_panel_launch_fn launch_panel; // knn_panel_kernel: the symmetric / exhaustive sweep in units (panel x query block)
+    size_t lds_bytes_panel;
     size_t lds_bytes_sym;
     int kst, kcap, qt, ct;
     size_t lds_bytes;

@@ -2,6 +2,7 @@
 // Compile with -DMCE_KCAP=<4|8|12|16|24|32>.
 #include "knn_mfma.hpp"
 #include "knn_f16.hpp"
+#include "knn_panel.hpp"
 #include "knn_dispatch.hpp"
 
 #ifndef MCE_KCAP
@@ -67,6 +68,28 @@ hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
 }
 #endif
 
+#if MCE_INST_F16
+template <int KST, int KCAP>
+hipError_t launch_panel_variant(const PanelArgs& a, hipStream_t st)
+{
+    constexpr size_t LDS = panel_lds_bytes(KST);
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    static bool attr_set[kMaxDevices] = {};
+    auto kern = knn_panel_kernel<KST, KCAP>;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= kMaxDevices || !attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (e != hipSuccess) return e;
+        if (dev < kMaxDevices) attr_set[dev] = true;
+    }
+    const int units = panel_unit_count(a.geom);
+    if (units <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3((unsigned)units), dim3(kHThreads), LDS, st, a);
+    return hipGetLastError();
+}
+#endif
+
 #define MCE_STR2(x) #x
 #define MCE_STR(x) MCE_STR2(x)
 #define MCE_VARIANT(KS)                                                                                  \
@@ -93,7 +116,8 @@ extern const KnnVariant MCE_CAT(g_knn_kcap, MCE_KCAP)[kMaxKS] = {
 #endif
 #define MCE_F16_VARIANT(KST, PRUNE_FN)                                                                   \
     {&launch_f16_variant<KST, MCE_KCAP, false>, PRUNE_FN, MCE_F16_LOWER(KST), &launch_f16_variant<KST, MCE_KCAP, false, false, 1>, \
-     &launch_f16_variant<KST, MCE_KCAP, false, false, 2>, &launch_f16_variant<KST, MCE_KCAP, false, false, 3>, f16_lds_bytes(KST, MCE_KCAP, true), KST, MCE_KCAP, f16_qt(MCE_KCAP), f16_chunk_tiles(KST), \
+     &launch_f16_variant<KST, MCE_KCAP, false, false, 2>, &launch_f16_variant<KST, MCE_KCAP, false, false, 3>, &launch_panel_variant<KST, MCE_KCAP>, panel_lds_bytes(KST), \
+     f16_lds_bytes(KST, MCE_KCAP, true), KST, MCE_KCAP, f16_qt(MCE_KCAP), f16_chunk_tiles(KST), \
      f16_lds_bytes(KST, MCE_KCAP), "knn_f16_kernel<KST=" #KST ",KCAP=" MCE_STR(MCE_KCAP) ">"}
 extern const KnnF16Variant MCE_CAT(g_knn_f16_kcap, MCE_KCAP)[kMaxKST] = {
     MCE_F16_VARIANT(1, (&launch_f16_variant<1, MCE_KCAP, true>)), MCE_F16_VARIANT(2, nullptr), MCE_F16_VARIANT(3, nullptr),
@@ -108,6 +132,10 @@ MCE_F16_INST(1, false, false, 0) MCE_F16_INST(2, false, false, 0) MCE_F16_INST(3
 MCE_F16_INST(1, false, false, 1) MCE_F16_INST(2, false, false, 1) MCE_F16_INST(3, false, false, 1) MCE_F16_INST(4, false, false, 1)
 MCE_F16_INST(1, false, false, 2) MCE_F16_INST(2, false, false, 2) MCE_F16_INST(3, false, false, 2) MCE_F16_INST(4, false, false, 2)
 MCE_F16_INST(1, false, false, 3) MCE_F16_INST(2, false, false, 3) MCE_F16_INST(3, false, false, 3) MCE_F16_INST(4, false, false, 3)
+template __global__ void knn_panel_kernel<1, MCE_KCAP>(PanelArgs);
+template __global__ void knn_panel_kernel<2, MCE_KCAP>(PanelArgs);
+template __global__ void knn_panel_kernel<3, MCE_KCAP>(PanelArgs);
+template __global__ void knn_panel_kernel<4, MCE_KCAP>(PanelArgs);
 #if MCE_KCAP == 16
 MCE_F16_INST(1, false, true, 0) MCE_F16_INST(2, false, true, 0) MCE_F16_INST(3, false, true, 0) MCE_F16_INST(4, false, true, 0)
 #endif

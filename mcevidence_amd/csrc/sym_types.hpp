@@ -57,4 +57,80 @@ MCE_HD inline void sym_unit_tiles(int p, int a, int tpb, int tpp, int ntiles, in
     hi = (p + 1) * tpp < hi_a ? (p + 1) * tpp : hi_a;
 }
 
+// ---------------------------------------------------------------------------
+// Units of the PANEL sweep (knn_panel.hpp), which generalises the above to a RANGE of query blocks [qb_lo, qb_hi):
+//   * sym_on = 0 (cross evidence, query shards): every block sweeps every tile [0, ntiles), column side only;
+//   * sym_on = 1 (auto evidence; one rank's share of it): the tiles of the blocks qb_lo..qb_hi-1 carry the row-side gate
+//     and block a takes them only up to its own (the pair of blocks {a, b}, qb_lo <= b < a, is handled by a alone);
+//     every other tile -- the blocks below qb_lo and from qb_hi on, i.e. the rows another rank owns -- is swept by every
+//     block, column side only.  With [qb_lo, qb_hi) = [0, nqblk) this is the single-GPU symmetric sweep.
+// Block a's tiles are therefore [0, hi_a) and [r2, ntiles), hi_a = sym_on ? min(tpb (a + 1), r1) : r1,
+// r1 = sym_on ? min(tpb qb_hi, ntiles) : ntiles, r2 = sym_on ? tpb qb_hi : ntiles.  Region 1 = [0, r1) is cut into
+// panels of tpp tiles from tile 0; region 2 = [r2, ntiles) into panels whose boundaries lie at r2c + k tpp, r2c = r2
+// rounded down to a whole chunk (ct tiles), so that only a region's first chunk can start inside a chunk.  Units are
+// numbered panel by panel (region 1, then region 2) and, within a panel, from the LAST block down; a block's units
+// hand its lists on in that order (panel_unit_seq = how many came before).
+// tests/native/sym_units_check.cpp checks the functions against each other.
+// ---------------------------------------------------------------------------
+struct PanelGeom {
+    int qb_lo = 0, qb_hi = 0;      // query blocks of the launch
+    int tpb = 16;                  // tiles per query block
+    int tpp = 0;                   // tiles per panel (a whole number of chunks)
+    int ct = 0;                    // tiles per chunk
+    int ntiles = 0;                // 32-row tiles holding reference rows, rounded up to even
+    int sym_on = 0;
+};
+MCE_HD inline int panel_r1(const PanelGeom& g) { return g.sym_on ? (g.tpb * g.qb_hi < g.ntiles ? g.tpb * g.qb_hi : g.ntiles) : g.ntiles; }
+MCE_HD inline int panel_r2(const PanelGeom& g) { return g.sym_on ? g.tpb * g.qb_hi : g.ntiles; }
+MCE_HD inline int panel_r2c(const PanelGeom& g) { return panel_r2(g) / g.ct * g.ct; }
+MCE_HD inline int panel_n1(const PanelGeom& g) { return (panel_r1(g) + g.tpp - 1) / g.tpp; }
+MCE_HD inline int panel_n2(const PanelGeom& g) { return panel_r2(g) < g.ntiles ? (g.ntiles - panel_r2c(g) + g.tpp - 1) / g.tpp : 0; }
+MCE_HD inline int panel_hi_a(const PanelGeom& g, int a)
+{
+    const int r1 = panel_r1(g);
+    return g.sym_on ? (g.tpb * (a + 1) < r1 ? g.tpb * (a + 1) : r1) : r1;
+}
+// first block with a unit in panel p (p < n1: region 1)
+MCE_HD inline int panel_amin(const PanelGeom& g, int p)
+{
+    if (!g.sym_on || p >= panel_n1(g)) return g.qb_lo;
+    const int amin = (int)(((int64_t)p * g.tpp) / g.tpb);
+    return amin > g.qb_lo ? amin : g.qb_lo;
+}
+MCE_HD inline int panel_unit_count(const PanelGeom& g)
+{
+    int total = 0;
+    const int np = panel_n1(g) + panel_n2(g);
+    for (int p = 0; p < np; ++p) total += g.qb_hi - panel_amin(g, p);
+    return total;
+}
+MCE_HD inline void panel_unit_decode(int u, const PanelGeom& g, int& p, int& a)
+{
+    for (p = 0;; ++p) {
+        const int cnt = g.qb_hi - panel_amin(g, p);
+        if (u < cnt) { a = g.qb_hi - 1 - u; return; }
+        u -= cnt;
+    }
+}
+MCE_HD inline void panel_unit_tiles(int p, int a, const PanelGeom& g, int& lo, int& hi)
+{
+    const int n1 = panel_n1(g);
+    if (p < n1) {
+        const int hi_a = panel_hi_a(g, a);
+        lo = p * g.tpp;
+        hi = (p + 1) * g.tpp < hi_a ? (p + 1) * g.tpp : hi_a;
+    } else {
+        const int r2 = panel_r2(g), r2c = panel_r2c(g), k = p - n1;
+        lo = k == 0 ? r2 : r2c + k * g.tpp;
+        hi = r2c + (k + 1) * g.tpp < g.ntiles ? r2c + (k + 1) * g.tpp : g.ntiles;
+    }
+}
+// units of block a before its unit in panel p
+MCE_HD inline int panel_unit_seq(int p, int a, const PanelGeom& g)
+{
+    const int n1 = panel_n1(g);
+    if (p < n1) return p;
+    return (panel_hi_a(g, a) + g.tpp - 1) / g.tpp + (p - n1);
+}
+
 }  // namespace mce

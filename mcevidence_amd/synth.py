@@ -16,7 +16,7 @@ import math
 
 import numpy as np
 
-__all__ = ["gaussian_chain", "planck_like_chains", "write_cosmomc_chains", "CONFIGS"]
+__all__ = ["gaussian_chain", "planck_like_chains", "write_cosmomc_chains", "CONFIGS", "config_chain"]
 
 
 def gaussian_chain(seed, n, d, *, weights="unit", cov="unit", nextra=0, dtype=np.float64):
@@ -118,3 +118,17 @@ CONFIGS = {
     "C4": dict(kind="gaussian_pair", seeds=(4, 5), n=1_000_000, d=15, kmax=4, cov="unit"),
     "C5": dict(kind="gaussian", seed=6, n=10_000_000, d=6, kmax=10, cov="corr"),
 }
+
+
+def config_chain(name, n=None):
+    """The chain array of a BASELINE.json GPU config and its (s1_rows, s2_rows) split (None, None for auto
+    evidence).  C4 is two independent chains stacked: s1 = the first, s2 = the second; ``n``
+    overrides the rows per chain (reduced-size variants for tests)."""
+    c = dict(CONFIGS[name])
+    n = int(n or c["n"])
+    if c["kind"] == "gaussian":
+        return gaussian_chain(seed=c["seed"], n=n, d=c["d"], cov=c["cov"]), (None, None)
+    if c["kind"] == "gaussian_pair":
+        a, b = (gaussian_chain(seed=s, n=n, d=c["d"], cov=c["cov"]) for s in c["seeds"])
+        return np.concatenate((a, b)), (np.arange(n), np.arange(n, 2 * n))
+    raise ValueError("config_chain: %s is not an in-memory Gaussian config" % name)

@@ -15,7 +15,7 @@ SURVEY.md section 8c) and records, for seeded synthetic chains made by
   * a few sampled rows of the whitened samples and of DkNN.
 
 Outputs are data only (JSON/NPZ under tests/golden/).  No reference source is
-copied.  Usage:  python oracle/gen_golden.py [--small] [--medium] [--big] [--sym] [--host]
+copied.  Usage:  python oracle/gen_golden.py [--small] [--medium] [--big] [--sym] [--host] [--c4 [--c4-n N]]
 """
 from __future__ import annotations
 
@@ -209,6 +209,73 @@ def gen_inmemory(ref, cases, tag):
     np.savez_compressed(os.path.join(GOLD, "evidence_%s.npz" % tag), **out_npz)
 
 
+def gen_c4(ref, n, tag):
+    """BASELINE configs[3] (C4): cross evidence of two INDEPENDENT chains of ``n`` rows each, d = 15, kmax = 4 --
+    ``synth.config_chain('C4')``: the two chains stacked, s1 = the first, s2 = the second.
+
+    The reference only knows a random split (``MCEvidence.py:221-226``: ``np.random.choice`` over the rows), so the
+    harness hands it the wanted one by wrapping ``np.random.choice`` for the duration of the constructor (harness-side,
+    like the sorted glob above; the reference source is untouched).  Its kNN call (``:1093-1104``, kd_tree at d = 15:
+    hours at n = 1M on 8 cores) runs ONCE: a spy on ``NearestNeighbors.kneighbors`` keeps the distances it returned,
+    from which ``dotp`` (``:1117``) and a few rows are recorded."""
+    from sklearn.neighbors import NearestNeighbors
+    from mcevidence_amd.synth import config_chain
+
+    chain, (r1, r2) = config_chain("C4", n=n)
+    kmax = 4
+    seen = {}
+    orig_kn, orig_choice = NearestNeighbors.kneighbors, np.random.choice
+
+    def spy(self, X=None, *a, **k):
+        out = orig_kn(self, X, *a, **k)
+        seen["DkNN"], seen["fit_method"], seen["n_fit"] = out[0], str(self._fit_method), int(self.n_samples_fit_)
+        return out
+
+    def first_half(rows, size=None, replace=True, p=None):
+        assert len(rows) == len(chain) and size == n and not replace
+        return np.arange(n)
+
+    NearestNeighbors.kneighbors = spy
+    np.random.choice = first_half
+    t0 = time.perf_counter()
+    try:
+        mce = ref.MCEvidence([chain], kmax=kmax, split=True, verbose=0)
+    finally:
+        np.random.choice = orig_choice
+    try:
+        lnE = mce.evidence()
+    finally:
+        NearestNeighbors.kneighbors = orig_kn
+    wall = time.perf_counter() - t0
+    assert np.array_equal(mce.gd.data["s1"].samples, chain[r1, 2:]) and np.array_equal(mce.gd.data["s2"].samples, chain[r2, 2:])
+    DkNN = seen["DkNN"]
+    S, D = int(mce.nchain[0][0]), int(mce.ndim)
+    s1, logL, w, _ = mce.get_samples(S, istart=0, rand=False, prewhiten=False, name="s1")
+    cov = mce.get_covariance()
+    X = mce.diagonalise_chain(s1.copy(), cov["eVec"], cov["eVal"])
+    logLmax = float(np.amax(logL))
+    fs = logL - logLmax
+    SumW = float(np.sum(mce.gd.data["s1"].adjusted_weights))
+    dotp, lnE_re = np.zeros(kmax), np.zeros(kmax)
+    for k in range(kmax):
+        vol = math.pi ** (D / 2) * DkNN[:, k] ** D / math.gamma(1 + D / 2)
+        dotp[k] = np.dot(vol / w, np.exp(fs))
+        lnE_re[k] = math.log(SumW * dotp[k] / (S * (k + 1) + 1.0) * cov["J"]) + logLmax - math.log(mce.priorvolume)
+    assert np.allclose(lnE_re[1:], lnE, rtol=0, atol=1e-12), (lnE_re, lnE)
+    rows = np.linspace(0, S - 1, 64).astype(np.int64)
+    name = "cross_n%d_d15_k4_C4" % n
+    js = dict(name=name, config="C4", n_per_chain=n, mce=dict(kmax=kmax, split=True), ev={}, S=S, N_ref=seen["n_fit"], ndim=D,
+              kmax=kmax, k0=0, J=float(cov["J"]), SumW=SumW, logLmax=logLmax, lnPriorVolume=math.log(mce.priorvolume),
+              dotp=[float(x) for x in dotp], lnE=[float(x) for x in lnE], lnE_all_k=[float(x) for x in lnE_re],
+              fit_method=seen["fit_method"], ref_wall_s=wall,
+              versions=dict(numpy=np.__version__, sklearn=__import__("sklearn").__version__))
+    with open(os.path.join(GOLD, "evidence_%s.json" % tag), "w") as fh:
+        json.dump([js], fh, indent=1)
+    np.savez_compressed(os.path.join(GOLD, "evidence_%s.npz" % tag), **{name + "__rows": rows, name + "__X_rows": X[rows],
+                                                                      name + "__DkNN_rows": DkNN[rows]})
+    print("%-36s lnE=%s fit=%s (%.1fs)" % (name, np.array2string(np.asarray(lnE), precision=10), seen["fit_method"], wall), flush=True)
+
+
 def gen_host_pins(ref):
     """Host-bookkeeping pins: file loading, burn-in,
     thinning, idchain, prior volume, error behaviour."""
@@ -312,6 +379,8 @@ def main():
     ap.add_argument("--big", action="store_true")
     ap.add_argument("--sym", action="store_true")
     ap.add_argument("--host", action="store_true")
+    ap.add_argument("--c4", action="store_true", help="BASELINE configs[3] at full size: hours of kd_tree on 8 cores")
+    ap.add_argument("--c4-n", type=int, default=1_000_000, help="rows per chain for --c4 (smaller: a quick harness check)")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     ref = import_reference()
@@ -327,6 +396,8 @@ def main():
         gen_inmemory(ref, SYM_CASES, "sym")
     if a.host:
         gen_host_pins(ref)
+    if a.c4:
+        gen_c4(ref, a.c4_n, "c4" if a.c4_n == 1_000_000 else "c4_n%d" % a.c4_n)
 
 
 if __name__ == "__main__":

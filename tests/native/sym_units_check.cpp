@@ -43,5 +43,48 @@ int main()
                     }
                 }
     printf("ok %ld units\n", checked);
+    // ---- panel sweep units (PanelGeom): a range of blocks, symmetric inside the range, column side only outside
+    long pchecked = 0;
+    for (int nqblk = 1; nqblk <= 60; nqblk += (nqblk < 10 ? 1 : 5))
+        for (int ct : {12, 24, 48})
+            for (int panel : {1, 2, 5, 96})
+                for (int sym_on = 0; sym_on < 2; ++sym_on)
+                    for (int parts = 1; parts <= 4; ++parts)
+                        for (int part = 0; part < parts; ++part)
+                            for (int cut = 0; cut < 2; ++cut) {
+                                mce::PanelGeom g;
+                                g.tpb = 16; g.ct = ct; g.tpp = panel * ct; g.sym_on = sym_on;
+                                g.ntiles = g.tpb * nqblk - (cut ? 6 : 0);
+                                if (g.ntiles <= g.tpb * (nqblk - 1)) g.ntiles = g.tpb * (nqblk - 1) + 2;
+                                g.qb_lo = (int)((long)nqblk * part / parts);
+                                g.qb_hi = (int)((long)nqblk * (part + 1) / parts);
+                                if (g.qb_hi <= g.qb_lo) continue;
+                                const int n = mce::panel_unit_count(g);
+                                std::vector<std::vector<char>> cover(nqblk, std::vector<char>(g.ntiles, 0));
+                                std::vector<int> seq(nqblk, 0);
+                                int last_p = 0, last_a = g.qb_hi;
+                                for (int u = 0; u < n; ++u) {
+                                    int p, a, lo, hi;
+                                    mce::panel_unit_decode(u, g, p, a);
+                                    mce::panel_unit_tiles(p, a, g, lo, hi);
+                                    if (a < g.qb_lo || a >= g.qb_hi) { printf("panel: bad block %d\n", a); return 1; }
+                                    if (p != last_p) last_a = g.qb_hi;
+                                    if (p < last_p || a >= last_a) { printf("panel: order broken at unit %d\n", u); return 1; }
+                                    last_p = p; last_a = a;
+                                    if (hi <= lo || (lo & 1) || (hi & 1) || hi > g.ntiles) { printf("panel: bad range [%d,%d) unit %d (p %d a %d) nqblk %d ct %d panel %d sym %d part %d/%d\n", lo, hi, u, p, a, nqblk, ct, panel, sym_on, part, parts); return 1; }
+                                    // one interval of chunks; only the first chunk may start inside a chunk
+                                    if (mce::panel_unit_seq(p, a, g) != seq[a]) { printf("panel: block %d unit %d has seq %d, expected %d\n", a, u, mce::panel_unit_seq(p, a, g), seq[a]); return 1; }
+                                    seq[a] += 1;
+                                    for (int t = lo; t < hi; ++t) { if (cover[a][t]) { printf("panel: tile %d of block %d covered twice\n", t, a); return 1; } cover[a][t] = 1; }
+                                    ++pchecked;
+                                }
+                                for (int a = g.qb_lo; a < g.qb_hi; ++a)
+                                    for (int t = 0; t < g.ntiles; ++t) {
+                                        const int tb = t / g.tpb;
+                                        const bool want = !sym_on || tb <= a || tb >= g.qb_hi;
+                                        if ((bool)cover[a][t] != want) { printf("panel: block %d tile %d covered %d, expected %d (nqblk %d ct %d panel %d part %d/%d ntiles %d)\n", a, t, cover[a][t], (int)want, nqblk, ct, panel, part, parts, g.ntiles); return 1; }
+                                    }
+                            }
+    printf("ok %ld panel units\n", pchecked);
     return 0;
 }

@@ -1,7 +1,13 @@
 // knn_sym_bench.hip -- developer microbench for the symmetric sweep (knn_f16_kernel<.., SYM>): prepass + sweep with the
 // per-wave statistics on; not part of the product.  Rows are sorted by distance from the mean on the host.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DMCE_STATS=1 -mllvm -amdgpu-sched-strategy=max-ilp tools/knn_sym_bench.hip -o tools/knn_bench_sym
+// -DPANEL=1 (default): the sweep runs on knn_panel_kernel (knn_panel.hpp; statistics with -DMCE_PANEL_STATS=1); -DPANEL=0: on the
+// SYM = 2 instantiation of knn_f16_kernel (statistics with -DMCE_STATS=1).
+#ifndef PANEL
+#define PANEL 1
+#endif
 #include "../mcevidence_amd/csrc/f16_prep.hpp"
+#include "../mcevidence_amd/csrc/knn_panel.hpp"
 #include "../mcevidence_amd/csrc/pack_refs.hpp"
 #include <cstdio>
 #include <cstdlib>
@@ -73,8 +79,21 @@ int main(int argc, char** argv)
     constexpr size_t LDS = f16_lds_bytes(KST, KCAP, true);
     auto kpre = knn_f16_kernel<KST, KCAP, false, false, 1>;
     auto kern = knn_f16_kernel<KST, KCAP, false, false, 2>;
+    auto kpanel = knn_panel_kernel<KST, KCAP>;
     CK(hipFuncSetAttribute((const void*)kpre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    CK(hipFuncSetAttribute((const void*)kpanel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds_bytes(KST)));
+    PanelArgs pa;
+    pa.Yh = Yh; pa.Xh = Xh; pa.qinfo = qinfo; pa.params = params; pa.X = X; pa.Y = X; pa.rperm = dperm; pa.part_d = pd; pa.part_i = pi;
+    pa.nq = n; pa.nr = n; pa.nq_pad = nq_pad; pa.self_offset = 0; pa.D = D; pa.ksel = KSEL; pa.self_exclude = 1; pa.spin_limit = 1 << 21; pa.debug = 0;
+    pa.sym = sp;
+    pa.geom.qb_lo = 0; pa.geom.qb_hi = nqblk; pa.geom.tpb = kHWaves * kHQT; pa.geom.ct = CT; pa.geom.tpp = panel * CT; pa.geom.sym_on = 1;
+    pa.geom.ntiles = (int)((n + 31) / 32) + (int)(((n + 31) / 32) & 1);
+    if (getenv("PARTS")) {      // one rank's share of a multi-GPU symmetric partition: PARTS=<nparts>,<part>
+        int np = 1, pt = 0; sscanf(getenv("PARTS"), "%d,%d", &np, &pt);
+        pa.geom.qb_lo = (int)((int64_t)nqblk * pt / np); pa.geom.qb_hi = (int)((int64_t)nqblk * (pt + 1) / np);
+    }
+    const int npanel_units = panel_unit_count(pa.geom);
     hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
     const int seed_mode = getenv("SEED_MODE") ? atoi(getenv("SEED_MODE")) : (KST >= 2 ? 1 : 0);      // as capi.hip: kSymSeedMode
     const int seed_cfg0 = f16_seed_cfg(nchunk, CT, KSEL + 1, seed_rows, 8, MCE_H_SEED_TG);
@@ -87,7 +106,8 @@ int main(int argc, char** argv)
                                         (const int*)nullptr, (const float*)nullptr, 0, dperm, (const int*)nullptr, (const float*)nullptr,
                                         (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr, seed_cfg, sp);
         CK(hipEventRecord(e1));
-        if (!getenv("SYM_REPAIR_ALL")) kern<<<nunits, kHThreads, LDS>>>(Yh, nchunk, 1, Xh, qinfo, params, X, X, n, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi,
+        if (PANEL && !getenv("SYM_REPAIR_ALL")) kpanel<<<npanel_units, kHThreads, panel_lds_bytes(KST)>>>(pa);
+        else if (!getenv("SYM_REPAIR_ALL")) kern<<<nunits, kHThreads, LDS>>>(Yh, nchunk, 1, Xh, qinfo, params, X, X, n, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi,
                                         (const int*)nullptr, (const float*)nullptr, 0, dperm, (const int*)nullptr, (const float*)nullptr,
                                         (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr, 0, sp);
         CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
@@ -106,7 +126,7 @@ int main(int argc, char** argv)
             printf("exhaustive column-only sweep over the sorted rows, thresholds from the prepass: %.2f ms\n", ms3);
         }
         float ms1, ms2; CK(hipEventElapsedTime(&ms1, e0, e1)); CK(hipEventElapsedTime(&ms2, e1, e2));
-         printf("panel=%d units=%d ", panel, nunits); printf("D=%d KST=%d KCAP=%d K=%d n=%lld grid=%d seed=%dx%d sorted=%d: prepass %.2f ms  sweep %.2f ms\n", D, KST, KCAP, KSEL, (long long)n, nqblk,
+         printf("%s panel=%d units=%d ", PANEL ? "panel-kernel" : "f16-kernel", panel, PANEL ? npanel_units : nunits); printf("D=%d KST=%d KCAP=%d K=%d n=%lld grid=%d seed=%dx%d sorted=%d: prepass %.2f ms  sweep %.2f ms\n", D, KST, KCAP, KSEL, (long long)n, nqblk,
                seed_cfg & 0xffff, (seed_cfg >> 16) & 0xfff, sorted, ms1, ms2);
     }
     {
@@ -116,7 +136,19 @@ int main(int argc, char** argv)
         for (int b = 0; b < nqblk; ++b) { tot += cnt[b]; mx = std::max<long long>(mx, cnt[b]); fl += cnt[nqblk + b]; }
         printf("buckets: %.1f entries per row on average, fullest %.1f per row (cap %d), %lld overflowed\n", (double)tot / n, (double)mx / qpb, per_row, fl);
     }
-#if MCE_STATS
+#if MCE_PANEL_STATS && PANEL
+    {
+        const size_t nw = (size_t)npanel_units * 8;
+        std::vector<double> hs(nw * 8);
+        CK(hipMemcpy(hs.data(), (char*)params + 128, nw * 64, hipMemcpyDeviceToHost));
+        double m[8] = {0};
+        for (size_t w = 0; w < nw; ++w) for (int k = 0; k < 8; ++k) m[k] += hs[w * 8 + k] / nw;
+        printf("per wave and unit (mean): drains %.1f  enq %.0f  redo tiles %.2f  event (tile, query tile)s %.0f | cycles: events %.3g (%.1f %%)  drains %.3g (%.1f %%)  prologue %.3g (%.1f %%)  kernel %.3g\n",
+               m[0], m[1], m[2], m[3], m[4], 100 * m[4] / m[6], m[5], 100 * m[5] / m[6], m[7], 100 * m[7] / m[6], m[6]);
+        printf("   per event %.0f cycles, per drain %.0f cycles, per queued pair %.1f drain cycles; enq per query (whole search) %.1f\n", m[4] / (m[3] > 0 ? m[3] : 1), m[5] / (m[0] > 0 ? m[0] : 1), m[5] / (m[1] > 0 ? m[1] : 1), m[1] * nw / 64.0 / n * 64.0 / 64.0);
+    }
+#endif
+#if MCE_STATS && !PANEL
     {
         const size_t nw = (size_t)nunits * 8;
         std::vector<double> hs(nw * 16);
