@@ -8,13 +8,14 @@
 #ifndef MCE_KCAP
 #error "compile with -DMCE_KCAP=n"
 #endif
-// MCE_INST_PART: 1 = the fp16 filter kernels only, 2 = the fp64 sweep kernels only (the Makefile builds them as
-// separate objects: they are compiled with different instruction schedulers), 0 = both
+// MCE_INST_PART: 1 = the fp16 filter kernels only, 2 = the fp64 sweep kernels only, 3 = the panel sweep kernels only (the
+// Makefile builds them as separate objects: they are compiled with different instruction schedulers), 0 = all
 #ifndef MCE_INST_PART
 #define MCE_INST_PART 0
 #endif
-#define MCE_INST_F16 (MCE_KCAP <= 16 && MCE_INST_PART != 2)
-#define MCE_INST_F64 (MCE_INST_PART != 1)
+#define MCE_INST_F16 (MCE_KCAP <= 16 && (MCE_INST_PART == 0 || MCE_INST_PART == 1))
+#define MCE_INST_F64 (MCE_INST_PART == 0 || MCE_INST_PART == 2)
+#define MCE_INST_PANEL (MCE_KCAP <= 16 && (MCE_INST_PART == 0 || MCE_INST_PART == 3))
 
 namespace mce {
 
@@ -68,9 +69,10 @@ hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
 }
 #endif
 
-#if MCE_INST_F16
+#if MCE_INST_F16 || MCE_INST_PANEL
 template <int KST, int KCAP>
 hipError_t launch_panel_variant(const PanelArgs& a, hipStream_t st)
+#if MCE_INST_PANEL
 {
     constexpr size_t LDS = panel_lds_bytes(KST);
     static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -88,6 +90,17 @@ hipError_t launch_panel_variant(const PanelArgs& a, hipStream_t st)
     hipLaunchKernelGGL(kern, dim3((unsigned)units), dim3(kHThreads), LDS, st, a);
     return hipGetLastError();
 }
+template hipError_t launch_panel_variant<1, MCE_KCAP>(const PanelArgs&, hipStream_t);
+template hipError_t launch_panel_variant<2, MCE_KCAP>(const PanelArgs&, hipStream_t);
+template hipError_t launch_panel_variant<3, MCE_KCAP>(const PanelArgs&, hipStream_t);
+template hipError_t launch_panel_variant<4, MCE_KCAP>(const PanelArgs&, hipStream_t);
+#else
+;     // defined in this list capacity's panel object (MCE_INST_PART = 3)
+extern template hipError_t launch_panel_variant<1, MCE_KCAP>(const PanelArgs&, hipStream_t);
+extern template hipError_t launch_panel_variant<2, MCE_KCAP>(const PanelArgs&, hipStream_t);
+extern template hipError_t launch_panel_variant<3, MCE_KCAP>(const PanelArgs&, hipStream_t);
+extern template hipError_t launch_panel_variant<4, MCE_KCAP>(const PanelArgs&, hipStream_t);
+#endif
 #endif
 
 #define MCE_STR2(x) #x
@@ -132,13 +145,15 @@ MCE_F16_INST(1, false, false, 0) MCE_F16_INST(2, false, false, 0) MCE_F16_INST(3
 MCE_F16_INST(1, false, false, 1) MCE_F16_INST(2, false, false, 1) MCE_F16_INST(3, false, false, 1) MCE_F16_INST(4, false, false, 1)
 MCE_F16_INST(1, false, false, 2) MCE_F16_INST(2, false, false, 2) MCE_F16_INST(3, false, false, 2) MCE_F16_INST(4, false, false, 2)
 MCE_F16_INST(1, false, false, 3) MCE_F16_INST(2, false, false, 3) MCE_F16_INST(3, false, false, 3) MCE_F16_INST(4, false, false, 3)
+#if MCE_KCAP == 16
+MCE_F16_INST(1, false, true, 0) MCE_F16_INST(2, false, true, 0) MCE_F16_INST(3, false, true, 0) MCE_F16_INST(4, false, true, 0)
+#endif
+#endif
+#if MCE_INST_PANEL
 template __global__ void knn_panel_kernel<1, MCE_KCAP>(PanelArgs);
 template __global__ void knn_panel_kernel<2, MCE_KCAP>(PanelArgs);
 template __global__ void knn_panel_kernel<3, MCE_KCAP>(PanelArgs);
 template __global__ void knn_panel_kernel<4, MCE_KCAP>(PanelArgs);
-#if MCE_KCAP == 16
-MCE_F16_INST(1, false, true, 0) MCE_F16_INST(2, false, true, 0) MCE_F16_INST(3, false, true, 0) MCE_F16_INST(4, false, true, 0)
-#endif
 #endif
 #if MCE_INST_F64
 #define MCE_INST(KS) template __global__ void knn_mfma_kernel<KS, MCE_KCAP>(const double*, int64_t, int, const double*, const double*, int64_t, int, int64_t, int, int, int64_t, int, double*, int*);

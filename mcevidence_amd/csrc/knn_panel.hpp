@@ -16,7 +16,9 @@
 //     ones, ~4 VALU per queued pair;
 //   * there is ONE drain in the code, at the end of a chunk; a queue that fills up inside a chunk defers the rest of the
 //     tile to a redo list, which the chunk end works off by multiplying those tiles again (the chunk is still in LDS);
-//   * the pipeline is flushed at the end of a chunk, so the accumulators are dead while the drain runs.
+//   * the pipeline is flushed at the end of a chunk, so the accumulators are dead while the drain runs.  (Measured on one
+//     box against a pipeline kept going across chunk boundaries, flushed only for a drain, redo from global memory:
+//     37.5 vs 39.3 ms at C3 -- the carried tile costs the loop more than the flush.)
 #pragma once
 #include "knn_f16.hpp"
 
@@ -42,17 +44,35 @@ struct PanelArgs {
 #ifndef MCE_PANEL_STATS
 #define MCE_PANEL_STATS 0       // tools/knn_sym_bench.hip: per-wave cycle / event counters appended to `params`
 #endif
+#ifndef MCE_PANEL_EVT
+#define MCE_PANEL_EVT 1         // how a tile with a candidate finds it: 1 = through the gate's first-level minima (9 compares), 0 = groups of four (16)
+#endif
+#ifndef MCE_PANEL_NPASS
+#define MCE_PANEL_NPASS 3       // drain, phase A: 8 * NPASS pairs in flight per trip
+#endif
+#ifndef MCE_PANEL_STAGE_KB
+#define MCE_PANEL_STAGE_KB MCE_H_STAGE_KB      // KB per staging buffer (two of them)
+#endif
+#ifndef MCE_PANEL_QUEUE
+#define MCE_PANEL_QUEUE MCE_H_QUEUE            // candidate queue entries per wave (16 B each)
+#endif
+#ifndef MCE_PANEL_TRIGGER
+#define MCE_PANEL_TRIGGER 192                  // a wave with this many queued candidates asks the workgroup to drain (96 -> 192: 35.4 -> 35.1 ms at C3)
+#endif
 #ifndef MCE_PANEL_ABL
-#define MCE_PANEL_ABL 0         // tools only: 1 = the gates never pass (results invalid)
+#define MCE_PANEL_ABL 0         // tools only: 1 = the gates never pass, 2 = no gate at all (results invalid)
 #endif
 
+// 32-row reference tiles per staged chunk (tile = KST KB): even, and a whole number of 16-byte vectors per thread
+__host__ __device__ constexpr int panel_chunk_tiles(int KST) { return MCE_PANEL_STAGE_KB / KST / 2 * 2; }
+constexpr int kPanelQueue = MCE_PANEL_QUEUE;
 __host__ __device__ constexpr size_t panel_lds_bytes(int KST)
 {
-    return (size_t)2 * f16_chunk_tiles(KST) * KST * 1024             // staging
-           + (size_t)kHWaves * kHQueue * 16                            // queues: d2 (8) + packed (4) + next (4)
+    return (size_t)2 * panel_chunk_tiles(KST) * KST * 1024           // staging
+           + (size_t)kHWaves * kPanelQueue * 16                        // queues: d2 (8) + packed (4) + next (4)
            + (size_t)kHWaves * kHQT * 32 * 4 + 128                     // chain heads + votes
            + (size_t)kHWaves * kHQT * 32 * 4                           // K-th bound per query as of the last drain (float, rounded up)
-           + (size_t)kHWaves * f16_chunk_tiles(KST) * kHQT * 4;        // redo list
+           + (size_t)kHWaves * panel_chunk_tiles(KST) * kHQT * 4;      // redo list
 }
 
 // pointers read out of the argument block are generic to the compiler; these say what they are (global memory), so that
@@ -81,11 +101,11 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
     constexpr int QPW = 64;                              // queries per wave
     constexpr int QPB = kHWaves * QPW;                   // 512
     constexpr int TPB = QPB / 32;
-    constexpr int CT = f16_chunk_tiles(KST);
+    constexpr int CT = panel_chunk_tiles(KST);
     constexpr int CHUNK_BYTES = CT * KST * 1024;
     constexpr int VPT = CHUNK_BYTES / 16 / kHThreads;
     static_assert(CHUNK_BYTES % (16 * kHThreads) == 0 && CT % 2 == 0, "chunk geometry");
-    constexpr int QN = kHQueue;
+    constexpr int QN = kPanelQueue;
     // The only explicit kernel argument is the struct, so it sits at offset 0 of the kernarg segment.  It is read through
     // this pointer, laundered before every cold use: the loads then happen THERE (scalar loads from constant memory)
     // instead of at kernel entry with the values held -- or spilled -- across the tile loop.
@@ -117,7 +137,7 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
 
 #if MCE_PANEL_STATS
     const long long t_kernel0 = clock64();
-    long long st_drains = 0, st_enq = 0, st_events = 0, st_redo = 0, st_tD = 0, st_tE = 0, st_tPro = 0, st_tFlush = 0;
+    long long st_drains = 0, st_enq = 0, st_events = 0, st_redo = 0, st_tD = 0, st_tE = 0, st_tPro = 0, st_tA = 0, st_tR = 0, st_tB = 0;
 #endif
 
     // ---- which unit ---------------------------------------------------------------------------------------------
@@ -197,22 +217,49 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
             G[qt] = -__builtin_huge_valf();
         }
     }
-    // gate of query (qt, lane & 31) from a bound `thr` on its K-th squared distance (input units): see knn_f16.hpp
-    auto gate_of = [&](double thr, int qt) __attribute__((always_inline)) -> float {
+    // Per-query constants of the gates, computed once and kept in registers (the drains re-read them from L2 before:
+    // a round trip per refresh): for the lane's two gated queries gq_a = e_x + max e_y (+ slack) and gq_c = eps - |x^|^2
+    // (-inf: padding query), for the query the lane OWNS own_a = the same sum; and the launch's scale^2 and the row gate's
+    // additive term.  See knn_f16.hpp (gate_of, sym_row_gate) for the bound.
+    double gq_a[QT], gq_c[QT], own_a = 0.0, s2c, rowc;
+    {
         const ArgsPtr a = MCE_ARGS();
-        const int64_t q = qwave0 + qt * 32 + (lane & 31);
-        if (!(q < a->nq) || MCE_PANEL_ABL == 1) return -__builtin_huge_valf();
-        if (!(thr < INF)) return __builtin_huge_valf();
         const auto params = gptr(a->params);
         const auto qinfo = gptr(a->qinfo);
-        const double ex = qinfo[2 * q], xn = qinfo[2 * q + 1];
-        const double s2 = params[HP_SCALE] * params[HP_SCALE];
-        const double r = sqrt(xn) + params[HP_YHATMAX];
-        const double ga = (ex + params[HP_EY]) * (1.0 + 1e-9) + 2.0 * sqrt(16.0 * KST) * 0x1p-14;
-        const double eps = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 1e-9) + params[HP_RHO] + 1e-30;
-        const double rr = sqrt(thr * s2) * (1.0 + 1e-12) + ga;
-        const double g = rr * rr * (1.0 + 1e-12) - xn + eps;
-        return __double2float_ru(g);
+        const double p_scale = params[HP_SCALE], p_ey = params[HP_EY], p_ym = params[HP_YHATMAX], p_rho = params[HP_RHO];
+        s2c = p_scale * p_scale;
+        rowc = 0x1p-22 * (p_ym * p_ym + 1.0) + 1e-30;
+        const double slack = 2.0 * sqrt(16.0 * KST) * 0x1p-14;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const int64_t q = qwave0 + qt * 32 + (lane & 31);
+            gq_a[qt] = 0.0;
+            gq_c[qt] = -INF;
+            if (q < a->nq && MCE_PANEL_ABL != 1) {
+                const double ex = qinfo[2 * q], xn = qinfo[2 * q + 1];
+                const double r = sqrt(xn) + p_ym;
+                const double eps = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 1e-9) + p_rho + 1e-30;
+                gq_a[qt] = (ex + p_ey) * (1.0 + 1e-9) + slack;
+                gq_c[qt] = eps - xn;
+            }
+        }
+        {
+            const int64_t q = qwave0 + lane;
+            if (q < a->nq) own_a = (qinfo[2 * q] + p_ey) * (1.0 + 1e-9) + slack;
+        }
+    }
+    // gate of query (qt, lane & 31) from a bound `thr` on its K-th squared distance (input units)
+    auto gate_of = [&](double thr, int qt) __attribute__((always_inline)) -> float {
+        if (!(gq_c[qt] > -INF)) return -__builtin_huge_valf();
+        if (!(thr < INF)) return __builtin_huge_valf();
+        const double rr = sqrt(thr * s2c) * (1.0 + 1e-12) + gq_a[qt];
+        return __double2float_ru(rr * rr * (1.0 + 1e-12) + gq_c[qt]);
+    };
+    // row-side gate constant R of the OWNED query from the bound on its K-th squared distance (sym_row_gate, knn_f16.hpp)
+    auto own_row_gate = [&](double thr) __attribute__((always_inline)) -> float {
+        if (!(thr < INF)) return __builtin_huge_valf();
+        const double rr = sqrt(thr * s2c) * (1.0 + 1e-12) + own_a;
+        return __double2float_ru(rr * rr * (1.0 + 1e-12) * (1.0 + 0x1p-22) + rowc);
     };
     {
         const ArgsPtr a = MCE_ARGS();
@@ -230,21 +277,15 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) G[qt] = gate_of(__shfl(t0, qt * 32 + (lane & 31), 64), qt);
         if (sym_on) {
-            const auto params = gptr(a->params);
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                const int64_t qq = qwave0 + qt * 32 + (lane & 31);
-                if (qq < a->nq && MCE_PANEL_ABL != 1) {
-                    const double xn = gptr(a->qinfo)[2 * qq + 1];
-                    const double r = sqrt(xn) + params[HP_YHATMAX];
-                    const double eps = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 1e-9) + params[HP_RHO] + 1e-30;
-                    cR[qt] = __double2float_ru(eps - xn);
-                }
-            }
+            for (int qt = 0; qt < QT; ++qt) cR[qt] = gq_c[qt] > -INF ? __double2float_ru(gq_c[qt]) : -__builtin_huge_valf();
         }
     }
 
     const int dbg_flags = MCE_ARGS()->debug;
+    // a hit is queued while at most this many entries are waiting (64 lanes may follow); beyond, the tile is deferred to the
+    // redo list.  (debug 8, tests: -1 -- every candidate of the sweep goes through the redo list)
+    const int qlimit_gate = (dbg_flags & 8) ? -1 : QN - 64;
     int qcount = 0;      // wave-uniform number of queued candidates
     int nredo = 0;       // wave-uniform number of deferred (tile, query tile) events of the current chunk
 
@@ -266,7 +307,7 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
             // phase A: 8 lanes share one queued pair and read the two rows in 64-byte segments; all loads of a group of
             // NPASS * 8 pairs are issued before the first use (the gather is latency-bound)
             const int sub = lane & 7;
-            constexpr int NPASS = KST > 2 ? 1 : 3;
+            constexpr int NPASS = KST > 2 ? 1 : MCE_PANEL_NPASS;
             constexpr int EPL = KST > 2 ? 8 : 4;        // elements per lane: 4 covers D <= 32, 8 covers D <= 63
             for (int b0 = 0; b0 < qcount; b0 += NPASS * 8) {
                 int qlp[NPASS], ep[NPASS];
@@ -320,6 +361,10 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#if MCE_PANEL_STATS
+        const long long t_dA = clock64();
+        st_tA += t_dA - t_d0;
+#endif
         {
             // phase R (one lane per queue entry): the ROW side of every evaluated pair whose lane passed the row gate --
             // through row j's K slots (replace the largest of the K smallest row-side distances so far, by
@@ -406,6 +451,10 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#if MCE_PANEL_STATS
+        const long long t_dR = clock64();
+        st_tR += t_dR - t_dA;
+#endif
         // ---- phase B: every owner lane folds its chain into its register list ----------
         {
             int cur = whead[lane];
@@ -444,15 +493,20 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
             float R = 0.0f;
             if (q < nq) {
                 if (t < INF) {
+                    // both fetch-mins in flight together: the row constant is formed from the list's own bound; whoever
+                    // published a tighter bound on this row published the matching constant with it, and it comes back here
                     const unsigned long long mb = (unsigned long long)__double_as_longlong(t);
+                    const unsigned rb = __float_as_uint(own_row_gate(t));
                     const unsigned long long ob = __hip_atomic_fetch_min(sp_thr + q, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned orb = __hip_atomic_fetch_min(sp_rrow + q, rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (!(a->debug & 1)) t = fmin(t, __longlong_as_double((long long)ob));
+                    R = __uint_as_float(rb < orb ? rb : orb);
                 } else {
                     if (!(a->debug & 1)) t = __longlong_as_double((long long)__hip_atomic_load(sp_thr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    const unsigned rb = __float_as_uint(own_row_gate(t));
+                    const unsigned orb = __hip_atomic_fetch_min(sp_rrow + q, rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    R = __uint_as_float(rb < orb ? rb : orb);
                 }
-                const unsigned rb = __float_as_uint(sym_row_gate(t, gptr(a->qinfo)[2 * q], a->params, KST));
-                const unsigned orb = __hip_atomic_fetch_min(sp_rrow + q, rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                R = __uint_as_float(rb < orb ? rb : orb);
             }
             thr_own = t;
             seed_thr = t;
@@ -475,19 +529,39 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
     // row of the tile; todo: the accumulators still to be looked at (a redo passes what is left).  Accumulator by
     // accumulator, in groups of four: a wave-wide compare each, scalar branches over the empty ones; the lanes under the
     // gate append (query, row) to the wave's queue.  Returns the accumulators NOT handled because the queue was full.
-    auto event = [&](const v16f& c, const int qt, const float gq, const bool rowflag, const int jb0, const unsigned todo, const bool defer_all = false) __attribute__((always_inline)) -> unsigned {
+    auto event = [&](const v16f& c, const float (&l1)[5], const int qt, const float gq, const bool rowflag, const int jb0, const unsigned todo, const int qlimit) __attribute__((always_inline)) -> unsigned {
+        (void)l1;
         const unsigned wbase = (lanew[qt] + (unsigned)jb0) | (rowflag ? (1u << kHSymRowBits) : 0u);
         unsigned rem = 0;
         float g = gq;
 #define MCE_HIT(R_, P_, S_)                                                                                               \
         if ((S_) != 0 && (todo & (1u << (R_)))) {                                                                         \
-            if (qcount > QN - 64 || defer_all) rem |= 1u << (R_);                                                         \
+            if (qcount > qlimit) rem |= 1u << (R_);                                                                       \
             else {                                                                                                        \
                 if (P_) wq[__builtin_amdgcn_mbcnt_hi((unsigned)((S_) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)(S_), (unsigned)qcount))] = \
                             (int)(wbase + (unsigned)(((R_) & 3) + 8 * ((R_) >> 2)));                                      \
                 qcount += __builtin_popcountll(S_);                                                                       \
             }                                                                                                             \
         }
+#if MCE_PANEL_EVT == 1
+        // the gate's own first-level minima say which triples of accumulators hold something: 6 wave-wide compares, then 3
+        // for each triple that does (usually one) -- 9 instead of 16
+        {
+            const bool q0 = l1[0] <= g, q1 = l1[1] <= g, q2 = l1[2] <= g, q3 = l1[3] <= g, q4 = l1[4] <= g, p15 = c[15] <= g;
+            const unsigned long long u0 = __ballot(q0), u1 = __ballot(q1), u2 = __ballot(q2), u3 = __ballot(q3), u4 = __ballot(q4), s15 = __ballot(p15);
+#define MCE_TRIPLE(I_, U_)                                                                                                \
+            if ((U_) != 0) {                                                                                              \
+                const bool p0 = c[3 * (I_) + 0] <= g, p1 = c[3 * (I_) + 1] <= g, p2 = c[3 * (I_) + 2] <= g;             \
+                const unsigned long long s0 = __ballot(p0), s1 = __ballot(p1), s2 = __ballot(p2);                        \
+                MCE_HIT(3 * (I_) + 0, p0, s0)                                                                             \
+                MCE_HIT(3 * (I_) + 1, p1, s1)                                                                             \
+                MCE_HIT(3 * (I_) + 2, p2, s2)                                                                             \
+            }
+            MCE_TRIPLE(0, u0) MCE_TRIPLE(1, u1) MCE_TRIPLE(2, u2) MCE_TRIPLE(3, u3) MCE_TRIPLE(4, u4)
+#undef MCE_TRIPLE
+            MCE_HIT(15, p15, s15)
+        }
+#else
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -502,6 +576,7 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
                 MCE_HIT(4 * grp + 3, p3, s3)
             }
         }
+#endif
 #undef MCE_HIT
         return rem;
     };
@@ -547,30 +622,44 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
 #else
 #define MCE_ORDER(GATED_, NEXT_) do {} while (0)
 #endif
-    auto min16 = [&](const v16f& c) __attribute__((always_inline)) -> float {
-        float m0 = min3f(c[0], c[1], c[2]);
-        float m1 = min3f(c[3], c[4], c[5]);
-        float m2 = min3f(c[6], c[7], c[8]);
-        float m3 = min3f(c[9], c[10], c[11]);
-        float m4 = min3f(c[12], c[13], c[14]);
-        m0 = min3f(m0, m1, m2);
-        m3 = min3f(m3, m4, c[15]);
+    // min of the lane's 16 accumulators (8 v_min3_f32); l1: the five first-level minima -- of the accumulators 3i .. 3i + 2 --
+    // which the event path looks at first
+    auto min16 = [&](const v16f& c, float (&l1)[5]) __attribute__((always_inline)) -> float {
+        l1[0] = min3f(c[0], c[1], c[2]);
+        l1[1] = min3f(c[3], c[4], c[5]);
+        l1[2] = min3f(c[6], c[7], c[8]);
+        l1[3] = min3f(c[9], c[10], c[11]);
+        l1[4] = min3f(c[12], c[13], c[14]);
+        const float m0 = min3f(l1[0], l1[1], l1[2]);
+        const float m3 = min3f(l1[3], l1[4], c[15]);
         return min3f(m0, m3, m3);
     };
-    // gate of one finished tile (both query tiles); tix: the tile's index in its chunk (for a redo); Rt: its row-side gate
-    // constant (wave-uniform; -inf: column side only)
-    auto gate_tile = [&](const v16f (&acc)[QT], const int jb0, const float Rt, const int tix) __attribute__((always_inline)) {
+    // gate of one finished tile (both query tiles): ONE branch per tile, so that the tile's MFMAs and the gate's VALU work
+    // share a basic block and interleave; tix: the tile's index in its chunk (for a redo); gq / rg: the lane's gates for
+    // the PAIR of tiles this one belongs to (either side / row side)
+    auto gate_tile = [&](const v16f (&acc)[QT], const int jb0, const float (&gq)[QT], const float (&rg)[QT], const int tix) __attribute__((always_inline)) {
+#if MCE_PANEL_ABL == 2      // tools only: no gate at all -- the MFMA + LDS stream alone (results invalid)
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" :: "v"(acc[0]), "v"(acc[1]));
+#endif
+        return;
+#endif
+        float l1[QT][5], mm[QT];
+        bool pq[QT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            const float mm = min16(acc[qt]);
-            const float rg = Rt + cR[qt];
-            const float gq = vmaxf(G[qt], rg);                 // either side
-            if (__any(mm <= gq)) {
+            mm[qt] = min16(acc[qt], l1[qt]);
+            pq[qt] = mm[qt] <= gq[qt];
+        }
+        if (__any(pq[0] || pq[1])) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                if (!__any(pq[qt])) continue;
 #if MCE_PANEL_STATS
                 st_events += 1;
                 const long long t_e0 = clock64();
 #endif
-                const unsigned rem = event(acc[qt], qt, gq, mm <= rg, jb0, 0xffffu, (dbg_flags & 8) != 0);      // (8: everything through the redo list)
+                const unsigned rem = event(acc[qt], l1[qt], qt, gq[qt], mm[qt] <= rg[qt], jb0, 0xffffu, qlimit_gate);
                 if (rem) {                                     // queue full: the chunk end multiplies this tile again
                     if (lane == 0) wredo[nredo] = (int)(rem | ((unsigned)qt << 16) | ((unsigned)tix << 17));
                     nredo += 1;
@@ -591,7 +680,10 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
         const int t = c * CT + lane;
         const int tb = t / TPB;
         const bool en = sym_on && lane < CT && tb >= qb_lo && tb < qblk && MCE_PANEL_ABL != 1 && !(dbg_flags & 4);
-        return en ? __hip_atomic_load(rtile_p + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -__builtin_huge_valf();
+        const float r = en ? __hip_atomic_load(rtile_p + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -__builtin_huge_valf();
+        // the tiles are gated in pairs (t, t + 1), t even, with the larger of the two constants: one gate refresh per pair
+        // (rows sorted by distance from the mean: neighbouring tiles differ little); a block is a whole number of pairs
+        return fmaxf(r, __shfl_xor(r, 1, 64));
     };
     float rt_cur = -__builtin_huge_valf(), rt_next;
     stage_async(cfirst, 0);
@@ -603,7 +695,7 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
     for (int k = 0; k < ntot; ++k) {
         const int buf = k & 1;
         const int c = cfirst + k;
-        if (qcount >= kHDrainTrigger && lane == 0) wvote[buf] = 1;
+        if (qcount >= MCE_PANEL_TRIGGER && lane == 0) wvote[buf] = 1;
         dma_barrier();
         rt_cur = rt_next;
         if (k + 1 < ntot) {
@@ -627,30 +719,34 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
             mfma_first(a0, accA);
             mfma_rest(a0, accA);
             int t = tlo;
+            float gqP[QT], rgP[QT];
             _Pragma("unroll 1") for (;;)
             {
-                const float rA = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(rt_cur), t));
+                const float rP = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(rt_cur), t));
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    rgP[qt] = rP + cR[qt];
+                    gqP[qt] = vmaxf(G[qt], rgP[qt]);            // either side
+                }
                 const bool more = t + 2 < thi;
                 load_a(lbuf + ((more ? t + 2 : t) * KST) * 1024, a0);        // (last trip: harmless re-read)
                 mfma_first(a1, accB);
                 MCE_ORDER(accA, accB);
                 mfma_rest(a1, accB);
-                gate_tile(accA, jchunk + t * 32, rA, t);
+                gate_tile(accA, jchunk + t * 32, gqP, rgP, t);
                 if (!more) break;
-                const float rB = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(rt_cur), t + 1));
                 load_a(lbuf + ((t + 3) * KST) * 1024, a1);
                 mfma_first(a0, accA);
                 MCE_ORDER(accB, accA);
                 mfma_rest(a0, accA);
-                gate_tile(accB, jchunk + (t + 1) * 32, rB, t + 1);
+                gate_tile(accB, jchunk + (t + 1) * 32, gqP, rgP, t + 1);
                 t += 2;
             }
             {   // the chunk's last tile: no MFMA behind it -- the wait states spelled out, then its gate (flush)
-                const float rB = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(rt_cur), t + 1));
 #if defined(__HIP_DEVICE_COMPILE__)
                 asm volatile("s_nop 15\n\ts_nop 3" : "+v"(accB[0]), "+v"(accB[1]));
 #endif
-                gate_tile(accB, jchunk + (t + 1) * 32, rB, t + 1);
+                gate_tile(accB, jchunk + (t + 1) * 32, gqP, rgP, t + 1);
             }
         }
         // ---- chunk end: the deferred tiles and the drain (ONE copy of it in the code) ------------------------------
@@ -680,12 +776,12 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
 #if defined(__HIP_DEVICE_COMPILE__)
                 asm volatile("s_nop 15\n\ts_nop 3" : "+v"(r_));
 #endif
-                const float mm = min16(r_);
+                float l1[5];
+                const float mm = min16(r_, l1);
                 const float rg = Rt + (qt ? cR[1] : cR[0]);
                 const float gq = vmaxf(qt ? G[1] : G[0], rg);
-                unsigned rem = todo;
-                if (__any(mm <= gq)) rem = event(r_, qt, gq, mm <= rg, jchunk + t * 32, todo);
-                else rem = 0;
+                unsigned rem = 0;
+                if (__any(mm <= gq)) rem = event(r_, l1, qt, gq, mm <= rg, jchunk + t * 32, todo, QN - 64);
                 if (rem) {
                     if (lane == 0) wredo[nredo] = (int)(rem | ((unsigned)qt << 16) | ((unsigned)t << 17));
                     nredo += 1;
@@ -703,6 +799,8 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
         double* o = const_cast<double*>(a->params) + 16 + ((int64_t)blockIdx.x * kHWaves + wave) * 8;
         o[0] = (double)st_drains; o[1] = (double)st_enq; o[2] = (double)st_redo; o[3] = (double)st_events;
         o[4] = (double)st_tE; o[5] = (double)st_tD; o[6] = (double)(clock64() - t_kernel0); o[7] = (double)st_tPro;
+        double* o2 = const_cast<double*>(a->params) + 16 + ((int64_t)gridDim.x * kHWaves) * 8 + ((int64_t)blockIdx.x * kHWaves + wave) * 8;
+        o2[0] = (double)st_tA; o2[1] = (double)st_tR; o2[2] = (double)(st_tD - st_tA - st_tR); o2[3] = 0; o2[4] = 0; o2[5] = 0; o2[6] = 0; o2[7] = 0;
     }
 #endif
     // ---- write the lists (lane l owns wave-local query l: coalesced) and hand them to the block's next unit ------------

@@ -36,12 +36,13 @@ int main(int argc, char** argv)
     const int panel = argc > 6 ? atoi(argv[6]) : 48;
     constexpr int D = DIM;
     constexpr int KST = f16_ksteps(D);
-    constexpr int CT = f16_chunk_tiles(KST);
+    constexpr int CT = f16_chunk_tiles(KST);            // the prepass's chunks
+    constexpr int PCT = panel_chunk_tiles(KST);         // the panel sweep's
     const int qpb = f16_qpb(KCAP);
     const int nqblk = (int)((n + qpb - 1) / qpb);
     const int64_t nq_pad = (int64_t)nqblk * qpb;
     const int64_t nchunk = (n + CT * 32 - 1) / (CT * 32);
-    const int64_t nrow_pad = nchunk * CT * 32;
+    const int64_t nrow_pad = (nchunk * CT * 32 + (int64_t)PCT * 32 * CT - 1) / ((int64_t)PCT * 32 * CT) * ((int64_t)PCT * 32 * CT);     // whole chunks of either kind
     std::vector<double> h((size_t)n * D), hsorted((size_t)n * D);
     std::mt19937_64 g(1); std::normal_distribution<double> nd;
     for (auto& v : h) v = nd(g);
@@ -87,7 +88,7 @@ int main(int argc, char** argv)
     pa.Yh = Yh; pa.Xh = Xh; pa.qinfo = qinfo; pa.params = params; pa.X = X; pa.Y = X; pa.rperm = dperm; pa.part_d = pd; pa.part_i = pi;
     pa.nq = n; pa.nr = n; pa.nq_pad = nq_pad; pa.self_offset = 0; pa.D = D; pa.ksel = KSEL; pa.self_exclude = 1; pa.spin_limit = 1 << 21; pa.debug = 0;
     pa.sym = sp;
-    pa.geom.qb_lo = 0; pa.geom.qb_hi = nqblk; pa.geom.tpb = kHWaves * kHQT; pa.geom.ct = CT; pa.geom.tpp = panel * CT; pa.geom.sym_on = 1;
+    pa.geom.qb_lo = 0; pa.geom.qb_hi = nqblk; pa.geom.tpb = kHWaves * kHQT; pa.geom.ct = PCT; pa.geom.tpp = panel * CT / PCT * PCT; pa.geom.sym_on = 1;
     pa.geom.ntiles = (int)((n + 31) / 32) + (int)(((n + 31) / 32) & 1);
     if (getenv("PARTS")) {      // one rank's share of a multi-GPU symmetric partition: PARTS=<nparts>,<part>
         int np = 1, pt = 0; sscanf(getenv("PARTS"), "%d,%d", &np, &pt);
@@ -139,10 +140,11 @@ int main(int argc, char** argv)
 #if MCE_PANEL_STATS && PANEL
     {
         const size_t nw = (size_t)npanel_units * 8;
-        std::vector<double> hs(nw * 8);
-        CK(hipMemcpy(hs.data(), (char*)params + 128, nw * 64, hipMemcpyDeviceToHost));
-        double m[8] = {0};
-        for (size_t w = 0; w < nw; ++w) for (int k = 0; k < 8; ++k) m[k] += hs[w * 8 + k] / nw;
+        std::vector<double> hs(nw * 16);
+        CK(hipMemcpy(hs.data(), (char*)params + 128, nw * 128, hipMemcpyDeviceToHost));
+        double m[16] = {0};
+        for (size_t w = 0; w < nw; ++w) for (int k = 0; k < 8; ++k) { m[k] += hs[w * 8 + k] / nw; m[8 + k] += hs[nw * 8 + w * 8 + k] / nw; }
+        printf("   drain phases (cycles per drain): A (exact distances) %.0f  R (row side) %.0f  B + publish + gates %.0f\n", m[8] / (m[0] > 0 ? m[0] : 1), m[9] / (m[0] > 0 ? m[0] : 1), m[10] / (m[0] > 0 ? m[0] : 1));
         printf("per wave and unit (mean): drains %.1f  enq %.0f  redo tiles %.2f  event (tile, query tile)s %.0f | cycles: events %.3g (%.1f %%)  drains %.3g (%.1f %%)  prologue %.3g (%.1f %%)  kernel %.3g\n",
                m[0], m[1], m[2], m[3], m[4], 100 * m[4] / m[6], m[5], 100 * m[5] / m[6], m[7], 100 * m[7] / m[6], m[6]);
         printf("   per event %.0f cycles, per drain %.0f cycles, per queued pair %.1f drain cycles; enq per query (whole search) %.1f\n", m[4] / (m[3] > 0 ? m[3] : 1), m[5] / (m[0] > 0 ? m[0] : 1), m[5] / (m[1] > 0 ? m[1] : 1), m[1] * nw / 64.0 / n * 64.0 / 64.0);
