@@ -1,32 +1,39 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the kNN evidence hot path on MI355X.
 
-Metric (BASELINE.json): kNN queries/s (+ |dlnE|) at N = 1M, D = 27, kmax = 10 (config C3:
-seeded synthetic Gaussian chain, `mcevidence_amd.synth.CONFIGS['C3']`), inputs resident in
-HBM when the timed region starts.  One "step" = one full pass of the hot path (pack ->
-kNN search -> merge -> volume/weight reduction -> dotp[kmax]) over this rank's query
-shard; with --gpus N the 1M queries are sharded over N ranks (reference set replicated),
-one RCCL all-reduce of kmax doubles per step: strong scaling.
+Metric (BASELINE.json): kNN queries/s (+ |dlnE|) at N = 1M, D = 27, kmax = 10 (config C3: seeded synthetic Gaussian
+chain, `mcevidence_amd.synth.CONFIGS['C3']`), inputs resident in HBM when the timed region starts.  One "step" = one full
+pass of the hot path (pack -> kNN search -> merge -> volume/weight reduction -> dotp[kmax]).  With --gpus N every rank
+takes its share of the auto-evidence search -- the symmetric partition of DESIGN.md 5: a contiguous range of the sorted
+query blocks, reference set replicated -- and ONE RCCL all-reduce of kmax doubles per step: strong scaling.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 1000000] [--d 27] [--kmax 10] [--mode 0|1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 1000000] [--d 27] [--kmax 10] [--mode 0|1] [--no-extras]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel, its launch duration
-measured with HIP events on the launch stream.  Default (--mode 0): knn_f16_kernel, the fp16-MFMA
-all-pairs filter + exact fp64 refine -- algorithmic flops per launch = nq * nr * 2 * 16*KST (the
-augmented product |y^|^2 - 2 x^.y^ the MFMA evaluates) against the 2.5 PFLOP/s dense
-fp16 peak.  At N = 1 (queries and references are one resident buffer) the library takes the symmetric
-sweep: each pair of rows is multiplied once and gated for both of its sides, so the
-kernel executes about half of those flops; `roofline.note` states the executed figure.  --mode 1: knn_mfma_kernel, the pure fp64 MFMA sweep -- nq * nr * 2 * 4*KS flops against
-78.6 TFLOP/s (tools/mfma_f64_peak.hip reaches 72-74 on this part).  `traffic` = HBM bytes per launch
-from the committed rocprofv3 PMC passes (profiles/).
-`cpu_baseline` = the reference's own CPU path (scikit-learn NearestNeighbors with its
-default algorithm + NumPy reduction, via the oracle) on a bounded query sample, rank 0.
+Prints ONE JSON line on rank 0.
+
+`roofline` is for the dominant kernel, its launch duration measured with HIP events on the launch stream.  `achieved` =
+the MFMA flops that kernel EXECUTED per launch (mce_last_search_stats: the symmetric sweep multiplies every pair of rows
+once -- about half of the all-pairs count; 2*16*KST flop per multiplied pair) / that duration; `peak` = 2.5 PFLOP/s dense
+fp16 (MI355X_MICROARCH.md); `frac` = achieved / peak.  It can be recomputed from profiles/: kernel_stats.csv (average
+duration) and pmc_summary.csv (SQ_INSTS_MFMA x 32 768 flop per v_mfma_f32_32x32x16_f16).  The all-pairs figure -- what a
+kernel WITHOUT the symmetry would have to execute for the same result -- is reported separately (`all_pairs_flops`,
+`algorithmic_speedup`), never as a fraction of peak.  `search` covers every launch of the search (prepass, sweep, repair,
+bucket merge).  `traffic`, `mfma_busy_frac`, `valu_per_mfma`, `wait_frac` are read from the committed rocprofv3 passes of
+this kernel (profiles/<round>/).  --mode 1: knn_mfma_kernel, the pure fp64 MFMA sweep, against 78.6 TFLOP/s.
+
+`cpu_baseline` = the reference's own CPU path -- scikit-learn NearestNeighbors exactly as MCEvidence.py:1093-1104 calls it
++ the NumPy volume/weight sum -- on a bounded query sample, rank 0, with the host it ran on.
+
+`configs` (N = 1, unless --no-extras): the other BASELINE.json GPU configs C2, C4, C5 through the same entry points
+(resident data), and `fp64_mode`: C3 through the fp64 sweep -- the reference-precision arithmetic end to end.
 """
 import argparse
+import glob
 import json
 import math
 import os
+import re
 import sys
 import time
 
@@ -37,50 +44,210 @@ sys.path.insert(0, REPO)
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 matrix = vector peak
 F16_PEAK_TFLOPS = 2500.0     # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+N_SIMD = 1024                # 256 CUs x 4
+PEAK_CLOCK_HZ = 2.4e9
 
 
-def hbm_traffic_from_profile(kernel_desc):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (profiles/<round>/pmc_summary.csv: FETCH_SIZE/WRITE_SIZE in KB, separate passes; FETCH_SIZE
-    doubled per MI355X_MICROARCH.md's gfx950 note).  None when no profile of this kernel exists."""
-    import glob
-    import re
+def profile_counters(kernel_desc):
+    """Counters of the dominant kernel from the newest committed rocprofv3 summary that has it
+    (profiles/<round>/pmc_summary.csv: separate --pmc passes; FETCH_SIZE / WRITE_SIZE in KB, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md's gfx950 note; kernel_stats.csv: average duration).  {} when no profile of this kernel exists."""
     m = re.match(r"(\w+)<\w+=(\d+),\w+=(\d+)>", kernel_desc)
     if not m:
-        return None
+        return {}
     name, p1, p2 = m.groups()
-    if name == "knn_f16_kernel":
-        # <KST, KCAP, PRUNE, LOWER, SYM>: the symmetric sweep is the SYM = 2 instantiation (round-1 profiles: no SYM parameter)
+    if name == "knn_f16_kernel" and "panel-kernel" in kernel_desc:
+        wants = ("knn_panel_kernelILi%sELi%sE" % (p1, p2), "knn_panel_kernel<%s, %s>" % (p1, p2))
+    elif name == "knn_f16_kernel":
         sy = "2" if " symmetric" in kernel_desc else "0"
         wants = ("%sILi%sELi%sELb0ELb0ELi%sE" % (name, p1, p2, sy),) + (("%sILi%sELi%sELb0ELb0EE" % (name, p1, p2),) if sy == "0" else ())
     else:
-        wants = ("%s<%s, %s>" % (name, p1, p2), "%sILi%sELi%sE" % (name, p1, p2))     # demangled / mangled spelling
+        wants = ("%s<%s, %s>" % (name, p1, p2), "%sILi%sELi%sE" % (name, p1, p2))
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*", "pmc_summary.csv")), reverse=True):
-        fetch = write = None
+        c = {}
         for ln in open(f):
-            c = ln.strip().split(",")
-            if len(c) >= 4 and any(w in ln for w in wants):
-                name, val, nd = c[-3], float(c[-2]), int(c[-1])
-                if name == "FETCH_SIZE":
-                    fetch = val / nd
-                if name == "WRITE_SIZE":
-                    write = val / nd
-        if fetch is not None and write is not None:
-            return dict(bytes=(2.0 * fetch + write) * 1024.0, source=os.path.relpath(f, REPO),
-                        note="per launch; (2*FETCH_SIZE + WRITE_SIZE) KB, separate --pmc passes")
-    return None
+            col = ln.strip().split(",")
+            if len(col) >= 4 and any(w in ln for w in wants):
+                try:
+                    c[col[-3]] = float(col[-2]) / int(col[-1])          # per dispatch
+                except ValueError:
+                    pass
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue
+        out = dict(source=os.path.relpath(f, REPO), traffic=(2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
+                   traffic_note="per launch; (2*FETCH_SIZE + WRITE_SIZE) KB, separate --pmc passes")
+        ks = os.path.join(os.path.dirname(f), "kernel_stats.csv")
+        avg_ns = None
+        if os.path.exists(ks):
+            for ln in open(ks):
+                if any(w in ln for w in wants):
+                    try:
+                        avg_ns = float(ln.split('",')[-1].split(",")[2]) if ln.startswith('"') else None
+                    except (ValueError, IndexError):
+                        avg_ns = None
+                    break
+        if avg_ns:
+            out["profile_kernel_ms"] = round(avg_ns / 1e6, 3)
+        if c.get("SQ_INSTS_MFMA"):
+            out["mfma_insts"] = c["SQ_INSTS_MFMA"]
+            out["valu_per_mfma"] = round(c.get("SQ_INSTS_VALU", 0.0) / c["SQ_INSTS_MFMA"], 2)
+            if avg_ns:      # SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles per 8-pass MFMA, summed over the SIMDs
+                out["mfma_busy_frac"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (N_SIMD * avg_ns * 1e-9 * PEAK_CLOCK_HZ), 3)
+                out["profile_tflops_from_SQ_INSTS_MFMA"] = round(c["SQ_INSTS_MFMA"] * 32768.0 / (avg_ns * 1e-9) / 1e12, 1)
+        if c.get("SQ_WAVE_CYCLES"):
+            out["wait_frac"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 3)
+        return out
+    return {}
+
+
+def host_info():
+    info = dict(os_cpu_count=os.cpu_count(), affinity=len(os.sched_getaffinity(0)))
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                info["cpu_model"] = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        import sklearn
+        info["sklearn"] = sklearn.__version__
+    except Exception:
+        pass
+    info["numpy"] = np.__version__
+    try:
+        from threadpoolctl import threadpool_info
+        info["threadpools"] = [dict(api=t.get("user_api"), lib=t.get("internal_api"), threads=t.get("num_threads"), version=t.get("version")) for t in threadpool_info()]
+    except Exception:
+        pass
+    return info
+
+
+def whiten_all(theta):
+    """covariance eigen-system of ALL rows (the reference's covtype='all', MCEvidence.py:851-882, :842-849)"""
+    cov = np.cov(theta.T)
+    ev, U = np.linalg.eigh(cov)
+    return np.ascontiguousarray((theta @ U) / np.sqrt(ev)), math.sqrt(float(np.prod(ev)))
+
+
+def time_resident(_capi, torch, X, Y, kmax, k0, steps, warmup, nsample, orc, mode=0, weight=None, fsv=None):
+    """One BASELINE config through mce_knn_dotp_f64_dev on resident data: ms per step, dominant-kernel ms, sampled rows
+    against the exact CPU search (oracle)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    nq, d = X.shape
+    nr = nq if Y is None else Y.shape[0]
+    Xd = torch.from_numpy(X).to(dev)
+    Yd = Xd if Y is None else torch.from_numpy(Y).to(dev)
+    w = torch.ones(nq, dtype=torch.float64, device=dev) if weight is None else torch.from_numpy(np.ascontiguousarray(weight)).to(dev)
+    fs = torch.zeros(nq, dtype=torch.float64, device=dev) if fsv is None else torch.from_numpy(np.ascontiguousarray(fsv)).to(dev)
+    K = kmax - k0
+    _capi.set_search_mode(mode)
+    wsb = _capi.knn_workspace_bytes(nq, nr, d, K) + _capi.dotp_workspace_bytes(nq, kmax)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    out = torch.zeros(kmax, dtype=torch.float64, device=dev)
+    dd = torch.zeros((nq, K), dtype=torch.float64, device=dev) if nsample else None
+    st = torch.cuda.current_stream().cuda_stream
+
+    def step(dist_out):
+        _capi.knn_dotp_dev(Xd.data_ptr(), nq, Yd.data_ptr(), nr, d, kmax, k0, 0, w.data_ptr(), fs.data_ptr(), out.data_ptr(),
+                           dist_out.data_ptr() if dist_out is not None else 0, ws.data_ptr(), wsb, st)
+    for _ in range(warmup):
+        step(None)
+    torch.cuda.synchronize()
+    _capi.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(None)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    stats = _capi.last_search_stats()
+    _capi.set_profiling(False)
+    res = dict(nq=nq, nr=nr, d=d, kmax=kmax, k0=k0, steps=steps, ms_per_step=round(ms, 3), kernel_ms=round(stats["kernel_ms"], 3),
+               search_ms=round(stats["search_ms"], 3), queries_per_s=round(nq / (ms * 1e-3), 1), kernel=_capi.last_kernel())
+    if stats["flops_main"] > 0:
+        res["executed_tflops"] = round(stats["flops_main"] / (stats["kernel_ms"] * 1e-3) / 1e12, 1)
+    if nsample:
+        step(dd)
+        torch.cuda.synchronize()
+        rng = np.random.default_rng(1)
+        rows = np.sort(rng.choice(nq, min(nsample, nq), replace=False))
+        od, _ = orc.knn_brute(X[rows], X if Y is None else Y, K + k0)
+        od = od[:, k0:] if k0 == 1 else od
+        got = dd[torch.from_numpy(rows).to(dev)].cpu().numpy()
+        res["sampled_rows"] = len(rows)
+        res["max_rel_dist_err_sampled_rows_vs_exact_cpu_search"] = float(np.max(np.abs(got - od) / od))
+    res["dotp"] = [float(x) for x in out.cpu().numpy()]
+    _capi.set_search_mode(0)
+    del Xd, Yd, ws, dd
+    torch.cuda.empty_cache()
+    return res
+
+
+def extra_configs(_capi, torch, orc, pkg):
+    """C2, C4, C5 of BASELINE.json (C1 is the CPU plumbing config) -- one GPU, resident data."""
+    from mcevidence_amd.synth import CONFIGS, config_chain
+    out = {}
+    # C2: auto, 100 k x 6, kmax 4
+    chain, _ = config_chain("C2")
+    X, _ = whiten_all(chain[:, 2:])
+    out["C2"] = time_resident(_capi, torch, X, None, CONFIGS["C2"]["kmax"], 1, steps=20, warmup=3, nsample=1000, orc=orc)
+    # C4: cross evidence of two independent chains, 1M + 1M x 15, kmax 4 (k0 = 0); whitened with the covariance of all rows
+    chain, (r1, r2) = config_chain("C4")
+    W, _ = whiten_all(chain[:, 2:])
+    X, Y = np.ascontiguousarray(W[r1]), np.ascontiguousarray(W[r2])
+    c4 = time_resident(_capi, torch, X, Y, CONFIGS["C4"]["kmax"], 0, steps=4, warmup=1, nsample=1000, orc=orc)
+    # ... and its ln E through the class (device feeders, from host arrays) against the REFERENCE's own output for this pair
+    gold = os.path.join(REPO, "tests", "golden", "evidence_c4.json")
+    if os.path.exists(gold):
+        ref = json.load(open(gold))[0]
+        mce = pkg.MCEvidence([chain], kmax=CONFIGS["C4"]["kmax"], verbose=0).set_split(r1, r2)
+        t0 = time.perf_counter()
+        lnE = mce.evidence()
+        c4["evidence_call_from_host_s"] = round(time.perf_counter() - t0, 4)
+        c4["lnE"] = [float(x) for x in lnE]
+        c4["max_abs_dlnE_vs_reference"] = float(np.max(np.abs(lnE - np.array(ref["lnE"]))))
+        c4["reference_wall_s"] = ref["ref_wall_s"]
+    # CPU: the reference's call picks kd_tree at d = 15 (MCEvidence.py:1093-1094) -- ~70 queries/s on a 128-core host, so it
+    # gets 1000 of the 20 000 sampled query rows (the full sample would take five minutes); brute next to it on all 20 000
+    rng = np.random.default_rng(0)
+    rows = np.sort(rng.choice(len(X), 20000, replace=False))
+    cpu = {}
+    for alg, nrows in (("auto", 1000), ("brute", 20000)):
+        from sklearn.neighbors import NearestNeighbors
+        t0 = time.perf_counter()
+        nb = NearestNeighbors(n_neighbors=CONFIGS["C4"]["kmax"] + 1, metric="euclidean", leaf_size=20, algorithm=alg, n_jobs=-1).fit(Y)
+        t_fit = time.perf_counter() - t0
+        dsk, _ = nb.kneighbors(X[rows[:: len(rows) // nrows]])
+        t_all = time.perf_counter() - t0
+        cpu[alg] = dict(fit_method=str(nb._fit_method), query_rows=nrows, fit_s=round(t_fit, 2), total_s=round(t_all, 2),
+                        queries_per_s=round(nrows / (t_all - t_fit), 1), queries_per_s_incl_fit=round(nrows / t_all, 1))
+    c4["cpu_baseline"] = dict(sample="random query rows of s1 against all 1M rows of s2 (every 20th of the 20 000-row sample for the tree)", algorithms=cpu)
+    out["C4"] = c4
+    del X, Y, W, chain
+    # C5: auto, 10 M x 6, one K = 9 search serves the kmax = 2..10 sweep
+    chain, _ = config_chain("C5")
+    X, _ = whiten_all(chain[:, 2:])
+    del chain
+    out["C5"] = time_resident(_capi, torch, X, None, CONFIGS["C5"]["kmax"], 1, steps=2, warmup=1, nsample=300, orc=orc)
+    try:
+        cf, tf = _capi.last_prune_stats()
+        out["C5"]["pruned_walk"] = dict(chunk_fraction=round(cf, 5), tile_fraction=round(tf, 5))
+    except Exception:
+        pass
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--d", type=int, default=27)
     ap.add_argument("--kmax", type=int, default=10)
     ap.add_argument("--cpu-sample", type=int, default=20000, help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--mode", type=int, default=0, help="0 auto (fp16 filter + fp64 refine), 1 fp64 MFMA sweep")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: skip the C2/C4/C5 and fp64-mode sections")
     a = ap.parse_args()
 
     import torch
@@ -103,7 +270,7 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
-    from mcevidence_amd import _capi, parallel
+    from mcevidence_amd import _capi
     _capi.set_search_mode(a.mode)
     from mcevidence_amd.synth import gaussian_chain
     import mcevidence_amd as pkg
@@ -119,34 +286,24 @@ def main():
     fsh = logL - logLmax
     SumW = float(np.sum(weight))
 
-    lo, hi = parallel.shard_bounds(n, world, rank)
-    nq = hi - lo
     K = kmax - 1
-    X = torch.from_numpy(Xh).to(dev)                       # reference set, replicated
-    Xq = X[lo:hi]                                          # this rank's query shard (a view)
-    w = torch.from_numpy(np.ascontiguousarray(weight[lo:hi])).to(dev)
-    fs = torch.from_numpy(np.ascontiguousarray(fsh[lo:hi])).to(dev)
-    wsb = _capi.knn_workspace_bytes(nq, n, d, K) + _capi.dotp_workspace_bytes(nq, kmax)
+    X = torch.from_numpy(Xh).to(dev)                       # the set, resident on every rank
+    w = torch.from_numpy(np.ascontiguousarray(weight)).to(dev)
+    fs = torch.from_numpy(np.ascontiguousarray(fsh)).to(dev)
+    wsb = _capi.knn_workspace_bytes(n, n, d, K) + _capi.dotp_workspace_bytes(n, kmax)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     dotp = torch.zeros(kmax, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream()
 
-    w_all = torch.from_numpy(np.ascontiguousarray(weight)).to(dev) if world > 1 else w
-    fs_all = torch.from_numpy(np.ascontiguousarray(fsh)).to(dev) if world > 1 else fs
-    if world > 1:
-        wsb = _capi.knn_workspace_bytes(n, n, d, K) + _capi.dotp_workspace_bytes(n, kmax)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-
     def step():
         if world > 1:
-            # this rank's part of the queries (the library picks the partition: rows [lo, hi) for the sweep)
-            _capi.knn_dotp_part_dev(X.data_ptr(), n, d, kmax, rank, world, w_all.data_ptr(), fs_all.data_ptr(),
+            # this rank's share (the library picks the partition: a range of the sorted blocks, symmetric inside)
+            _capi.knn_dotp_part_dev(X.data_ptr(), n, d, kmax, rank, world, w.data_ptr(), fs.data_ptr(),
                                     dotp.data_ptr(), ws.data_ptr(), wsb, stream.cuda_stream)
-        else:
-            _capi.knn_dotp_dev(Xq.data_ptr(), nq, X.data_ptr(), n, d, kmax, 1, lo, w.data_ptr(), fs.data_ptr(),
-                               dotp.data_ptr(), 0, ws.data_ptr(), wsb, stream.cuda_stream)
-        if world > 1:
             dist.all_reduce(dotp, op=dist.ReduceOp.SUM)    # the single collective of the path
+        else:
+            _capi.knn_dotp_dev(X.data_ptr(), n, X.data_ptr(), n, d, kmax, 1, 0, w.data_ptr(), fs.data_ptr(),
+                               dotp.data_ptr(), 0, ws.data_ptr(), wsb, stream.cuda_stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -157,80 +314,104 @@ def main():
     for _ in range(a.warmup):
         step()
     barrier()
-    _capi.set_profiling(True)          # hipEvent brackets around each knn_mfma_kernel launch, on its stream
+    _capi.set_profiling(True)          # hipEvent brackets around the dominant kernel and around the whole search, on the launch stream
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    kern_ms = _capi.last_kernel_ms()   # mean over the K timed launches (read after the timed region)
+    stats = _capi.last_search_stats()  # means over the K timed steps (read after the timed region)
     _capi.set_profiling(False)
+    kern_ms = stats["kernel_ms"]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_step = elapsed / a.steps * 1e3
-    # ---- ln E from the device result, and parity against the golden / CPU sample ----
+    # ---- ln E from the device result (MCEvidence.py:1120-1131) ----
     dp = dotp.cpu().numpy()
     lnE = np.array([math.log(SumW * dp[k] / (n * k + 1.0) * cov["J"]) + logLmax - math.log(1.0) for k in range(1, kmax)])
 
     out = None
     if rank == 0:
         kdesc = _capi.last_kernel()
-        if kdesc.startswith("knn_f16"):
-            # fp16-MFMA filter sweep: algorithmic flops = the padded augmented dot product it evaluates
-            # for every (query, reference) pair, 2 * 16*KST per pair; peak = dense fp16 MFMA.
-            kst = (d + 3 + 15) // 16
-            flops = float(nq) * n * 2.0 * 16 * kst
-            peak, note = F16_PEAK_TFLOPS, "fp16 MFMA pre-filter over all pairs (2*16*KST flop/pair) + exact fp64 refine of the survivors"
-            if " symmetric" in kdesc:
-                # d(i,j) = d(j,i): block a (512 rows) multiplies only the tiles of blocks 0..a, each tile gated for both
-                # of its sides.  `achieved` stays the ALGORITHMIC all-pairs figure over the sweep kernel's duration (the
-                # contract's definition); what the matrix cores execute is about half of it:
-                nb = (n + 511) // 512
-                executed = float(512) * 512 * nb * (nb + 1) / 2.0 * 2.0 * 16 * kst
-                note = ("symmetric sweep: every pair of rows multiplied once (blocks 0..a per block a of 512 rows) and gated for both sides; "
-                        "algorithmic flops = all pairs (2*16*KST flop/pair), executed MFMA flops in the sweep kernel = %.3g "
-                        "(%.1f TFLOP/s); the prepass, repair and merge kernels of the same search are in ms_per_step, not in kernel_ms" %
-                        (executed, executed / (kern_ms * 1e-3) / 1e12))
+        is_f16 = kdesc.startswith("knn_f16")
+        kst = (d + 3 + 15) // 16
+        KS = (d + 1 + 3) // 4
+        if is_f16:
+            peak, flop_pair = F16_PEAK_TFLOPS, 2.0 * 16 * kst
+            what = "fp16 MFMA filter (2*16*KST flop per multiplied pair) + exact fp64 refine of the survivors"
         else:
-            KS = (d + 1 + 3) // 4
-            flops = float(nq) * n * 2.0 * 4 * KS
-            peak, note = FP64_PEAK_TFLOPS, "fp64 MFMA sweep (2*4*KS flop/pair), fp64 MFMA-bound (SURVEY 8d)"
-        achieved = flops / (kern_ms * 1e-3) / 1e12
-        traffic = hbm_traffic_from_profile(kdesc)
-        roof = dict(bound="mfma", achieved=round(achieved, 3), peak=peak, unit="TFLOP/s",
-                    frac=round(achieved / peak, 4), traffic=(traffic or {}).get("bytes"), traffic_source=(traffic or {}).get("source"),
-                    traffic_note=(traffic or {}).get("note"),
-                    hbm_gbps=(round(traffic["bytes"] / (kern_ms * 1e-3) / 1e9, 1) if traffic else None),
-                    hbm_frac_of_8TBps=(round(traffic["bytes"] / (kern_ms * 1e-3) / 8e12, 4) if traffic else None),
-                    kernel_ms=round(kern_ms, 3), kernel=kdesc, algorithmic_flops_per_launch=flops, note=note,
-                    fp64_equivalent_tflops=round(float(nq) * n * 2.0 * 4 * ((d + 4) // 4) / (kern_ms * 1e-3) / 1e12, 2))
+            peak, flop_pair = FP64_PEAK_TFLOPS, 2.0 * 4 * KS
+            what = "fp64 MFMA sweep (2*4*KS flop/pair), fp64 MFMA-bound (SURVEY 8d)"
+        executed = stats["flops_main"]
+        achieved = executed / (kern_ms * 1e-3) / 1e12
+        all_pairs = float(n) * n * flop_pair / world                 # what a sweep without the symmetry would execute on this rank
+        prof = profile_counters(kdesc)
+        roof = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
+                    traffic=prof.get("traffic"), kernel_ms=round(kern_ms, 3), kernel=kdesc,
+                    executed_flops_per_launch=executed, flop_per_multiplied_pair=flop_pair, what=what,
+                    all_pairs_flops=all_pairs, algorithmic_speedup=round(all_pairs / executed, 3) if executed > 0 else None,
+                    all_pairs_equivalent_tflops=round(all_pairs / (kern_ms * 1e-3) / 1e12, 1),
+                    search=dict(ms=round(stats["search_ms"], 3), executed_flops=stats["flops_all"],
+                                tflops=round(stats["flops_all"] / (stats["search_ms"] * 1e-3) / 1e12, 2),
+                                frac=round(stats["flops_all"] / (stats["search_ms"] * 1e-3) / 1e12 / peak, 4),
+                                note="every launch of the search: packing, prepass, sweep, repair, bucket merge"),
+                    traffic_source=prof.get("source"), traffic_note=prof.get("traffic_note"),
+                    hbm_gbps=(round(prof["traffic"] / (kern_ms * 1e-3) / 1e9, 1) if prof.get("traffic") else None),
+                    hbm_frac_of_8TBps=(round(prof["traffic"] / (kern_ms * 1e-3) / 8e12, 4) if prof.get("traffic") else None),
+                    mfma_busy_frac=prof.get("mfma_busy_frac"), valu_per_mfma=prof.get("valu_per_mfma"), wait_frac=prof.get("wait_frac"),
+                    profile_kernel_ms=prof.get("profile_kernel_ms"), profile_tflops_from_SQ_INSTS_MFMA=prof.get("profile_tflops_from_SQ_INSTS_MFMA"),
+                    fp64_equivalent_tflops=round(float(n) * n / world * 2.0 * 4 * KS / (kern_ms * 1e-3) / 1e12, 2))
         cpu = None
         dlnE = None
-        if a.cpu_sample > 0 and world == 1:         # CPU baseline: rank 0, N=1 only
-            from oracle import oracle_np as orc                 # checker / baseline only
-            rng = np.random.default_rng(0)
-            rows = np.sort(rng.choice(n, size=min(a.cpu_sample, n), replace=False))
-            t1 = time.perf_counter()
-            dsk, _ = orc.knn_sklearn(Xh[rows], Xh, kmax + 1)  # the reference's exact call (MCEvidence.py:1093-1104)
-            full = orc.dotp_literal(dsk, weight[rows], fsh[rows], d, 1, kmax)
-            t_cpu = time.perf_counter() - t1
-            cpu = dict(value=round(len(rows) / t_cpu, 1), unit="queries/s", cores=len(os.sched_getaffinity(0)), kind="port",
-                       sample="%d random query rows of the same chain against the full %d-row reference set; sklearn NearestNeighbors(algorithm='auto', n_jobs=-1) + NumPy volume/weight sum" % (len(rows), n))
-            # row-level parity on the sample: distances of the sampled rows, GPU vs CPU
-            dg, _ = _capi.knn(Xh[rows], Xh, kmax + 1, self_mode=_capi.SELF_NONE)
-            rel = float(np.max(np.abs(dg[:, 1:kmax] - dsk[:, 1:kmax]) / dsk[:, 1:kmax]))
-            cpu["max_rel_dist_err_vs_gpu"] = rel
-        # whole MCEvidence(...).evidence() call from host arrays (device feeders + H2D + hot path): the
-        # PCIe-inclusive figure, reported next to `value` (which is HBM-resident), N=1 only
+        extras = None
+        fp64_mode = None
         e2e = None
         if world == 1:
+            from oracle import oracle_np as orc                 # checker / baseline only
+            if a.cpu_sample > 0:
+                rng = np.random.default_rng(0)
+                rows = np.sort(rng.choice(n, size=min(a.cpu_sample, n), replace=False))
+                from sklearn.neighbors import NearestNeighbors
+                t1 = time.perf_counter()
+                nb = NearestNeighbors(n_neighbors=kmax + 1, metric="euclidean", leaf_size=20, algorithm="auto", n_jobs=-1).fit(Xh)   # MCEvidence.py:1100-1101
+                dsk, _ = nb.kneighbors(Xh[rows])                                                                                  # :1104
+                orc.dotp_literal(dsk, weight[rows], fsh[rows], d, 1, kmax)                                                        # :1107-1117
+                t_cpu = time.perf_counter() - t1
+                cpu = dict(value=round(len(rows) / t_cpu, 1), unit="queries/s", cores=len(os.sched_getaffinity(0)), kind="reference",
+                           what="the reference's own CPU path: sklearn.neighbors.NearestNeighbors(n_neighbors=kmax+1, metric='euclidean', leaf_size=20, algorithm='auto', n_jobs=-1) "
+                                "exactly as MCEvidence.py:1093-1104 calls it + its NumPy volume/weight sum (third-party library code, imported; nothing of the reference is compiled or copied)",
+                           sample="%d random query rows of the same chain against the full %d-row reference set (%.1f s)" % (len(rows), n, t_cpu),
+                           fit_method=str(nb._fit_method), host=host_info())
+                # row-level parity on the sample: distances of the sampled rows, GPU vs CPU
+                dg, _ = _capi.knn(Xh[rows], Xh, kmax + 1, self_mode=_capi.SELF_NONE)
+                cpu["max_rel_dist_err_vs_gpu"] = float(np.max(np.abs(dg[:, 1:kmax] - dsk[:, 1:kmax]) / dsk[:, 1:kmax]))
+                full = os.path.join(REPO, "profiles", "cpu_full_c3.json")          # the full 1M-query CPU pass, run once on a GPU box (tools/cpu_full_c3.py)
+                if os.path.exists(full) and (n, d, kmax) == (1_000_000, 27, 10):
+                    fc = json.load(open(full))
+                    cpu["full_run_cached"] = dict(seconds=fc["seconds"], queries_per_s=fc["queries_per_s"], cores=fc["host"]["affinity"], cpu_model=fc["host"].get("cpu_model"),
+                                                  max_abs_dlnE_gpu_vs_this_cpu_run=float(np.max(np.abs(lnE - np.array(fc["lnE"])))), source="profiles/cpu_full_c3.json")
+            # whole MCEvidence(...).evidence() call from host arrays (device feeders + H2D + hot path): the PCIe-inclusive
+            # figure, reported next to `value` (which is HBM-resident)
             mce.evidence()
             t2 = time.perf_counter()
             lnE_e2e = mce.evidence()
             e2e = dict(seconds=round(time.perf_counter() - t2, 4), queries_per_s=round(n / (time.perf_counter() - t2), 1),
                        max_abs_dlnE_vs_resident_path=float(np.max(np.abs(lnE_e2e - lnE))))
+            if not a.no_extras and (n, d, kmax, a.mode) == (1_000_000, 27, 10, 0):
+                del ws
+                torch.cuda.empty_cache()
+                fp64_mode = time_resident(_capi, torch, Xh, None, kmax, 1, steps=3, warmup=1, nsample=0, orc=orc, mode=1, weight=weight, fsv=fsh)
+                fp64_mode["roofline"] = dict(bound="mfma", achieved=round(float(n) * n * 2.0 * 4 * KS / (fp64_mode["kernel_ms"] * 1e-3) / 1e12, 2), peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+                                             frac=round(float(n) * n * 2.0 * 4 * KS / (fp64_mode["kernel_ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
+                                             note="pure fp64 arithmetic: v_mfma_f64_16x16x4_f64 over all pairs (2*4*KS flop/pair, unpadded rows) + fp64 refine")
+                dp64 = np.array(fp64_mode.pop("dotp"))
+                l64 = np.array([math.log(SumW * dp64[k] / (n * k + 1.0) * cov["J"]) + logLmax for k in range(1, kmax)])
+                fp64_mode["max_abs_dlnE_vs_default_mode"] = float(np.max(np.abs(l64 - lnE)))
+                extras = extra_configs(_capi, torch, orc, pkg)
+                for c in extras.values():
+                    c.pop("dotp", None)
         gold = os.path.join(REPO, "tests", "golden", "evidence_big.json")
         if (n, d, kmax) == (1_000_000, 27, 10) and os.path.exists(gold):
             for c in json.load(open(gold)):
@@ -239,10 +420,11 @@ def main():
         out = dict(metric="knn_queries_per_sec", value=round(n / (ms_step * 1e-3), 1), unit="queries/s", n_gpus=world,
                    steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True,
                    scaling="strong", vs_baseline=None, dtype="f64" if a.mode == 1 else "f16 filter + f64 refine (exact f64 results)", data="synthetic",
-                   config=dict(workload="C3: auto-evidence, seeded Gaussian chain N=%d D=%d kmax=%d (K=%d true neighbours/query), query-sharded over %d GPU(s)" % (n, d, kmax, K, world),
-                               N=n, D=d, kmax=kmax, queries_per_rank=nq),
+                   config=dict(workload="C3: auto-evidence, seeded Gaussian chain N=%d D=%d kmax=%d (K=%d true neighbours/query), %s" %
+                               (n, d, kmax, K, "one GPU" if world == 1 else "symmetric partition over %d GPUs (DESIGN.md 5), one all-reduce of kmax doubles" % world),
+                               N=n, D=d, kmax=kmax, ranks=world),
                    max_abs_dlnE_vs_reference=dlnE, lnE=[round(float(x), 10) for x in lnE],
-                   roofline=roof, cpu_baseline=cpu, evidence_call_from_host=e2e)
+                   roofline=roof, cpu_baseline=cpu, evidence_call_from_host=e2e, configs=extras, fp64_mode=fp64_mode)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

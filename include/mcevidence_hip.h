@@ -214,6 +214,16 @@ int mce_last_prune_stats(double *chunk_fraction, double *tile_fraction);
  * roofline figure. */
 void mce_set_profiling(int on);
 double mce_last_kernel_ms(void);
+/* What the last search on this thread asked of the matrix cores, for rooflines that follow from a profile (bench.py):
+ *   out[0]  MFMA flops EXECUTED by the dominant kernel (the one mce_last_kernel_ms() brackets) -- a symmetric sweep
+ *           multiplies each pair of rows once, so this is about half of the all-pairs figure; -1: only device counters
+ *           know (pruned walk: mce_last_prune_stats)
+ *   out[1]  the same over every launch of the search (prepass / seed phases included)
+ *   out[2]  milliseconds of the whole search, packing to the last list kernel (HIP events on the launch stream, mean per
+ *           search since mce_set_profiling(1)); -1 without profiling
+ *   out[3]  mce_last_kernel_ms()
+ * Bookkeeping of the measurement hooks; no counterpart in the reference. */
+int mce_last_search_stats(double* out, int32_t n);
 
 #ifdef __cplusplus
 }

@@ -49,6 +49,7 @@ SIGNATURES = {
     "mce_last_prune_stats": (_c.c_int, [_c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "mce_set_profiling": (None, [_c.c_int]),
     "mce_last_kernel_ms": (_c.c_double, []),
+    "mce_last_search_stats": (_c.c_int, [_c.c_void_p, _c.c_int32]),
     "mce_knn_f64": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _c.c_int32]),
     "mce_dotp_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_int32]),
     "mce_knn_dotp_f64": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _P, _P, _P, _c.c_int32]),
@@ -169,6 +170,13 @@ def set_profiling(on):
 
 def last_kernel_ms():
     return float(load().mce_last_kernel_ms())
+
+
+def last_search_stats():
+    """dict(flops_main, flops_all, search_ms, kernel_ms) of the last search on this thread (mce_last_search_stats)."""
+    out = (_c.c_double * 4)()
+    check(load().mce_last_search_stats(_c.cast(out, _c.c_void_p), 4))
+    return dict(flops_main=out[0], flops_all=out[1], search_ms=out[2], kernel_ms=out[3])
 
 
 def check(rc):

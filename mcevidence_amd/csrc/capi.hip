@@ -41,6 +41,11 @@ thread_local size_t g_ev_calls = 0;                                       // sea
 thread_local bool g_in_tail = false;                                      // inside the tail part of a split search
 thread_local int g_split_depth = 0;                                       // > 0: inside a part of a split search
 thread_local double g_last_prune_geom[3] = {0, 0, 0};                     // blocks, chunks, tiles per chunk
+// what the matrix cores executed in the last search on this thread (mce_last_search_stats): flops of the dominant kernel and
+// of every launch of the search (prepass / seed phases included); -1: not known on the host (pruned walk: device counters)
+thread_local double g_last_flops_main = 0.0, g_last_flops_all = 0.0;
+thread_local std::vector<std::pair<hipEvent_t, hipEvent_t>> g_evs_pool;  // brackets around the WHOLE search (packing .. last list kernel)
+thread_local size_t g_evs_used = 0;
 
 int fail(int code, const char* fmt, ...)
 {
@@ -259,7 +264,9 @@ struct Plan {
     double cost = 0.0;                        // the split model's estimate for this plan (cycles per SIMD; exhaustive kernels)
     bool twopass = false;                     // fp16 filter, 16 < K <= 32: two sweeps of 16-entry lists (knn_f16.hpp, LOWER)
     bool prune = false;                       // fp16 filter walking k-d ordered chunk lists (prune.hpp)
-    int part = 0, nparts = 1;                 // pruned walk over query blocks part, part + nparts, ... only
+    int part = 0, nparts = 1;                 // pruned walk over query blocks part, part + nparts, ... only; symmetric sweep: the
+                                              // contiguous range of sorted blocks [sym_qb_lo, sym_qb_hi) (one rank's share)
+    int sym_qb_lo = 0, sym_qb_hi = 0;         // set by run_search when the symmetric sweep ran
     int64_t pl_nr = 0;                        // reference rows the plan was made for
     mce::PruneLayout pl;
     size_t off_prune = 0;
@@ -507,6 +514,22 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
     hipLaunchKernelGGL(mce::col_stats_final_kernel, dim3(1), dim3(64), 0, st, msum, nr, (int)d, center, box_y);
     MCE_HIP(hipGetLastError());
     const bool prof = g_prof_on && g_ev_used < 1024;
+    // bracket of the whole search: closed by the caller-visible end of run_search (SearchBracket's destructor)
+    struct SearchBracket {
+        hipStream_t st; bool on;
+        SearchBracket(hipStream_t s, bool o) : st(s), on(o)
+        {
+            if (!on) return;
+            if (g_evs_used == g_evs_pool.size()) {
+                hipEvent_t e0, e1;
+                if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { on = false; return; }
+                g_evs_pool.emplace_back(e0, e1);
+            }
+            (void)hipEventRecord(g_evs_pool[g_evs_used].first, st);
+        }
+        ~SearchBracket() { if (on) { (void)hipEventRecord(g_evs_pool[g_evs_used].second, st); ++g_evs_used; } }
+    } search_bracket(st, prof && g_evs_used < 1024);
+    g_last_flops_main = g_last_flops_all = 0.0;
     auto prof_begin = [&]() -> int {
         if (!prof) return MCE_OK;
         if (g_ev_used == g_ev_pool.size()) {
@@ -586,6 +609,7 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             rc = prof_end();
             if (rc != MCE_OK) return rc;
             g_last_params = params;
+            g_last_flops_main = g_last_flops_all = -1.0;        // (tiles multiplied: a device counter, mce_last_prune_stats)
             g_last_prune_geom[0] = p.nqblk; g_last_prune_geom[1] = (double)p.nchunk; g_last_prune_geom[2] = p.CT;
             snprintf(g_last_kernel, sizeof(g_last_kernel), "%s pruned grid=%d block=64 lds=%zu qt=%d ct=%d chunks=%lld", p.vh->name,
                      p.nqblk * mce::kHWaves, mce::f16_prune_lds_bytes(p.KST, d, p.KCAP), p.QT, p.CT, (long long)p.nchunk);
@@ -626,12 +650,23 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
                 const char* const e_mode = getenv("MCE_SYM_SEED_MODE");
                 a.seed_cfg |= ((e_mode ? atoi(e_mode) : kSymSeedMode[p.KST]) & 3) << 28;
             }
-            MCE_HIP(p.vh->launch_sym_pre(a, st));
+            // One rank's share of a multi-GPU partition: the contiguous range of sorted blocks [qb_lo, qb_hi).  Their tiles
+            // carry the row-side gate; everybody else's rows are swept column side only (sym_types.hpp, PanelGeom) -- no
+            // exchange between the ranks, each ends with complete lists for its own rows.  Only they need a prepass bound.
+            const int qb_lo = p.nparts > 1 ? (int)((int64_t)p.nqblk * p.part / p.nparts) : 0;
+            const int qb_hi = p.nparts > 1 ? (int)((int64_t)p.nqblk * (p.part + 1) / p.nparts) : p.nqblk;
+            p.sym_qb_lo = qb_lo;
+            p.sym_qb_hi = qb_hi;
+            a.qblk0 = qb_lo;
+            a.nqblk_run = qb_hi - qb_lo;
+            if (qb_hi > qb_lo) MCE_HIP(p.vh->launch_sym_pre(a, st));
+            a.qblk0 = 0;
+            a.nqblk_run = 0;
             const int seed_used = a.seed_cfg;
             a.seed_cfg = 0;
             int rc = prof_begin();             // (the bracket of mce_last_kernel_ms(): the dominant kernel, as for the other searches)
             if (rc != MCE_OK) return rc;
-            const bool panel_kernel = sym_use_panel_kernel();
+            const bool panel_kernel = sym_use_panel_kernel() || p.nparts > 1;
             if (panel_kernel) {
                 mce::PanelArgs pa;
                 pa.Yh = yh; pa.Xh = xh; pa.qinfo = qinfo; pa.params = params; pa.X = sX; pa.Y = sY; pa.rperm = a.rperm;
@@ -639,7 +674,7 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
                 pa.D = d; pa.ksel = K; pa.self_exclude = a.self_exclude; pa.spin_limit = sym_spin_limit();
                 pa.sym = a.sym;
                 pa.debug = getenv("MCE_PANEL_DEBUG") ? atoi(getenv("MCE_PANEL_DEBUG")) : 0;
-                pa.geom.qb_lo = 0; pa.geom.qb_hi = p.nqblk; pa.geom.tpb = mce::kHWaves * mce::kHQT; pa.geom.ct = p.CT;
+                pa.geom.qb_lo = qb_lo; pa.geom.qb_hi = qb_hi; pa.geom.tpb = mce::kHWaves * mce::kHQT; pa.geom.ct = p.CT;
                 pa.geom.tpp = a.sym.panel * p.CT; pa.geom.sym_on = getenv("MCE_PANEL_NOSYM") ? 0 : 1;      // (debugging: every block sweeps every tile, column side only)
                 pa.geom.ntiles = (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1);
                 MCE_HIP(p.vh->launch_panel(pa, st));
@@ -650,20 +685,43 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             if (rc != MCE_OK) return rc;
             MCE_HIP(p.vh->launch_sym_repair(a, st));      // blocks whose bucket overflowed (normally none: every workgroup exits at once)
             {
-                const dim3 g((unsigned)p.nqblk), b(mce::kSymMergeThreads);
+                const dim3 g((unsigned)std::max(1, qb_hi - qb_lo)), b(mce::kSymMergeThreads);
                 static_assert(mce::kSymMergeThreads == mce::f16_qpb(4), "one merge block per query block");
                 switch (p.KCAP) {
-                    case 4: hipLaunchKernelGGL(mce::sym_merge_kernel<4>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap); break;
-                    case 8: hipLaunchKernelGGL(mce::sym_merge_kernel<8>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap); break;
-                    case 12: hipLaunchKernelGGL(mce::sym_merge_kernel<12>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap); break;
-                    default: hipLaunchKernelGGL(mce::sym_merge_kernel<16>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap); break;
+                    case 4: hipLaunchKernelGGL(mce::sym_merge_kernel<4>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
+                    case 8: hipLaunchKernelGGL(mce::sym_merge_kernel<8>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
+                    case 12: hipLaunchKernelGGL(mce::sym_merge_kernel<12>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
+                    default: hipLaunchKernelGGL(mce::sym_merge_kernel<16>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
                 }
                 MCE_HIP(hipGetLastError());
             }
             p.sym_active = true;
             p.L = 1;
+            int sym_units = mce::sym_unit_count(p.nqblk, mce::kHWaves * mce::kHQT, a.sym.panel * p.CT, (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1));
+            if (panel_kernel) {
+                mce::PanelGeom g;
+                g.qb_lo = qb_lo; g.qb_hi = qb_hi; g.tpb = mce::kHWaves * mce::kHQT; g.ct = p.CT; g.tpp = a.sym.panel * p.CT; g.sym_on = 1;
+                g.ntiles = (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1);
+                sym_units = mce::panel_unit_count(g);
+                // executed MFMA flops: every unit's tiles x 16 query tiles x (32 x 32 x 16 KST) multiply-adds
+                double tiles = 0.0;
+                for (int u = 0; u < sym_units; ++u) {
+                    int pp, aa, lo, hi;
+                    mce::panel_unit_decode(u, g, pp, aa);
+                    mce::panel_unit_tiles(pp, aa, g, lo, hi);
+                    tiles += hi - lo;
+                }
+                g_last_flops_main = tiles * 16.0 * 1024.0 * 32.0 * p.KST;
+            } else {
+                const double nb = p.nqblk, tpb = mce::kHWaves * mce::kHQT, T = (double)((nr + 31) / 32);
+                double tiles = 0.0;
+                for (int b = 0; b < p.nqblk; ++b) tiles += std::min(tpb * (b + 1), T);
+                (void)nb;
+                g_last_flops_main = tiles * 16.0 * 1024.0 * 32.0 * p.KST;
+            }
+            g_last_flops_all = g_last_flops_main + (double)(seed_used & 0xffff) * p.CT * (double)(qb_hi - qb_lo) * 16.0 * 1024.0 * 32.0 * p.KST;
             snprintf(g_last_kernel, sizeof(g_last_kernel), "%s symmetric%s grid=%d block=%d lds=%zu qt=%d ct=%d panel=%d seed=%dx%d/%d bucket=%d", p.vh->name, panel_kernel ? " panel-kernel" : "",
-                     mce::sym_unit_count(p.nqblk, mce::kHWaves * mce::kHQT, a.sym.panel * p.CT, (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1)),
+                     sym_units,
                      mce::kHThreads, panel_kernel ? p.vh->lds_bytes_panel : p.vh->lds_bytes_sym, p.QT, p.CT, a.sym.panel, seed_used & 0xffff, (seed_used >> 16) & 0xfff, (seed_used >> 28) & 3, p.sl.cap);
             return MCE_OK;
         }
@@ -689,6 +747,9 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
         rc = prof_end();
         if (rc != MCE_OK) return rc;
         const int seed_first = p.twopass ? seed_cfg(16) : a.seed_cfg;
+        g_last_flops_main = (double)p.nqblk * ((double)p.nchunk + (double)(seed_first & 0xffff) * p.rsplit) * p.CT * 16.0 * 1024.0 * 32.0 * p.KST +
+                            (p.twopass ? (double)p.nqblk * (double)p.nchunk * p.CT * 16.0 * 1024.0 * 32.0 * p.KST : 0.0);
+        g_last_flops_all = g_last_flops_main;
         char seed_txt[48] = "";
         if (seed_first) snprintf(seed_txt, sizeof(seed_txt), " seed=%dx%d", seed_first & 0xffff, seed_first >> 16);   // chunks x tiles per group
         snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d%s%s", p.vh->name,
@@ -722,6 +783,7 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
     if (rc != MCE_OK) return rc;
     snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d", p.v->name,
              p.nqblk * p.rsplit, mce::kThreads, p.v->lds_bytes, p.QT, p.CT, p.rsplit);
+    g_last_flops_main = g_last_flops_all = (double)p.nq_pad * (double)p.nrow_pad * 2.0 * 4.0 * p.KS;
     return MCE_OK;
 }
 
@@ -735,8 +797,13 @@ int launch_merge(const Plan& p, bool write_dist, bool fuse, const double* dX, co
     // enumerate those columns compactly
     const int qpb = p.vh ? mce::f16_qpb(p.KCAP) : 1;
     int64_t ncol = nq;
-    if (p.nparts > 1) ncol = (int64_t)((p.nqblk - p.part + p.nparts - 1) / p.nparts) * qpb;
-    const unsigned blocks = (unsigned)((ncol + mce::kRedThreads - 1) / mce::kRedThreads);
+    int64_t col0 = 0, col1 = INT64_MAX;
+    if (p.sym_active && p.nparts > 1) {         // one rank's blocks of a symmetric partition: a contiguous range of list columns
+        col0 = (int64_t)p.sym_qb_lo * qpb;
+        col1 = std::min<int64_t>((int64_t)p.sym_qb_hi * qpb, nq);
+        ncol = std::max<int64_t>(col1 - col0, 0);
+    } else if (p.nparts > 1) ncol = (int64_t)((p.nqblk - p.part + p.nparts - 1) / p.nparts) * qpb;
+    const unsigned blocks = (unsigned)std::max<int64_t>((ncol + mce::kRedThreads - 1) / mce::kRedThreads, 1);
     const double* pd = reinterpret_cast<const double*>(ws + p.off_pd);
     const int* pi = reinterpret_cast<const int*>(ws + p.off_pi);
     const bool refine = p.vh == nullptr && !p.generic;   // fp64 sweep keys are GEMM-form: refine; the others are exact
@@ -749,7 +816,7 @@ int launch_merge(const Plan& p, bool write_dist, bool fuse, const double* dX, co
 #define MCE_MERGE(W, F, R)                                                                                          \
     hipLaunchKernelGGL((mce::merge_lists_kernel<W, F, R>), dim3(blocks), dim3(mce::kRedThreads), 0, st, pd, pi, p.L,  \
                        p.KCAP, nq, p.nq_pad, dX, dY, (int)d, K, self_mode, self_offset, d_dist, d_idx, K, k0, kmax, \
-                       d_w, d_fs, lnc, partial, qperm, p.part, p.nparts, qpb, border, p.nqblk)
+                       d_w, d_fs, lnc, partial, qperm, p.part, p.nparts, qpb, border, p.nqblk, col0, col1)
     if (write_dist && !fuse) { if (refine) MCE_MERGE(true, false, true); else MCE_MERGE(true, false, false); }
     else if (write_dist && fuse) { if (refine) MCE_MERGE(true, true, true); else MCE_MERGE(true, true, false); }
     else { if (refine) MCE_MERGE(false, true, true); else MCE_MERGE(false, true, false); }
@@ -821,7 +888,27 @@ int mce_last_prune_stats(double* chunk_fraction, double* tile_fraction)
 void mce_set_profiling(int on)
 {
     g_prof_on = on ? 1 : 0;
-    if (on) { g_ev_used = 0; g_ev_calls = 0; }
+    if (on) { g_ev_used = 0; g_ev_calls = 0; g_evs_used = 0; }
+}
+
+int mce_last_search_stats(double* out, int32_t n)
+{
+    if (!out || n < 4) return fail(MCE_ERR_INVALID, "mce_last_search_stats: out[4] expected");
+    out[0] = g_last_flops_main;
+    out[1] = g_last_flops_all;
+    out[2] = -1.0;
+    out[3] = mce_last_kernel_ms();
+    if (g_evs_used > 0) {
+        double sum = 0.0;
+        for (size_t i = 0; i < g_evs_used; ++i) {
+            float ms = 0.0f;
+            if (hipEventSynchronize(g_evs_pool[i].second) != hipSuccess ||
+                hipEventElapsedTime(&ms, g_evs_pool[i].first, g_evs_pool[i].second) != hipSuccess) return fail(MCE_ERR_HIP, "event timing failed");
+            sum += ms;
+        }
+        out[2] = sum / (double)(g_ev_calls ? g_ev_calls : g_evs_used);
+    }
+    return MCE_OK;
 }
 
 double mce_last_kernel_ms(void)
@@ -1036,6 +1123,31 @@ int mce_knn_dotp_part_f64_dev(const double* dY, int64_t nr, int32_t d, int32_t k
     const size_t need = p.total + dotp_ws_bytes(nr, kmax);
     if (ws_bytes < need) return fail(MCE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!p.prune && p.sym && nparts > 1) {
+        // Auto evidence of a set large enough for the symmetric sweep: every rank takes a contiguous range of the SORTED
+        // blocks, symmetric within its range and column side only against everybody else's rows (no exchange).
+        // Per rank n^2/W (1 - 1/2W) tile products instead of the n^2/W of a query shard -- and at the symmetric sweep's
+        // cost per tile, not twice the single-GPU run's work.
+        p.part = part;
+        p.nparts = nparts;
+        char* wsc = static_cast<char*>(ws);
+        SameSetHint hint(true);
+        rc = run_search(p, dY, nr, dY, nr, d, K, MCE_SELF_EXCLUDE, 0, wsc, st);
+        if (rc != MCE_OK) return rc;
+        if (p.sym_active) {
+            if (p.sym_qb_hi <= p.sym_qb_lo) { MCE_HIP(mce::zero_async(d_dotp, (size_t)kmax * sizeof(double), st)); return MCE_OK; }
+            double* partial = reinterpret_cast<double*>(wsc + p.total);
+            rc = launch_merge(p, false, true, dY, dY, nr, d, K, MCE_SELF_EXCLUDE, 0, nullptr, nullptr, 1, (int)kmax, d_w, d_fs, partial, wsc, st);
+            if (rc != MCE_OK) return rc;
+            const int64_t qpb = mce::f16_qpb(p.KCAP);
+            const int64_t ncol = std::min<int64_t>((int64_t)p.sym_qb_hi * qpb, nr) - (int64_t)p.sym_qb_lo * qpb;
+            const unsigned blocks = (unsigned)((ncol + mce::kRedThreads - 1) / mce::kRedThreads);
+            hipLaunchKernelGGL(mce::dotp_final_kernel, dim3((unsigned)kmax), dim3(mce::kRedThreads), 0, st, partial, (int64_t)blocks, 1, (int)kmax, d_dotp);
+            MCE_HIP(hipGetLastError());
+            return MCE_OK;
+        }
+        return fail(MCE_ERR_INVALID, "symmetric partition: the sweep did not run");
+    }
     if (!p.prune) {
         // contiguous rows: exactly the query shard of SURVEY.md section 8e
         const int64_t lo = nr * part / nparts, hi = nr * (int64_t)(part + 1) / nparts;

@@ -296,7 +296,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
     int sym_a = 0, sym_p = 0;
     if constexpr (SYM == 2) sym_unit_decode((int)blockIdx.x, nqblk, kHWaves * kHQT, sym.panel * f16_chunk_tiles(KST), sym_p, sym_a);
     if constexpr (SYM == 2) MCE_CHK(sym_a >= 0 && sym_a < nqblk && sym_p >= 0, 5, sym_a, sym_p, nqblk);
-    const int qblk = PRUNE ? border[qblk0 + (int)(blockIdx.x / kHWaves) * qblk_stride] : (SYM == 2 ? sym_a : (int)(blockIdx.x % nqblk));
+    // (SYM == 1, the prepass: the blocks qblk0, qblk0 + 1, ... of the launch -- one rank's share of a multi-GPU partition)
+    const int qblk = PRUNE ? border[qblk0 + (int)(blockIdx.x / kHWaves) * qblk_stride] : (SYM == 2 ? sym_a : (SYM == 1 ? qblk0 + (int)blockIdx.x : (int)(blockIdx.x % nqblk)));
     const int split = PRUNE ? 0 : (SYM >= 2 ? 0 : (int)(blockIdx.x / nqblk));
 
     if constexpr (SYM >= 2) {

@@ -61,7 +61,8 @@ hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
     // symmetric sweep: one workgroup per unit (sym_types.hpp); its prepass and repair launches: one per query block
     const int ntiles_even = (int)((a.nr + 31) / 32) + (int)(((a.nr + 31) / 32) & 1);
     const dim3 grid((unsigned)(PRUNE ? (a.nqblk_run ? a.nqblk_run : a.nqblk) * kHWaves
-                               : SYM == 2 ? sym_unit_count(a.nqblk, kHWaves * kHQT, a.sym.panel * f16_chunk_tiles(KST), ntiles_even) : a.nqblk * a.rsplit));
+                               : SYM == 2 ? sym_unit_count(a.nqblk, kHWaves * kHQT, a.sym.panel * f16_chunk_tiles(KST), ntiles_even)
+                               : SYM == 1 ? (a.nqblk_run ? a.nqblk_run : a.nqblk) : a.nqblk * a.rsplit));
     hipLaunchKernelGGL(kern, grid, dim3(PRUNE ? 64 : kHThreads), LDS, st, static_cast<const _Float16*>(a.Yh), a.nchunk_total, a.rsplit,
                        static_cast<const _Float16*>(a.Xh), a.qinfo, a.params, a.X, a.Y, a.nq, a.nr, a.D, a.nq_pad, a.nqblk,
                        a.self_exclude, a.self_offset, a.ksel, a.part_d, a.part_i, a.clist, a.cdist, a.list_len, a.rperm, a.qperm, a.tbox_r, a.tbox_q, a.cbox_r, a.qblk0, a.qblk_stride, a.border, a.lo_d, a.lo_i, a.seed_cfg, a.sym);

@@ -65,13 +65,16 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
     int self_mode, int64_t self_offset,
     double* __restrict__ dist, int64_t* __restrict__ idx, int ld_out,
     int k0, int kmax, const double* __restrict__ w, const double* __restrict__ fs, double lnc,
-    double* __restrict__ partial, const int* __restrict__ qperm, int part, int nparts, int qpb, const int* __restrict__ border, int nqblk)
+    double* __restrict__ partial, const int* __restrict__ qperm, int part, int nparts, int qpb, const int* __restrict__ border, int nqblk,
+    int64_t col0, int64_t col1)
 {
     __shared__ double red[kRedThreads / 64];
     // nparts > 1: this launch covers the query blocks part, part + nparts, ... (qpb list columns each) of a
-    // pruned search; the thread index is the compact position among them
-    int64_t q = (int64_t)blockIdx.x * kRedThreads + threadIdx.x;
-    if (nparts > 1) {
+    // pruned search; the thread index is the compact position among them.  col0, col1: the launch covers the list
+    // columns [col0, col1) (one rank's blocks of a symmetric partition; the whole set: 0, nq)
+    int64_t q = col0 + (int64_t)blockIdx.x * kRedThreads + threadIdx.x;
+    if (q >= col1) q = nq;
+    if (nparts > 1 && border) {
         const int64_t slot = (q / qpb) * nparts + part;          // position in the dispatch order
         q = slot < nqblk ? (int64_t)border[slot] * qpb + q % qpb : nq;
     }
@@ -187,13 +190,13 @@ constexpr int kSymMergeBatch = 2048;
 template <int KCAP>
 __global__ __launch_bounds__(kSymMergeThreads) void sym_merge_kernel(double* __restrict__ part_d, int* __restrict__ part_i, int64_t nq_pad,
                                                                      const int* __restrict__ bucket_cnt, const int* __restrict__ bucket_flag,
-                                                                     const SymEntry* __restrict__ bucket, int cap)
+                                                                     const SymEntry* __restrict__ bucket, int cap, int b0)
 {
     __shared__ double e_d[kSymMergeBatch];
     __shared__ int e_i[kSymMergeBatch];
     __shared__ int e_nx[kSymMergeBatch];
     __shared__ int head[kSymMergeThreads];
-    const int b = blockIdx.x, t = threadIdx.x;
+    const int b = b0 + blockIdx.x, t = threadIdx.x;      // (b0: first block of the launch -- one rank's range of a partition)
     if (bucket_flag[b]) return;
     int n = bucket_cnt[b];
     if (n <= 0) return;

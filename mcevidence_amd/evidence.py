@@ -156,6 +156,22 @@ class MCEvidence(object):
         self.logger.info("chain array dimensions: %s x %s =" % (self.nsample, self.ndim))
         self.set_batch()
 
+    def set_split(self, s1_rows, s2_rows):
+        """Cross evidence of a CALLER-CHOSEN pair instead of the reference's random split (:221-226), e.g. two
+        independent chains stacked in one array: s1 = rows ``s1_rows`` (the samples whose evidence sum is taken),
+        s2 = rows ``s2_rows`` (the set the nearest neighbours are sought in).  Extension of the reference's API
+        (SURVEY.md 8d, config C4); everything downstream is the reference's split=True path."""
+        self.split = True
+        self.snames = ["s1", "s2"]
+        self.gd.set_split(s1_rows, s2_rows)
+        self.nsample = [self.gd.get_shape(name=s)[0] for s in self.snames]
+        self.info["Nsamples"] = ", ".join(str(x) for x in self.nsample)
+        self.powers = np.zeros((self.nbatch, 2))
+        self.bsize = np.zeros((self.nbatch, 2), dtype=int)
+        self.nchain = np.zeros((self.nbatch, 2), dtype=int)
+        self.set_batch()
+        return self
+
     # ------------------------------------------------------------------ batching
     def summary(self):
         print()

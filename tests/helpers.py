@@ -25,7 +25,7 @@ DIST_RTOL = 1e-10
 
 def load_golden():
     out = {}
-    for tag in ("small", "medium", "big", "sym"):
+    for tag in ("small", "medium", "big", "sym", "c4_n20000", "c4"):
         jp = os.path.join(GOLD, "evidence_%s.json" % tag)
         if not os.path.exists(jp):
             continue
@@ -33,6 +33,7 @@ def load_golden():
         for case in json.load(open(jp)):
             case = dict(case)
             case["tag"] = tag
+            case.setdefault("seed_split", None)          # (config cases -- C4 -- carry an explicit split instead: explicit_split_of)
             case["arrays"] = {k[len(case["name"]) + 2:]: arrays[k] for k in arrays.files if k.startswith(case["name"] + "__")}
             out[case["name"]] = case
     return out
@@ -43,7 +44,19 @@ def host_pins():
 
 
 def chain_of(case):
+    if case.get("config"):                      # a BASELINE.json config recipe (synth.config_chain): C4 = two chains stacked
+        from mcevidence_amd.synth import config_chain
+        return config_chain(case["config"], n=case.get("n_per_chain"))[0]
     return gaussian_chain(**case["chain"])
+
+
+def explicit_split_of(case):
+    """(s1_rows, s2_rows) of a config case with a caller-chosen split, else None"""
+    if case.get("config"):
+        from mcevidence_amd.synth import config_chain
+        r1, r2 = config_chain(case["config"], n=case.get("n_per_chain"))[1]
+        return None if r1 is None else (r1, r2)
+    return None
 
 
 class OracleBackend(object):
@@ -108,3 +121,19 @@ class OracleFeedBackend(OracleBackend):
 def lnE_from_dotp(case, dotp):
     return orc.mle_from_dotp(np.asarray(dotp), case["S"], case["k0"], case["kmax"], case["SumW"], case["J"],
                              case["logLmax"], case["lnPriorVolume"])
+
+
+def build_mce(case, **kw):
+    """The drop-in class set up as the reference was when it produced ``case``: the global RNG seeded before a random
+    split, or the explicit split of a config case (C4: two independent chains stacked, s1 = the first)."""
+    import mcevidence_amd as pkg
+    if case["seed_split"] is not None:
+        np.random.seed(case["seed_split"])
+    mk = dict(case["mce"])
+    split = explicit_split_of(case)
+    if split is not None:
+        mk.pop("split", None)
+    mce = pkg.MCEvidence([chain_of(case)], verbose=0, **mk, **kw)
+    if split is not None:
+        mce.set_split(*split)
+    return mce

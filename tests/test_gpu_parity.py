@@ -6,7 +6,7 @@ import math
 import numpy as np
 import pytest
 
-from helpers import DIST_RTOL, LNE_TOL, OracleBackend, chain_of, load_golden, orc
+from helpers import DIST_RTOL, LNE_TOL, OracleBackend, build_mce, chain_of, load_golden, orc
 
 pytestmark = pytest.mark.gpu
 logging.disable(logging.CRITICAL)
@@ -38,7 +38,10 @@ def test_knn_matches_oracle_over_dims(capi, d):
     dist, idx = capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE)
     od, oi = orc.knn_brute(Y, Y, K, self_mode=2)
     assert _rel(dist, od) < DIST_RTOL
-    assert np.mean(idx == oi) > 0.9999            # identical neighbour sets (ties aside)
+    if capi.get_search_mode() == capi.MODE_F64:
+        assert np.mean(idx == oi) > 0.9999        # the fp64 sweep SELECTS on GEMM-form keys: a near-tie can swap two rows
+    else:
+        assert np.array_equal(idx, oi)            # filter mode: exact keys, rigorous bound -- the oracle's rows, all of them
     assert np.all(np.diff(dist, axis=1) >= 0)
 
 
@@ -412,15 +415,13 @@ def test_class_on_gpu_reproduces_reference(name, capi):
     case = G[name]
     if case["tag"] == "big" and capi.get_search_mode() == capi.MODE_F64 and case["ndim"] < 10:
         pytest.skip("1M x 6 through the fp64 sweep is covered by the auto mode")
-    if case["seed_split"] is not None:
-        np.random.seed(case["seed_split"])
-    mce = pkg.MCEvidence([chain_of(case)], verbose=0, **case["mce"])
+    mce = build_mce(case)
     assert mce.backend.name == "hip"
     lnE = mce.evidence(**case["ev"])
     assert np.max(np.abs(lnE - np.array(case["lnE"]))) < LNE_TOL, (lnE, case["lnE"])
 
 
-@pytest.mark.parametrize("name", [n for n in sorted(G) if G[n]["tag"] != "big"])
+@pytest.mark.parametrize("name", [n for n in sorted(G) if G[n]["tag"] not in ("big", "c4")])
 def test_device_feeder_route_matches_reference_and_host_route(name):
     """covariance + whitening on the device (mce_evidence_feed_f64) vs the reference's outputs, and vs
     the host-feeder route of the same class."""
@@ -434,9 +435,7 @@ def test_device_feeder_route_matches_reference_and_host_route(name):
             return super().evidence_feed(*a, **k)
 
     def run(backend):
-        if case["seed_split"] is not None:
-            np.random.seed(case["seed_split"])
-        return pkg.MCEvidence([chain_of(case)], verbose=0, backend=backend, **case["mce"]).evidence(**case["ev"])
+        return build_mce(case, backend=backend).evidence(**case["ev"])
 
     dev = run(Spy())
     host = run(type("H", (), {"name": "hip", "knn_dotp": pkg.HipBackend().knn_dotp})())

@@ -52,7 +52,8 @@ def test_symmetric_sweep_is_bit_identical(sym, n, d, K):
     m = min(n, 2000)
     od, oi = orc.knn_brute(Y[-m:], Y, K, self_mode=2, self_offset=n - m)
     g, gi = capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE)
-    assert _rel(g[-m:], od) < DIST_RTOL and np.mean(gi[-m:] == oi) > 0.999
+    # continuous data, no ties: the exact-distance lists select EXACTLY the oracle's rows (filter mode is rigorous)
+    assert _rel(g[-m:], od) < DIST_RTOL and np.array_equal(gi[-m:], oi)
 
 
 def _rel(a, b):
@@ -418,3 +419,63 @@ def test_sampled_rows_at_2M_rows():
     keep = np.array([[c for c in oi[r] if c != rows[r]][:K] for r in range(len(rows))])
     want = np.sqrt(((X[rows][:, None, :] - X[keep]) ** 2).sum(-1))
     assert np.allclose(dist[rows], want, rtol=DIST_RTOL, atol=0) and np.array_equal(idx[rows], keep)
+
+
+# --------------------------------------------------------------------------- multi-GPU partition of the symmetric sweep
+@pytest.mark.parametrize("n,d,kmax,W", [(40000, 27, 10, 2), (30001, 6, 5, 3), (150000, 20, 6, 4), (70001, 27, 10, 8), (5000, 15, 3, 4), (2000, 6, 4, 8)])
+def test_symmetric_partition_parts_add_up_to_the_whole(sym, n, d, kmax, W):
+    """mce_knn_dotp_part_f64 for auto evidence: every rank takes a contiguous range of the SORTED blocks, symmetric within
+    its range and column side only against the other ranks' rows.  All W shares computed one after the
+    other on this GPU add up to the single-rank sum (which itself equals the oracle's) -- whatever W, also when ranks
+    end up with no blocks at all (2000 rows = 4 blocks over 8 ranks)."""
+    capi = sym
+    rng = np.random.default_rng(n + W)
+    Y = _data(n, d, n + 3 * W)
+    w = rng.integers(1, 6, n).astype(np.float64)
+    fs = -0.5 * rng.random(n) * 5.0
+    capi.set_sym_mode(capi.SYM_OFF)
+    whole = capi.knn_dotp(Y, None, w, fs, kmax, 1)
+    assert "symmetric" not in capi.last_kernel()
+    capi.set_sym_mode(capi.SYM_FORCE)
+    parts = []
+    for r in range(W):
+        parts.append(capi.knn_dotp_part(Y, w, fs, kmax, r, W))
+        assert "symmetric" in capi.last_kernel() and "panel-kernel" in capi.last_kernel(), capi.last_kernel()
+    total = np.sum(parts, axis=0)
+    assert np.allclose(total[1:], whole[1:], rtol=1e-12, atol=0), (total, whole)
+    if n <= 40000:
+        od, _ = orc.knn_brute(Y, Y, kmax - 1, self_mode=2)
+        full = np.zeros((n, kmax)); full[:, 1:] = od
+        assert np.allclose(total[1:], orc.dotp_literal(full, w, fs, d, 1, kmax)[1:], rtol=1e-10, atol=0)
+
+
+def test_unit_that_gives_up_waiting_is_repaired(sym, monkeypatch):
+    """The wait of a unit for its block's previous unit is bounded (knn_panel.hpp).  With the bound at 0 every wait that
+    is not already satisfied gives up at once: the unit starts from empty lists, flags its block, and the repair launch
+    searches that block again exhaustively -- the result must not change.  Small panels make many units per block."""
+    capi = sym
+    Y = _data(60000, 20, 7)
+    monkeypatch.setenv("MCE_SYM_PANEL", "2")
+    (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(Y, Y, 6, self_mode=capi.SELF_EXCLUDE))
+    assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+    monkeypatch.setenv("MCE_SYM_SPIN_LIMIT", "0")
+    capi.set_sym_mode(capi.SYM_FORCE)
+    d2, i2 = capi.knn(Y, Y, 6, self_mode=capi.SELF_EXCLUDE)
+    assert "symmetric" in capi.last_kernel()
+    assert np.array_equal(d0, d2) and np.array_equal(i0, i2)
+
+
+def test_every_candidate_through_the_redo_list(sym, monkeypatch):
+    """A tile whose candidates do not fit the wave's queue is deferred to a redo list and multiplied again after the
+    next drain.  MCE_PANEL_DEBUG=8 sends EVERY candidate of the sweep that way: identical results."""
+    capi = sym
+    for n, d, K in ((7777, 27, 9), (20000, 6, 10), (1024, 2, 1)):
+        Y = _data(n, d, n)
+        capi.set_sym_mode(capi.SYM_OFF)
+        d0, i0 = capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE)
+        monkeypatch.setenv("MCE_PANEL_DEBUG", "8")
+        capi.set_sym_mode(capi.SYM_FORCE)
+        d1, i1 = capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE)
+        monkeypatch.delenv("MCE_PANEL_DEBUG")
+        assert "panel-kernel" in capi.last_kernel()
+        assert np.array_equal(d0, d1) and np.array_equal(i0, i1)

@@ -10,7 +10,7 @@ import pytest
 
 import mcevidence_amd as pkg
 from mcevidence_amd.synth import gaussian_chain, planck_like_chains, write_cosmomc_chains
-from helpers import LNE_TOL, OracleBackend, OracleFeedBackend, chain_of, host_pins, load_golden
+from helpers import LNE_TOL, OracleBackend, OracleFeedBackend, build_mce, chain_of, host_pins, load_golden
 
 logging.disable(logging.CRITICAL)
 G = load_golden()
@@ -262,3 +262,16 @@ def test_missing_native_reader_falls_back_to_loadtxt(tmp_path, monkeypatch):
         got = pkg.MCEvidence(root, kmax=3, verbose=0, backend=OracleBackend()).evidence()
     assert np.array_equal(want, got)
     monkeypatch.setattr(chains, "_NATIVE_READER", None)
+
+
+def test_class_with_an_explicit_pair_reproduces_the_reference_C4_shape():
+    """``MCEvidence.set_split``: a caller-chosen (s1, s2) pair -- config C4's two independent chains -- instead of the
+    reference's random split; the reference's own ln E for that pair (reduced-size golden) through the host route and
+    through the device-feeder route's CPU double."""
+    case = G["cross_n20000_d15_k4_C4"]
+    for be in (OracleBackend(), OracleFeedBackend()):
+        mce = build_mce(case, backend=be)
+        assert mce.split and mce.nsample == [20000, 20000] and mce.snames == ["s1", "s2"]
+        lnE = mce.evidence()
+        assert np.allclose(lnE, case["lnE"], rtol=0, atol=LNE_TOL)
+        assert be.calls[0]["nq"] == 20000 and be.calls[0]["nr"] == 20000 and be.calls[0]["k0"] == 0

@@ -6,7 +6,7 @@ import math
 import numpy as np
 import pytest
 
-from helpers import DIST_RTOL, LNE_TOL, chain_of, load_golden, orc
+from helpers import DIST_RTOL, LNE_TOL, chain_of, explicit_split_of, load_golden, orc
 
 G = load_golden()
 SMALL = [n for n, c in G.items() if c["tag"] == "small"]
@@ -114,3 +114,19 @@ def test_duplicates_give_zero_volume_terms():
     for f in (orc.dotp_literal, orc.dotp_logdomain, orc.dotp_c):
         out = f(full, w, fs, 4, 1, 4)
         assert np.all(np.isfinite(out[1:])) and np.all(out[1:] > 0)
+
+
+def test_oracle_reproduces_the_reference_on_an_explicit_pair_C4_shape():
+    """BASELINE configs[3] (C4) at 1/50 of its size: two independent chains, s1 = the first, s2 = the second, d = 15,
+    kmax = 4, cross evidence (k0 = 0).  The reference was handed that split (oracle/gen_golden.py --c4 --c4-n 20000); the
+    oracle with the same pair reproduces its ln E (all kmax columns), its dotp and its kd_tree distances."""
+    case = G["cross_n20000_d15_k4_C4"]
+    r1, r2 = explicit_split_of(case)
+    for knn in ("sklearn", "brute"):
+        out = orc.evidence_from_chain(chain_of(case), kmax=4, knn=knn, s1_idx=r1, s2_idx=r2)
+        assert out["k0"] == 0 and out["S"] == case["S"] == 20000
+        assert np.allclose(out["lnE"], case["lnE"], rtol=0, atol=LNE_TOL)
+        assert np.allclose(out["dotp"], case["dotp"], rtol=1e-10)
+        rows = case["arrays"]["rows"]
+        assert np.allclose(out["DkNN"][rows][:, :4], case["arrays"]["DkNN_rows"][:, :4], rtol=DIST_RTOL, atol=0)
+    assert case["fit_method"] == "kd_tree"

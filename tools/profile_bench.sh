@@ -6,12 +6,12 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$tag -o kt -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $out/bench_under_kernel_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$tag -o kt -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-extras > $out/bench_under_kernel_trace.log 2>&1
 cp $(find /tmp/kt_$tag -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv 2>/dev/null
 # HBM traffic counters: separate passes (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf_$tag -o pf -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $out/bench_under_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw_$tag -o pw -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $out/bench_under_write.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d /tmp/ps_$tag -o ps -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $out/bench_under_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf_$tag -o pf -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-extras > $out/bench_under_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw_$tag -o pw -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-extras > $out/bench_under_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d /tmp/ps_$tag -o ps -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-extras > $out/bench_under_sq.log 2>&1
 python3 - $tag $out <<'PY'
 import csv, sys, glob, collections
 tag, out = sys.argv[1], sys.argv[2]
