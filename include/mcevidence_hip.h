@@ -19,7 +19,8 @@
  *                  scratch of at least mce_*_workspace_bytes().
  *   - return 0 on success, a negative MCE_ERR_* otherwise; mce_last_error()
  *     returns a thread-local message for the last failure on this thread.
- *   - one caller thread per device; calls are re-entrant across devices.
+ *   - one caller thread per device; calls are re-entrant across devices.  Several threads may share a device; the
+ *     search / prune / symmetric modes then travel WITH the call (mce_options), not through the process-wide setters.
  *
  * Neighbour semantics (all entry points): Euclidean distance, the K smallest
  * per query in ascending order, ties broken by smaller reference index --
@@ -35,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MCE_ABI_VERSION 1
+#define MCE_ABI_VERSION 2     /* 2: per-call options (mce_options, *_opt), mce_last_search_stats */
 
 #define MCE_OK 0
 #define MCE_ERR_INVALID (-1)   /* bad argument (NULL, d<1, K<1, ...)        -> ValueError  */
@@ -180,12 +181,39 @@ void mce_release_device_memory(void);
 int mce_set_search_mode(int mode);
 int mce_get_search_mode(void);
 
+/* Per-call options.  The three mode setters (this one, mce_set_prune_mode, mce_set_sym_mode) set PROCESS-WIDE DEFAULTS;
+ * two threads with different needs would race on them.  A call carries its own modes instead:
+ *   - the *_opt entry points below take a trailing `const mce_options*` (NULL: the defaults);
+ *   - mce_options_push(&o) ... mce_options_pop() bracket any other entry point: the pushed modes apply to the calls THIS
+ *     THREAD makes in between (they nest; threads the library starts itself, one per device, inherit them).
+ * A mode of -1 means "the process default".  `size` must be sizeof(mce_options) (room to grow). */
+typedef struct mce_options {
+    int32_t size;
+    int32_t search_mode;   /* as mce_set_search_mode */
+    int32_t prune_mode;    /* as mce_set_prune_mode  */
+    int32_t sym_mode;      /* as mce_set_sym_mode    */
+    int32_t reserved[4];   /* 0 */
+} mce_options;
+int mce_options_push(const mce_options* opt);
+int mce_options_pop(void);
+int mce_knn_f64_opt(const double* X, int64_t nq, const double* Y, int64_t nr, int32_t d, int32_t K, int32_t self_mode,
+                    int64_t self_offset, double* dist, int64_t* idx, int32_t device, const mce_options* opt);
+int mce_knn_dotp_f64_opt(const double* X, int64_t nq, const double* Y, int64_t nr, int32_t d, int32_t kmax, int32_t k0,
+                         int64_t self_offset, const double* w, const double* fs, double* dotp, double* dist_out,
+                         const int32_t* devices, int32_t ndev, const mce_options* opt);
+int mce_knn_dotp_f64_dev_opt(const double* dX, int64_t nq, const double* dY, int64_t nr, int32_t d, int32_t kmax, int32_t k0,
+                             int64_t self_offset, const double* d_w, const double* d_fs, double* d_dotp, double* d_dist_out,
+                             void* ws, size_t ws_bytes, void* stream, const mce_options* opt);
+size_t mce_knn_workspace_bytes_opt(int64_t nq, int64_t nr, int32_t d, int32_t K, const mce_options* opt);
+
 /* Spatial pruning of the fp16-filter search for low-dimensional, large reference sets (d <= 13):
  * both point sets are put in k-d order on the device (cells of 32 rows) and every wave of 64 queries
  * visits the reference chunks nearest-box-first, multiplies only the 32-row tiles whose box is within
  * reach, and stops once no remaining chunk can hold a neighbour.  Same neighbours, distances and
- * tie-breaks as the exhaustive search.  0 (default): used where it was measured faster -- d <= 2 from
- * 100 k reference rows, d <= 4 from 150 k, d <= 6 from 300 k, d = 7 from 800 k, d = 8 from 2 M; 1: never; 2: whenever the shape allows it (d <= 15, K <= 16).  Process-wide. */
+ * tie-breaks as the exhaustive search.  0 (default): used where it was measured faster -- d <= 3 from
+ * 100 k reference rows, d = 4 from 150 k, d <= 6 from 300 k, d = 7 from 800 k, d = 8 from 2 M (capi.hip: kPruneAutoMinRows),
+ * and at least 32 k queries, no fewer than an eighth of the reference rows; 1: never; 2: whenever the shape allows it
+ * (d <= 15, K <= 16).  Process-wide default (per call: mce_options). */
 int mce_set_prune_mode(int mode);
 int mce_get_prune_mode(void);
 
@@ -195,10 +223,13 @@ int mce_get_prune_mode(void);
  * the rows are sorted by distance from the mean, a prepass bounds every row's K-th distance, every block of
  * 512 rows sweeps only the blocks before it, and each tile is gated for the streamed rows
  * too; their candidates are merged into the lists afterwards.  Same neighbours, distances and tie-breaks as
- * the exhaustive search.  0 (default): where it was measured faster and pruning does not apply -- from 786 k rows
- * at d <= 15, 131 k at d <= 31, 65 k beyond;
- * 1: never; 2: whenever the shape allows it (fp16-filter shapes with K <= 16, at least 1024 rows).
- * Process-wide; the environment variable MCE_SYM sets the initial value. */
+ * the exhaustive search.  0 (default): where it was measured faster and pruning does not apply -- from 1024 blocks of
+ * 512 rows (524 k rows; 1 M with K > 12) where the filter takes one 16-wide k-step (d <= 14), from 257 blocks (131 k rows)
+ * where it takes two or more (capi.hip: kSymAutoMinBlocks);
+ * 1: never; 2: whenever the shape allows it (fp16-filter shapes with K <= 16, more than 512 rows).
+ * Process-wide default (per call: mce_options); the environment variable MCE_SYM sets the initial value.
+ * Multi-GPU: mce_knn_dotp_part_f64 partitions such a search by ranges of the sorted blocks (symmetric within a rank's
+ * range, column side only against the other ranks' rows) -- no exchange between the ranks. */
 int mce_set_sym_mode(int mode);
 int mce_get_sym_mode(void);
 /* Work actually done by the last pruned search launched by this thread through a *_dev entry point

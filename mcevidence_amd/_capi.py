@@ -50,6 +50,12 @@ SIGNATURES = {
     "mce_set_profiling": (None, [_c.c_int]),
     "mce_last_kernel_ms": (_c.c_double, []),
     "mce_last_search_stats": (_c.c_int, [_c.c_void_p, _c.c_int32]),
+    "mce_options_push": (_c.c_int, [_P]),
+    "mce_options_pop": (_c.c_int, []),
+    "mce_knn_f64_opt": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _c.c_int32, _P]),
+    "mce_knn_dotp_f64_opt": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _P, _P, _P, _c.c_int32, _P]),
+    "mce_knn_dotp_f64_dev_opt": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _P, _P, _P, _c.c_size_t, _P, _P]),
+    "mce_knn_workspace_bytes_opt": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _P]),
     "mce_knn_f64": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _c.c_int32]),
     "mce_dotp_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_int32]),
     "mce_knn_dotp_f64": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _P, _P, _P, _c.c_int32]),
@@ -102,7 +108,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.mce_abi_version() != 1 or lib.mce_feed_problem_size() != ctypes.sizeof(FeedProblem):
+        if lib.mce_abi_version() != 2 or lib.mce_feed_problem_size() != ctypes.sizeof(FeedProblem):
             raise RuntimeError("mcevidence_amd: ABI version mismatch")
         _lib = lib
     return _lib
@@ -172,6 +178,31 @@ def last_kernel_ms():
     return float(load().mce_last_kernel_ms())
 
 
+class Options(_c.Structure):
+    """``mce_options``: the search / prune / symmetric modes of ONE call (-1: the process default)."""
+    _fields_ = [("size", _c.c_int32), ("search_mode", _c.c_int32), ("prune_mode", _c.c_int32), ("sym_mode", _c.c_int32),
+                ("reserved", _c.c_int32 * 4)]
+
+    def __init__(self, search_mode=-1, prune_mode=-1, sym_mode=-1):
+        super().__init__(_c.sizeof(Options), int(search_mode), int(prune_mode), int(sym_mode))
+
+
+class options(object):
+    """``with _capi.options(sym_mode=_capi.SYM_FORCE): ...`` -- the modes apply to the library calls THIS THREAD makes
+    inside the block (mce_options_push / mce_options_pop); other threads are not affected."""
+
+    def __init__(self, **modes):
+        self.opt = Options(**modes)
+
+    def __enter__(self):
+        check(load().mce_options_push(_c.byref(self.opt)))
+        return self
+
+    def __exit__(self, *exc):
+        check(load().mce_options_pop())
+        return False
+
+
 def last_search_stats():
     """dict(flops_main, flops_all, search_ms, kernel_ms) of the last search on this thread (mce_last_search_stats)."""
     out = (_c.c_double * 4)()
@@ -219,9 +250,9 @@ def _f64_fs(a, name="fs"):
 # ---------------------------------------------------------------------------
 # host-pointer wrappers (NumPy in, NumPy out)
 # ---------------------------------------------------------------------------
-def knn(X, Y, K, self_mode=SELF_NONE, self_offset=0, return_index=True, device=0):
+def knn(X, Y, K, self_mode=SELF_NONE, self_offset=0, return_index=True, device=0, options=None):
     """K nearest reference rows (Euclidean) for every query row.  Returns
-    (dist[nq,K] ascending, idx[nq,K] int64 or None)."""
+    (dist[nq,K] ascending, idx[nq,K] int64 or None).  ``options``: an ``Options`` for THIS call (mce_knn_f64_opt)."""
     lib = load()
     X = _f64(X, "X")
     Y = _f64(Y, "Y")
@@ -232,8 +263,12 @@ def knn(X, Y, K, self_mode=SELF_NONE, self_offset=0, return_index=True, device=0
     K = int(K)
     dist = np.empty((nq, K), dtype=np.float64)
     idx = np.empty((nq, K), dtype=np.int64) if return_index else None
-    check(lib.mce_knn_f64(X.ctypes.data, nq, Y.ctypes.data, nr, d, K, int(self_mode), int(self_offset),
-                          dist.ctypes.data, idx.ctypes.data if idx is not None else None, int(device)))
+    if options is None:
+        check(lib.mce_knn_f64(X.ctypes.data, nq, Y.ctypes.data, nr, d, K, int(self_mode), int(self_offset),
+                              dist.ctypes.data, idx.ctypes.data if idx is not None else None, int(device)))
+    else:
+        check(lib.mce_knn_f64_opt(X.ctypes.data, nq, Y.ctypes.data, nr, d, K, int(self_mode), int(self_offset),
+                                  dist.ctypes.data, idx.ctypes.data if idx is not None else None, int(device), _c.addressof(options)))
     return dist, idx
 
 

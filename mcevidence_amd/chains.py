@@ -39,8 +39,10 @@ def rank0_draw(draw):
     if not parallel.is_distributed():
         return draw()
     import torch.distributed as dist
-    box = [draw() if dist.get_rank() == 0 else None]
-    dist.broadcast_object_list(box, src=0)
+    group = parallel.current_group()           # the group of the evidence computation (parallel.set_group), default: world
+    lead = dist.get_rank(group) == 0
+    box = [draw() if lead else None]
+    dist.broadcast_object_list(box, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
     return box[0]
 
 

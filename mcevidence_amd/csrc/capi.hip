@@ -95,6 +95,15 @@ int sym_spin_limit()
     const char* e = getenv("MCE_SYM_SPIN_LIMIT");
     return e ? atoi(e) : (1 << 21);
 }
+// Per-call options (mce_options, include/mcevidence_hip.h): the *_opt entry points and mce_options_push / _pop set them for
+// the calls the CURRENT THREAD makes; -1 = the process-wide default of the setters above.  Threads the library starts
+// itself (one per device) inherit the caller's.  The planner reads the modes through these three functions only.
+struct CallOptions { int search = -1, prune = -1, sym = -1; };
+thread_local CallOptions t_opt;
+thread_local std::vector<CallOptions> t_opt_stack;
+int eff_search_mode() { return t_opt.search >= 0 ? t_opt.search : g_mode.load(); }
+int eff_prune_mode() { return t_opt.prune >= 0 ? t_opt.prune : g_prune_mode.load(); }
+int eff_sym_mode() { return t_opt.sym >= 0 ? t_opt.sym : sym_mode(); }
 // query blocks (512 rows each) from which the automatic mode takes it, by 16-wide k-steps of the filter.  Measured
 // (tools/sym_crossover.py -> profiles/r02_symmetric/crossover.json; fused search + reduction, exhaustive -> symmetric, ms).
 // Up to 256 blocks -- one round of workgroups -- the seeded exhaustive sweep with its reference splits is as fast or
@@ -346,7 +355,7 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     int ki = 0;
     while (ki < mce::kNumKcap - 1 && mce::kKcapList[ki] < K) ++ki;
     p.KCAP = mce::kKcapList[ki];
-    const bool f16 = (g_mode.load() != 1) && mce::f16_supported(d, K);
+    const bool f16 = (eff_search_mode() != 1) && mce::f16_supported(d, K);
     int qpb, rows_per_tile;
     if (f16) {
         if (K > 16) {                          // 16 nearest per reference split first, then the next K - 16 beyond them
@@ -379,7 +388,7 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
 
     if (f16 && !p.twopass && p.KST == 1 && d <= mce::kPruneMaxDim && p.vh->launch_prune && nq > 0 &&
         p.nrow_pad <= ((int64_t)1 << mce::kHRelBits) && (int64_t)p.nqblk * p.nchunk <= mce::kPruneMaxPairs) {
-        const int pm = g_prune_mode.load();
+        const int pm = eff_prune_mode();
         // (the k-d ordering costs ~4 ms per million reference rows whatever the number of queries, and sparse
         // query sets make large query tiles: measured at 2 M x 6, separate sets, the walk wins from nq ~ nr/10)
         p.prune = pm == 2 || (pm == 0 && kPruneAutoMinRows[d] > 0 && nr >= kPruneAutoMinRows[d] && nq >= kPruneAutoMinQueries &&
@@ -454,7 +463,7 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     }
     // symmetric sweep: auto-evidence searches (the caller passes ONE buffer as X and Y; only the sizes are known here)
     if (f16 && !p.twopass && !p.prune && nq == nr && p.vh->launch_sym && p.nqblk >= 2 && p.nrow_pad <= ((int64_t)1 << mce::kHSymRowBits)) {
-        const int sm = sym_mode();
+        const int sm = eff_sym_mode();
         p.sym = sm == 2 || (sm == 0 && p.nqblk >= kSymAutoMinBlocks[p.KST] * ((p.KST == 1 && p.KCAP == 16) ? 2 : 1));     // (1M x 15, K = 16: 62.3 vs 62.7 ms)
         if (g_same_set_hint == 0) p.sym = false;
     }
@@ -867,6 +876,27 @@ int mce_set_sym_mode(int mode)
 }
 
 int mce_get_sym_mode(void) { return sym_mode(); }
+
+int mce_options_push(const mce_options* opt)
+{
+    if (!opt) return fail(MCE_ERR_INVALID, "null options");
+    if (opt->size < (int32_t)(4 * sizeof(int32_t))) return fail(MCE_ERR_INVALID, "mce_options.size=%d: set it to sizeof(mce_options)", opt->size);
+    if (opt->search_mode < -1 || opt->search_mode > 2 || opt->prune_mode < -1 || opt->prune_mode > 2 || opt->sym_mode < -1 || opt->sym_mode > 2)
+        return fail(MCE_ERR_INVALID, "mce_options: modes are -1 (default), 0, 1 or 2");
+    t_opt_stack.push_back(t_opt);
+    if (opt->search_mode >= 0) t_opt.search = opt->search_mode;
+    if (opt->prune_mode >= 0) t_opt.prune = opt->prune_mode;
+    if (opt->sym_mode >= 0) t_opt.sym = opt->sym_mode;
+    return MCE_OK;
+}
+
+int mce_options_pop(void)
+{
+    if (t_opt_stack.empty()) return fail(MCE_ERR_INVALID, "mce_options_pop without a push on this thread");
+    t_opt = t_opt_stack.back();
+    t_opt_stack.pop_back();
+    return MCE_OK;
+}
 
 int mce_last_prune_stats(double* chunk_fraction, double* tile_fraction)
 {
@@ -1731,7 +1761,8 @@ int mce_evidence_feed_batch_f64(mce_feed_problem* problems, int64_t nprob, const
         work(0);
     } else {
         std::vector<std::thread> th;
-        for (int i = 0; i < n; ++i) th.emplace_back(work, i);
+        const CallOptions inherited = t_opt;
+        for (int i = 0; i < n; ++i) th.emplace_back([&, i]() { t_opt = inherited; work(i); });
         for (auto& t : th) t.join();
     }
     for (int i = 0; i < n; ++i)
@@ -1796,7 +1827,8 @@ int mce_knn_dotp_f64(const double* X, int64_t nq, const double* Y, int64_t nr, i
         work(0);
     } else {
         std::vector<std::thread> th;
-        for (int i = 0; i < n; ++i) th.emplace_back(work, i);
+        const CallOptions inherited = t_opt;
+        for (int i = 0; i < n; ++i) th.emplace_back([&, i]() { t_opt = inherited; work(i); });
         for (auto& t : th) t.join();
     }
     for (int i = 0; i < n; ++i)
@@ -1834,6 +1866,55 @@ int mce_knn_dotp_part_f64(const double* Y, int64_t nr, int32_t d, int32_t kmax, 
     MCE_HIP(hipDeviceSynchronize());
     MCE_HIP(hipMemcpy(dotp, dO.p, (size_t)kmax * sizeof(double), hipMemcpyDeviceToHost));
     return MCE_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// per-call options: the three drop-in entry points with a trailing mce_options (NULL: the defaults)
+// ---------------------------------------------------------------------------
+namespace {
+struct ScopedOptions {
+    bool pushed = false;
+    int rc = MCE_OK;
+    explicit ScopedOptions(const mce_options* o) { if (o) { rc = mce_options_push(o); pushed = rc == MCE_OK; } }
+    ~ScopedOptions() { if (pushed) (void)mce_options_pop(); }
+};
+}  // namespace
+
+extern "C" {
+
+int mce_knn_f64_opt(const double* X, int64_t nq, const double* Y, int64_t nr, int32_t d, int32_t K, int32_t self_mode,
+                    int64_t self_offset, double* dist, int64_t* idx, int32_t device, const mce_options* opt)
+{
+    ScopedOptions so(opt);
+    if (so.rc != MCE_OK) return so.rc;
+    return mce_knn_f64(X, nq, Y, nr, d, K, self_mode, self_offset, dist, idx, device);
+}
+
+int mce_knn_dotp_f64_opt(const double* X, int64_t nq, const double* Y, int64_t nr, int32_t d, int32_t kmax, int32_t k0,
+                         int64_t self_offset, const double* w, const double* fs, double* dotp, double* dist_out,
+                         const int32_t* devices, int32_t ndev, const mce_options* opt)
+{
+    ScopedOptions so(opt);
+    if (so.rc != MCE_OK) return so.rc;
+    return mce_knn_dotp_f64(X, nq, Y, nr, d, kmax, k0, self_offset, w, fs, dotp, dist_out, devices, ndev);
+}
+
+int mce_knn_dotp_f64_dev_opt(const double* dX, int64_t nq, const double* dY, int64_t nr, int32_t d, int32_t kmax, int32_t k0,
+                             int64_t self_offset, const double* d_w, const double* d_fs, double* d_dotp, double* d_dist_out,
+                             void* ws, size_t ws_bytes, void* stream, const mce_options* opt)
+{
+    ScopedOptions so(opt);
+    if (so.rc != MCE_OK) return so.rc;
+    return mce_knn_dotp_f64_dev(dX, nq, dY, nr, d, kmax, k0, self_offset, d_w, d_fs, d_dotp, d_dist_out, ws, ws_bytes, stream);
+}
+
+size_t mce_knn_workspace_bytes_opt(int64_t nq, int64_t nr, int32_t d, int32_t K, const mce_options* opt)
+{
+    ScopedOptions so(opt);
+    if (so.rc != MCE_OK) return 0;
+    return mce_knn_workspace_bytes(nq, nr, d, K);
 }
 
 }  // extern "C"

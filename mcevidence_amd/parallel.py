@@ -17,12 +17,32 @@ from __future__ import annotations
 import numpy as np
 
 
-def is_distributed():
+_GROUP = None      # process group of the evidence computation; None = the default (world) group
+
+
+def set_group(group):
+    """Run the multi-rank paths (``sharded_knn_dotp``, ``farm_evidence_feed``, the rank-0 random draws of
+    ``chains.rank0_draw``) on a sub-group of the job instead of the world group.  Call it on every member of the
+    group before constructing ``MCEvidence``; ranks outside the group behave as single processes."""
+    global _GROUP
+    _GROUP = group
+
+
+def current_group():
+    return _GROUP
+
+
+def is_distributed(group=None):
     try:
         import torch.distributed as dist
     except Exception:
         return False
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    group = _GROUP if group is None else group
+    if group is not None and dist.get_rank(group) < 0:      # this process is not a member
+        return False
+    return dist.get_world_size(group) > 1
 
 
 def shard_bounds(n, world, rank):
@@ -52,23 +72,19 @@ def _reduce_partial(part, group=None):
 
 
 def replica_fingerprint(*arrays):
-    """63-bit fingerprint of the replicated inputs: shapes, every value of vectors, and for matrices
-    ~4096 evenly spaced rows plus the column sums (one pass; ~10 ms per 200 MB).  Not cryptographic --
-    it is there to catch ranks that hold DIFFERENT partitions (an unsynchronised random split)."""
-    import zlib
-    h = 0
+    """63-bit fingerprint (BLAKE2b, 8-byte digest, top bit dropped so it fits a signed int64 tensor) of the
+    replicated inputs: shapes and EVERY byte of every array (~0.3 s per GB).  It is there to catch ranks that hold
+    different partitions (an unsynchronised random split) or differently thinned chains."""
+    import hashlib
+    h = hashlib.blake2b(digest_size=8)
     for a in arrays:
         if a is None:
-            h = zlib.crc32(b"none", h)
+            h.update(b"none")
             continue
         a = np.ascontiguousarray(a, dtype=np.float64)
-        h = zlib.crc32(np.asarray(a.shape, dtype=np.int64).tobytes(), h)
-        if a.ndim < 2 or a.shape[0] <= 4096:
-            h = zlib.crc32(a.tobytes(), h)
-        else:
-            h = zlib.crc32(np.ascontiguousarray(a[:: a.shape[0] // 4096]).tobytes(), h)
-            h = zlib.crc32(a.sum(axis=0).tobytes(), h)
-    return int(h)
+        h.update(np.asarray(a.shape, dtype=np.int64).tobytes())
+        h.update(memoryview(a).cast("B"))
+    return int.from_bytes(h.digest(), "little") & ((1 << 63) - 1)
 
 
 def check_replicas(X, Y, weight, fs, group=None):
@@ -77,6 +93,7 @@ def check_replicas(X, Y, weight, fs, group=None):
     a mismatch raises on every rank instead of returning a silently wrong, rank-dependent ln E."""
     import torch
     import torch.distributed as dist
+    group = _GROUP if group is None else group
     h = replica_fingerprint(X, Y, weight, fs)
     backend = dist.get_backend(group)
     device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
@@ -90,13 +107,33 @@ def check_replicas(X, Y, weight, fs, group=None):
             "drawn on rank 0 and broadcast), from the same chains.")
 
 
-def sharded_knn_dotp(X, Y, weight, fs, kmax, k0, want_dist=False, group=None, local_fn=None, verify=True):
-    """Query-sharded fused kNN + reduction.  Every rank passes the FULL arrays (they are
+def symmetric_partition_rows(Y, world, rank, block=512):
+    """The rows whose evidence terms rank ``rank`` of ``world`` sums when the library partitions a symmetric
+    auto-evidence search (``mce_knn_dotp_part_f64``) -- restated on the host for tests and diagnostics:
+    rows sorted by their squared distance from the column means (compared as fp32, ties in the caller's order), cut
+    into blocks of 512, rank r taking the contiguous block range [B r / W, B (r + 1) / W).  Inside the library a rank
+    searches its rows symmetrically among themselves and column side only against everybody else's; the SUMS only
+    depend on which rows a rank owns."""
+    Y = np.asarray(Y, dtype=np.float64)
+    n = Y.shape[0]
+    key = ((Y - Y.mean(axis=0)) ** 2).sum(axis=1).astype(np.float32)
+    order = np.argsort(key, kind="stable")
+    nblk = (n + block - 1) // block
+    lo, hi = (nblk * rank) // world, (nblk * (rank + 1)) // world
+    return order[lo * block: min(hi * block, n)]
+
+
+def sharded_knn_dotp(X, Y, weight, fs, kmax, k0, want_dist=False, group=None, local_fn=None, verify=True, part_fn=None):
+    """Multi-rank fused kNN + reduction.  Every rank passes the FULL arrays (they are
     replicated host-side, as the reference set must be anyway) and gets the full
-    ``dotp`` back.  ``local_fn`` lets the CPU tests substitute the per-shard compute.
+    ``dotp`` back.  Auto evidence: the library chooses each rank's share (``part_fn``, default
+    ``_capi.knn_dotp_part``: the symmetric partition for large sets, block-cyclic parts of the pruned walk,
+    row shards otherwise); cross evidence: contiguous query rows.  ``local_fn`` / ``part_fn`` let the CPU tests
+    substitute the per-rank compute.
     ``verify``: compare a fingerprint of the inputs across the ranks first (``check_replicas``)."""
     import torch
     import torch.distributed as dist
+    group = _GROUP if group is None else group
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if verify:
@@ -104,12 +141,16 @@ def sharded_knn_dotp(X, Y, weight, fs, kmax, k0, want_dist=False, group=None, lo
     n = X.shape[0]
     lo, hi = shard_bounds(n, world, rank)
     ref = X if Y is None else Y
-    if Y is None and local_fn is None and not want_dist:
-        # auto evidence: let the library choose the partition (rows for the sweep, k-d cells for the pruned
-        # walk, whose shards must be spatially compact to stay efficient): mce_knn_dotp_part_f64
-        from . import _capi
-        dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
-        part = _capi.knn_dotp_part(X, weight, fs, kmax, rank, world, device=dev)
+    if Y is None and (local_fn is None or part_fn is not None) and not want_dist:
+        # auto evidence: let the library choose the partition (sorted blocks for the symmetric sweep, k-d cells for
+        # the pruned walk -- whose shards must be spatially compact to stay efficient --, rows otherwise):
+        # mce_knn_dotp_part_f64
+        if part_fn is None:
+            from . import _capi
+            dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
+            part = _capi.knn_dotp_part(X, weight, fs, kmax, rank, world, device=dev)
+        else:
+            part = part_fn(X, weight, fs, kmax, rank, world)
         return _reduce_partial(part, group), None
     fn = local_fn or _local_hip
     if hi > lo:
@@ -154,6 +195,7 @@ def farm_evidence_feed(problems, group=None, local_fn=None):
     Returns [(dotp[kmax], J)] in input order.  A problem that fails on its owner raises on every rank."""
     import torch
     import torch.distributed as dist
+    group = _GROUP if group is None else group
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n = len(problems)

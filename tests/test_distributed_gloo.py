@@ -230,3 +230,77 @@ def test_random_split_and_thinning_agree_across_ranks():
     one = pkg.MCEvidence([gaussian_chain(5, 1400, 4, weights="int")], kmax=4, split=True, s1frac=0.4, verbose=0, backend=OracleBackend())
     assert np.array_equal(np.asarray(one.gd.data["s1"].ichain), rows_a)
     assert np.allclose(one.evidence(covtype="all"), lnE_a, atol=1e-12)
+
+
+# --------------------------------------------------------------------------- the symmetric partition (auto evidence)
+def _part_oracle(Y, w, fs, kmax, rank, world):
+    """CPU double of ``_capi.knn_dotp_part``: the library's partition restated on the host
+    (``parallel.symmetric_partition_rows``), each owned row searched exactly among ALL rows."""
+    from mcevidence_amd import parallel
+    rows = parallel.symmetric_partition_rows(Y, world, rank)
+    out = np.zeros(kmax)
+    if len(rows):
+        d, _ = orc.knn_brute(Y[rows], Y, kmax, self_mode=0)          # column 0: the row itself
+        full = np.zeros((len(rows), kmax))
+        full[:, 1:] = d[:, 1:kmax]
+        out = orc.dotp_literal(full, w[rows], fs[rows], Y.shape[1], 1, kmax)
+    return out
+
+
+def _part_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mcevidence_amd import parallel
+    rng = np.random.default_rng(7)
+    n, d, kmax = 2600, 6, 5                                             # 6 blocks of 512: ranks of a 4-rank job own 1 or 2
+    Y = rng.standard_normal((n, d)) * (1.0 + rng.random((1, d)))
+    w = rng.integers(1, 4, n).astype(float)
+    fs = -rng.random(n)
+    dotp, _ = parallel.sharded_knn_dotp(Y, None, w, fs, kmax, 1, part_fn=_part_oracle)
+    owned = parallel.symmetric_partition_rows(Y, world, rank)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, owned.tolist())
+    if rank == 0:
+        q.put((dotp, gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_symmetric_partition_over_ranks_equals_the_single_rank_sum(world):
+    """world sizes 2 and 4 over gloo: every rank sums the evidence terms of ITS range of the sorted blocks, ONE
+    all-reduce; the result equals the single-process sum to 1e-12 and the ranks' rows tile the set exactly once."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_part_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    dotp, owned = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(7)
+    n, d, kmax = 2600, 6, 5
+    Y = rng.standard_normal((n, d)) * (1.0 + rng.random((1, d)))
+    w = rng.integers(1, 4, n).astype(float)
+    fs = -rng.random(n)
+    one = _part_oracle(Y, w, fs, kmax, 0, 1)
+    assert np.allclose(dotp[1:], one[1:], rtol=1e-12, atol=0)
+    allrows = np.concatenate([np.asarray(o, dtype=np.int64) for o in owned])
+    assert len(allrows) == n and np.array_equal(np.sort(allrows), np.arange(n))
+    sizes = [len(o) for o in owned]
+    assert max(sizes) - min(sizes) <= 512 + 511                          # whole blocks; the last one is partial
+
+
+def test_replica_fingerprint_sees_every_row():
+    from mcevidence_amd.parallel import replica_fingerprint
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((50000, 7))
+    h = replica_fingerprint(A, None, A[:, 0])
+    B = A.copy()
+    B[12345, 3] = np.nextafter(B[12345, 3], 1.0)                         # one bit in one row that no sampling would hit
+    assert replica_fingerprint(B, None, B[:, 0]) != h
+    assert replica_fingerprint(A, None, A[:, 0]) == h and 0 <= h < 2 ** 63

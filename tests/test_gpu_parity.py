@@ -997,3 +997,47 @@ def test_feed_route_reports_non_finite_input():
             _capi.evidence_feed(T, None, 4, 0, 3, w, fs)
         out = _capi.evidence_feed_batch([(S, None, 4, 0, 3, w, fs), (T, None, 4, 0, 3, w, fs)], return_exceptions=True)
         assert isinstance(out[1], ValueError) and not isinstance(out[0], Exception)
+
+
+# --------------------------------------------------------------------------- per-call options
+def test_two_threads_with_different_modes_on_one_device():
+    """The search / prune / symmetric modes travel with the call (mce_options, ABI 2): two threads share the device, one
+    asks for the fp64 sweep, the other for the symmetric filter sweep, many calls each, concurrently.  Every call must
+    run the kernel ITS options name (mce_last_kernel() is thread-local) and return the same neighbours; the process-wide
+    defaults are untouched."""
+    import threading
+    from mcevidence_amd import _capi
+    rng = np.random.default_rng(5)
+    Y = rng.standard_normal((6000, 9))
+    want_d, want_i = orc.knn_brute(Y, Y, 5, self_mode=2)
+    _capi.set_search_mode(_capi.MODE_AUTO); _capi.set_sym_mode(_capi.SYM_AUTO); _capi.set_prune_mode(_capi.PRUNE_AUTO)
+    errors = []
+
+    def worker(opt, must_contain, must_not):
+        try:
+            for _ in range(12):
+                d, i = _capi.knn(Y, Y, 5, self_mode=_capi.SELF_EXCLUDE, options=opt)
+                k = _capi.last_kernel()
+                assert must_contain in k and (must_not is None or must_not not in k), k
+                assert np.array_equal(i, want_i) and _rel(d, want_d) < DIST_RTOL
+        except Exception as e:          # noqa: BLE001
+            errors.append(repr(e))
+
+    a = threading.Thread(target=worker, args=(_capi.Options(search_mode=_capi.MODE_F64), "knn_mfma_kernel", None))
+    b = threading.Thread(target=worker, args=(_capi.Options(sym_mode=_capi.SYM_FORCE, prune_mode=_capi.PRUNE_OFF), "symmetric", "knn_mfma"))
+    a.start(); b.start(); a.join(); b.join()
+    assert not errors, errors
+    assert _capi.get_search_mode() == _capi.MODE_AUTO and _capi.get_sym_mode() == _capi.SYM_AUTO
+    # the scoped form, nested
+    with _capi.options(search_mode=_capi.MODE_F64):
+        _capi.knn(Y, Y, 5, self_mode=_capi.SELF_EXCLUDE)
+        assert "knn_mfma_kernel" in _capi.last_kernel()
+        with _capi.options(search_mode=_capi.MODE_AUTO, sym_mode=_capi.SYM_FORCE, prune_mode=_capi.PRUNE_OFF):
+            _capi.knn(Y, Y, 5, self_mode=_capi.SELF_EXCLUDE)
+            assert "symmetric" in _capi.last_kernel()
+        _capi.knn(Y, Y, 5, self_mode=_capi.SELF_EXCLUDE)
+        assert "knn_mfma_kernel" in _capi.last_kernel()
+    _capi.knn(Y, Y, 5, self_mode=_capi.SELF_EXCLUDE)
+    assert "knn_f16" in _capi.last_kernel() and "symmetric" not in _capi.last_kernel()
+    with pytest.raises(ValueError):
+        _capi.knn(Y, Y, 5, options=_capi.Options(search_mode=7))
