@@ -256,6 +256,12 @@ double mce_last_kernel_ms(void);
  * Bookkeeping of the measurement hooks; no counterpart in the reference. */
 int mce_last_search_stats(double* out, int32_t n);
 
+/* Test hook: one 32 x 32 tile of the filter's matrix product exactly as the search kernels issue it
+ * (v_mfma_f32_32x32x16_f16, `kst` chained k-steps): out[row * 32 + query] = sum_k yprime[row][k] * xprime[query][k], rows of
+ * 16 * kst fp16 values (bit patterns) each.  tests/test_gpu_parity.py::test_mfma_error_model checks the error model the
+ * rigorous filter bound assumes (knn_f16.hpp) against it.  No counterpart in the reference. */
+int mce_debug_mfma_tile_f16(const uint16_t* yprime, const uint16_t* xprime, int32_t kst, float* out, int32_t device);
+
 #ifdef __cplusplus
 }
 #endif

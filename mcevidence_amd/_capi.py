@@ -50,6 +50,7 @@ SIGNATURES = {
     "mce_set_profiling": (None, [_c.c_int]),
     "mce_last_kernel_ms": (_c.c_double, []),
     "mce_last_search_stats": (_c.c_int, [_c.c_void_p, _c.c_int32]),
+    "mce_debug_mfma_tile_f16": (_c.c_int, [_P, _P, _c.c_int32, _P, _c.c_int32]),
     "mce_options_push": (_c.c_int, [_P]),
     "mce_options_pop": (_c.c_int, []),
     "mce_knn_f64_opt": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _c.c_int32, _P]),
@@ -455,3 +456,15 @@ def knn_dotp_part_dev(dY, nr, d, kmax, part, nparts, d_w, d_fs, d_dotp, ws, ws_b
 def knn_dotp_dev(dX, nq, dY, nr, d, kmax, k0, self_offset, d_w, d_fs, d_dotp, d_dist_out, ws, ws_bytes, stream=0):
     check(load().mce_knn_dotp_f64_dev(dX, nq, dY, nr, d, kmax, k0, self_offset, d_w, d_fs, d_dotp, d_dist_out or None,
                                       ws, ws_bytes, stream or None))
+
+
+def debug_mfma_tile(yprime, xprime, device=0):
+    """Test hook (mce_debug_mfma_tile_f16): the 32 x 32 fp32 tile ``yprime @ xprime.T`` as the filter kernels' MFMA
+    sequence computes it; ``yprime``, ``xprime``: float16 arrays [32, 16 * kst]."""
+    y = np.ascontiguousarray(yprime, dtype=np.float16)
+    x = np.ascontiguousarray(xprime, dtype=np.float16)
+    if y.shape != x.shape or y.shape[0] != 32 or y.shape[1] % 16 or not 1 <= y.shape[1] // 16 <= 4:
+        raise ValueError("yprime and xprime must be float16 [32, 16*kst], kst = 1..4")
+    out = np.empty((32, 32), dtype=np.float32)
+    check(load().mce_debug_mfma_tile_f16(y.ctypes.data, x.ctypes.data, y.shape[1] // 16, out.ctypes.data, int(device)))
+    return out

@@ -1041,3 +1041,124 @@ def test_two_threads_with_different_modes_on_one_device():
     assert "knn_f16" in _capi.last_kernel() and "symmetric" not in _capi.last_kernel()
     with pytest.raises(ValueError):
         _capi.knn(Y, Y, 5, options=_capi.Options(search_mode=7))
+
+
+# --------------------------------------------------------------------------- the matrix-core error model, measured
+@pytest.mark.parametrize("kst", [1, 2, 3, 4])
+def test_mfma_error_model(kst):
+    """The filter's bound (knn_f16.hpp) assumes: products of two fp16 values are exact, and the fp32 accumulation of the
+    16 KST terms of A = |y^|^2 - 2 x^.y^ errs by at most eps_q = 32 KST 2^-24 (|x^| + max |y^|)^2.  Measured here on the
+    instruction itself (mce_debug_mfma_tile_f16: the kernels' own MFMA sequence) against the exactly rounded sum, at the
+    radius the kernels scale to (200), on the worst case for cancellation -- reference rows next to the query, so that
+    |y^|^2 ~ 2 x^.y^ ~ 40 000 while A itself is ~ -|x^|^2 + tiny -- with every sign pattern of the partial sums, and on
+    plain random rows.  The observed error must stay within eps_q (it is ~50x smaller)."""
+    import math as _m
+    from mcevidence_amd import _capi
+    rng = np.random.default_rng(1000 + kst)
+    D = 16 * kst - 3                                      # three norm pieces fill the last k-step
+    worst = 0.0
+    for trial in range(24):
+        x = rng.standard_normal((32, D))
+        x *= 200.0 / np.linalg.norm(x, axis=1, keepdims=True) * (0.5 + 0.5 * rng.random((32, 1)))
+        if trial % 3 == 0:      # references within a hair of the queries (row j next to query j, and to its neighbours)
+            y = x[rng.permutation(32)] + rng.standard_normal((32, D)) * 10.0 ** rng.uniform(-3, 0.5)
+        elif trial % 3 == 1:    # antipodal / sign-flipped copies: the products all have one sign, partial sums peak
+            y = -x[rng.permutation(32)] * (1.0 + 0.01 * rng.standard_normal((32, 1)))
+        else:
+            y = rng.standard_normal((32, D))
+            y *= 200.0 / np.linalg.norm(y, axis=1, keepdims=True) * rng.random((32, 1))
+        xh = x.astype(np.float16)
+        yh = y.astype(np.float16)
+        n2 = (yh.astype(np.float64) ** 2).sum(axis=1)     # |y^|^2 from the CONVERTED values, split into three fp16 pieces
+        n_hi = n2.astype(np.float16)
+        n_mid = (n2 - n_hi.astype(np.float64)).astype(np.float16)
+        n_lo = (n2 - n_hi.astype(np.float64) - n_mid.astype(np.float64)).astype(np.float16)
+        yp = np.concatenate([(-2.0 * yh.astype(np.float64)).astype(np.float16), n_hi[:, None], n_mid[:, None], n_lo[:, None]], axis=1)
+        xp = np.concatenate([xh, np.ones((32, 3), dtype=np.float16)], axis=1)
+        assert yp.shape[1] == 16 * kst and np.all(np.isfinite(yp.astype(np.float64)))
+        A = _capi.debug_mfma_tile(yp, xp).astype(np.float64)            # [row, query]
+        yp64, xp64 = yp.astype(np.float64), xp.astype(np.float64)
+        exact = np.array([[_m.fsum(yp64[j] * xp64[i]) for i in range(32)] for j in range(32)])     # products exact in fp64, sum exactly rounded
+        xn = np.sqrt((xh.astype(np.float64) ** 2).sum(axis=1))
+        ymax = np.sqrt(n2.max())
+        eps = 32.0 * kst * 2.0 ** -24 * (xn[None, :] + ymax) ** 2
+        err = np.abs(A - exact)
+        assert np.all(err <= eps), (kst, trial, float((err / eps).max()))
+        worst = max(worst, float((err / eps).max()))
+    assert worst < 0.5, worst             # headroom: the model is not tight
+
+
+# --------------------------------------------------------------------------- config C1 on the hardware
+def test_C1_file_root_through_the_hip_backend(tmp_path):
+    """BASELINE configs[0]: the CosmoMC-format file root (4 chains, 26 862 rows, ndim = 6, kmax = 2) read by libmcechains
+    and fed to mce_evidence_feed_f64 -- the whole file -> ln E route on the GPU box -- against the ln E the REFERENCE
+    returned for the same files (tests/golden/host_pins.json: C1_all, C1_chain1..4)."""
+    import mcevidence_amd as pkg
+    from mcevidence_amd.synth import planck_like_chains, write_cosmomc_chains
+    from helpers import host_pins
+    pins = host_pins()
+    chains, names, ranges = planck_like_chains(seed=1)
+    root = str(tmp_path / "base_plikHM_TT_lowTEB")
+    write_cosmomc_chains(root, chains, ranges)
+    pi = pkg.params_info(root, cosmo=True)
+    m = pkg.MCEvidence(root, ndim=pi["ndim"], priorvolume=pi["volume"], kmax=2, verbose=0)
+    assert m.backend.name == "hip" and m.nsample[0] == pins["C1_all"]["N"] == 26862
+    lnE = m.evidence()
+    assert np.allclose(lnE, pins["C1_all"]["lnE"], rtol=0, atol=1e-8)          # (text round trip of the chains: a few 1e-10)
+    for ic in (1, 2, 3, 4):
+        mi = pkg.MCEvidence(root, ndim=6, priorvolume=pi["volume"], kmax=2, verbose=0, idchain=ic)
+        assert np.allclose(mi.evidence(), pins["C1_chain%d" % ic]["lnE"], rtol=0, atol=1e-8)
+
+
+# --------------------------------------------------------------------------- full-size reductions
+def test_cross_evidence_reduction_at_full_size_C4():
+    """BASELINE configs[3]: the FUSED search + volume/weight sum of cross evidence (k0 = 0: all kmax columns count,
+    MCEvidence.py:1093-1096, 1120-1122) at 1M x 1M x 15, integer weights and a non-trivial likelihood column.  The sum is
+    linear in the rows, so it is checked in two steps that together cover it: the fused sums over ALL rows equal the
+    literal sum formed on the host from the distances the same call returns, and on 30 000 sampled rows those distances
+    equal the exact CPU search's (the search over all 10^6 rows takes the oracle 14 minutes on 256 threads: done once,
+    round 3, same result)."""
+    from mcevidence_amd import _capi
+    from mcevidence_amd.synth import config_chain
+    chain, (r1, r2) = config_chain("C4")
+    theta = chain[:, 2:]
+    ev, U = np.linalg.eigh(np.cov(theta.T))
+    W = (theta @ U) / np.sqrt(ev)
+    X, Y = np.ascontiguousarray(W[r1]), np.ascontiguousarray(W[r2])
+    rng = np.random.default_rng(4)
+    w = rng.integers(1, 6, len(X)).astype(np.float64)
+    fs = -chain[r1, 1] - np.max(-chain[r1, 1])
+    kmax = 4
+    dotp, dist = _capi.knn_dotp(X, Y, w, fs, kmax, 0, return_dist=True)
+    assert "knn_f16" in _capi.last_kernel()
+    assert np.allclose(dotp, orc.dotp_literal(dist, w, fs, X.shape[1], 0, kmax), rtol=1e-11, atol=0)
+    rows = np.sort(rng.choice(len(X), 30_000, replace=False))
+    od, _ = orc.knn_brute(X[rows], Y, kmax)
+    assert np.allclose(dist[rows], od, rtol=DIST_RTOL, atol=0)
+    assert np.allclose(orc.dotp_literal(dist[rows], w[rows], fs[rows], X.shape[1], 0, kmax), orc.dotp_literal(od, w[rows], fs[rows], X.shape[1], 0, kmax), rtol=1e-11, atol=0)
+
+
+def test_auto_evidence_reduction_at_full_size_C5():
+    """BASELINE configs[4]: 10M x 6, K = 9 through the automatic path (k-d pruned walk).  The fused sums over ALL rows
+    equal the sums formed on the host from the distances the same call returns; on 6000 sampled rows those distances
+    -- hence those rows' partial sums -- are checked against the exact CPU search (200 000 rows, 18 minutes of the
+    oracle: done once, round 3, same result)."""
+    from mcevidence_amd import _capi
+    _capi.set_prune_mode(_capi.PRUNE_AUTO); _capi.set_sym_mode(_capi.SYM_AUTO); _capi.set_search_mode(_capi.MODE_AUTO)
+    rng = np.random.default_rng(56)
+    n, d, kmax = 10_000_000, 6, 10
+    X = rng.standard_normal((n, d)) @ (np.eye(d) + 0.3 * rng.standard_normal((d, d)))
+    ev, U = np.linalg.eigh(np.cov(X.T))
+    X = np.ascontiguousarray((X @ U) / np.sqrt(ev))
+    w = rng.integers(1, 6, n).astype(np.float64)
+    fs = -0.5 * (X ** 2).sum(axis=1)
+    fs -= fs.max()
+    dotp, dist = _capi.knn_dotp(X, None, w, fs, kmax, 1, return_dist=True)
+    assert "pruned" in _capi.last_kernel()
+    full = np.zeros((n, kmax)); full[:, 1:] = dist
+    assert np.allclose(dotp[1:], orc.dotp_literal(full, w, fs, d, 1, kmax)[1:], rtol=1e-11, atol=0)
+    rows = np.sort(rng.choice(n, 6000, replace=False))
+    od, _ = orc.knn_brute(X[rows], X, kmax)                # column 0: the row itself
+    assert np.allclose(dist[rows], od[:, 1:], rtol=DIST_RTOL, atol=0)
+    fo = np.zeros((len(rows), kmax)); fo[:, 1:] = od[:, 1:]
+    assert np.allclose(orc.dotp_literal(full[rows], w[rows], fs[rows], d, 1, kmax)[1:], orc.dotp_literal(fo, w[rows], fs[rows], d, 1, kmax)[1:], rtol=1e-11, atol=0)
