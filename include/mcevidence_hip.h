@@ -192,7 +192,9 @@ typedef struct mce_options {
     int32_t search_mode;   /* as mce_set_search_mode */
     int32_t prune_mode;    /* as mce_set_prune_mode  */
     int32_t sym_mode;      /* as mce_set_sym_mode    */
-    int32_t reserved[4];   /* 0 */
+    int32_t same_set;      /* workspace queries: 1 = X and Y will be ONE buffer (auto evidence), 0 = they will not (no scratch
+                              for the symmetric sweep is reserved: ~1.7 GB at 1 M rows, K = 9), -1 = unknown (reserved) */
+    int32_t reserved[3];   /* 0 */
 } mce_options;
 int mce_options_push(const mce_options* opt);
 int mce_options_pop(void);

@@ -182,10 +182,10 @@ def last_kernel_ms():
 class Options(_c.Structure):
     """``mce_options``: the search / prune / symmetric modes of ONE call (-1: the process default)."""
     _fields_ = [("size", _c.c_int32), ("search_mode", _c.c_int32), ("prune_mode", _c.c_int32), ("sym_mode", _c.c_int32),
-                ("reserved", _c.c_int32 * 4)]
+                ("same_set", _c.c_int32), ("reserved", _c.c_int32 * 3)]
 
-    def __init__(self, search_mode=-1, prune_mode=-1, sym_mode=-1):
-        super().__init__(_c.sizeof(Options), int(search_mode), int(prune_mode), int(sym_mode))
+    def __init__(self, search_mode=-1, prune_mode=-1, sym_mode=-1, same_set=-1):
+        super().__init__(_c.sizeof(Options), int(search_mode), int(prune_mode), int(sym_mode), int(same_set))
 
 
 class options(object):
@@ -430,8 +430,13 @@ def evidence_feed_batch(problems, devices=None, return_exceptions=False):
 # ---------------------------------------------------------------------------
 # device-pointer wrappers (raw addresses: torch tensors' data_ptr(), stream handle)
 # ---------------------------------------------------------------------------
-def knn_workspace_bytes(nq, nr, d, K):
-    n = int(load().mce_knn_workspace_bytes(int(nq), int(nr), int(d), int(K)))
+def knn_workspace_bytes(nq, nr, d, K, options=None):
+    """Scratch bytes a *_dev search needs.  ``options=Options(same_set=0)``: queries and references will be two buffers
+    (cross evidence with equal halves): no scratch for the symmetric sweep is reserved."""
+    if options is None:
+        n = int(load().mce_knn_workspace_bytes(int(nq), int(nr), int(d), int(K)))
+    else:
+        n = int(load().mce_knn_workspace_bytes_opt(int(nq), int(nr), int(d), int(K), _c.addressof(options)))
     if n == 0:
         raise ValueError(last_error())
     return n

@@ -98,7 +98,7 @@ int sym_spin_limit()
 // Per-call options (mce_options, include/mcevidence_hip.h): the *_opt entry points and mce_options_push / _pop set them for
 // the calls the CURRENT THREAD makes; -1 = the process-wide default of the setters above.  Threads the library starts
 // itself (one per device) inherit the caller's.  The planner reads the modes through these three functions only.
-struct CallOptions { int search = -1, prune = -1, sym = -1; };
+struct CallOptions { int search = -1, prune = -1, sym = -1, same_set = -1; };
 thread_local CallOptions t_opt;
 thread_local std::vector<CallOptions> t_opt_stack;
 int eff_search_mode() { return t_opt.search >= 0 ? t_opt.search : g_mode.load(); }
@@ -444,6 +444,12 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     }
     if (p.prune) best_r = 1;                  // every workgroup walks its own chunk list
     p.rsplit = best_r;
+    {   // the model's cost of the split count actually taken (the overrides above may have left its minimum)
+        const double n_r = (double)nr / best_r;
+        const double lnf = 1.0 + std::log(std::max(1.0, n_r / K));
+        const double block = f16 ? 64.0 * p.QT * p.KST * (n_r / 32.0) + 300.0 * 32.0 * p.QT * K * lnf : 256.0 * p.KS * (n_r / 16.0) + 1000.0 * 32.0 * K * lnf;
+        best_c = std::ceil((double)p.nqblk * best_r / kAssumedCUs) * block;
+    }
     p.cost = best_c;
     p.L = p.twopass ? 2 * p.rsplit : p.rsplit;
 
@@ -465,7 +471,9 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     if (f16 && !p.twopass && !p.prune && nq == nr && p.vh->launch_sym && p.nqblk >= 2 && p.nrow_pad <= ((int64_t)1 << mce::kHSymRowBits)) {
         const int sm = eff_sym_mode();
         p.sym = sm == 2 || (sm == 0 && p.nqblk >= kSymAutoMinBlocks[p.KST] * ((p.KST == 1 && p.KCAP == 16) ? 2 : 1));     // (1M x 15, K = 16: 62.3 vs 62.7 ms)
-        if (g_same_set_hint == 0) p.sym = false;
+        // the symmetric sweep needs queries and references to be ONE buffer: known from the pointers (host entry points, and
+        // the *_dev ones at call time) or said by the caller of a workspace query (mce_options.same_set); unknown: reserve
+        if (g_same_set_hint == 0 || (g_same_set_hint < 0 && t_opt.same_set == 0)) p.sym = false;
     }
     const int l_alloc = p.L;
     p.off_pd = off;
@@ -887,6 +895,7 @@ int mce_options_push(const mce_options* opt)
     if (opt->search_mode >= 0) t_opt.search = opt->search_mode;
     if (opt->prune_mode >= 0) t_opt.prune = opt->prune_mode;
     if (opt->sym_mode >= 0) t_opt.sym = opt->sym_mode;
+    if (opt->same_set >= 0) t_opt.same_set = opt->same_set ? 1 : 0;
     return MCE_OK;
 }
 
@@ -1011,8 +1020,14 @@ int mce_knn_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t nr, 
 {
     if (!dX || !dY || !d_dist || !ws) return fail(MCE_ERR_INVALID, "null pointer argument");
     Plan p;
+    SameSetHint hint(dX == dY && nq == nr && self_offset == 0);
     int rc = make_plan(nq, nr, d, K, self_mode, p);
     if (rc != MCE_OK) return rc;
+    if (ws_bytes < p.total && p.sym) {          // a workspace sized with same_set = 0: the exhaustive plan fits it
+        g_same_set_hint = 0;
+        rc = make_plan(nq, nr, d, K, self_mode, p);
+        if (rc != MCE_OK) return rc;
+    }
     if (ws_bytes < p.total) return fail(MCE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, p.total);
     if (nq == 0) return MCE_OK;
     if (const int64_t nm = tail_split_rows(p, nq, nr, d, K, self_mode, ws_bytes, dX == dY && self_offset == 0)) {
@@ -1078,8 +1093,14 @@ int mce_knn_dotp_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t
     const int K = kmax - k0;
     const int self_mode = k0 == 1 ? MCE_SELF_EXCLUDE : MCE_SELF_NONE;
     Plan p;
+    SameSetHint hint(dX == dY && nq == nr && self_offset == 0);
     int rc = make_plan(nq, nr, d, K, self_mode, p);
     if (rc != MCE_OK) return rc;
+    if (ws_bytes < p.total + dotp_ws_bytes(nq, kmax) && p.sym) {          // a workspace sized with same_set = 0: the exhaustive plan fits it
+        g_same_set_hint = 0;
+        rc = make_plan(nq, nr, d, K, self_mode, p);
+        if (rc != MCE_OK) return rc;
+    }
     const size_t need = p.total + dotp_ws_bytes(nq, kmax);
     if (ws_bytes < need) return fail(MCE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -127,3 +127,19 @@ def test_symmetric_sweep_unit_enumeration(tmp_path):
                            os.path.join(REPO, "tests", "native", "sym_units_check.cpp"), "-o", exe])
     out = subprocess.check_output([exe]).decode()
     assert out.startswith("ok ")
+
+
+def test_workspace_query_with_the_same_set_hint():
+    """mce_knn_workspace_bytes_opt: a caller who knows that queries and references are two buffers (cross evidence with
+    equal halves) says so and is not charged the symmetric sweep's scratch (~1.7 GB at 1M rows, K = 9); sizes only, no
+    device needed."""
+    from mcevidence_amd import _capi
+    n, d, K = 1_000_000, 27, 9
+    unknown = _capi.knn_workspace_bytes(n, n, d, K)
+    same = _capi.knn_workspace_bytes(n, n, d, K, options=_capi.Options(same_set=1))
+    apart = _capi.knn_workspace_bytes(n, n, d, K, options=_capi.Options(same_set=0))
+    assert unknown == same and apart < same - 1_000_000_000
+    never = _capi.knn_workspace_bytes(n, n, d, K, options=_capi.Options(sym_mode=_capi.SYM_OFF))
+    assert never == apart
+    with pytest.raises(ValueError):
+        _capi.knn_workspace_bytes(n, n, d, K, options=_capi.Options(prune_mode=5))
