@@ -225,9 +225,9 @@ int mce_get_prune_mode(void);
  * the rows are sorted by distance from the mean, a prepass bounds every row's K-th distance, every block of
  * 512 rows sweeps only the blocks before it, and each tile is gated for the streamed rows
  * too; their candidates are merged into the lists afterwards.  Same neighbours, distances and tie-breaks as
- * the exhaustive search.  0 (default): where it was measured faster and pruning does not apply -- from 1024 blocks of
- * 512 rows (524 k rows; 1 M with K > 12) where the filter takes one 16-wide k-step (d <= 14), from 257 blocks (131 k rows)
- * where it takes two or more (capi.hip: kSymAutoMinBlocks);
+ * the exhaustive search.  0 (default): where it was measured faster and pruning does not apply -- from 768 blocks of
+ * 512 rows (393 k rows; twice that with K > 12) where the filter takes one 16-wide k-step (d <= 14), from 257 blocks
+ * (131 k rows) with two (d <= 30), from 193 (99 k rows) beyond (capi.hip: kSymAutoMinBlocks);
  * 1: never; 2: whenever the shape allows it (fp16-filter shapes with K <= 16, more than 512 rows).
  * Process-wide default (per call: mce_options); the environment variable MCE_SYM sets the initial value.
  * Multi-GPU: mce_knn_dotp_part_f64 partitions such a search by ranges of the sorted blocks (symmetric within a rank's

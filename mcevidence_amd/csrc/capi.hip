@@ -104,16 +104,17 @@ thread_local std::vector<CallOptions> t_opt_stack;
 int eff_search_mode() { return t_opt.search >= 0 ? t_opt.search : g_mode.load(); }
 int eff_prune_mode() { return t_opt.prune >= 0 ? t_opt.prune : g_prune_mode.load(); }
 int eff_sym_mode() { return t_opt.sym >= 0 ? t_opt.sym : sym_mode(); }
-// query blocks (512 rows each) from which the automatic mode takes it, by 16-wide k-steps of the filter.  Measured
-// (tools/sym_crossover.py -> profiles/r02_symmetric/crossover.json; fused search + reduction, exhaustive -> symmetric, ms).
-// Up to 256 blocks -- one round of workgroups -- the seeded exhaustive sweep with its reference splits is as fast or
-// faster (d = 27: 0.49 vs 0.78 at 16 k rows, 1.01 vs 1.53 at 65 k, 2.0 vs 2.5 at 131 k; d = 45: 2.6 vs 2.6 at 131 k); past
-// that the symmetric sweep wins at once where the filter takes two k-steps or more (d = 27: 3.05 -> 2.86 at 147 k, 4.1 -> 3.4
-// at 197 k, 19.1 -> 14.5 at 524 k, 65.0 -> 42.8 at 1 M, 232 -> 148 at 2 M; d = 45: 3.7 -> 3.1 at 147 k, 27.1 -> 16.6 at 524 k,
-// 94.3 -> 52.0 at 1 M) and from ~0.5 M rows with one k-step (d = 15 / 10 / 6: 7.0 -> 6.9 / 6.9 -> 7.1 / 6.9 -> 8.3 at 393 k,
-// 11.7 -> 11.2 / 11.5 -> 11.3 / 11.5 -> 12.4 at 524 k, 39.9 -> 32.9 / 39.1 -> 33.3 / 38.7 -> 35.3 at 1 M; d <= 8: the pruned walk
-// takes over before that).  The more of a search is MFMA work, the more halving the products pays.
-constexpr int kSymAutoMinBlocks[5] = {0, 1024, 257, 257, 257};
+// query blocks (512 rows each) from which the automatic mode takes it, by 16-wide k-steps of the filter.  Measured with the
+// panel kernel (tools/sym_crossover.py -> profiles/r03_panel/crossover.json; fused search + reduction, exhaustive -> symmetric,
+// ms).  Up to ~256 blocks -- one round of workgroups -- the seeded exhaustive sweep with its reference splits is faster
+// (d = 27: 0.68 vs 0.96 at 32 k rows, 1.03 vs 1.36 at 65 k, 2.03 vs 2.20 at 131 k); past that the symmetric sweep wins at once
+// where the filter takes two k-steps or more (d = 27: 4.2 -> 3.0 at 197 k, 6.0 -> 4.2 at 262 k, 19.8 -> 12.8 at 524 k,
+// 66.2 -> 38.3 at 1 M; d = 45: 2.06 -> 2.02 at 98 k, 2.70 -> 2.52 at 131 k, 5.7 -> 3.6 at 197 k, 96.2 -> 50.4 at 1 M) and from
+// ~0.4 M rows with one k-step (d = 15 / 10 / 6: 3.56 -> 3.44 / 3.53 -> 3.79 / 3.48 -> 4.48 at 262 k, 7.1 -> 6.1 / 7.0 -> 6.2 /
+// 7.0 -> 7.4 at 393 k, 11.9 -> 9.7 / 11.6 -> 9.9 / 11.5 -> 11.1 at 524 k, 40.6 -> 28.0 / 39.5 -> 28.5 / 39.0 -> 30.7 at 1 M;
+// d <= 6 from 300 k rows: the pruned walk takes over before that).  The more of a search is MFMA work, the more halving the
+// products pays.
+constexpr int kSymAutoMinBlocks[5] = {0, 768, 257, 193, 193};
 // prepass rows by k-steps: 0 spread over the sorted rows, 1 the rows nearest the mean, 2 half and half.  Fused call, ms,
 // spread / nearest / half: 1M x 3 42.6 / 152.6 / 45.2; 1M x 6 36.1 / 50.1 / 37.1; 1M x 10 34.4 / 36.8 / 34.8; 1M x 15
 // 33.8 / 33.4 / 33.2; 1M x 20 50.2 / 45.9 / 46.8; 1M x 27 48.8 / 44.4 / 45.5 (tools/sym_seedmode.py)

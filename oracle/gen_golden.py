@@ -179,8 +179,9 @@ BIG_CASES = [
 ]
 
 
-# medium sizes at which the symmetric sweep is the automatic choice: from 131 k rows at two 16-wide
-# k-steps (d = 16..31), from 65 k at three (d = 32..47)
+# medium sizes around the symmetric sweep's automatic range (capi.hip: kSymAutoMinBlocks -- from 257 blocks of 512 rows at
+# two 16-wide k-steps, d = 16..30; from 193 blocks beyond): 135 k x 27 and 140 k x 20 are inside it, 70 k x 45 (137 blocks)
+# is below it and takes the exhaustive sweep unless the symmetric one is forced -- the tests run it both ways
 SYM_CASES = [
     ("auto_n135000_d27_k10_corr", dict(seed=21, n=135_000, d=27, cov="corr"), dict(kmax=10), {}, None),
     ("auto_n70000_d45_k6", dict(seed=22, n=70_000, d=45), dict(kmax=6), {}, None),
