@@ -68,6 +68,56 @@ int fail(int code, const char* fmt, ...)
 std::atomic<int> g_mode{0};
 // spatial pruning (prune.hpp): 0 auto (low d, large reference sets), 1 never, 2 whenever the shape allows it
 std::atomic<int> g_prune_mode{0};
+// ---------------------------------------------------------------------------------------------------------------------
+// Tuning and test knobs.  This is the ONE place where the library reads the environment; every knob is result-neutral
+// (the tests run the same searches under different settings and compare bit for bit) and exists for tests, bisecting and
+// tuning -- production callers set none of them.  Read at every call (a dozen getenv per search), so tests can change
+// them between calls; the workspace LAYOUT depends on sym / sym_bucket / rsplit / the seed knobs, which must therefore not
+// change between a workspace query and the call that uses the workspace.
+//   MCE_SYM=0|1|2                initial value of mce_set_sym_mode (read once)
+//   MCE_SYM_KERNEL=f16           the symmetric sweep on knn_f16_kernel<.., SYM = 2> (round 2) instead of knn_panel_kernel
+//   MCE_SYM_SPIN_LIMIT=n         ~microseconds a unit waits for its block's previous unit before it gives up (2^21)
+//   MCE_SYM_BUCKET=n             row-side candidates per row the buckets hold (6K + 24)
+//   MCE_SYM_PANEL=n              chunks per panel of reference rows (256; 96 with one k-step)
+//   MCE_SYM_SEED_ROWS / _SHARE / _MODE   prepass: rows (32768; 65536), at most 1/share of the chunks (2), where (by k-steps)
+//   MCE_F16_SEED_ROWS / _SHARE / _TG     seed phase of the exhaustive sweep: rows (24576), share (4), tiles per group (8)
+//   MCE_RSPLIT=n                 reference splits of the exhaustive sweep (the model's choice)
+//   MCE_TAIL_SPLIT=0             keep a search with a nearly empty last round of workgroups in one launch
+//   MCE_PANEL_DEBUG=bits         knn_panel.hpp bisecting aids (8: every candidate through the redo list)
+//   MCE_PANEL_NOSYM=1            the panel kernel with every tile column side only (bisecting)
+//   MCE_FEED_WAVE_BYTES=n        batched feed: bytes of host data per upload wave (tests: force several waves)
+//   MCE_FEED_UPLOAD=async        batched feed: uploads on the job's stream (read once)
+//   MCE_PRUNE_PROF=1             print the pruned walk's per-wave cycle breakdown (builds with -DMCE_PRUNE_PROF)
+// ---------------------------------------------------------------------------------------------------------------------
+struct Tuning {
+    bool sym_kernel_f16 = false, tail_split = true, panel_nosym = false, prune_prof = false;
+    int spin_limit = 1 << 21, sym_bucket = 0, sym_panel = 0, sym_seed_rows = 0, sym_seed_share = 2, sym_seed_mode = -1;
+    int f16_seed_rows = -1, f16_seed_share = -1, f16_seed_tg = -1, rsplit = 0, panel_debug = 0;
+    size_t feed_wave_bytes = 0;
+};
+Tuning read_tuning()
+{
+    Tuning t;
+    auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    const char* e = getenv("MCE_SYM_KERNEL");
+    t.sym_kernel_f16 = e && strcmp(e, "f16") == 0;
+    t.spin_limit = num("MCE_SYM_SPIN_LIMIT", 1 << 21);
+    t.sym_bucket = num("MCE_SYM_BUCKET", 0);
+    t.sym_panel = num("MCE_SYM_PANEL", 0);
+    t.sym_seed_rows = num("MCE_SYM_SEED_ROWS", 0);
+    t.sym_seed_share = num("MCE_SYM_SEED_SHARE", 2);
+    t.sym_seed_mode = num("MCE_SYM_SEED_MODE", -1);
+    t.f16_seed_rows = num("MCE_F16_SEED_ROWS", -1);
+    t.f16_seed_share = num("MCE_F16_SEED_SHARE", -1);
+    t.f16_seed_tg = num("MCE_F16_SEED_TG", -1);
+    t.rsplit = num("MCE_RSPLIT", 0);
+    t.tail_split = num("MCE_TAIL_SPLIT", 1) != 0;
+    t.panel_debug = num("MCE_PANEL_DEBUG", 0);
+    t.panel_nosym = getenv("MCE_PANEL_NOSYM") != nullptr;
+    t.prune_prof = getenv("MCE_PRUNE_PROF") != nullptr;
+    if ((e = getenv("MCE_FEED_WAVE_BYTES"))) t.feed_wave_bytes = (size_t)std::strtoull(e, nullptr, 10);
+    return t;
+}
 // symmetric sweep of an auto-evidence search (knn_f16.hpp): 0 auto (large sets), 1 never, 2 whenever the shape allows it.
 // MCE_SYM in the environment sets the initial value.
 std::atomic<int> g_sym_mode{-1};
@@ -85,16 +135,8 @@ int sym_mode()
 // which kernel sweeps: knn_panel_kernel (default) or the SYM = 2 instantiation of knn_f16_kernel (MCE_SYM_KERNEL=f16: kept
 // for comparisons).  A unit of the panel kernel waits for its block's previous unit at most this many ~1 us sleeps
 // (MCE_SYM_SPIN_LIMIT; 0 in the tests: every wait that is not already satisfied gives up, and the repair launch takes over)
-bool sym_use_panel_kernel()
-{
-    const char* e = getenv("MCE_SYM_KERNEL");
-    return !(e && strcmp(e, "f16") == 0);
-}
-int sym_spin_limit()
-{
-    const char* e = getenv("MCE_SYM_SPIN_LIMIT");
-    return e ? atoi(e) : (1 << 21);
-}
+bool sym_use_panel_kernel() { return !read_tuning().sym_kernel_f16; }
+int sym_spin_limit() { return read_tuning().spin_limit; }
 // Per-call options (mce_options, include/mcevidence_hip.h): the *_opt entry points and mce_options_push / _pop set them for
 // the calls the CURRENT THREAD makes; -1 = the process-wide default of the setters above.  Threads the library starts
 // itself (one per device) inherit the caller's.  The planner reads the modes through these three functions only.
@@ -136,9 +178,8 @@ constexpr int kSymPanelChunks[5] = {0, 96, 256, 256, 256};
 // bucket entries per row: a row receives ~K ln(N/2 / seed rows) + K row-side candidates; MCE_SYM_BUCKET overrides (tests)
 int sym_bucket_per_row(int K)
 {
-    const char* e = getenv("MCE_SYM_BUCKET");
-    if (e && atoi(e) > 0) return atoi(e);
-    return 6 * K + 24;
+    const int b = read_tuning().sym_bucket;
+    return b > 0 ? b : 6 * K + 24;
 }
 // measured on MI355X (tools/prune_sweep.sh, tools/prune_sweep_small.sh; search + preparation, K = 10):
 //   d = 1: 0.3 M 3.3 vs 54 ms, 1 M 6.8 vs 474 ms      d = 2: 0.3 M 2.9 vs 11.8 ms
@@ -308,12 +349,10 @@ const mce::KnnVariant* variant_for(int KS, int kcap_idx)
 // 1.93; 197 k x 27: 5.35 -> 4.10; from ~400 k rows the row budget binds as before.
 int sweep_seed_cfg(int64_t cps, int CT, int kneed)
 {
-    const char* const e_rows = getenv("MCE_F16_SEED_ROWS");
-    const char* const e_share = getenv("MCE_F16_SEED_SHARE");
-    const char* const e_tg = getenv("MCE_F16_SEED_TG");
-    if (e_rows || e_share || e_tg)
-        return mce::f16_seed_cfg(cps, CT, kneed, e_rows ? atoi(e_rows) : MCE_H_SEED_ROWS, e_share ? atoi(e_share) : MCE_H_SEED_SHARE,
-                                 e_tg ? atoi(e_tg) : MCE_H_SEED_TG);
+    const Tuning t = read_tuning();
+    if (t.f16_seed_rows >= 0 || t.f16_seed_share >= 0 || t.f16_seed_tg >= 0)
+        return mce::f16_seed_cfg(cps, CT, kneed, t.f16_seed_rows >= 0 ? t.f16_seed_rows : MCE_H_SEED_ROWS, t.f16_seed_share >= 0 ? t.f16_seed_share : MCE_H_SEED_SHARE,
+                                 t.f16_seed_tg >= 0 ? t.f16_seed_tg : MCE_H_SEED_TG);
     for (int share = MCE_H_SEED_SHARE; share >= 2; share /= 2)
         for (int tg = MCE_H_SEED_TG; tg >= 2; tg /= 2)
             if (const int cfg = mce::f16_seed_cfg(cps, CT, kneed, MCE_H_SEED_ROWS, share, tg)) return cfg;
@@ -439,8 +478,7 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
         for (int r = std::min(rmax, kAssumedCUs / p.nqblk); r >= std::max(1, rmin); --r)
             if (sweep_seed_cfg(p.nchunk / r, p.CT, kneed)) { best_r = r; break; }
     }
-    if (const char* e = getenv("MCE_RSPLIT")) {          // tuning
-        const int r = atoi(e);
+    if (const int r = read_tuning().rsplit) {          // tuning
         if (r >= std::max(1, rmin) && r <= rmax) best_r = r;
     }
     if (p.prune) best_r = 1;                  // every workgroup walks its own chunk list
@@ -650,23 +688,20 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             a.sym.cap = p.sl.cap;
             a.sym.done = reinterpret_cast<int*>(sw + p.sl.done);
             // panel = the packed rows one L2 (4 MB per XCD) serves to the units running at the same time; MCE_SYM_PANEL: chunks (tuning)
-            const char* const e_panel = getenv("MCE_SYM_PANEL");
-            a.sym.panel = e_panel && atoi(e_panel) > 0 ? atoi(e_panel) : kSymPanelChunks[p.KST];
+            const Tuning tun = read_tuning();
+            a.sym.panel = tun.sym_panel > 0 ? tun.sym_panel : kSymPanelChunks[p.KST];
             // prepass: every row's bound before any block runs (the seed phase as its own launch)
-            const char* const e_rows = getenv("MCE_SYM_SEED_ROWS");
-            const char* const e_share = getenv("MCE_SYM_SEED_SHARE");
             // about 32 k rows (one k-step: 64 k), at most half of the chunks (tools/_tmp-style scans, fused call, share 8 -> 2:
             // 49 k x 27 1.51 -> 1.32 ms, 98 k 2.18 -> 2.03, 131 k 2.58 -> 2.47, from 197 k rows the same; 393 k x 15 7.04 -> 6.88)
-            const int seed_rows = e_rows ? atoi(e_rows) : (p.KST == 1 ? 65536 : 32768);
-            const int seed_share = e_share ? atoi(e_share) : 2;
+            const int seed_rows = tun.sym_seed_rows > 0 ? tun.sym_seed_rows : (p.KST == 1 ? 65536 : 32768);
+            const int seed_share = tun.sym_seed_share;
             a.seed_cfg = mce::f16_seed_cfg(p.nchunk, p.CT, K + a.self_exclude, seed_rows, seed_share, MCE_H_SEED_TG);
             // tiny sets (forced mode): smaller groups, so that half of the chunks still hold twice the K groups a bound needs --
             // without any bound every pair would go through the row side (20 k x 27: 10.8 ms instead of 0.8)
             for (int tg = MCE_H_SEED_TG / 2; a.seed_cfg == 0 && tg >= 1; tg /= 2)
                 a.seed_cfg = mce::f16_seed_cfg(p.nchunk, p.CT, K + a.self_exclude, seed_rows, seed_share, tg);
             if (a.seed_cfg) {
-                const char* const e_mode = getenv("MCE_SYM_SEED_MODE");
-                a.seed_cfg |= ((e_mode ? atoi(e_mode) : kSymSeedMode[p.KST]) & 3) << 28;
+                a.seed_cfg |= ((tun.sym_seed_mode >= 0 ? tun.sym_seed_mode : kSymSeedMode[p.KST]) & 3) << 28;
             }
             // One rank's share of a multi-GPU partition: the contiguous range of sorted blocks [qb_lo, qb_hi).  Their tiles
             // carry the row-side gate; everybody else's rows are swept column side only (sym_types.hpp, PanelGeom) -- no
@@ -684,16 +719,16 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             a.seed_cfg = 0;
             int rc = prof_begin();             // (the bracket of mce_last_kernel_ms(): the dominant kernel, as for the other searches)
             if (rc != MCE_OK) return rc;
-            const bool panel_kernel = sym_use_panel_kernel() || p.nparts > 1;
+            const bool panel_kernel = !tun.sym_kernel_f16 || p.nparts > 1;
             if (panel_kernel) {
                 mce::PanelArgs pa;
                 pa.Yh = yh; pa.Xh = xh; pa.qinfo = qinfo; pa.params = params; pa.X = sX; pa.Y = sY; pa.rperm = a.rperm;
                 pa.part_d = pd; pa.part_i = pi; pa.nq = nq; pa.nr = nr; pa.nq_pad = p.nq_pad; pa.self_offset = 0;
-                pa.D = d; pa.ksel = K; pa.self_exclude = a.self_exclude; pa.spin_limit = sym_spin_limit();
+                pa.D = d; pa.ksel = K; pa.self_exclude = a.self_exclude; pa.spin_limit = tun.spin_limit;
                 pa.sym = a.sym;
-                pa.debug = getenv("MCE_PANEL_DEBUG") ? atoi(getenv("MCE_PANEL_DEBUG")) : 0;
+                pa.debug = tun.panel_debug;
                 pa.geom.qb_lo = qb_lo; pa.geom.qb_hi = qb_hi; pa.geom.tpb = mce::kHWaves * mce::kHQT; pa.geom.ct = p.CT;
-                pa.geom.tpp = a.sym.panel * p.CT; pa.geom.sym_on = getenv("MCE_PANEL_NOSYM") ? 0 : 1;      // (debugging: every block sweeps every tile, column side only)
+                pa.geom.tpp = a.sym.panel * p.CT; pa.geom.sym_on = tun.panel_nosym ? 0 : 1;      // (debugging: every block sweeps every tile, column side only)
                 pa.geom.ntiles = (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1);
                 MCE_HIP(p.vh->launch_panel(pa, st));
             } else {
@@ -918,7 +953,7 @@ int mce_last_prune_stats(double* chunk_fraction, double* tile_fraction)
     const double pairs = g_last_prune_geom[0] * g_last_prune_geom[1];
     *chunk_fraction = hp[mce::HP_STAT_CHUNKS] / pairs;
     *tile_fraction = hp[mce::HP_STAT_TILES] / (pairs * mce::kHWaves * g_last_prune_geom[2]);
-    if (std::getenv("MCE_PRUNE_PROF")) {
+    if (read_tuning().prune_prof) {
         const double nw = g_last_prune_geom[0] * mce::kHWaves;
         fprintf(stderr, "[prune prof] per wave (cycles@100MHz): walk %.0f stage %.0f mul %.0f drain %.0f total %.0f  candidates drained %.0f | tiles with enqueue %.0f (process %.0f cyc each), without: process total %.0f\n", hp[8] / nw, hp[9] / nw, hp[10] / nw, hp[11] / nw, hp[12] / nw, hp[13] / nw, hp[14] / nw, hp[15] / std::max(1.0, hp[14]), hp[7] / nw);
     }
@@ -993,8 +1028,7 @@ int64_t tail_split_rows(const Plan& p, int64_t nq, int64_t nr, int32_t d, int32_
 {
     if (g_split_depth > 0 || !p.vh || p.prune || p.generic || p.rsplit != 1 || p.nqblk <= kAssumedCUs) return 0;
     if (p.sym && same_set) return 0;          // symmetric sweep: one launch over the whole set
-    const char* const off = getenv("MCE_TAIL_SPLIT");
-    if (off && atoi(off) == 0) return 0;
+    if (!read_tuning().tail_split) return 0;
     const int tail = p.nqblk % kAssumedCUs;
     if (tail == 0 || 2 * tail > kAssumedCUs) return 0;
     const int64_t nq_main = (int64_t)(p.nqblk - tail) * mce::f16_qpb(p.KCAP);
@@ -1652,7 +1686,7 @@ int feed_run_on_device(int device, std::vector<FeedJob*>& jobs)
         }
     }
     size_t wave_bytes = kWaveBytes;
-    if (const char* e = std::getenv("MCE_FEED_WAVE_BYTES")) wave_bytes = (size_t)std::strtoull(e, nullptr, 10);   // tests: force several waves
+    if (const size_t wb = read_tuning().feed_wave_bytes) wave_bytes = wb;   // tests: force several waves
     size_t lo = 0;
     while (lo < jobs.size()) {
         size_t hi = lo, dev_bytes = 0, host_bytes = 0;
