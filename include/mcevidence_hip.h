@@ -85,9 +85,12 @@ int mce_dotp_f64(const double *dist, int64_t nq, int32_t ld, int32_t k0, int32_t
  * set X was cut from; self excluded by index), k0 = 0 -> cross evidence.
  * dotp[kmax] as above.  dist_out (optional, may be NULL) receives the
  * [nq, kmax-k0] neighbour distances that entered the sum (columns k0..kmax-1 of
- * the reference's DkNN).  The query rows are split evenly over `ndev` devices
- * (devices[i] = HIP ordinal; NULL/0 -> device 0 only); partial sums are added on
- * the host in device order. */
+ * the reference's DkNN).  With ndev > 1 (devices[i] = HIP ordinal; NULL/0 -> device 0 only) the work is split over the
+ * devices -- auto evidence of one set: the library's partition (mce_knn_dotp_part_f64), otherwise equal ranges of the
+ * query rows -- by one host thread per device, and the partial sums are added ON THE HOST in device order (bitwise
+ * reproducible whatever the device count; SURVEY.md 8e's "alternatively").  The library itself has no RCCL dependency:
+ * the one collective of a multi-PROCESS run -- an all-reduce of kmax doubles -- is the caller's
+ * (mcevidence_amd/parallel.py: torch.distributed over RCCL), on the partial sums mce_knn_dotp_part_f64 returns. */
 int mce_knn_dotp_f64(const double *X, int64_t nq, const double *Y, int64_t nr, int32_t d, int32_t kmax,
                      int32_t k0, int64_t self_offset, const double *w, const double *fs, double *dotp,
                      double *dist_out, const int32_t *devices, int32_t ndev);
