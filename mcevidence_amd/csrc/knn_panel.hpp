@@ -36,7 +36,8 @@ struct PanelArgs {
     int* part_i;
     int64_t nq, nr, nq_pad, self_offset;
     int D, ksel, self_exclude, spin_limit;
-    int debug;                   // bisecting aid (MCE_PANEL_DEBUG): 1 no bound taken back from the row side, 2 no chain filter, 4 no row gate
+    int debug;                   // bisecting / test aids (MCE_PANEL_DEBUG): 1 no bound taken back from the row side, 2 no chain filter, 4 no row gate,
+                                 // 8 every candidate through the redo list, 16 the odd waves of every block's second unit give up waiting at once
     SymParams sym;               // .done, .panel always; the row-side state only with geom.sym_on
     PanelGeom geom;
 };
@@ -168,20 +169,31 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
     // A block's lists travel from one of its units to the next through the list arrays.  Units are dispatched in number
     // order, panel by panel, so the previous unit of this block started a whole panel's worth of units ago and the wait
     // practically never spins.  It is BOUNDED all the same: in-order dispatch is an observation, not a guarantee (several
-    // searches on different streams share the chip).  A unit that gives up starts from empty lists and flags its block:
-    // the repair launch then searches that block again exhaustively -- the result never depends on the wait.
+    // searches on different streams share the chip).  A wave that gives up starts from empty lists and flags its block:
+    // the repair launch then searches that block again exhaustively -- the result never depends on the wait.  (The eight
+    // waves of a unit wait independently; under load some give up and others do not -- found with
+    // tools/stress_concurrent.py at a 50 us limit: whole waves of 64 queries with incomplete lists in a block only wave 0
+    // would have flagged.)
     {
         const ArgsPtr a = MCE_ARGS();
         if (useq > 0) {
             int spins = 0;
-            const int limit = a->spin_limit;
+            // (debug 16, tests: in every block's second unit the ODD waves give up at once -- the waves of a workgroup wait
+            //  independently, so a give-up can be any subset of them)
+            const int limit = ((a->debug & 16) && useq == 1 && (wave & 1)) ? -1 : a->spin_limit;
             bool ok = true;
             const auto done = gptr(a->sym.done);
-            while (__hip_atomic_load(done + qblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < useq) {
+            while (spins > limit || __hip_atomic_load(done + qblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < useq) {
                 if (++spins > limit) { ok = false; break; }
                 __builtin_amdgcn_s_sleep(32);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // A block in which some unit has given up is being searched by units that no longer run one after the other:
+            // two of them may write the lists at the same time, and what a later unit would load can hold the same row
+            // twice -- a K-th entry BELOW the true K-th distance, which would be published as a bound (and the repair launch
+            // starts from the published bounds).  Such a block is flagged already (the flag is set before the sweep of the
+            // unit that gave up, and this unit has seen all its predecessors finish): its units start from empty lists.
+            if (ok && gptr(a->sym.bucket_flag)[qblk] != 0) ok = false;
             if (ok) {
                 const int64_t q = qwave0 + lane;
                 const int64_t np = a->nq_pad;
@@ -192,7 +204,8 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
                     own_d[k] = pd[(int64_t)k * np + q];
                     own_i[k] = pi[(int64_t)k * np + q];
                 }
-            } else if (tid == 0) {
+            } else if (lane == 0) {
+                // (every WAVE waits on its own and may be the only one of its workgroup to give up: each flags the block)
                 gptr_w(a->sym.bucket_flag)[qblk] = 1;
             }
         }

@@ -465,6 +465,28 @@ def test_unit_that_gives_up_waiting_is_repaired(sym, monkeypatch):
     assert np.array_equal(d0, d2) and np.array_equal(i0, i2)
 
 
+def test_some_waves_of_a_unit_give_up(sym, monkeypatch):
+    """The eight waves of a unit wait for the block's previous unit independently, so under load any subset of them can give
+    up: each must flag the block (found with tools/stress_concurrent.py at a 50 us limit -- whole waves of 64 queries with
+    incomplete lists in a block that only wave 0 would have flagged).  MCE_PANEL_DEBUG=16 makes the odd waves of every
+    block's second unit give up at once, which reproduces it without a loaded chip (22 332 wrong rows at 60 000 x 20 before
+    the fix).  It also covers what a give-up does to the rest of the block: its units no longer run one after the other,
+    and lists written by two of them at once are not trusted (a flagged block's units start from empty lists)."""
+    capi = sym
+    monkeypatch.setenv("MCE_SYM_PANEL", "2")
+    for n, d, K in ((60000, 20, 6), (45000, 45, 8), (80000, 6, 4)):
+        Y = _data(n, d, n + 1)
+        capi.set_sym_mode(capi.SYM_OFF)
+        d0, i0 = capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE)
+        capi.set_sym_mode(capi.SYM_FORCE)
+        monkeypatch.setenv("MCE_PANEL_DEBUG", "16")
+        for _ in range(3):
+            d1, i1 = capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE)
+            assert "panel-kernel" in capi.last_kernel()
+            assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+        monkeypatch.delenv("MCE_PANEL_DEBUG")
+
+
 def test_every_candidate_through_the_redo_list(sym, monkeypatch):
     """A tile whose candidates do not fit the wave's queue is deferred to a redo list and multiplied again after the
     next drain.  MCE_PANEL_DEBUG=8 sends EVERY candidate of the sweep that way: identical results."""
