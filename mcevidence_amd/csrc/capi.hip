@@ -161,6 +161,8 @@ constexpr int kSymAutoMinBlocks[5] = {0, 768, 257, 193, 193};
 // spread / nearest / half: 1M x 3 42.6 / 152.6 / 45.2; 1M x 6 36.1 / 50.1 / 37.1; 1M x 10 34.4 / 36.8 / 34.8; 1M x 15
 // 33.8 / 33.4 / 33.2; 1M x 20 50.2 / 45.9 / 46.8; 1M x 27 48.8 / 44.4 / 45.5 (tools/sym_seedmode.py)
 constexpr int kSymSeedMode[5] = {0, 0, 1, 1, 1};
+// largest rank count for which a multi-GPU auto-evidence search is partitioned symmetrically (mce_knn_dotp_part_f64)
+constexpr int kSymPartitionMaxParts = 4;
 // The planner sees sizes only; the host-pointer entry points see the pointers.  They say here whether queries and
 // references are one buffer, so that cross evidence with equal halves (split = True, s1frac = 0.5: nq == nr) does not
 // reserve ~1 GB of scratch it can never use.  -1: unknown (the *_dev entry points: the workspace query must cover both).
@@ -1209,11 +1211,12 @@ int mce_knn_dotp_part_f64_dev(const double* dY, int64_t nr, int32_t d, int32_t k
     const size_t need = p.total + dotp_ws_bytes(nr, kmax);
     if (ws_bytes < need) return fail(MCE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!p.prune && p.sym && nparts > 1) {
+    if (!p.prune && p.sym && nparts > 1 && nparts <= kSymPartitionMaxParts) {
         // Auto evidence of a set large enough for the symmetric sweep: every rank takes a contiguous range of the SORTED
         // blocks, symmetric within its range and column side only against everybody else's rows (no exchange).
-        // Per rank n^2/W (1 - 1/2W) tile products instead of the n^2/W of a query shard -- and at the symmetric sweep's
-        // cost per tile, not twice the single-GPU run's work.
+        // Per rank n^2/W (1 - 1/2W) tile products instead of the n^2/W of a query shard, at the symmetric kernel's cost per
+        // product (1.08 x the exhaustive kernel's) + ~1 ms of sorting and prepass per rank: it wins up to four ranks
+        // (C3, slowest rank, same box: 26.7 vs 32.5 ms at 2, 15.9 vs 16.4 at 4, 9.5 vs 8.4 at 8); beyond, query shards.
         p.part = part;
         p.nparts = nparts;
         char* wsc = static_cast<char*>(ws);
