@@ -233,8 +233,9 @@ int mce_get_prune_mode(void);
  * (131 k rows) with two (d <= 30), from 193 (99 k rows) beyond (capi.hip: kSymAutoMinBlocks);
  * 1: never; 2: whenever the shape allows it (fp16-filter shapes with K <= 16, more than 512 rows).
  * Process-wide default (per call: mce_options); the environment variable MCE_SYM sets the initial value.
- * Multi-GPU: mce_knn_dotp_part_f64 partitions such a search by ranges of the sorted blocks (symmetric within a rank's
- * range, column side only against the other ranks' rows) -- no exchange between the ranks. */
+ * Multi-GPU: up to four ranks mce_knn_dotp_part_f64 partitions such a search by ranges of the sorted blocks (symmetric
+ * within a rank's range, column side only against the other ranks' rows) -- no exchange between the ranks; larger jobs
+ * shard the query rows. */
 int mce_set_sym_mode(int mode);
 int mce_get_sym_mode(void);
 /* Work actually done by the last pruned search launched by this thread through a *_dev entry point
