@@ -36,8 +36,8 @@ struct PanelArgs {
     int* part_i;
     int64_t nq, nr, nq_pad, self_offset;
     int D, ksel, self_exclude, spin_limit;
-    int debug;                   // bisecting / test aids (MCE_PANEL_DEBUG): 1 no bound taken back from the row side, 2 no chain filter, 4 no row gate,
-                                 // 8 every candidate through the redo list, 16 the odd waves of every block's second unit give up waiting at once
+    int debug;                   // test hooks (MCE_PANEL_DEBUG): 8 every candidate through the redo list, 16 the odd waves of every block's
+                                 // second unit give up waiting at once
     SymParams sym;               // .done, .panel always; the row-side state only with geom.sym_on
     PanelGeom geom;
 };
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
                     // query's list (K-th bound of the last drain) joins its chain
                     if (sub == 0 && ep[u] < qcount) {
                         wqd[ep[u]] = okp[u] ? a0 : -1.0;
-                        if (okp[u] && (!(a0 > (double)sthr[qlp[u]]) || (a->debug & 2))) wnx[ep[u]] = atomicExch(&whead[qlp[u]], ep[u]);
+                        if (okp[u] && !(a0 > (double)sthr[qlp[u]])) wnx[ep[u]] = atomicExch(&whead[qlp[u]], ep[u]);
                     }
                 }
             }
@@ -512,10 +512,10 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
                     const unsigned rb = __float_as_uint(own_row_gate(t));
                     const unsigned long long ob = __hip_atomic_fetch_min(sp_thr + q, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned orb = __hip_atomic_fetch_min(sp_rrow + q, rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (!(a->debug & 1)) t = fmin(t, __longlong_as_double((long long)ob));
+                    t = fmin(t, __longlong_as_double((long long)ob));
                     R = __uint_as_float(rb < orb ? rb : orb);
                 } else {
-                    if (!(a->debug & 1)) t = __longlong_as_double((long long)__hip_atomic_load(sp_thr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    t = __longlong_as_double((long long)__hip_atomic_load(sp_thr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                     const unsigned rb = __float_as_uint(own_row_gate(t));
                     const unsigned orb = __hip_atomic_fetch_min(sp_rrow + q, rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     R = __uint_as_float(rb < orb ? rb : orb);
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
     auto rt_load = [&](int c) -> float {
         const int t = c * CT + lane;
         const int tb = t / TPB;
-        const bool en = sym_on && lane < CT && tb >= qb_lo && tb < qblk && MCE_PANEL_ABL != 1 && !(dbg_flags & 4);
+        const bool en = sym_on && lane < CT && tb >= qb_lo && tb < qblk && MCE_PANEL_ABL != 1;
         const float r = en ? __hip_atomic_load(rtile_p + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -__builtin_huge_valf();
         // the tiles are gated in pairs (t, t + 1), t even, with the larger of the two constants: one gate refresh per pair
         // (rows sorted by distance from the mean: neighbouring tiles differ little); a block is a whole number of pairs
