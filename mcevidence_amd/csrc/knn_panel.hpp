@@ -1,24 +1,28 @@
 // knn_panel.hpp -- the PANEL sweep: the fp16-MFMA filter + exact fp64 refine of knn_f16.hpp (same bound, same lists, same
-// results: reference MCEvidence.py:1093-1104) as a dedicated kernel for large searches, written around its register and
-// instruction budget.  It serves
-//   * the symmetric sweep of auto evidence (knn_f16.hpp, "Symmetric sweep": every pair of rows multiplied once, gated for
-//     both of its sides), on one GPU or as one rank's share of it (sym_types.hpp, PanelGeom), and
-//   * the exhaustive sweep of cross evidence / query shards (column side only),
-// with the work cut into UNITS (panel of reference rows x query block) that hand a block's register lists on.
+// results: reference MCEvidence.py:1093-1104) as a dedicated kernel, written around its register and instruction budget.
+// It runs the symmetric sweep of auto evidence (knn_f16.hpp, "Symmetric sweep": every pair of rows multiplied once, gated
+// for both of its sides) on one GPU, or one rank's share of it (sym_types.hpp, PanelGeom: the tiles of the rank's own range
+// of blocks symmetrically, everybody else's column side only), with the work cut into UNITS (panel of reference rows x
+// query block) that hand a block's register lists on.  (geom.sym_on = 0 -- every tile column side only, i.e. the exhaustive
+// sweep of cross evidence in units -- works and was measured: no faster than knn_f16_kernel's seeded sweep, so the library
+// does not take it)
 //
 // Why a second kernel.  knn_f16_kernel<.., SYM = 2> carries the pruned walk, the two-pass search and the seed phase in one
 // body: 256 VGPRs, 104 SGPRs with scalars spilled to VGPR lanes INSIDE the tile loop, six inlined copies of the drain, and a
 // per-lane 16-bit mask built with ~40 VALU instructions on every tile that has a candidate -- 13 VALU per MFMA measured
-// (rocprofv3, profiles/r02_symmetric) where the gate needs 5.5.  Here:
+// (rocprofv3, profiles/r02_symmetric) where the gate needs 5.5.  Here (8.2 VALU per MFMA, profiles/r03_panel):
 //   * arguments are read through the kernarg pointer WHERE THEY ARE USED (cold paths re-load them), so the tile loop holds a
 //     handful of scalars and nothing is spilled;
-//   * a tile with a candidate is resolved with wave-uniform ballots: 16 v_cmp, scalar branches over the (usually 15) empty
-//     ones, ~4 VALU per queued pair;
+//   * the two query tiles of a tile share ONE branch, so the tile's MFMAs and its gate form one basic block and interleave;
+//   * a tile with a candidate is resolved with wave-uniform compares: the gate's five first-level minima + the sixteenth
+//     accumulator, then the three members of a triple that fired -- 9 v_cmp, scalar branches over the rest, ~4 VALU per
+//     queued pair;
 //   * there is ONE drain in the code, at the end of a chunk; a queue that fills up inside a chunk defers the rest of the
 //     tile to a redo list, which the chunk end works off by multiplying those tiles again (the chunk is still in LDS);
 //   * the pipeline is flushed at the end of a chunk, so the accumulators are dead while the drain runs.  (Measured on one
 //     box against a pipeline kept going across chunk boundaries, flushed only for a drain, redo from global memory:
 //     37.5 vs 39.3 ms at C3 -- the carried tile costs the loop more than the flush.)
+//   * the wait of a unit for its block's previous unit is bounded; waves that give up flag the block for the repair launch.
 #pragma once
 #include "knn_f16.hpp"
 
