@@ -3,12 +3,19 @@
 
 Metric (BASELINE.json): kNN queries/s (+ |dlnE|) at N = 1M, D = 27, kmax = 10 (config C3: seeded synthetic Gaussian
 chain, `mcevidence_amd.synth.CONFIGS['C3']`), inputs resident in HBM when the timed region starts.  One "step" = one full
-pass of the hot path (pack -> kNN search -> merge -> volume/weight reduction -> dotp[kmax]).  With --gpus N every rank
-takes its share of the auto-evidence search -- the symmetric partition of DESIGN.md 5: a contiguous range of the sorted
-query blocks, reference set replicated -- and ONE RCCL all-reduce of kmax doubles per step: strong scaling.
+pass of the hot path (pack -> kNN search -> merge -> volume/weight reduction -> dotp[kmax]).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--n 1000000] [--d 27] [--kmax 10] [--mode 0|1] [--no-extras]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` with N > 1 works both ways: started by a launcher (`python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N ...`: WORLD_SIZE is set, this process is one rank) or plainly (`python bench.py --gpus N`: the parent
+starts the N ranks itself as child processes BEFORE anything touches the GPU -- their output, rank 0's JSON line
+included, goes to the parent's stdout -- and exits with the job's code).  One process per GPU, the set replicated on every rank, and per step ONE all-reduce of
+kmax doubles (RCCL): strong scaling.  What a rank computes is the library's choice: auto evidence -- the
+symmetric partition (a contiguous range of the sorted query blocks) or block-cyclic parts of the pruned walk
+(`mce_knn_dotp_part_f64_dev`); cross evidence -- contiguous query rows of s1 against the replicated s2.  Under N > 1 the
+line carries C3 (headline) AND, unless --no-extras, `configs.C2 / C4 / C5` timed the same way (barrier + synchronize
+on both sides, max over ranks), `ranks_seen`, and per rank its device ordinal and its own HIP-event search time.
 
 Prints ONE JSON line on rank 0.
 
@@ -19,21 +26,27 @@ fp16 (MI355X_MICROARCH.md); `frac` = achieved / peak.  It can be recomputed from
 duration) and pmc_summary.csv (SQ_INSTS_MFMA x 32 768 flop per v_mfma_f32_32x32x16_f16).  The all-pairs figure -- what a
 kernel WITHOUT the symmetry would have to execute for the same result -- is reported separately (`all_pairs_flops`,
 `algorithmic_speedup`), never as a fraction of peak.  `search` covers every launch of the search (prepass, sweep, repair,
-bucket merge).  `traffic`, `mfma_busy_frac`, `valu_per_mfma`, `wait_frac` are read from the committed rocprofv3 passes of
-this kernel (profiles/<round>/).  --mode 1: knn_mfma_kernel, the pure fp64 MFMA sweep, against 78.6 TFLOP/s.
+bucket merge).  `traffic`, `mfma_busy_frac`, `valu_per_mfma`, `wait_frac` come from the committed rocprofv3 passes of
+this kernel (profiles/<round>/) and are only reported when that profile was taken from the SAME kernel sources as the
+loaded library (profiles/<round>/meta.json: source_hash == mce_source_hash()); otherwise they are null and
+`traffic_stale` is true.  --mode 1: knn_mfma_kernel, the pure fp64 MFMA sweep, against 78.6 TFLOP/s.
 
 `cpu_baseline` = the reference's own CPU path -- scikit-learn NearestNeighbors exactly as MCEvidence.py:1093-1104 calls it
 + the NumPy volume/weight sum -- on a bounded query sample, rank 0, with the host it ran on.
 
-`configs` (N = 1, unless --no-extras): the other BASELINE.json GPU configs C2, C4, C5 through the same entry points
-(resident data), and `fp64_mode`: C3 through the fp64 sweep -- the reference-precision arithmetic end to end.
+`configs` (unless --no-extras): the other BASELINE.json GPU configs C2, C4, C5 through the same entry points (resident
+data), each with ln E against the reference's own golden output and (N = 1) a CPU baseline on a query sample;
+`fp64_mode` (N = 1): C3 through the fp64 sweep -- the reference-precision arithmetic end to end.
 """
 import argparse
 import glob
+import hashlib
 import json
 import math
 import os
 import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -48,10 +61,21 @@ N_SIMD = 1024                # 256 CUs x 4
 PEAK_CLOCK_HZ = 2.4e9
 
 
-def profile_counters(kernel_desc):
+def source_hash():
+    """SHA-256 over the kernel sources (csrc/*.hpp, csrc/*.hip, sorted by name) -- the same digest csrc/Makefile bakes
+    into the library (mce_source_hash()) and tools/profile_bench.sh stores next to a profile (meta.json)."""
+    h = hashlib.sha256()
+    src = os.path.join(REPO, "mcevidence_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.hpp")) + glob.glob(os.path.join(src, "*.hip")), key=os.path.basename):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def profile_counters(kernel_desc, library_hash=None):
     """Counters of the dominant kernel from the newest committed rocprofv3 summary that has it
     (profiles/<round>/pmc_summary.csv: separate --pmc passes; FETCH_SIZE / WRITE_SIZE in KB, FETCH_SIZE doubled per
-    MI355X_MICROARCH.md's gfx950 note; kernel_stats.csv: average duration).  {} when no profile of this kernel exists."""
+    MI355X_MICROARCH.md's gfx950 note; kernel_stats.csv: average duration).  {} when no profile of this kernel exists.
+    `stale` = the profile's meta.json names other kernel sources than `library_hash` (or names none)."""
     m = re.match(r"(\w+)<\w+=(\d+),\w+=(\d+)>", kernel_desc)
     if not m:
         return {}
@@ -76,6 +100,9 @@ def profile_counters(kernel_desc):
             continue
         out = dict(source=os.path.relpath(f, REPO), traffic=(2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
                    traffic_note="per launch; (2*FETCH_SIZE + WRITE_SIZE) KB, separate --pmc passes")
+        meta = os.path.join(os.path.dirname(f), "meta.json")
+        out["profile_source_hash"] = json.load(open(meta)).get("source_hash") if os.path.exists(meta) else None
+        out["stale"] = library_hash is not None and out["profile_source_hash"] != library_hash
         ks = os.path.join(os.path.dirname(f), "kernel_stats.csv")
         avg_ns = None
         if os.path.exists(ks):
@@ -123,6 +150,50 @@ def host_info():
     return info
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without a launcher
+# ---------------------------------------------------------------------------------------------------------------------
+def self_launch(argv, gpus):
+    """Start the N ranks as children -- one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment,
+    exactly what a launcher would hand them -- and wait.  Runs before torch is imported: this process never touches the GPU,
+    and nothing is exec'ed from a process that has.  (Not through `python -m torch.distributed.run`: its argument parser
+    rejects script options that abbreviate its own, e.g. `--n`.)  Returns the first non-zero exit code of a rank; the other
+    ranks are then stopped by PID."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or gpus) // gpus)))
+    base.update(WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    procs = []
+    for r in range(gpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:           # a rank failed: the others would wait for it in the next collective
+                    q.terminate()
+        if live:
+            time.sleep(0.05)
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the BASELINE.json configs as hot-path inputs (host side: chain -> whitened sets, weights, fs, the scalars of ln E)
+# ---------------------------------------------------------------------------------------------------------------------
+GOLDENS = {"C2": ("evidence_medium.json", "auto_n100000_d6_k4_C2"), "C3": ("evidence_big.json", "auto_n1000000_d27_k10_C3"),
+           "C4": ("evidence_c4.json", "cross_n1000000_d15_k4_C4"), "C5": ("evidence_c5.json", "auto_n10000000_d6_k10_C5")}
+
+
 def whiten_all(theta):
     """covariance eigen-system of ALL rows (the reference's covtype='all', MCEvidence.py:851-882, :842-849)"""
     cov = np.cov(theta.T)
@@ -130,110 +201,193 @@ def whiten_all(theta):
     return np.ascontiguousarray((theta @ U) / np.sqrt(ev)), math.sqrt(float(np.prod(ev)))
 
 
-def time_resident(_capi, torch, X, Y, kmax, k0, steps, warmup, nsample, orc, mode=0, weight=None, fsv=None):
-    """One BASELINE config through mce_knn_dotp_f64_dev on resident data: ms per step, dominant-kernel ms, sampled rows
-    against the exact CPU search (oracle)."""
-    dev = torch.device("cuda", torch.cuda.current_device())
-    nq, d = X.shape
-    nr = nq if Y is None else Y.shape[0]
-    Xd = torch.from_numpy(X).to(dev)
-    Yd = Xd if Y is None else torch.from_numpy(Y).to(dev)
-    w = torch.ones(nq, dtype=torch.float64, device=dev) if weight is None else torch.from_numpy(np.ascontiguousarray(weight)).to(dev)
-    fs = torch.zeros(nq, dtype=torch.float64, device=dev) if fsv is None else torch.from_numpy(np.ascontiguousarray(fsv)).to(dev)
+def prep_config(name, scale=1.0):
+    """X (queries = s1), Y (None: auto evidence), weight, fs, and the scalars MCEvidence.py:1120-1131 needs.
+    `scale` < 1: the same recipe with fewer rows (functional checks of the N > 1 path on small boxes)."""
+    from mcevidence_amd.synth import CONFIGS, config_chain
+    chain, (r1, r2) = config_chain(name, n=max(2048, int(CONFIGS[name]["n"] * scale)))
+    W, J = whiten_all(chain[:, 2:])
+    if r1 is None:
+        X, Y, c1 = W, None, chain
+    else:
+        X, Y, c1 = np.ascontiguousarray(W[r1]), np.ascontiguousarray(W[r2]), chain[r1]
+    logL = -c1[:, 1]                                   # column 1 = -ln L (MCEvidence.py:399)
+    logLmax = float(np.amax(logL))
+    return dict(name=name, X=X, Y=Y, weight=np.ascontiguousarray(c1[:, 0]), fs=np.ascontiguousarray(logL - logLmax),
+                kmax=CONFIGS[name]["kmax"], k0=1 if Y is None else 0, S=len(X), SumW=float(np.sum(c1[:, 0])), J=J, logLmax=logLmax,
+                chain=chain if r1 is not None else None, split=(r1, r2))
+
+
+def lnE_from_dotp(dotp, cfg, lnPV=0.0):
+    """MCEvidence.py:1120-1131 + the slice of :1157: k_nn = k (auto) / k + 1 (cross); returned MLE[1:]"""
+    k0 = cfg["k0"]
+    out = []
+    for k in range(max(k0, 1), cfg["kmax"]):
+        k_nn = k if k0 == 1 else k + 1
+        out.append(math.log(cfg["SumW"] * dotp[k] / (cfg["S"] * k_nn + 1.0) * cfg["J"]) + cfg["logLmax"] - lnPV)
+    return np.array(out)
+
+
+def golden_lnE(name, cfg):
+    f, case = GOLDENS.get(name, (None, None))
+    p = os.path.join(REPO, "tests", "golden", f) if f else None
+    if not p or not os.path.exists(p):
+        return None
+    for c in json.load(open(p)):
+        if c["name"] == case and c["S"] == cfg["S"] and c["kmax"] == cfg["kmax"]:
+            return c
+    return None
+
+
+class Ctx(object):
+    """process-wide bits every timed config needs"""
+
+    def __init__(self, torch, dist, _capi, world, rank, dev):
+        self.torch, self.dist, self.capi, self.world, self.rank, self.dev = torch, dist, _capi, world, rank, dev
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+
+def time_config(ctx, cfg, steps, warmup, mode=0, nsample=0, orc=None):
+    """One config through the device-pointer entry points on resident data.  world = 1: mce_knn_dotp_f64_dev over the whole
+    set.  world > 1: this rank's share + ONE all-reduce of kmax doubles per step -- auto evidence through
+    mce_knn_dotp_part_f64_dev (the library's partition), cross evidence on the contiguous query rows [S r / W, S (r+1) / W)
+    of s1 against the replicated s2.  EXACTLY `steps` timed steps between barrier + synchronize; ms = max over ranks."""
+    torch, dist, _capi, world, rank, dev = ctx.torch, ctx.dist, ctx.capi, ctx.world, ctx.rank, ctx.dev
+    X, Y, kmax, k0 = cfg["X"], cfg["Y"], cfg["kmax"], cfg["k0"]
+    S, d = X.shape
     K = kmax - k0
+    auto = Y is None
+    lo, hi = (0, S) if (world == 1 or auto) else ((S * rank) // world, (S * (rank + 1)) // world)
+    Xd = torch.from_numpy(X[lo:hi]).to(dev)
+    Yd = Xd if auto else torch.from_numpy(Y).to(dev)
+    nq, nr = hi - lo, (S if auto else Y.shape[0])
+    w = torch.from_numpy(cfg["weight"][lo:hi]).to(dev)
+    fs = torch.from_numpy(cfg["fs"][lo:hi]).to(dev)
     _capi.set_search_mode(mode)
     wsb = _capi.knn_workspace_bytes(nq, nr, d, K) + _capi.dotp_workspace_bytes(nq, kmax)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     out = torch.zeros(kmax, dtype=torch.float64, device=dev)
-    dd = torch.zeros((nq, K), dtype=torch.float64, device=dev) if nsample else None
     st = torch.cuda.current_stream().cuda_stream
 
-    def step(dist_out):
-        _capi.knn_dotp_dev(Xd.data_ptr(), nq, Yd.data_ptr(), nr, d, kmax, k0, 0, w.data_ptr(), fs.data_ptr(), out.data_ptr(),
-                           dist_out.data_ptr() if dist_out is not None else 0, ws.data_ptr(), wsb, st)
+    def step(dist_out=0):
+        if world > 1 and auto:
+            _capi.knn_dotp_part_dev(Xd.data_ptr(), nr, d, kmax, rank, world, w.data_ptr(), fs.data_ptr(), out.data_ptr(), ws.data_ptr(), wsb, st)
+        else:
+            _capi.knn_dotp_dev(Xd.data_ptr(), nq, Yd.data_ptr(), nr, d, kmax, k0, 0, w.data_ptr(), fs.data_ptr(), out.data_ptr(),
+                               dist_out, ws.data_ptr(), wsb, st)
+        if world > 1:
+            dist.all_reduce(out, op=dist.ReduceOp.SUM)          # the single collective of the path
+
     for _ in range(warmup):
-        step(None)
-    torch.cuda.synchronize()
-    _capi.set_profiling(True)
+        step()
+    ctx.barrier()
+    _capi.set_profiling(True)          # hipEvent brackets around the dominant kernel and around the whole search, on the launch stream
     t0 = time.perf_counter()
     for _ in range(steps):
-        step(None)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    stats = _capi.last_search_stats()
+        step()
+    ctx.barrier()
+    elapsed = time.perf_counter() - t0
+    stats = _capi.last_search_stats()  # means over the timed steps (read after the timed region)
     _capi.set_profiling(False)
-    res = dict(nq=nq, nr=nr, d=d, kmax=kmax, k0=k0, steps=steps, ms_per_step=round(ms, 3), kernel_ms=round(stats["kernel_ms"], 3),
-               search_ms=round(stats["search_ms"], 3), queries_per_s=round(nq / (ms * 1e-3), 1), kernel=_capi.last_kernel())
-    if stats["flops_main"] > 0:
+    kdesc = _capi.last_kernel()
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([elapsed, stats["search_ms"], stats["kernel_ms"], float(torch.cuda.current_device()), float(nq)], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = [t.cpu().numpy() for t in allr]
+        elapsed = max(float(t[0]) for t in allr)
+        per_rank = [dict(rank=i, device=int(t[3]), search_ms=round(float(t[1]), 3), kernel_ms=round(float(t[2]), 3), query_rows=int(t[4]),
+                         ms_per_step=round(float(t[0]) / steps * 1e3, 3)) for i, t in enumerate(allr)]
+    ms = elapsed / steps * 1e3
+    dotp = out.cpu().numpy().copy()
+    res = dict(nq=S, nr=nr, d=d, kmax=kmax, k0=k0, steps=steps, warmup=warmup, ms_per_step=round(ms, 3), kernel_ms=round(stats["kernel_ms"], 3),
+               search_ms=round(stats["search_ms"], 3), queries_per_s=round(S / (ms * 1e-3), 1), kernel=kdesc, ranks=world)
+    if per_rank:
+        res["per_rank"] = per_rank
+        res["partition"] = ("library partition of the auto-evidence search (mce_knn_dotp_part_f64_dev), one all-reduce" if auto
+                            else "contiguous query rows of s1 against the replicated s2, one all-reduce")
+    if stats["flops_main"] > 0 and stats["kernel_ms"] > 0:
         res["executed_tflops"] = round(stats["flops_main"] / (stats["kernel_ms"] * 1e-3) / 1e12, 1)
-    if nsample:
-        step(dd)
+    lnE = lnE_from_dotp(dotp, cfg)
+    res["lnE"] = [float(x) for x in lnE]
+    g = golden_lnE(cfg["name"], cfg)
+    if g is not None:
+        res["max_abs_dlnE_vs_reference"] = float(np.max(np.abs(lnE - np.array(g["lnE"]))))
+        res["reference_wall_s"] = round(g.get("ref_wall_s", 0.0), 1)
+    if nsample and world == 1 and orc is not None:
+        dd = torch.zeros((nq, K), dtype=torch.float64, device=dev)
+        step(dd.data_ptr())
         torch.cuda.synchronize()
         rng = np.random.default_rng(1)
         rows = np.sort(rng.choice(nq, min(nsample, nq), replace=False))
-        od, _ = orc.knn_brute(X[rows], X if Y is None else Y, K + k0)
+        od, _ = orc.knn_brute(X[rows], X if auto else Y, K + k0)
         od = od[:, k0:] if k0 == 1 else od
         got = dd[torch.from_numpy(rows).to(dev)].cpu().numpy()
         res["sampled_rows"] = len(rows)
         res["max_rel_dist_err_sampled_rows_vs_exact_cpu_search"] = float(np.max(np.abs(got - od) / od))
-    res["dotp"] = [float(x) for x in out.cpu().numpy()]
+        del dd
     _capi.set_search_mode(0)
-    del Xd, Yd, ws, dd
+    del Xd, Yd, ws, w, fs
     torch.cuda.empty_cache()
-    return res
+    return res, stats, dotp
 
 
-def extra_configs(_capi, torch, orc, pkg):
-    """C2, C4, C5 of BASELINE.json (C1 is the CPU plumbing config) -- one GPU, resident data."""
-    from mcevidence_amd.synth import CONFIGS, config_chain
+def sklearn_baseline(cfg, algs, orc, seed=0, nrows_all=20000):
+    """The reference's CPU call (MCEvidence.py:1093-1104) on a bounded sample of query rows against the full set."""
+    from sklearn.neighbors import NearestNeighbors
+    X, Y = cfg["X"], cfg["X"] if cfg["Y"] is None else cfg["Y"]
+    rng = np.random.default_rng(seed)
+    rows = np.sort(rng.choice(len(X), min(nrows_all, len(X)), replace=False))
     out = {}
-    # C2: auto, 100 k x 6, kmax 4
-    chain, _ = config_chain("C2")
-    X, _ = whiten_all(chain[:, 2:])
-    out["C2"] = time_resident(_capi, torch, X, None, CONFIGS["C2"]["kmax"], 1, steps=20, warmup=3, nsample=1000, orc=orc)
-    # C4: cross evidence of two independent chains, 1M + 1M x 15, kmax 4 (k0 = 0); whitened with the covariance of all rows
-    chain, (r1, r2) = config_chain("C4")
-    W, _ = whiten_all(chain[:, 2:])
-    X, Y = np.ascontiguousarray(W[r1]), np.ascontiguousarray(W[r2])
-    c4 = time_resident(_capi, torch, X, Y, CONFIGS["C4"]["kmax"], 0, steps=4, warmup=1, nsample=1000, orc=orc)
-    # ... and its ln E through the class (device feeders, from host arrays) against the REFERENCE's own output for this pair
-    gold = os.path.join(REPO, "tests", "golden", "evidence_c4.json")
-    if os.path.exists(gold):
-        ref = json.load(open(gold))[0]
-        mce = pkg.MCEvidence([chain], kmax=CONFIGS["C4"]["kmax"], verbose=0).set_split(r1, r2)
+    for alg, nrows in algs:
+        sub = rows[:: max(1, len(rows) // nrows)]
         t0 = time.perf_counter()
-        lnE = mce.evidence()
-        c4["evidence_call_from_host_s"] = round(time.perf_counter() - t0, 4)
-        c4["lnE"] = [float(x) for x in lnE]
-        c4["max_abs_dlnE_vs_reference"] = float(np.max(np.abs(lnE - np.array(ref["lnE"]))))
-        c4["reference_wall_s"] = ref["ref_wall_s"]
-    # CPU: the reference's call picks kd_tree at d = 15 (MCEvidence.py:1093-1094) -- ~70 queries/s on a 128-core host, so it
-    # gets 1000 of the 20 000 sampled query rows (the full sample would take five minutes); brute next to it on all 20 000
-    rng = np.random.default_rng(0)
-    rows = np.sort(rng.choice(len(X), 20000, replace=False))
-    cpu = {}
-    for alg, nrows in (("auto", 1000), ("brute", 20000)):
-        from sklearn.neighbors import NearestNeighbors
-        t0 = time.perf_counter()
-        nb = NearestNeighbors(n_neighbors=CONFIGS["C4"]["kmax"] + 1, metric="euclidean", leaf_size=20, algorithm=alg, n_jobs=-1).fit(Y)
+        nb = NearestNeighbors(n_neighbors=cfg["kmax"] + 1, metric="euclidean", leaf_size=20, algorithm=alg, n_jobs=-1).fit(Y)
         t_fit = time.perf_counter() - t0
-        dsk, _ = nb.kneighbors(X[rows[:: len(rows) // nrows]])
+        dsk, _ = nb.kneighbors(X[sub])
+        orc.dotp_literal(dsk, cfg["weight"][sub], cfg["fs"][sub], X.shape[1], cfg["k0"], cfg["kmax"])
         t_all = time.perf_counter() - t0
-        cpu[alg] = dict(fit_method=str(nb._fit_method), query_rows=nrows, fit_s=round(t_fit, 2), total_s=round(t_all, 2),
-                        queries_per_s=round(nrows / (t_all - t_fit), 1), queries_per_s_incl_fit=round(nrows / t_all, 1))
-    c4["cpu_baseline"] = dict(sample="random query rows of s1 against all 1M rows of s2 (every 20th of the 20 000-row sample for the tree)", algorithms=cpu)
-    out["C4"] = c4
-    del X, Y, W, chain
-    # C5: auto, 10 M x 6, one K = 9 search serves the kmax = 2..10 sweep
-    chain, _ = config_chain("C5")
-    X, _ = whiten_all(chain[:, 2:])
-    del chain
-    out["C5"] = time_resident(_capi, torch, X, None, CONFIGS["C5"]["kmax"], 1, steps=2, warmup=1, nsample=300, orc=orc)
-    try:
-        cf, tf = _capi.last_prune_stats()
-        out["C5"]["pruned_walk"] = dict(chunk_fraction=round(cf, 5), tile_fraction=round(tf, 5))
-    except Exception:
-        pass
+        out[alg] = dict(fit_method=str(nb._fit_method), query_rows=len(sub), fit_s=round(t_fit, 2), total_s=round(t_all, 2),
+                        queries_per_s=round(len(sub) / (t_all - t_fit), 1), queries_per_s_incl_fit=round(len(sub) / t_all, 1))
+    return dict(sample="random query rows against the full reference set; kind = the reference's own sklearn call, imported",
+                cores=len(os.sched_getaffinity(0)), algorithms=out)
+
+
+def extra_configs(ctx, orc, pkg, scale=1.0):
+    """C2, C4, C5 of BASELINE.json (C1 is the CPU plumbing config): resident data, the same timing as the headline."""
+    torch, _capi, world = ctx.torch, ctx.capi, ctx.world
+    out = {}
+    plan = (("C2", 20, 3, 1000, (("auto", 20000),)),
+            ("C4", 4, 1, 1000, (("auto", 1000), ("brute", 20000))),      # the reference's call picks kd_tree at d = 15: ~140 queries/s
+            ("C5", 3, 1, 300, (("auto", 20000),)))
+    for name, steps, warmup, nsample, algs in plan:
+        cfg = prep_config(name, scale)
+        if scale != 1.0:
+            nsample, algs = min(nsample, 100), tuple((alg, min(nr, 500)) for alg, nr in algs)
+        res, _, _ = time_config(ctx, cfg, steps, warmup, nsample=nsample if world == 1 else 0, orc=orc)
+        if ctx.rank == 0 and world == 1:
+            if name == "C4" and "max_abs_dlnE_vs_reference" in res:
+                # ... and ln E through the class (device feeders, from host arrays) for this pair
+                mce = pkg.MCEvidence([cfg["chain"]], kmax=cfg["kmax"], verbose=0).set_split(*cfg["split"])
+                t0 = time.perf_counter()
+                lnE = mce.evidence()
+                res["evidence_call_from_host_s"] = round(time.perf_counter() - t0, 4)
+                res["max_abs_dlnE_class_vs_resident_path"] = float(np.max(np.abs(lnE - np.array(res["lnE"]))))
+            if name == "C5":
+                try:
+                    cf, tf = _capi.last_prune_stats()
+                    res["pruned_walk"] = dict(chunk_fraction=round(cf, 5), tile_fraction=round(tf, 5))
+                except Exception:
+                    pass
+            res["cpu_baseline"] = sklearn_baseline(cfg, algs, orc)
+        out[name] = res
+        del cfg
     return out
 
 
@@ -248,18 +402,26 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=20000, help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--mode", type=int, default=0, help="0 auto (fp16 filter + fp64 refine), 1 fp64 MFMA sweep")
     ap.add_argument("--no-extras", action="store_true", help="headline only: skip the C2/C4/C5 and fp64-mode sections")
+    ap.add_argument("--extras-scale", type=float, default=1.0, help="rows of the C2/C4/C5 sections x this factor (functional checks; 1 = BASELINE.json sizes)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become one (before torch is imported -- this process never initialises the GPU)
+        sys.exit(self_launch(sys.argv[1:], a.gpus))
 
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 or world > 1:
-        assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without a launcher)" % (a.gpus, world, a.gpus))
+    if world > 1:
         # (MCE_BENCH_BACKEND=gloo MCE_BENCH_ONE_DEVICE=1: functional check of the N>1 path on a 1-GPU box)
         if os.environ.get("MCE_BENCH_ONE_DEVICE") == "1":
             local = 0
+        elif local >= torch.cuda.device_count():
+            raise SystemExit("bench.py: rank %d wants GPU %d of %d" % (rank, local, torch.cuda.device_count()))
         torch.cuda.set_device(local)
         backend = os.environ.get("MCE_BENCH_BACKEND", "nccl")
         if backend == "nccl":
@@ -274,6 +436,7 @@ def main():
     _capi.set_search_mode(a.mode)
     from mcevidence_amd.synth import gaussian_chain
     import mcevidence_amd as pkg
+    ctx = Ctx(torch, dist, _capi, world, rank, dev)
 
     # ---- synthetic chain (config C3 recipe) + host-side feeders (whitening etc.) ----
     n, d, kmax = a.n, a.d, a.kmax
@@ -283,60 +446,29 @@ def main():
     s1, logL, weight, _ = mce.get_samples(n, prewhiten=False)
     Xh = np.ascontiguousarray(mce.diagonalise_chain(s1, cov["eVec"], cov["eVal"]))
     logLmax = float(np.amax(logL))
-    fsh = logL - logLmax
-    SumW = float(np.sum(weight))
-
+    fsh = np.ascontiguousarray(logL - logLmax)
+    weight = np.ascontiguousarray(weight, dtype=np.float64)
+    c3 = dict(name="C3", X=Xh, Y=None, weight=weight, fs=fsh, kmax=kmax, k0=1, S=n, SumW=float(np.sum(weight)), J=cov["J"], logLmax=logLmax)
     K = kmax - 1
-    X = torch.from_numpy(Xh).to(dev)                       # the set, resident on every rank
-    w = torch.from_numpy(np.ascontiguousarray(weight)).to(dev)
-    fs = torch.from_numpy(np.ascontiguousarray(fsh)).to(dev)
-    wsb = _capi.knn_workspace_bytes(n, n, d, K) + _capi.dotp_workspace_bytes(n, kmax)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    dotp = torch.zeros(kmax, dtype=torch.float64, device=dev)
-    stream = torch.cuda.current_stream()
 
-    def step():
-        if world > 1:
-            # this rank's share (the library picks the partition: a range of the sorted blocks, symmetric inside)
-            _capi.knn_dotp_part_dev(X.data_ptr(), n, d, kmax, rank, world, w.data_ptr(), fs.data_ptr(),
-                                    dotp.data_ptr(), ws.data_ptr(), wsb, stream.cuda_stream)
-            dist.all_reduce(dotp, op=dist.ReduceOp.SUM)    # the single collective of the path
-        else:
-            _capi.knn_dotp_dev(X.data_ptr(), n, X.data_ptr(), n, d, kmax, 1, 0, w.data_ptr(), fs.data_ptr(),
-                               dotp.data_ptr(), 0, ws.data_ptr(), wsb, stream.cuda_stream)
+    head, stats, dp = time_config(ctx, c3, a.steps, a.warmup, mode=a.mode)
+    ms_step, kern_ms = head["ms_per_step"], stats["kernel_ms"]
+    lnE = np.array(head["lnE"])
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        step()
-    barrier()
-    _capi.set_profiling(True)          # hipEvent brackets around the dominant kernel and around the whole search, on the launch stream
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    stats = _capi.last_search_stats()  # means over the K timed steps (read after the timed region)
-    _capi.set_profiling(False)
-    kern_ms = stats["kernel_ms"]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_step = elapsed / a.steps * 1e3
-    # ---- ln E from the device result (MCEvidence.py:1120-1131) ----
-    dp = dotp.cpu().numpy()
-    lnE = np.array([math.log(SumW * dp[k] / (n * k + 1.0) * cov["J"]) + logLmax - math.log(1.0) for k in range(1, kmax)])
+    orc = None
+    if rank == 0:
+        from oracle import oracle_np as orc                 # checker / CPU baseline only; never inside a timed region
+    extras = None
+    want_extras = not a.no_extras and a.mode == 0 and ((n, d, kmax) == (1_000_000, 27, 10) or a.extras_scale != 1.0)
+    if want_extras and world > 1:
+        extras = extra_configs(ctx, orc, pkg, a.extras_scale)   # every rank takes part
 
     out = None
     if rank == 0:
-        kdesc = _capi.last_kernel()
+        kdesc = head["kernel"]
         is_f16 = kdesc.startswith("knn_f16")
-        kst = (d + 3 + 15) // 16
+        mk = re.search(r"KST=(\d+)", kdesc)
+        kst = int(mk.group(1)) if mk else (d + 16) // 16     # capi.hip: f16_ksteps(D) = (D + 16) / 16
         KS = (d + 1 + 3) // 4
         if is_f16:
             peak, flop_pair = F16_PEAK_TFLOPS, 2.0 * 16 * kst
@@ -347,9 +479,12 @@ def main():
         executed = stats["flops_main"]
         achieved = executed / (kern_ms * 1e-3) / 1e12
         all_pairs = float(n) * n * flop_pair / world                 # what a sweep without the symmetry would execute on this rank
-        prof = profile_counters(kdesc)
+        lib_hash = _capi.source_hash()
+        prof = profile_counters(kdesc, lib_hash)
+        stale = bool(prof.get("stale", True))
+        live = (lambda k: None if stale else prof.get(k))           # counters of other sources are not this kernel's
         roof = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
-                    traffic=prof.get("traffic"), kernel_ms=round(kern_ms, 3), kernel=kdesc,
+                    traffic=live("traffic"), kernel_ms=round(kern_ms, 3), kernel=kdesc,
                     executed_flops_per_launch=executed, flop_per_multiplied_pair=flop_pair, what=what,
                     all_pairs_flops=all_pairs, algorithmic_speedup=round(all_pairs / executed, 3) if executed > 0 else None,
                     all_pairs_equivalent_tflops=round(all_pairs / (kern_ms * 1e-3) / 1e12, 1),
@@ -357,19 +492,18 @@ def main():
                                 tflops=round(stats["flops_all"] / (stats["search_ms"] * 1e-3) / 1e12, 2),
                                 frac=round(stats["flops_all"] / (stats["search_ms"] * 1e-3) / 1e12 / peak, 4),
                                 note="every launch of the search: packing, prepass, sweep, repair, bucket merge"),
-                    traffic_source=prof.get("source"), traffic_note=prof.get("traffic_note"),
-                    hbm_gbps=(round(prof["traffic"] / (kern_ms * 1e-3) / 1e9, 1) if prof.get("traffic") else None),
-                    hbm_frac_of_8TBps=(round(prof["traffic"] / (kern_ms * 1e-3) / 8e12, 4) if prof.get("traffic") else None),
-                    mfma_busy_frac=prof.get("mfma_busy_frac"), valu_per_mfma=prof.get("valu_per_mfma"), wait_frac=prof.get("wait_frac"),
-                    profile_kernel_ms=prof.get("profile_kernel_ms"), profile_tflops_from_SQ_INSTS_MFMA=prof.get("profile_tflops_from_SQ_INSTS_MFMA"),
+                    traffic_stale=stale, traffic_source=prof.get("source"), traffic_note=prof.get("traffic_note"),
+                    library_source_hash=lib_hash, profile_source_hash=prof.get("profile_source_hash"),
+                    source_hash_matches_tree=(lib_hash == source_hash()),
+                    hbm_gbps=(round(prof["traffic"] / (kern_ms * 1e-3) / 1e9, 1) if live("traffic") else None),
+                    hbm_frac_of_8TBps=(round(prof["traffic"] / (kern_ms * 1e-3) / 8e12, 4) if live("traffic") else None),
+                    mfma_busy_frac=live("mfma_busy_frac"), valu_per_mfma=live("valu_per_mfma"), wait_frac=live("wait_frac"),
+                    profile_kernel_ms=live("profile_kernel_ms"), profile_tflops_from_SQ_INSTS_MFMA=live("profile_tflops_from_SQ_INSTS_MFMA"),
                     fp64_equivalent_tflops=round(float(n) * n / world * 2.0 * 4 * KS / (kern_ms * 1e-3) / 1e12, 2))
         cpu = None
-        dlnE = None
-        extras = None
         fp64_mode = None
         e2e = None
         if world == 1:
-            from oracle import oracle_np as orc                 # checker / baseline only
             if a.cpu_sample > 0:
                 rng = np.random.default_rng(0)
                 rows = np.sort(rng.choice(n, size=min(a.cpu_sample, n), replace=False))
@@ -399,30 +533,22 @@ def main():
             lnE_e2e = mce.evidence()
             e2e = dict(seconds=round(time.perf_counter() - t2, 4), queries_per_s=round(n / (time.perf_counter() - t2), 1),
                        max_abs_dlnE_vs_resident_path=float(np.max(np.abs(lnE_e2e - lnE))))
-            if not a.no_extras and (n, d, kmax, a.mode) == (1_000_000, 27, 10, 0):
-                del ws
-                torch.cuda.empty_cache()
-                fp64_mode = time_resident(_capi, torch, Xh, None, kmax, 1, steps=3, warmup=1, nsample=0, orc=orc, mode=1, weight=weight, fsv=fsh)
-                fp64_mode["roofline"] = dict(bound="mfma", achieved=round(float(n) * n * 2.0 * 4 * KS / (fp64_mode["kernel_ms"] * 1e-3) / 1e12, 2), peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
-                                             frac=round(float(n) * n * 2.0 * 4 * KS / (fp64_mode["kernel_ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
+            if want_extras:
+                fp64_mode, _, _ = time_config(ctx, c3, 3, 1, mode=1)
+                fl = float(n) * n * 2.0 * 4 * KS / (fp64_mode["kernel_ms"] * 1e-3) / 1e12
+                fp64_mode["roofline"] = dict(bound="mfma", achieved=round(fl, 2), peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=round(fl / FP64_PEAK_TFLOPS, 4),
                                              note="pure fp64 arithmetic: v_mfma_f64_16x16x4_f64 over all pairs (2*4*KS flop/pair, unpadded rows) + fp64 refine")
-                dp64 = np.array(fp64_mode.pop("dotp"))
-                l64 = np.array([math.log(SumW * dp64[k] / (n * k + 1.0) * cov["J"]) + logLmax for k in range(1, kmax)])
-                fp64_mode["max_abs_dlnE_vs_default_mode"] = float(np.max(np.abs(l64 - lnE)))
-                extras = extra_configs(_capi, torch, orc, pkg)
-                for c in extras.values():
-                    c.pop("dotp", None)
-        gold = os.path.join(REPO, "tests", "golden", "evidence_big.json")
-        if (n, d, kmax) == (1_000_000, 27, 10) and os.path.exists(gold):
-            for c in json.load(open(gold)):
-                if c["name"] == "auto_n1000000_d27_k10_C3":
-                    dlnE = float(np.max(np.abs(lnE - np.array(c["lnE"]))))
+                fp64_mode["max_abs_dlnE_vs_default_mode"] = float(np.max(np.abs(np.array(fp64_mode["lnE"]) - lnE)))
+                extras = extra_configs(ctx, orc, pkg, a.extras_scale)
+        dlnE = head.get("max_abs_dlnE_vs_reference") if (n, d, kmax) == (1_000_000, 27, 10) else None
         out = dict(metric="knn_queries_per_sec", value=round(n / (ms_step * 1e-3), 1), unit="queries/s", n_gpus=world,
                    steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True,
                    scaling="strong", vs_baseline=None, dtype="f64" if a.mode == 1 else "f16 filter + f64 refine (exact f64 results)", data="synthetic",
                    config=dict(workload="C3: auto-evidence, seeded Gaussian chain N=%d D=%d kmax=%d (K=%d true neighbours/query), %s" %
-                               (n, d, kmax, K, "one GPU" if world == 1 else "symmetric partition over %d GPUs (DESIGN.md 5), one all-reduce of kmax doubles" % world),
+                               (n, d, kmax, K, "one GPU" if world == 1 else "the library's partition over %d GPUs (DESIGN.md 5), one all-reduce of kmax doubles" % world),
                                N=n, D=d, kmax=kmax, ranks=world),
+                   ranks_seen=(dist.get_world_size() if world > 1 else 1), backend=(dist.get_backend() if world > 1 else None),
+                   per_rank=head.get("per_rank"),
                    max_abs_dlnE_vs_reference=dlnE, lnE=[round(float(x), 10) for x in lnE],
                    roofline=roof, cpu_baseline=cpu, evidence_call_from_host=e2e, configs=extras, fp64_mode=fp64_mode)
         print(json.dumps(out), flush=True)

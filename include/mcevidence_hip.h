@@ -88,7 +88,8 @@ int mce_dotp_f64(const double *dist, int64_t nq, int32_t ld, int32_t k0, int32_t
  * the reference's DkNN).  With ndev > 1 (devices[i] = HIP ordinal; NULL/0 -> device 0 only) the work is split over the
  * devices -- auto evidence of one set: the library's partition (mce_knn_dotp_part_f64), otherwise equal ranges of the
  * query rows -- by one host thread per device, and the partial sums are added ON THE HOST in device order (bitwise
- * reproducible whatever the device count; SURVEY.md 8e's "alternatively").  The library itself has no RCCL dependency:
+ * reproducible run to run FOR A GIVEN DEVICE COUNT: the partition, hence the order of the sum, changes with the count;
+ * SURVEY.md 8e's "alternatively").  The library itself has no RCCL dependency:
  * the one collective of a multi-PROCESS run -- an all-reduce of kmax doubles -- is the caller's
  * (mcevidence_amd/parallel.py: torch.distributed over RCCL), on the partial sums mce_knn_dotp_part_f64 returns. */
 int mce_knn_dotp_f64(const double *X, int64_t nq, const double *Y, int64_t nr, int32_t d, int32_t kmax,
@@ -173,6 +174,10 @@ int mce_knn_dotp_part_f64(const double *Y, int64_t nr, int32_t d, int32_t kmax, 
 /* Name of the dominant kernel last launched by this thread and its launch
  * geometry (for bench.py / profiles): "knn_mfma_f64<KS=7,KCAP=12>" etc. */
 const char *mce_last_kernel(void);
+/* SHA-256 (hex) of the kernel sources this library was built from (every .hpp and .hip file of csrc/ in name order; csrc/Makefile).
+ * A committed rocprofv3 profile carries the same digest (profiles/<round>/meta.json): bench.py only quotes counters of a
+ * profile that was taken from THESE sources. */
+const char *mce_source_hash(void);
 
 /* The host-pointer entry points keep their small device buffers (<= 64 MB each) in a per-thread
  * pool between calls; this frees them. */
@@ -189,7 +194,8 @@ int mce_get_search_mode(void);
  *   - the *_opt entry points below take a trailing `const mce_options*` (NULL: the defaults);
  *   - mce_options_push(&o) ... mce_options_pop() bracket any other entry point: the pushed modes apply to the calls THIS
  *     THREAD makes in between (they nest; threads the library starts itself, one per device, inherit them).
- * A mode of -1 means "the process default".  `size` must be sizeof(mce_options) (room to grow). */
+ * A mode of -1 means "the process default".  `size` = sizeof(mce_options) as the CALLER was built (room to grow): at least
+ * 16 (size + the three modes); a field beyond `size` is never read and counts as -1. */
 typedef struct mce_options {
     int32_t size;
     int32_t search_mode;   /* as mce_set_search_mode */
@@ -229,8 +235,8 @@ int mce_get_prune_mode(void);
  * 512 rows sweeps only the blocks before it, and each tile is gated for the streamed rows
  * too; their candidates are merged into the lists afterwards.  Same neighbours, distances and tie-breaks as
  * the exhaustive search.  0 (default): where it was measured faster and pruning does not apply -- from 768 blocks of
- * 512 rows (393 k rows; twice that with K > 12) where the filter takes one 16-wide k-step (d <= 14), from 257 blocks
- * (131 k rows) with two (d <= 30), from 193 (99 k rows) beyond (capi.hip: kSymAutoMinBlocks);
+ * 512 rows (393 k rows; twice that with K > 12) where the filter takes one 16-wide k-step (d <= 15: capi.hip
+ * f16_ksteps(d) = (d + 16) / 16), from 257 blocks (131 k rows) with two (d <= 31), from 193 (99 k rows) beyond (kSymAutoMinBlocks);
  * 1: never; 2: whenever the shape allows it (fp16-filter shapes with K <= 16, more than 512 rows).
  * Process-wide default (per call: mce_options); the environment variable MCE_SYM sets the initial value.
  * Multi-GPU: up to four ranks mce_knn_dotp_part_f64 partitions such a search by ranges of the sorted blocks (symmetric

@@ -39,6 +39,7 @@ SIGNATURES = {
     "mce_device_count": (_c.c_int, []),
     "mce_last_error": (_c.c_char_p, []),
     "mce_last_kernel": (_c.c_char_p, []),
+    "mce_source_hash": (_c.c_char_p, []),
     "mce_release_device_memory": (None, []),
     "mce_set_search_mode": (_c.c_int, [_c.c_int]),
     "mce_get_search_mode": (_c.c_int, []),
@@ -121,6 +122,11 @@ def last_error():
 
 def last_kernel():
     return load().mce_last_kernel().decode("utf-8", "replace")
+
+
+def source_hash():
+    """SHA-256 of the kernel sources the loaded library was built from (csrc/Makefile: src_hash.h)"""
+    return load().mce_source_hash().decode("ascii")
 
 
 MODE_AUTO, MODE_F64, MODE_F16_FILTER = 0, 1, 2

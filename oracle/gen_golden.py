@@ -15,7 +15,7 @@ SURVEY.md section 8c) and records, for seeded synthetic chains made by
   * a few sampled rows of the whitened samples and of DkNN.
 
 Outputs are data only (JSON/NPZ under tests/golden/).  No reference source is
-copied.  Usage:  python oracle/gen_golden.py [--small] [--medium] [--big] [--sym] [--host] [--c4 [--c4-n N]]
+copied.  Usage:  python oracle/gen_golden.py [--small] [--medium] [--big] [--sym] [--host] [--c4 [--c4-n N]] [--c5 [--c5-n N]]
 """
 from __future__ import annotations
 
@@ -277,6 +277,63 @@ def gen_c4(ref, n, tag):
     print("%-36s lnE=%s fit=%s (%.1fs)" % (name, np.array2string(np.asarray(lnE), precision=10), seen["fit_method"], wall), flush=True)
 
 
+def gen_c5(ref, n, tag):
+    """BASELINE configs[4] (C5): auto evidence of ``synth.config_chain('C5')`` -- n rows, d = 6, kmax = 10 (ONE K = 11
+    search serves the k = 2..10 sweep the config names: the reference returns ln E for k_nn = 1..kmax-1 from one call,
+    ``MCEvidence.py:1107-1131, :1157``).  kd_tree at d = 6 (``:1099-1104``); a spy on ``NearestNeighbors.kneighbors`` keeps
+    the distances the reference's own call returned, from which ``dotp`` (``:1117``) and a few rows are recorded."""
+    from sklearn.neighbors import NearestNeighbors
+    from mcevidence_amd.synth import config_chain, CONFIGS
+
+    chain, _ = config_chain("C5", n=n)
+    kmax = CONFIGS["C5"]["kmax"]
+    seen = {}
+    orig_kn = NearestNeighbors.kneighbors
+
+    def spy(self, X=None, *a, **k):
+        t = time.perf_counter()
+        out = orig_kn(self, X, *a, **k)
+        seen["DkNN"], seen["fit_method"], seen["n_fit"] = out[0], str(self._fit_method), int(self.n_samples_fit_)
+        seen["knn_s"] = time.perf_counter() - t
+        return out
+
+    NearestNeighbors.kneighbors = spy
+    t0 = time.perf_counter()
+    try:
+        mce = ref.MCEvidence([chain], kmax=kmax, verbose=0)
+        lnE = mce.evidence()
+    finally:
+        NearestNeighbors.kneighbors = orig_kn
+    wall = time.perf_counter() - t0
+    DkNN = seen["DkNN"]
+    S, D = int(mce.nchain[0][0]), int(mce.ndim)
+    s1, logL, w, _ = mce.get_samples(S, istart=0, rand=False, prewhiten=False, name="s1")
+    cov = mce.get_covariance()
+    X = mce.diagonalise_chain(s1.copy(), cov["eVec"], cov["eVal"])
+    logLmax = float(np.amax(logL))
+    fs = logL - logLmax
+    SumW = float(np.sum(mce.gd.data["s1"].adjusted_weights))
+    dotp, lnE_re = np.zeros(kmax), np.zeros(kmax)
+    for k in range(1, kmax):
+        vol = math.pi ** (D / 2) * DkNN[:, k] ** D / math.gamma(1 + D / 2)
+        dotp[k] = np.dot(vol / w, np.exp(fs))
+        lnE_re[k] = math.log(SumW * dotp[k] / (S * k + 1.0) * cov["J"]) + logLmax - math.log(mce.priorvolume)
+    assert np.allclose(lnE_re[1:], lnE, rtol=0, atol=1e-12), (lnE_re, lnE)
+    rows = np.linspace(0, S - 1, 64).astype(np.int64)
+    name = "auto_n%d_d6_k10_C5" % n
+    js = dict(name=name, config="C5", n_per_chain=n, chain=dict(seed=CONFIGS["C5"]["seed"], n=n, d=6, cov="corr"), mce=dict(kmax=kmax), ev={},
+              seed_split=None, S=S, N_ref=seen["n_fit"], ndim=D, kmax=kmax, k0=1, J=float(cov["J"]), SumW=SumW, logLmax=logLmax,
+              lnPriorVolume=math.log(mce.priorvolume), dotp=[float(x) for x in dotp], lnE=[float(x) for x in lnE],
+              fit_method=seen["fit_method"], ref_wall_s=wall, ref_kneighbors_s=seen["knn_s"], ref_cores=os.cpu_count(),
+              versions=dict(numpy=np.__version__, sklearn=__import__("sklearn").__version__))
+    with open(os.path.join(GOLD, "evidence_%s.json" % tag), "w") as fh:
+        json.dump([js], fh, indent=1)
+    np.savez_compressed(os.path.join(GOLD, "evidence_%s.npz" % tag), **{name + "__rows": rows, name + "__X_rows": X[rows],
+                                                                      name + "__DkNN_rows": DkNN[rows]})
+    print("%-36s lnE=%s fit=%s (%.1fs, kneighbors %.1fs)" % (name, np.array2string(np.asarray(lnE), precision=10), seen["fit_method"],
+                                                          wall, seen["knn_s"]), flush=True)
+
+
 def gen_host_pins(ref):
     """Host-bookkeeping pins: file loading, burn-in,
     thinning, idchain, prior volume, error behaviour."""
@@ -382,6 +439,8 @@ def main():
     ap.add_argument("--host", action="store_true")
     ap.add_argument("--c4", action="store_true", help="BASELINE configs[3] at full size: hours of kd_tree on 8 cores")
     ap.add_argument("--c4-n", type=int, default=1_000_000, help="rows per chain for --c4 (smaller: a quick harness check)")
+    ap.add_argument("--c5", action="store_true", help="BASELINE configs[4] at full size: ~20 min of kd_tree + the Python volume loop")
+    ap.add_argument("--c5-n", type=int, default=10_000_000, help="rows for --c5 (smaller: a quick harness check)")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     ref = import_reference()
@@ -399,6 +458,8 @@ def main():
         gen_host_pins(ref)
     if a.c4:
         gen_c4(ref, a.c4_n, "c4" if a.c4_n == 1_000_000 else "c4_n%d" % a.c4_n)
+    if a.c5:
+        gen_c5(ref, a.c5_n, "c5" if a.c5_n == 10_000_000 else "c5_n%d" % a.c5_n)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,113 @@
+"""bench.py's own logic: the self-launch of `--gpus N`, ln E from the reduced sums, the staleness guard of the profile
+counters (CPU), and the whole N = 2 path from a plain shell on the GPU box (both ranks on its one GPU, gloo)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import LNE_TOL, load_golden
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = load_golden()
+
+
+def test_self_launch_starts_one_rank_per_gpu(monkeypatch):
+    import bench
+    started = []
+
+    class FakeProc(object):
+        def __init__(self, cmd, env=None):
+            self.cmd, self.env, self.code, self.terminated = cmd, env, (3 if env["RANK"] == "2" else 0), False
+            started.append(self)
+
+        def poll(self):
+            return self.code
+
+        def terminate(self):
+            self.terminated = True
+
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    assert bench.self_launch(["--gpus", "4", "--n", "5000"], 4) == 3          # a failing rank's exit code is the parent's
+    assert [p.env["RANK"] for p in started] == ["0", "1", "2", "3"] and [p.env["LOCAL_RANK"] for p in started] == ["0", "1", "2", "3"]
+    for p in started:
+        assert p.cmd == [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--n", "5000"]
+        assert p.env["WORLD_SIZE"] == "4" and p.env["MASTER_ADDR"] == "127.0.0.1" and 0 < int(p.env["MASTER_PORT"]) < 65536
+        assert p.env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert len({p.env["MASTER_PORT"] for p in started}) == 1
+
+
+def test_parent_of_a_self_launch_never_imports_torch():
+    """`python bench.py --gpus 2` without a launcher: the parent only spawns (nothing that could initialise the GPU is even
+    imported); here the ranks are replaced by a stub."""
+    code = ("import sys, runpy, subprocess\n"
+            "class P(object):\n"
+            "    def __init__(self, cmd, env=None): print('SPAWN', 'torch' in sys.modules, env['RANK'], env['WORLD_SIZE'])\n"
+            "    def poll(self): return 0\n"
+            "subprocess.Popen = P\n"
+            "sys.argv = ['bench.py', '--gpus', '2']\n"
+            "runpy.run_path(%r, run_name='__main__')\n" % os.path.join(REPO, "bench.py"))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "SPAWN False 0 2" in r.stdout and "SPAWN False 1 2" in r.stdout
+
+
+@pytest.mark.parametrize("name", ["auto_n1000000_d27_k10_C3", "cross_n1000000_d15_k4_C4", "auto_n100000_d6_k4_C2"])
+def test_lnE_from_the_reduced_sums_is_the_references(name):
+    """bench.lnE_from_dotp restates MCEvidence.py:1120-1131 + the slice of :1157 -- fed the reference's own dotp and scalars
+    it must give the reference's ln E (auto: k_nn = 1..kmax-1; cross: 2..kmax)."""
+    import bench
+    c = G[name]
+    cfg = dict(k0=c["k0"], kmax=c["kmax"], S=c["S"], SumW=c["SumW"], J=c["J"], logLmax=c["logLmax"])
+    got = bench.lnE_from_dotp(np.array(c["dotp"]), cfg, c["lnPriorVolume"])
+    assert got.shape == (c["kmax"] - 1,) and np.max(np.abs(got - np.array(c["lnE"]))) < 1e-12
+
+
+def test_counters_of_a_profile_from_other_sources_are_flagged_stale():
+    import bench
+    desc = "knn_f16_kernel<KST=2,KCAP=12> symmetric panel-kernel grid=5964"
+    c = bench.profile_counters(desc, library_hash="not-the-hash-of-any-profile")
+    if not c:
+        pytest.skip("no committed profile of the panel kernel")
+    assert c["stale"] is True
+    if c.get("profile_source_hash"):
+        assert bench.profile_counters(desc, library_hash=c["profile_source_hash"])["stale"] is False
+
+
+def test_library_carries_the_digest_of_the_sources_in_the_tree():
+    import bench
+    from mcevidence_amd import _capi
+    assert _capi.source_hash() == bench.source_hash()
+
+
+def _bench_line(args, env_extra, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout, cwd=REPO)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_from_a_plain_shell():
+    """`python bench.py --gpus 2` with no launcher around it (what the driver's SCALE run does): the parent starts two ranks,
+    every config is timed under N = 2 with one all-reduce per step, and the sums equal the single-rank run's.  Both ranks
+    share this box's one GPU (MCE_BENCH_ONE_DEVICE=1) over gloo; sizes scaled down."""
+    common = ["--steps", "2", "--warmup", "1", "--n", "150000", "--d", "27", "--kmax", "10", "--cpu-sample", "0", "--extras-scale", "0.05"]
+    two = _bench_line(["--gpus", "2"] + common, dict(MCE_BENCH_BACKEND="gloo", MCE_BENCH_ONE_DEVICE="1"))
+    one = _bench_line(["--gpus", "1"] + common, {})
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and two["backend"] == "gloo" and one["n_gpus"] == 1
+    assert [r["rank"] for r in two["per_rank"]] == [0, 1] and all(r["device"] == 0 for r in two["per_rank"])
+    assert two["steps"] == 2 and two["warmup"] == 1 and two["scaling"] == "strong"
+    assert np.max(np.abs(np.array(two["lnE"]) - np.array(one["lnE"]))) < LNE_TOL
+    for name in ("C2", "C4", "C5"):
+        a, b = two["configs"][name], one["configs"][name]
+        assert a["ranks"] == 2 and len(a["per_rank"]) == 2 and a["ms_per_step"] > 0
+        assert np.max(np.abs(np.array(a["lnE"]) - np.array(b["lnE"]))) < LNE_TOL, name
+    assert sum(r["query_rows"] for r in two["configs"]["C4"]["per_rank"]) == two["configs"]["C4"]["nq"]      # cross: row shards of s1
+    assert "pruned" in two["configs"]["C5"]["kernel"] and "pruned" in one["configs"]["C5"]["kernel"]

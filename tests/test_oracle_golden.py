@@ -130,3 +130,18 @@ def test_oracle_reproduces_the_reference_on_an_explicit_pair_C4_shape():
         rows = case["arrays"]["rows"]
         assert np.allclose(out["DkNN"][rows][:, :4], case["arrays"]["DkNN_rows"][:, :4], rtol=DIST_RTOL, atol=0)
     assert case["fit_method"] == "kd_tree"
+
+
+def test_oracle_reproduces_the_reference_at_C5_shape():
+    """BASELINE configs[4] (C5) at 1/50 of its size: synth.config_chain('C5', n=200000) -- d = 6, kmax = 10, auto evidence,
+    kd_tree in the reference (oracle/gen_golden.py --c5 --c5-n 200000).  The oracle reproduces ln E for the whole k sweep,
+    the per-k dotp and the sampled distance rows, through the reference's sklearn call and through the exact C search."""
+    case = G["auto_n200000_d6_k10_C5"]
+    for knn in ("sklearn", "brute"):
+        out = orc.evidence_from_chain(chain_of(case), kmax=10, knn=knn)
+        assert out["k0"] == 1 and out["S"] == case["S"] == 200000
+        assert np.allclose(out["lnE"], case["lnE"], rtol=0, atol=LNE_TOL)
+        assert np.allclose(out["dotp"][1:], case["dotp"][1:], rtol=1e-10)
+        rows = case["arrays"]["rows"]
+        assert np.allclose(out["DkNN"][rows][:, 1:10], case["arrays"]["DkNN_rows"][:, 1:10], rtol=DIST_RTOL, atol=0)
+    assert case["fit_method"] == "kd_tree"

@@ -2,7 +2,6 @@
 # GPU box: A/B of microbench binaries on ONE box (boxes of the pool differ by several per cent): each binary twice, interleaved.
 # usage: tools/ab.sh "<args>" bin1 bin2 ...   -> one line per binary: the sweep times of the last repetition of each run
 args=$1; shift
-for b in "$@"; do r[$b]=""; done
 declare -A res
 for i in 1 2; do
   for b in "$@"; do
