@@ -455,6 +455,19 @@ def main():
     ms_step, kern_ms = head["ms_per_step"], stats["kernel_ms"]
     lnE = np.array(head["lnE"])
 
+    e2e_ranks = None
+    if world > 1:
+        # the whole MCEvidence(...).evidence() call from host arrays under the process group: each rank uploads the chain once,
+        # whitens on its device, searches its share (mce_evidence_feed_part_f64), ONE all-reduce -- the PCIe-inclusive figure
+        mce.evidence()
+        ctx.barrier()
+        t2 = time.perf_counter()
+        lnE_e2e = mce.evidence()
+        mine = torch.tensor([time.perf_counter() - t2, float(np.max(np.abs(lnE_e2e - lnE)))], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        e2e_ranks = [dict(rank=i, seconds=round(float(t[0]), 4), max_abs_dlnE_vs_resident_path=float(t[1])) for i, t in enumerate(allr)]
+
     orc = None
     if rank == 0:
         from oracle import oracle_np as orc                 # checker / CPU baseline only; never inside a timed region
@@ -540,6 +553,11 @@ def main():
                                              note="pure fp64 arithmetic: v_mfma_f64_16x16x4_f64 over all pairs (2*4*KS flop/pair, unpadded rows) + fp64 refine")
                 fp64_mode["max_abs_dlnE_vs_default_mode"] = float(np.max(np.abs(np.array(fp64_mode["lnE"]) - lnE)))
                 extras = extra_configs(ctx, orc, pkg, a.extras_scale)
+        if e2e_ranks:
+            slow = max(r["seconds"] for r in e2e_ranks)
+            e2e = dict(seconds=slow, queries_per_s=round(n / slow, 1), per_rank=e2e_ranks,
+                       max_abs_dlnE_vs_resident_path=max(r["max_abs_dlnE_vs_resident_path"] for r in e2e_ranks),
+                       note="every rank: one upload of the chain, device covariance + whitening, its share of the search, one all-reduce")
         dlnE = head.get("max_abs_dlnE_vs_reference") if (n, d, kmax) == (1_000_000, 27, 10) else None
         out = dict(metric="knn_queries_per_sec", value=round(n / (ms_step * 1e-3), 1), unit="queries/s", n_gpus=world,
                    steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True,

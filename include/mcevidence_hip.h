@@ -113,6 +113,19 @@ int mce_evidence_feed_f64(const double *S1, int64_t n1, int64_t ld1, const doubl
                           int32_t d, int32_t cov_mode, int32_t kmax, const double *w, const double *fs,
                           double *dotp, double *jacobian, double *eigenvalues, int32_t device);
 
+/* One rank's share of mce_evidence_feed_f64 (multi-GPU, one process per GPU: SURVEY.md 8e; reference
+ * MCEvidence.py:1034-1131): every rank passes the SAME arrays; this rank uploads them once, computes covariance, eigen-system
+ * and whitening on its device like the single-rank call (identical on every rank), and searches only its share -- auto
+ * evidence: the library's partition (mce_knn_dotp_part_f64); cross evidence: the rows [n1 part / nparts, n1 (part + 1) /
+ * nparts) of S1 against all of S2.  dotp_part[kmax] = this rank's partial sums: ONE all-reduce(sum) over the ranks -- the
+ * caller's (parallel.py: RCCL) -- completes them; jacobian / eigenvalues as in mce_evidence_feed_f64.
+ * *checksum (may be NULL): a 64-bit fingerprint of the uploaded rows, weights and fs computed ON THE DEVICE (one extra
+ * pass at HBM speed) -- ranks that were handed different samples are detected by comparing it, without hashing on the host. */
+int mce_evidence_feed_part_f64(const double *S1, int64_t n1, int64_t ld1, const double *S2, int64_t n2, int64_t ld2,
+                               int32_t d, int32_t cov_mode, int32_t kmax, const double *w, const double *fs,
+                               int32_t part, int32_t nparts, double *dotp_part, double *jacobian, double *eigenvalues,
+                               uint64_t *checksum, int32_t device);
+
 /* Many independent evidence problems in one call: the reference's Planck driver
  * runs MCEvidence(...).evidence() once per (data set, model, chain) -- ~600-2400 chains of 6k-100k
  * rows, D = 6-8 -- farmed over MPI ranks (planck_mcevidence.py:306-348).  One such chain fills a

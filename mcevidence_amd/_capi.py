@@ -63,6 +63,8 @@ SIGNATURES = {
     "mce_knn_dotp_f64": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _P, _P, _P, _c.c_int32]),
     "mce_evidence_feed_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32,
                                          _P, _P, _P, _P, _P, _c.c_int32]),
+    "mce_evidence_feed_part_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32,
+                                              _P, _P, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _c.c_int32]),
     "mce_knn_dotp_part_f64_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _c.c_size_t, _P]),
     "mce_knn_dotp_part_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_int32]),
     "mce_knn_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32]),
@@ -369,6 +371,30 @@ def evidence_feed(S1, S2, d, cov_mode, kmax, w, fs, device=0):
                                     0 if S2 is None else S2.strides[0] // 8, int(d), int(cov_mode), int(kmax),
                                     w.ctypes.data, fs.ctypes.data, out.ctypes.data, ctypes.byref(jac), ev.ctypes.data, int(device)))
     return out, float(jac.value), ev
+
+
+def evidence_feed_part(S1, S2, d, cov_mode, kmax, w, fs, part, nparts, device=0, want_checksum=True):
+    """One rank's share of ``evidence_feed`` (``mce_evidence_feed_part_f64``): every rank passes the same arrays, uploads them
+    once, whitens on its device and searches its share.  Returns (dotp_part[kmax], jacobian, eigenvalues[d], checksum) --
+    the partial sums still to be all-reduced over the ranks, and the device-side fingerprint of the uploaded inputs
+    (None if not asked for)."""
+    lib = load()
+    S1 = _rows_f64(S1, "samples", d, check=False)
+    S2 = None if S2 is None else _rows_f64(S2, "samples2", d, check=False)
+    w = _f64(w, "weight")
+    fs = _f64_fs(fs)
+    if w.shape != (S1.shape[0],) or fs.shape != w.shape:
+        raise ValueError("weight and fs must have one entry per s1 row")
+    out = np.zeros(int(kmax))
+    jac = ctypes.c_double(0.0)
+    ev = np.zeros(int(d))
+    csum = ctypes.c_uint64(0)
+    check(lib.mce_evidence_feed_part_f64(S1.ctypes.data, S1.shape[0], S1.strides[0] // 8,
+                                         S2.ctypes.data if S2 is not None else None, 0 if S2 is None else S2.shape[0],
+                                         0 if S2 is None else S2.strides[0] // 8, int(d), int(cov_mode), int(kmax),
+                                         w.ctypes.data, fs.ctypes.data, int(part), int(nparts), out.ctypes.data, ctypes.byref(jac),
+                                         ev.ctypes.data, ctypes.byref(csum) if want_checksum else None, int(device)))
+    return out, float(jac.value), ev, (int(csum.value) if want_checksum else None)
 
 
 def _devices_arg(devices):

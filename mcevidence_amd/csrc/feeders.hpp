@@ -112,4 +112,28 @@ __global__ __launch_bounds__(kWhitenRows) void whiten_kernel(const double* S, in
     }
 }
 
+
+// 64-bit fingerprint of a device buffer of 8-byte words: sum over i of mix64(word_i + (salt + i) * golden) -- the sum of
+// per-word hashes is order-independent (integer adds), position-sensitive (i enters the hash), and costs one pass at HBM
+// speed.  Used by the multi-rank feed (mce_evidence_feed_part_f64) to check that every rank was handed the same samples,
+// weights and likelihoods -- where the host route hashed all bytes with BLAKE2b (0.3 s per GB).  `out` accumulates:
+// clear it, then launch once per buffer with different salts.
+constexpr int kSumThreads = 256;
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(kSumThreads) void checksum_kernel(const unsigned long long* __restrict__ words, int64_t n,
+                                                               unsigned long long salt, unsigned long long* __restrict__ out)
+{
+    unsigned long long h = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kSumThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kSumThreads)
+        h += mix64(words[i] + (salt + (unsigned long long)i) * 0x9E3779B97F4A7C15ull);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) h += __shfl_xor(h, o, 64);
+    if ((threadIdx.x & 63) == 0 && h != 0) atomicAdd(out, h);
+}
+
 }  // namespace mce

@@ -40,16 +40,32 @@ class HipBackend(object):
 
     name = "hip"
 
-    def __init__(self, devices=None):
+    def __init__(self, devices=None, verify=True):
         self.devices = devices
+        self.verify = verify        # multi-rank runs: compare a fingerprint of the inputs across the ranks on every call
 
     def evidence_feed(self, S1, S2, ndim, cov_mode, kmax, weight, fs):
         """feeders on the device too (get_covariance + diagonalise_chain + the hot path, one upload);
         returns (dotp, J) or None when this route does not apply (multi-process / multi-device runs)."""
         from . import parallel
-        if parallel.is_distributed() or self.devices not in (None, [0], (0,)) or ndim > 63:
+        if ndim > 63:
             return None
         from . import _capi
+        if parallel.is_distributed():
+            # one process per GPU: every rank uploads the (replicated) chain once, whitens it on ITS device and searches
+            # its share; ONE all-reduce of kmax (+ 8: the input fingerprints) doubles completes the sums
+            # (mce_evidence_feed_part_f64; reference MCEvidence.py:1034-1131)
+            import torch
+            import torch.distributed as dist
+            if self.devices not in (None, [0], (0,)) and len(self.devices) != 1:
+                return None
+            group = parallel.current_group()
+            dev = self.devices[0] if self.devices else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+            part, jac, _, csum = _capi.evidence_feed_part(S1, S2, ndim, cov_mode, kmax, weight, fs, dist.get_rank(group),
+                                                          dist.get_world_size(group), device=dev, want_checksum=self.verify)
+            return parallel.feed_part_reduce(part, csum, group), jac
+        if self.devices not in (None, [0], (0,)):
+            return None
         dotp, jac, _ = _capi.evidence_feed(S1, S2, ndim, cov_mode, kmax, weight, fs)
         return dotp, jac
 

@@ -107,6 +107,33 @@ def check_replicas(X, Y, weight, fs, group=None):
             "drawn on rank 0 and broadcast), from the same chains.")
 
 
+def feed_part_reduce(dotp_part, checksum, group=None):
+    """The ONE collective of a multi-rank ``evidence()`` on the device-feeder route: all-reduce(sum) of this rank's
+    partial sums, with the comparison of the ranks' input fingerprints riding in the same message.  The 64 bits of the
+    checksum travel as four 16-bit pieces p and their squares: every rank holds the same piece iff
+    W * sum(p^2) == (sum p)^2 (Cauchy-Schwarz; all exact in fp64 for W <= 1024: both sides < 2^52).  Raises on every rank
+    when the inputs differ."""
+    import torch.distributed as dist
+    group = _GROUP if group is None else group
+    world = dist.get_world_size(group)
+    kmax = len(dotp_part)
+    vec = np.zeros(kmax + 8)
+    vec[:kmax] = dotp_part
+    if checksum is not None:
+        pieces = [float((int(checksum) >> (16 * i)) & 0xFFFF) for i in range(4)]
+        vec[kmax:kmax + 4] = pieces
+        vec[kmax + 4:] = [p * p for p in pieces]
+    vec = _reduce_partial(vec, group)
+    if checksum is not None and world <= 1024:
+        s, s2 = vec[kmax:kmax + 4], vec[kmax + 4:]
+        if np.any(world * s2 != s * s):
+            raise RuntimeError(
+                "mcevidence_amd: the ranks of this process group hold different samples/weights (fingerprints differ). "
+                "Construct MCEvidence on every rank AFTER init_process_group (random splits and thinning are then "
+                "drawn on rank 0 and broadcast), from the same chains.")
+    return vec[:kmax]
+
+
 def symmetric_partition_rows(Y, world, rank, block=512):
     """The rows whose evidence terms rank ``rank`` of ``world`` sums when the library partitions a symmetric
     auto-evidence search (``mce_knn_dotp_part_f64``) -- restated on the host for tests and diagnostics:

@@ -104,6 +104,8 @@ def test_bench_gpus_2_from_a_plain_shell():
     assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and two["backend"] == "gloo" and one["n_gpus"] == 1
     assert [r["rank"] for r in two["per_rank"]] == [0, 1] and all(r["device"] == 0 for r in two["per_rank"])
     assert two["steps"] == 2 and two["warmup"] == 1 and two["scaling"] == "strong"
+    e2e = two["evidence_call_from_host"]                  # the class under the process group: part feed + one all-reduce
+    assert len(e2e["per_rank"]) == 2 and e2e["max_abs_dlnE_vs_resident_path"] < LNE_TOL
     assert np.max(np.abs(np.array(two["lnE"]) - np.array(one["lnE"]))) < LNE_TOL
     for name in ("C2", "C4", "C5"):
         a, b = two["configs"][name], one["configs"][name]

@@ -304,3 +304,102 @@ def test_replica_fingerprint_sees_every_row():
     B[12345, 3] = np.nextafter(B[12345, 3], 1.0)                         # one bit in one row that no sampling would hit
     assert replica_fingerprint(B, None, B[:, 0]) != h
     assert replica_fingerprint(A, None, A[:, 0]) == h and 0 <= h < 2 ** 63
+
+
+# ---- the device-feeder route of the class under a process group (mce_evidence_feed_part_f64) -------------------------------
+def _fake_feed_part(S1, S2, d, cov_mode, kmax, w, fs, part, nparts, device=0, want_checksum=True):
+    """CPU stand-in for _capi.evidence_feed_part (tests only): whitening with the covariance of all rows, this rank's
+    contiguous rows of s1 through the oracle, a byte fingerprint as the checksum."""
+    import hashlib
+    S1 = np.ascontiguousarray(np.asarray(S1)[:, :d])
+    S2a = None if S2 is None else np.ascontiguousarray(np.asarray(S2)[:, :d])
+    allrows = S1 if S2a is None else np.concatenate((S1, S2a))
+    cov = np.atleast_2d(np.cov(allrows.T))
+    ev, U = np.linalg.eigh(cov)
+    X = (S1 @ U) / np.sqrt(ev)
+    Y = X if S2a is None else (S2a @ U) / np.sqrt(ev)
+    k0 = 1 if S2a is None else 0
+    lo, hi = (len(X) * part) // nparts, (len(X) * (part + 1)) // nparts
+    dotp, _ = _local_oracle(np.ascontiguousarray(X[lo:hi]), Y, w[lo:hi], fs[lo:hi], kmax, k0, lo if k0 == 1 else 0, False)
+    h = hashlib.blake2b(digest_size=8)
+    for a in (S1, S2a, w, fs):
+        h.update(b"-" if a is None else np.ascontiguousarray(a).tobytes())
+    return dotp, float(np.sqrt(np.prod(ev))), ev[::-1].copy(), (int.from_bytes(h.digest(), "little") if want_checksum else None)
+
+
+def _feed_part_worker(rank, world, port, q, split, poison):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import logging
+    logging.disable(logging.CRITICAL)
+    import mcevidence_amd as pkg
+    from mcevidence_amd import _capi
+    from mcevidence_amd.synth import gaussian_chain
+    _capi.evidence_feed_part = _fake_feed_part
+    chain = gaussian_chain(5, 1400, 4, weights="int", cov="corr")
+    if poison and rank == 1:
+        chain = chain.copy()
+        chain[777, 3] = np.nextafter(chain[777, 3], 9.0)         # one bit of one sample differs on one rank
+    kw = dict(split=True, s1frac=0.4) if split else {}
+    m = pkg.MCEvidence([chain], kmax=4, verbose=0, **kw)
+    assert isinstance(m.backend, pkg.HipBackend)
+    try:
+        out = ("ok", m.evidence())
+    except RuntimeError as e:
+        out = ("raised", str(e))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("split,poison", [(False, False), (True, False), (False, True)])
+def test_class_under_a_process_group_takes_the_part_feed_and_one_all_reduce(split, poison):
+    """MCEvidence(...).evidence() with HipBackend under a 2-rank group: every rank hands the library the whole chain
+    (evidence_feed_part: here a CPU stand-in), gets its share of the sums, ONE all-reduce carries sums and input
+    fingerprints.  Same ln E as one process; ranks holding different samples raise on BOTH ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_feed_part_worker, args=(r, 2, port, q, split, poison)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if poison:
+        assert got[0][0] == got[1][0] == "raised" and "different samples" in got[0][1]
+        return
+    assert got[0][0] == got[1][0] == "ok" and np.array_equal(got[0][1], got[1][1])
+    import mcevidence_amd as pkg
+    from mcevidence_amd.synth import gaussian_chain
+    from helpers import OracleBackend
+    if split:
+        return      # (the realised split is rank 0's draw from the global RNG: both ranks agree -- checked above; the value itself
+                    #  is compared with a single process on the GPU box, tests/test_gpu_parity.py, with a caller-chosen split)
+    one = pkg.MCEvidence([gaussian_chain(5, 1400, 4, weights="int", cov="corr")], kmax=4, verbose=0, backend=OracleBackend()).evidence()
+    assert np.allclose(got[0][1], one, atol=1e-11)
+
+
+def test_feed_part_reduce_checks_fingerprints_exactly():
+    """the Cauchy-Schwarz test on four 16-bit pieces: exact in fp64 up to 1024 ranks"""
+    from mcevidence_amd import parallel
+    import unittest.mock as um
+    for world, sums in ((1024, [0xFFFFFFFFFFFFFFFF] * 1024), (1024, [0xFFFFFFFFFFFFFFFF] * 1023 + [0xFFFFFFFFFFFFFFFE]), (3, [5, 5, 5]), (3, [5, 5, 1 << 63])):
+        def fake_reduce(vec, group=None, _w=world, _s=sums):
+            tot = np.zeros_like(vec)
+            for c in _s:
+                p = [float((c >> (16 * i)) & 0xFFFF) for i in range(4)]
+                tot[-8:-4] += p
+                tot[-4:] += [x * x for x in p]
+            tot[:-8] = vec[:-8] * _w
+            return tot
+        with um.patch.object(parallel, "_reduce_partial", fake_reduce), um.patch("torch.distributed.get_world_size", lambda g=None: world):
+            same = len(set(sums)) == 1
+            if same:
+                assert np.array_equal(parallel.feed_part_reduce(np.array([0.0, 2.0]), sums[0]), [0.0, 2.0 * world])
+            else:
+                with pytest.raises(RuntimeError):
+                    parallel.feed_part_reduce(np.array([0.0, 2.0]), sums[0])

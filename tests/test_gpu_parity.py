@@ -1162,3 +1162,121 @@ def test_auto_evidence_reduction_at_full_size_C5():
     assert np.allclose(dist[rows], od[:, 1:], rtol=DIST_RTOL, atol=0)
     fo = np.zeros((len(rows), kmax)); fo[:, 1:] = od[:, 1:]
     assert np.allclose(orc.dotp_literal(full[rows], w[rows], fs[rows], d, 1, kmax)[1:], orc.dotp_literal(fo, w[rows], fs[rows], d, 1, kmax)[1:], rtol=1e-11, atol=0)
+
+
+# --------------------------------------------------------------------------- multi-rank evidence() on the device-feeder route
+@pytest.mark.parametrize("n,d,kmax,cross", [(60000, 6, 5, False), (150000, 27, 10, False), (310000, 6, 4, False), (50000, 15, 4, True)])
+def test_feed_parts_add_up_to_the_single_rank_feed(n, d, kmax, cross):
+    """mce_evidence_feed_part_f64: one upload, device covariance / whitening, this rank's share of the search.  The shares
+    of 1, 2, 3 and 8 ranks (all on this GPU, one after the other) add up to mce_evidence_feed_f64's sums; Jacobian and
+    eigenvalues are the single-rank ones on every rank; the device-side checksum is the same on every rank and moves with
+    one bit of one sample, weight or likelihood."""
+    from mcevidence_amd import _capi
+    from mcevidence_amd.synth import gaussian_chain
+    ch = gaussian_chain(seed=n + d, n=n, d=d, weights="int", cov="corr")
+    S1, w = ch[:, 2:], ch[:, 0]
+    fs = -ch[:, 1] - np.max(-ch[:, 1])
+    S2 = gaussian_chain(seed=n + d + 1, n=n - 1234, d=d, cov="corr")[:, 2:] if cross else None
+    full, jac, ev = _capi.evidence_feed(S1, S2, d, 0, kmax, w, fs)
+    k0 = 0 if cross else 1
+    sums = set()
+    for nparts in (1, 2, 3, 8):
+        tot = np.zeros(kmax)
+        for r in range(nparts):
+            part, j, e, cs = _capi.evidence_feed_part(S1, S2, d, 0, kmax, w, fs, r, nparts)
+            assert j == jac and np.array_equal(e, ev)
+            tot += part
+            sums.add(cs)
+        assert np.allclose(tot[k0:], full[k0:], rtol=1e-12, atol=0), nparts
+    assert len(sums) == 1
+    base = sums.pop()
+    for which in range(3):
+        A, ww, ff = S1.copy(), w.copy(), fs.copy()
+        tgt = (A, ww, ff)[which]
+        tgt[(4321,) + ((d - 1,) if which == 0 else ())] = np.nextafter(tgt[(4321,) + ((d - 1,) if which == 0 else ())], 1e9)
+        assert _capi.evidence_feed_part(A, S2, d, 0, kmax, ww, ff, 0, 2)[3] != base
+    assert _capi.evidence_feed_part(S1, S2, d, 0, kmax, w, fs, 0, 2, want_checksum=False)[3] is None
+    with pytest.raises(ValueError):
+        _capi.evidence_feed_part(S1, S2, d, 0, kmax, w, fs, 2, 2)
+
+
+def _class_rank(rank, world, port, q, cross, poison):
+    import os
+    import sys
+    import time
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)                                 # one GPU on the test box: both ranks share it
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    logging.disable(logging.CRITICAL)
+    import mcevidence_amd as pkg
+    from mcevidence_amd import _capi
+    from mcevidence_amd.synth import config_chain, gaussian_chain
+    if cross:
+        chain, (r1, r2) = config_chain("C4", n=120000)
+    else:
+        chain, r1 = gaussian_chain(seed=3, n=300000, d=27, cov="corr"), None
+    if poison and rank == 1:
+        chain = chain.copy()
+        chain[1000, 5] = np.nextafter(chain[1000, 5], 1e9)
+    m = pkg.MCEvidence([chain], kmax=4 if cross else 10, verbose=0)
+    if cross:
+        m.set_split(r1, r2)
+    try:
+        m.evidence()
+        t0 = time.perf_counter()
+        lnE = m.evidence()
+        out = ("ok", lnE, time.perf_counter() - t0, _capi.last_kernel())
+    except RuntimeError as e:
+        out = ("raised", str(e), 0.0, "")
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cross,poison", [(False, False), (True, False), (False, True)])
+def test_class_under_two_ranks_equals_the_single_rank_lnE(cross, poison):
+    """MCEvidence(...).evidence() under a 2-rank gloo group on the GPU box (both ranks on its one GPU): each rank uploads the
+    chain ONCE, whitens on the device and searches its share (mce_evidence_feed_part_f64), one all-reduce -- no host
+    covariance, no host hashing.  ln E equals the single-process result to 1e-12; a rank with one different bit makes
+    BOTH ranks raise."""
+    import socket
+    import time
+    import torch.multiprocessing as mp
+    import mcevidence_amd as pkg
+    from mcevidence_amd.synth import config_chain, gaussian_chain
+    if not poison:
+        if cross:
+            chain, (r1, r2) = config_chain("C4", n=120000)
+            m = pkg.MCEvidence([chain], kmax=4, verbose=0).set_split(r1, r2)
+        else:
+            m = pkg.MCEvidence([gaussian_chain(seed=3, n=300000, d=27, cov="corr")], kmax=10, verbose=0)
+        m.evidence()
+        t0 = time.perf_counter()
+        one = m.evidence()
+        t_one = time.perf_counter() - t0
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_class_rank, args=(r, 2, port, q, cross, poison)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    if poison:
+        assert got[0][0] == got[1][0] == "raised" and "different samples" in got[0][1]
+        return
+    assert got[0][0] == got[1][0] == "ok"
+    assert np.array_equal(got[0][1], got[1][1])
+    assert np.max(np.abs(got[0][1] - one)) < 1e-12, (got[0][1], one)
+    # both ranks share ONE GPU here, so a call cannot be faster than the single-process one; it must not be the old
+    # host detour either (np.cov + eig + whitening + BLAKE2b of the whole set on every rank: ~10x the device call)
+    assert max(got[0][2], got[1][2]) < 4.0 * t_one + 0.05, (got[0][2], got[1][2], t_one)
+    if not cross:
+        assert "symmetric" in got[0][3]          # 300 k x 27 over two ranks: the symmetric partition
