@@ -286,6 +286,8 @@ int mce_last_search_stats(double* out, int32_t n);
  * 16 * kst fp16 values (bit patterns) each.  tests/test_gpu_parity.py::test_mfma_error_model checks the error model the
  * rigorous filter bound assumes (knn_f16.hpp) against it.  No counterpart in the reference. */
 int mce_debug_mfma_tile_f16(const uint16_t* yprime, const uint16_t* xprime, int32_t kst, float* out, int32_t device);
+/* the same for `ntiles` independent tiles in one launch (yprime, xprime: [ntiles][32][16 kst]; out: [ntiles][32][32]) */
+int mce_debug_mfma_tiles_f16(const uint16_t* yprime, const uint16_t* xprime, int32_t kst, int32_t ntiles, float* out, int32_t device);
 
 #ifdef __cplusplus
 }

@@ -65,12 +65,15 @@ struct KnnF16Args {
     const float* tbox_r = nullptr;
     const float* tbox_q = nullptr;
     const float* cbox_r = nullptr;
-    const double* lo_d = nullptr;  // second pass (K > 16): the first pass's lists
+    const double* lo_d = nullptr;  // second pass (K > 16): the first pass's lists; pruned walk: the heavy blocks' side lists (written)
     const int* lo_i = nullptr;
-    int seed_cfg = 0;              // exhaustive sweep: seed phase (f16_seed_cfg: chunks | tiles per group << 16), 0 = none
-    const int* border = nullptr;   // pruned walk: dispatch order of the query blocks
-    int qblk0 = 0, qblk_stride = 1, nqblk_run = 0;   // pruned walk: nqblk_run query blocks qblk0, qblk0 + stride, ... (0: all)
+    int seed_cfg = 0;              // exhaustive sweep: seed phase (f16_seed_cfg: chunks | tiles per group << 16), 0 = none;
+                                   // pruned walk: nheavy | S << 24 -- the first nheavy waves of the launch's order are served by S workgroups each
+    const int* border = nullptr;   // pruned walk: dispatch order of the WAVES (block * 8 + wave), largest box first
+    int qblk0 = 0, qblk_stride = 1, nqblk_run = 0;   // pruned walk: nqblk_run waves border[qblk0], border[qblk0 + stride], ... (0: all);
+                                                     // symmetric prepass: nqblk_run blocks from qblk0
     SymParams sym;                 // symmetric sweep (launch_sym_pre / launch_sym); rperm = sorted position -> caller's row
+    float* wg_us = nullptr;        // diagnostic: per-workgroup duration in microseconds (MCE_PRUNE_TIMES), normally null
 };
 typedef hipError_t (*knn_f16_launch_fn)(const KnnF16Args&, hipStream_t);
 struct PanelArgs;                  // knn_panel.hpp

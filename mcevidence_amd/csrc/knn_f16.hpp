@@ -236,6 +236,13 @@ __host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST, int D, int KCA
 // entries at a time before any tile box is read.  The lists then carry the CALLER's
 // row numbers (rperm), so ties break exactly as without pruning; the own row of query q is
 // rperm-row self_offset + qperm[q].  rsplit must be 1.
+//   HEAVY waves: the first `nheavy` waves of the launch's dispatch order (largest boxes: sparse cells and waves holding a far
+//   outlier walk 10-30x the average list -- alone they are the tail of a multi-GPU part) are served by S workgroups
+//   instead of one: sub-wave s does the bootstrap like everybody, then takes the list windows s, s + S, ... and keeps its
+//   own lists; sub-wave 0's go to part_d / part_i, the others' to the side arrays (passed in lo_d / lo_i:
+//   [S - 1][KCAP][nheavy * 64]), and prune_heavy_fold_kernel (reduce_kernels.hpp) folds them into the wave's columns (what
+//   the shared bootstrap found twice is dropped there).  seed_cfg carries nheavy | S << 24 for this instantiation (it has
+//   no seed phase).
 //
 // LOWER = true: second pass of a search for 16 < K <= 32 neighbours.  The lists hold 16 entries, so the
 // first pass finds the 16 nearest per (query, reference split) and the second, identical sweep keeps only
@@ -251,8 +258,10 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
     const int* __restrict__ clist, const float* __restrict__ cdist, int list_len,
     const int* __restrict__ rperm, const int* __restrict__ qperm,
     const float* __restrict__ tbox_r, const float* __restrict__ tbox_q, const float* __restrict__ cbox_r, int qblk0, int qblk_stride, const int* __restrict__ border,
-    const double* __restrict__ lo_d, const int* __restrict__ lo_i, int seed_cfg, SymParams sym)
+    const double* __restrict__ lo_d, const int* __restrict__ lo_i, int seed_cfg, SymParams sym, float* __restrict__ wg_us)
 {
+    // wg_us (diagnostic, normally null): every workgroup leaves its duration in microseconds (capi.hip: MCE_PRUNE_TIMES)
+    const unsigned long long wg_t0 = wg_us ? wall_clock64() : 0ull;
     static_assert(!(PRUNE && LOWER), "second pass: exhaustive sweep only");
     static_assert(SYM == 0 || (!PRUNE && !LOWER), "symmetric sweep: exhaustive, single pass");
     static_assert(SYM == 0 || kHNL == 1, "symmetric sweep: one list per owner lane");
@@ -288,16 +297,25 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int lwave = PRUNE ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);                  // index into the LDS regions
-    const int wave = PRUNE ? (int)(blockIdx.x % kHWaves) : lwave;                            // position inside the query block
-    // PRUNE: the launch's (or part's) blocks are border[qblk0], border[qblk0 + stride], ...: the dispatch
-    // order puts the largest boxes -- the longest walks -- first
+    // PRUNE: workgroup -> (position k in the launch's dispatch order, sub-wave): the order is over WAVES (border[k] =
+    // block * 8 + wave, largest box first: prune.hip); the first hv_n positions hold S sub-waves each (heavy waves, see
+    // above), the rest one
+    const int hv_n = PRUNE ? (seed_cfg & 0xffffff) : 0;
+    const int hv_S = PRUNE ? (((seed_cfg >> 24) & 0x7f) > 1 ? ((seed_cfg >> 24) & 0x7f) : 1) : 1;
+    const int hv_wgs = hv_n * hv_S;
+    const bool hv_on = PRUNE && (int)blockIdx.x < hv_wgs;
+    const int pr_k = !PRUNE ? 0 : (hv_on ? (int)blockIdx.x / hv_S : hv_n + ((int)blockIdx.x - hv_wgs));
+    const int pr_sub = hv_on ? (int)blockIdx.x % hv_S : 0;
+    const int pr_step = hv_on ? hv_S : 1;                     // this wave takes every pr_step-th window of its block's list
+    const int pr_gw = PRUNE ? border[qblk0 + pr_k * qblk_stride] : 0;      // the launch's (or part's) waves: border[qblk0], border[qblk0 + stride], ...
+    const int wave = PRUNE ? pr_gw % kHWaves : lwave;                      // position inside the query block
     // SYM == 2: workgroup = UNIT (panel p of the reference rows, query block a), numbered panel by panel
     // (sym_unit_count): the units running at the same time stream the same few MB of packed rows through L2
     int sym_a = 0, sym_p = 0;
     if constexpr (SYM == 2) sym_unit_decode((int)blockIdx.x, nqblk, kHWaves * kHQT, sym.panel * f16_chunk_tiles(KST), sym_p, sym_a);
     if constexpr (SYM == 2) MCE_CHK(sym_a >= 0 && sym_a < nqblk && sym_p >= 0, 5, sym_a, sym_p, nqblk);
     // (SYM == 1, the prepass: the blocks qblk0, qblk0 + 1, ... of the launch -- one rank's share of a multi-GPU partition)
-    const int qblk = PRUNE ? border[qblk0 + (int)(blockIdx.x / kHWaves) * qblk_stride] : (SYM == 2 ? sym_a : (SYM == 1 ? qblk0 + (int)blockIdx.x : (int)(blockIdx.x % nqblk)));
+    const int qblk = PRUNE ? pr_gw / kHWaves : (SYM == 2 ? sym_a : (SYM == 1 ? qblk0 + (int)blockIdx.x : (int)(blockIdx.x % nqblk)));
     const int split = PRUNE ? 0 : (SYM >= 2 ? 0 : (int)(blockIdx.x / nqblk));
 
     if constexpr (SYM >= 2) {
@@ -1231,7 +1249,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
 #else
 #define MCE_PT(acc) do {} while (0)
 #endif
-        int e = 0;
+        int e = pr_sub * 64;                        // (heavy blocks: sub-wave s takes the windows s, s + S, ...)
         unsigned long long need = 0, cand = 0;
         int c = 0, win_c = 0;
         // Bootstrap (queries that ARE the references, same k-d order): the tiles next to the wave's own in
@@ -1314,7 +1332,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) reach |= !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]);
                         cand = __ballot(in && !far && reach);
-                        e = (__ballot(in && far) != 0) ? list_len : e + 64;
+                        e = (__ballot(in && far) != 0) ? list_len : e + 64 * pr_step;
                         st_chunks += 1;
                         if (xb_state == 0) {                           // first window of a separate query set
                             float amin = acc[0];
@@ -1483,6 +1501,19 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
 #pragma unroll
     for (int nl = 0; nl < kHNL; ++nl) {
         const int64_t q = qwave0 + nl * 64 + lane;
+        if (PRUNE && pr_sub > 0) {
+            // a heavy block's extra sub-wave: its lists go to the side arrays, column = position among the heavy blocks
+            const int64_t hcols = (int64_t)hv_n * QPW;
+            const int64_t hc = (int64_t)pr_k * QPW + nl * 64 + lane;
+            double* const hd = const_cast<double*>(lo_d);
+            int* const hi_ = const_cast<int*>(lo_i);
+#pragma unroll
+            for (int k = 0; k < KCAP; ++k) {
+                hd[((int64_t)(pr_sub - 1) * KCAP + k) * hcols + hc] = own_d[nl][k];
+                hi_[((int64_t)(pr_sub - 1) * KCAP + k) * hcols + hc] = own_i[nl][k];
+            }
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < KCAP; ++k) {
             const int64_t o = ((int64_t)split * KCAP + k) * nq_pad + q;
@@ -1497,6 +1528,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(sym.done + qblk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (wg_us && tid == 0) wg_us[blockIdx.x] = (float)(wall_clock64() - wg_t0) * 0.01f;      // 100 MHz counter
 }
 
 }  // namespace mce

@@ -60,12 +60,14 @@ hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
     // pruned walk: one 64-thread workgroup per wave of a query block
     // symmetric sweep: one workgroup per unit (sym_types.hpp); its prepass and repair launches: one per query block
     const int ntiles_even = (int)((a.nr + 31) / 32) + (int)(((a.nr + 31) / 32) & 1);
-    const dim3 grid((unsigned)(PRUNE ? (a.nqblk_run ? a.nqblk_run : a.nqblk) * kHWaves
+    const int hv_n = PRUNE ? (a.seed_cfg & 0xffffff) : 0, hv_S = PRUNE && ((a.seed_cfg >> 24) & 0x7f) > 1 ? ((a.seed_cfg >> 24) & 0x7f) : 1;
+    // (pruned walk: nqblk_run counts WAVES of the dispatch order -- 0: all nqblk * 8 of them)
+    const dim3 grid((unsigned)(PRUNE ? (a.nqblk_run ? a.nqblk_run : a.nqblk * kHWaves) + hv_n * (hv_S - 1)
                                : SYM == 2 ? sym_unit_count(a.nqblk, kHWaves * kHQT, a.sym.panel * f16_chunk_tiles(KST), ntiles_even)
                                : SYM == 1 ? (a.nqblk_run ? a.nqblk_run : a.nqblk) : a.nqblk * a.rsplit));
     hipLaunchKernelGGL(kern, grid, dim3(PRUNE ? 64 : kHThreads), LDS, st, static_cast<const _Float16*>(a.Yh), a.nchunk_total, a.rsplit,
                        static_cast<const _Float16*>(a.Xh), a.qinfo, a.params, a.X, a.Y, a.nq, a.nr, a.D, a.nq_pad, a.nqblk,
-                       a.self_exclude, a.self_offset, a.ksel, a.part_d, a.part_i, a.clist, a.cdist, a.list_len, a.rperm, a.qperm, a.tbox_r, a.tbox_q, a.cbox_r, a.qblk0, a.qblk_stride, a.border, a.lo_d, a.lo_i, a.seed_cfg, a.sym);
+                       a.self_exclude, a.self_offset, a.ksel, a.part_d, a.part_i, a.clist, a.cdist, a.list_len, a.rperm, a.qperm, a.tbox_r, a.tbox_q, a.cbox_r, a.qblk0, a.qblk_stride, a.border, a.lo_d, a.lo_i, a.seed_cfg, a.sym, a.wg_us);
     return hipGetLastError();
 }
 #endif
@@ -141,7 +143,7 @@ extern const KnnF16Variant MCE_CAT(g_knn_f16_kcap, MCE_KCAP)[kMaxKST] = {
 #else
 // device pass: force the kernel instantiations
 #if MCE_INST_F16
-#define MCE_F16_INST(KST, PR, LW, SY) template __global__ void knn_f16_kernel<KST, MCE_KCAP, PR, LW, SY>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*, int, int, const int*, const double*, const int*, int, SymParams);
+#define MCE_F16_INST(KST, PR, LW, SY) template __global__ void knn_f16_kernel<KST, MCE_KCAP, PR, LW, SY>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*, int, int, const int*, const double*, const int*, int, SymParams, float*);
 MCE_F16_INST(1, false, false, 0) MCE_F16_INST(2, false, false, 0) MCE_F16_INST(3, false, false, 0) MCE_F16_INST(4, false, false, 0) MCE_F16_INST(1, true, false, 0)
 MCE_F16_INST(1, false, false, 1) MCE_F16_INST(2, false, false, 1) MCE_F16_INST(3, false, false, 1) MCE_F16_INST(4, false, false, 1)
 MCE_F16_INST(1, false, false, 2) MCE_F16_INST(2, false, false, 2) MCE_F16_INST(3, false, false, 2) MCE_F16_INST(4, false, false, 2)

@@ -160,20 +160,32 @@ __global__ __launch_bounds__(kThreads) void box_dist_kernel(const float* __restr
     out_c[e] = c;
 }
 
-// dispatch order of the query blocks: largest box first (the sparse corner cells of the k-d order walk ten
-// times farther than the rest: started last they would BE the tail of the launch)
-__global__ __launch_bounds__(kThreads) void block_cost_kernel(const float* __restrict__ qbox, int nqblk, int d, float* __restrict__ keys,
-                                                              int* __restrict__ vals)
+// dispatch order of the WAVES (tpw query tiles each: the unit a workgroup of the walk serves): largest box first.  The sparse
+// cells of the k-d order -- and any wave holding a far outlier, whose K-th neighbour distance sets the reach of the whole
+// wave -- walk 10-30x farther than the rest: started last they would BE the tail of the launch.  (Round 3 ordered whole
+// 512-query blocks by the block's box: one outlier makes that box large but only one of the block's eight waves slow.)
+// Waves of padding queries only (they skip the walk) sort last.
+__global__ __launch_bounds__(kThreads) void wave_cost_kernel(const float* __restrict__ tbox_q, int nwaves, int tpw, int64_t ntiles, int d,
+                                                             float* __restrict__ keys, int* __restrict__ vals)
 {
-    const int b = blockIdx.x * kThreads + threadIdx.x;
-    if (b >= nqblk) return;
+    const int g = blockIdx.x * kThreads + threadIdx.x;
+    if (g >= nwaves) return;
     float s = 0.0f;
+    bool any = false;
     for (int i = 0; i < d; ++i) {
-        const float w = qbox[((int64_t)b * 2 + 1) * d + i] - qbox[((int64_t)b * 2) * d + i];
-        s += (w > 0.0f && w < 3.0e38f) ? w * w : 0.0f;
+        float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf();
+        for (int t = 0; t < tpw; ++t) {
+            const int64_t tt = (int64_t)g * tpw + t;
+            if (tt < ntiles) {
+                lo = fminf(lo, tbox_q[(tt * 2 + 0) * d + i]);
+                hi = fmaxf(hi, tbox_q[(tt * 2 + 1) * d + i]);
+            }
+        }
+        const float w = hi - lo;
+        if (w >= 0.0f && w < 3.0e38f) { s += w * w; any = true; }
     }
-    keys[b] = s;
-    vals[b] = b;
+    keys[g] = any ? s : -1.0f;
+    vals[g] = g;
 }
 
 struct SegmentOffset {
@@ -270,17 +282,18 @@ int prune_layout(int64_t nq, int64_t nq_pad, int nqblk, int64_t nr, int64_t nr_p
     L.tboxT_r = take((size_t)(nr_pad / kPruneTileRows) * 2 * d * 4);
     L.box_r = take((size_t)nchunk * 2 * d * 4);
     L.box_q = take((size_t)nqblk * 2 * d * 4);
-    L.bkey_a = take((size_t)nqblk * 4);
-    L.bkey_b = take((size_t)nqblk * 4);
-    L.bval_a = take((size_t)nqblk * 4);
-    L.border = take((size_t)nqblk * 4);
+    const size_t nwaves = (size_t)nqblk * kPruneWavesPerBlock;
+    L.bkey_a = take(nwaves * 4);
+    L.bkey_b = take(nwaves * 4);
+    L.bval_a = take(nwaves * 4);
+    L.border = take(nwaves * 4);
     L.list_d_a = take((size_t)pairs * 4);
     L.list_c_a = take((size_t)pairs * 4);
     L.list_d_b = take((size_t)pairs * 4);
     L.list_c_b = take((size_t)pairs * 4);
     size_t border_tmp = 0;
     (void)rocprim::radix_sort_pairs_desc(nullptr, border_tmp, (const float*)nullptr, (float*)nullptr, (const int*)nullptr, (int*)nullptr,
-                                         (size_t)nqblk, 0u, 32u);
+                                         nwaves, 0u, 32u);
     L.tmp_bytes = std::max(std::max(sort_tmp_bytes(nmax), segsort_tmp_bytes(nqblk, nchunk)), border_tmp);
     L.tmp = take(L.tmp_bytes);
     L.total = off;
@@ -356,10 +369,15 @@ hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t
         float* bkey_b = reinterpret_cast<float*>(ws + L.bkey_b);
         int* bval_a = reinterpret_cast<int*>(ws + L.bval_a);
         int* border = reinterpret_cast<int*>(ws + L.border);
-        hipLaunchKernelGGL(block_cost_kernel, dim3((unsigned)((nqblk + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, box_q, nqblk, d, bkey_a, bval_a);
+        const int nwaves = nqblk * kPruneWavesPerBlock;
+        const int tpw = qpb / kPruneTileRows / kPruneWavesPerBlock;
+        hipLaunchKernelGGL(wave_cost_kernel, dim3((unsigned)((nwaves + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, out.tbox_q, nwaves, tpw,
+                           same_set ? ntile_r : ntile_q, d, bkey_a, bval_a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         size_t tb2 = L.tmp_bytes;
-        e = rocprim::radix_sort_pairs_desc(tmp, tb2, (const float*)bkey_a, bkey_b, (const int*)bval_a, border, (size_t)nqblk, 0u, 32u, st);
+        // (the keys are non-negative floats or -1: as unsigned bit patterns -1 would sort FIRST in descending order -- the
+        //  float comparison of rocPRIM's radix sort handles the sign)
+        e = rocprim::radix_sort_pairs_desc(tmp, tb2, (const float*)bkey_a, bkey_b, (const int*)bval_a, border, (size_t)nwaves, 0u, 32u, st);
         if (e != hipSuccess) return e;
         out.border = border;
     }

@@ -27,6 +27,7 @@ namespace mce {
 constexpr int kPruneTileRows = 32;                        // k-d cells = MFMA reference tiles = query tiles
 constexpr int kPruneMaxDim = 15;                          // KST = 1 variants only
 constexpr int64_t kPruneMaxPairs = (int64_t)1 << 30;      // nqblk * nchunk list entries
+constexpr int kPruneWavesPerBlock = 8;                    // == kHWaves (knn_f16.hpp): the walk's workgroups serve one wave of a query block each
 
 struct PruneLayout {
     size_t perm_r = 0, perm_q = 0;          // int32 [nr_pad], [nq_pad]: sorted position -> caller's row (-1: padding)
@@ -36,7 +37,7 @@ struct PruneLayout {
     size_t tbox_r = 0, tbox_q = 0;          // float [tiles][2][d] (lo | hi), rounded outward
     size_t tboxT_r = 0;                     // float [nchunk][2][d][tiles per chunk]: the kernel's layout
     size_t box_r = 0, box_q = 0;            // float [nchunk][2][d], [nqblk][2][d]
-    size_t bkey_a = 0, bkey_b = 0, bval_a = 0, border = 0;   // query blocks by descending box size: [nqblk]
+    size_t bkey_a = 0, bkey_b = 0, bval_a = 0, border = 0;   // the walk's waves (block * 8 + wave) by descending box size: [nqblk * 8]
     size_t list_d_a = 0, list_c_a = 0;      // float / int32 [nqblk * nchunk] unsorted
     size_t list_d_b = 0, list_c_b = 0;      // sorted
     size_t tmp = 0, tmp_bytes = 0;          // rocPRIM scratch
@@ -56,7 +57,7 @@ struct PruneOut {
     const float* tbox_r = nullptr;          // reference tile boxes, [chunk][2][d][tiles per chunk]
     const float* tbox_q = nullptr;          // query tile boxes
     const float* cbox_r = nullptr;          // reference chunk boxes [chunk][2][d]
-    const int* border = nullptr;            // dispatch order of the query blocks (largest box first)
+    const int* border = nullptr;            // dispatch order of the walk's waves (block * 8 + wave), largest box first
 };
 
 // same_set: the queries ARE the reference rows (same pointer, nq == nr): one ordering serves both

@@ -177,6 +177,43 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// pruned walk, heavy waves (knn_f16.hpp): the extra sub-waves of the first `nheavy` waves of the launch's dispatch
+// order left their lists in side arrays hv_d / hv_i [S - 1][KCAP][nheavy * qpb] (qpb = the 64 queries of a wave; border[k]
+// = block * 8 + wave, so wave k's columns start at border[k] * qpb); fold them into those columns of part_d / part_i
+// (ascending, ties by row -- the lists' own order).  Every sub-wave multiplied the same bootstrap tiles, so the same
+// (distance, row) may sit in several lists: it is taken once.  One thread per heavy query.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kRedThreads) void prune_heavy_fold_kernel(double* __restrict__ part_d, int* __restrict__ part_i, int64_t nq_pad, int KCAP,
+                                                                       const double* __restrict__ hv_d, const int* __restrict__ hv_i, int nheavy, int S, int qpb,
+                                                                       const int* __restrict__ border, int qblk0, int qblk_stride)
+{
+    const int64_t hcols = (int64_t)nheavy * qpb;
+    const int64_t hc = (int64_t)blockIdx.x * kRedThreads + threadIdx.x;
+    if (hc >= hcols) return;
+    const int64_t q = (int64_t)border[qblk0 + (int)(hc / qpb) * qblk_stride] * qpb + hc % qpb;
+    double d[kMaxK];
+    int r[kMaxK];
+    for (int k = 0; k < KCAP; ++k) { d[k] = part_d[(int64_t)k * nq_pad + q]; r[k] = part_i[(int64_t)k * nq_pad + q]; }
+    for (int s = 0; s < S - 1; ++s)
+        for (int k = 0; k < KCAP; ++k) {
+            const int iv = hv_i[((int64_t)s * KCAP + k) * hcols + hc];
+            if (iv < 0) break;                                   // list exhausted
+            const double dv = hv_d[((int64_t)s * KCAP + k) * hcols + hc];
+            // beyond the current last entry (or equal to it): nothing to do -- and neither for the rest of this sorted list
+            if (r[KCAP - 1] >= 0 && (dv > d[KCAP - 1] || (dv == d[KCAP - 1] && iv >= r[KCAP - 1]))) break;
+            int p = KCAP - 1;
+            bool dup = false;
+            while (p > 0 && !(r[p - 1] >= 0 && (d[p - 1] < dv || (d[p - 1] == dv && r[p - 1] <= iv)))) --p;      // first position whose predecessor sorts before (dv, iv)
+            if (p > 0 && r[p - 1] == iv && d[p - 1] == dv) dup = true;
+            if (dup) continue;
+            for (int m = KCAP - 1; m > p; --m) { d[m] = d[m - 1]; r[m] = r[m - 1]; }
+            d[p] = dv;
+            r[p] = iv;
+        }
+    for (int k = 0; k < KCAP; ++k) { part_d[(int64_t)k * nq_pad + q] = d[k]; part_i[(int64_t)k * nq_pad + q] = r[k]; }
+}
+
+// ---------------------------------------------------------------------------
 // symmetric sweep (knn_f16.hpp): fold the row-side candidates of one query block -- its bucket -- into the
 // block's lists.  One thread per query keeps its list in registers; the bucket is taken in batches through LDS:
 // every entry is linked onto its row's chain (atomic exchange on the chain head), then every thread walks its

@@ -1088,6 +1088,30 @@ def test_mfma_error_model(kst):
     assert worst < 0.5, worst             # headroom: the model is not tight
 
 
+@pytest.mark.parametrize("kst", [1, 2, 3, 4])
+def test_mfma_error_model_over_thousands_of_tiles(kst):
+    """The same model as a DISTRIBUTION: 3 000+ tiles per k-step count (12 000+ in all) through the kernels' MFMA sequence
+    in one launch (mce_debug_mfma_tiles_f16) -- near-coincident rows, antipodal rows, random rows, fp16 subnormals next to
+    full-size components, rows on the scaling radius with their energy in one to three components, one-signed equal
+    components (every partial sum at full magnitude), rows of very different norms in one tile.  Every entry within
+    eps_q; the observed maximum stays below half of it (tools/mfma_error_hist.py writes the histogram)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("mfma_error_hist", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "mfma_error_hist.py"))
+    eh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(eh)
+    rng = np.random.default_rng(77 + kst)
+    worst, tiles = {}, 0
+    for kind in eh.KINDS:
+        yp, xp = eh.make_tiles(kind, kst, 150 if kind == "max_magnitude" else 500, rng)
+        r = eh.error_over_bound(yp, xp, kst)
+        tiles += len(yp)
+        assert np.all(r <= 1.0), (kind, kst, float(r.max()))
+        worst[kind] = float(r.max())
+    assert tiles >= 3000
+    assert max(worst.values()) < 0.5, worst
+
+
 # --------------------------------------------------------------------------- config C1 on the hardware
 def test_C1_file_root_through_the_hip_backend(tmp_path):
     """BASELINE configs[0]: the CosmoMC-format file root (4 chains, 26 862 rows, ndim = 6, kmax = 2) read by libmcechains

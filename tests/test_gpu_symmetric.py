@@ -503,3 +503,92 @@ def test_every_candidate_through_the_redo_list(sym, monkeypatch):
         monkeypatch.delenv("MCE_PANEL_DEBUG")
         assert "panel-kernel" in capi.last_kernel()
         assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+
+
+# --------------------------------------------------------------------------- many searches at once (tools/stress_concurrent.py, in the suite)
+@pytest.mark.parametrize("spin_limit", [50, None])
+def test_concurrent_searches_on_many_streams_and_threads_are_bit_identical(spin_limit, monkeypatch):
+    """Twelve searches of every kind -- symmetric sweep (panel kernel), exhaustive sweep with splits and seeds, pruned walk
+    -- enqueued at once on twelve streams, first from one thread, then from four threads (modes through the thread-scoped
+    mce_options), several rounds in shuffled order: distances and sums bit-identical to the same searches run one at a time.
+    With MCE_SYM_SPIN_LIMIT = 50 (~50 us) units of the symmetric sweep that meet a loaded chip give up waiting for their
+    block's previous unit -- any subset of a unit's waves -- and the repair launch must make up for it (the hole
+    tools/stress_concurrent.py found in round 3: only wave 0 flagged the block); with the default limit nothing gives up."""
+    import threading
+    import torch
+    from mcevidence_amd import _capi as capi
+    if spin_limit is not None:
+        monkeypatch.setenv("MCE_SYM_SPIN_LIMIT", str(spin_limit))
+    else:
+        monkeypatch.delenv("MCE_SYM_SPIN_LIMIT", raising=False)
+    rng = np.random.default_rng(11)
+    shapes = [(9000, 6, 2, 0), (26862, 6, 2, 0), (60000, 8, 3, 0), (40000, 27, 10, 0),          # kind 0: exhaustive (automatic splits, seeds)
+              (150000, 27, 10, 2), (120000, 45, 6, 2), (200000, 20, 4, 2), (70000, 27, 10, 2),    # kind 2: symmetric sweep
+              (300000, 3, 5, 1), (400000, 6, 4, 1), (250000, 2, 3, 1), (131072, 10, 5, 0)]         # kind 1: pruned walk
+    modes = {0: dict(prune_mode=capi.PRUNE_OFF, sym_mode=capi.SYM_OFF), 1: dict(prune_mode=capi.PRUNE_FORCE, sym_mode=capi.SYM_OFF),
+             2: dict(prune_mode=capi.PRUNE_OFF, sym_mode=capi.SYM_FORCE)}
+    jobs = []
+    for (n, d, kmax, kind) in shapes:
+        X = torch.from_numpy(rng.standard_normal((n, d)) @ (np.eye(d) + 0.3 * rng.standard_normal((d, d)))).cuda()
+        K = kmax - 1
+        with capi.options(**modes[kind]):
+            wsb = capi.knn_workspace_bytes(n, n, d, K) + capi.dotp_workspace_bytes(n, kmax)
+        jobs.append(dict(n=n, d=d, kmax=kmax, kind=kind, X=X, w=torch.ones(n, dtype=torch.float64, device="cuda"),
+                         fs=torch.zeros(n, dtype=torch.float64, device="cuda"), ws=torch.empty(wsb, dtype=torch.uint8, device="cuda"), wsb=wsb,
+                         out=torch.zeros(kmax, dtype=torch.float64, device="cuda"), dd=torch.zeros((n, K), dtype=torch.float64, device="cuda"),
+                         st=torch.cuda.Stream()))
+
+    def enqueue(j, stream):
+        with capi.options(**modes[j["kind"]]):
+            capi.knn_dotp_dev(j["X"].data_ptr(), j["n"], j["X"].data_ptr(), j["n"], j["d"], j["kmax"], 1, 0, j["w"].data_ptr(), j["fs"].data_ptr(),
+                              j["out"].data_ptr(), j["dd"].data_ptr(), j["ws"].data_ptr(), j["wsb"], stream)
+            return capi.last_kernel()
+
+    ref = []
+    for j in jobs:                                  # one at a time
+        k = enqueue(j, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        ref.append((j["dd"].cpu().numpy().copy(), j["out"].cpu().numpy().copy()))
+        assert ("pruned" in k) == (j["kind"] == 1) and ("symmetric" in k) == (j["kind"] == 2), k
+        if j["kind"] == 2:
+            assert "panel-kernel" in k
+
+    def check(tag):
+        bad = []
+        for i, j in enumerate(jobs):
+            dd, out = j["dd"].cpu().numpy(), j["out"].cpu().numpy()
+            if not (np.array_equal(dd, ref[i][0]) and np.array_equal(out, ref[i][1])):
+                bad.append((tag, j["n"], j["d"], j["kind"], int(np.any(dd != ref[i][0], axis=1).sum())))
+        assert not bad, bad
+
+    for rnd in range(3):                            # all at once, from ONE thread
+        for j in jobs:
+            j["dd"].zero_(); j["out"].zero_()
+        torch.cuda.synchronize()
+        for i in rng.permutation(len(jobs)):
+            enqueue(jobs[i], jobs[i]["st"].cuda_stream)
+        torch.cuda.synchronize()
+        check("streams round %d" % rnd)
+    errors = []
+
+    def worker(mine):
+        try:
+            for _ in range(2):
+                for i in mine:
+                    enqueue(jobs[i], jobs[i]["st"].cuda_stream)
+        except Exception as e:       # noqa: BLE001
+            errors.append(repr(e))
+
+    for rnd in range(2):                            # ... and from FOUR threads, every thread a mix of kinds
+        for j in jobs:
+            j["dd"].zero_(); j["out"].zero_()
+        torch.cuda.synchronize()
+        order = rng.permutation(len(jobs))
+        th = [threading.Thread(target=worker, args=([int(i) for i in order[t::4]],)) for t in range(4)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        assert not errors, errors
+        check("threads round %d" % rnd)

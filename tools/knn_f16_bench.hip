@@ -59,7 +59,7 @@ int main(int argc, char** argv)
         kern<<<nqblk * rsplit, kHThreads, LDS>>>(Yh, nchunk, rsplit, Xh, qinfo, params, X, X, n, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi,
                                                 (const int*)nullptr, (const float*)nullptr, 0, (const int*)nullptr, (const int*)nullptr, (const float*)nullptr,
                                                 (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr,
-                                                f16_seed_cfg((nchunk + rsplit - 1) / rsplit, CT, KSEL + 1, seed_rows, MCE_H_SEED_SHARE, seed_tg));
+                                                f16_seed_cfg((nchunk + rsplit - 1) / rsplit, CT, KSEL + 1, seed_rows, MCE_H_SEED_SHARE, seed_tg), SymParams(), (float*)nullptr);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("D=%d KST=%d KCAP=%d K=%d CT=%d ablate=%d lds=%zu n=%lld rsplit=%d grid=%d: %.2f ms  %.3f Mq/s  %.1f TF(f16 flops)\n", D, KST, KCAP, KSEL, CT, MCE_ABLATE, LDS,

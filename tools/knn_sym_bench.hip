@@ -105,12 +105,12 @@ int main(int argc, char** argv)
         CK(hipEventRecord(e0));
         kpre<<<nqblk, kHThreads, LDS>>>(Yh, nchunk, 1, Xh, qinfo, params, X, X, n, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi,
                                         (const int*)nullptr, (const float*)nullptr, 0, dperm, (const int*)nullptr, (const float*)nullptr,
-                                        (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr, seed_cfg, sp);
+                                        (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr, seed_cfg, sp, (float*)nullptr);
         CK(hipEventRecord(e1));
         if (PANEL && !getenv("SYM_REPAIR_ALL")) kpanel<<<npanel_units, kHThreads, panel_lds_bytes(KST)>>>(pa);
         else if (!getenv("SYM_REPAIR_ALL")) kern<<<nunits, kHThreads, LDS>>>(Yh, nchunk, 1, Xh, qinfo, params, X, X, n, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi,
                                         (const int*)nullptr, (const float*)nullptr, 0, dperm, (const int*)nullptr, (const float*)nullptr,
-                                        (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr, 0, sp);
+                                        (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr, 0, sp, (float*)nullptr);
         CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
         if (getenv("SYM_REPAIR_ALL")) {      // experiment: the exhaustive column-only sweep over the sorted rows (every block "repaired")
             std::vector<int> ones(nqblk, 1);
@@ -121,7 +121,7 @@ int main(int argc, char** argv)
             CK(hipEventRecord(e2));
             krep<<<nqblk, kHThreads, LDS>>>(Yh, nchunk, 1, Xh, qinfo, params, X, X, n, n, D, nq_pad, nqblk, 1, 0, KSEL, pd, pi,
                                             (const int*)nullptr, (const float*)nullptr, 0, dperm, (const int*)nullptr, (const float*)nullptr,
-                                            (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr, 0, sp);
+                                            (const float*)nullptr, (const float*)nullptr, 0, 1, (const int*)nullptr, (const double*)nullptr, (const int*)nullptr, 0, sp, (float*)nullptr);
             CK(hipEventRecord(e3)); CK(hipEventSynchronize(e3));
             float ms3; CK(hipEventElapsedTime(&ms3, e2, e3));
             printf("exhaustive column-only sweep over the sorted rows, thresholds from the prepass: %.2f ms\n", ms3);
