@@ -18,7 +18,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmcevidence_hip.so")
+# (MCE_LIB: another build of the same library -- same-box A/B of kernel variants, tools/; never a different backend)
+LIB_PATH = os.environ.get("MCE_LIB") or os.path.join(_HERE, "libmcevidence_hip.so")
 
 MCE_OK = 0
 MCE_ERR_INVALID = -1
