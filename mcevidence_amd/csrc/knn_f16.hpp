@@ -43,7 +43,8 @@
 #define MCE_STATS 0    // tools/knn_f16_bench.hip only: per-wave clock64/event counters appended to `params`
 #endif
 #ifndef MCE_ABLATE
-#define MCE_ABLATE 0   // tools/knn_f16_bench.hip only: 1 = gate never passes, 2 = no gate at all, 3 = 1 + no barriers, 5 = 1 + no LDS reads, 6 = 2 + 5 (results invalid)
+#define MCE_ABLATE 0   // tools/knn_f16_bench.hip only: 1 = gate never passes, 2 = no gate at all, 3 = 1 + no barriers, 5 = 1 + no LDS reads, 6 = 2 + 5,
+                       // 7 / 8 = 1 + the FAST path of a two-level gate: the lane minima of 4 / 2 consecutive tiles folded, one compare + branch per group (results invalid)
 #endif
 
 namespace mce {
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks)
             b[qt][ks] = *reinterpret_cast<const v8h*>(Xh + q * (int64_t)(16 * KST) + 16 * ks + 8 * (lane >> 5));
-        G[qt] = (q < nq && MCE_ABLATE != 1 && MCE_ABLATE != 3 && MCE_ABLATE != 5) ? __builtin_huge_valf() : -__builtin_huge_valf();     // padding queries never pass
+        G[qt] = (q < nq && MCE_ABLATE != 1 && MCE_ABLATE != 3 && MCE_ABLATE != 5 && MCE_ABLATE != 7 && MCE_ABLATE != 8) ? __builtin_huge_valf() : -__builtin_huge_valf();     // padding queries never pass
     }
     // SYM: c_i = eps_i - |x^_i|^2 of the lane's query (rounded up): the row-side gate is  min A <= R_tile + c_i
     float cR[QT];
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
     // and keeping them in registers would cost 6 VGPRs per query tile in the sweep.
     auto gate_of = [&](double thr, int qt) __attribute__((always_inline)) -> float {
         const int64_t q = qwave0 + qt * 32 + (lane & 31);
-        if (!(q < nq) || MCE_ABLATE == 1 || MCE_ABLATE == 3 || MCE_ABLATE == 5) return -__builtin_huge_valf();
+        if (!(q < nq) || MCE_ABLATE == 1 || MCE_ABLATE == 3 || MCE_ABLATE == 5 || MCE_ABLATE == 7 || MCE_ABLATE == 8) return -__builtin_huge_valf();
         if (!(thr < INF)) return __builtin_huge_valf();
         const double ex = qinfo[2 * q], xn = qinfo[2 * q + 1];
         const double r = sqrt(xn) + params[HP_YHATMAX];
@@ -776,6 +777,12 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
     // gate + enqueue for one finished tile; jb0 = first reference row of the tile.
     // C layout of 32x32 f32: lane l -> query column l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5)
     // SYM: Rt = the tile's row-side gate constant (wave-uniform; -inf: column side only)
+#if MCE_ABLATE == 7 || MCE_ABLATE == 8
+    float fold_mm[QT];
+    int fold_ctr = 0;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) fold_mm[qt] = __builtin_huge_valf();
+#endif
     auto process = [&](const v16f (&acc)[QT], int jb0, float Rt) __attribute__((always_inline)) {
 #if MCE_ABLATE == 2 || MCE_ABLATE == 6
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -797,11 +804,22 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
             float m4 = min3f(c[12], c[13], c[14]);
             m0 = min3f(m0, m1, m2);
             m3 = min3f(m3, m4, c[15]);
+#if MCE_ABLATE == 7 || MCE_ABLATE == 8
+            mm[qt] = min3f(m0, m3, fold_mm[qt]);           // the group's running minimum rides in the tree's free third input
+            fold_mm[qt] = mm[qt];
+#else
             mm[qt] = min3f(m0, m3, m3);
+#endif
             if constexpr (SYM == 2) passq[qt] = mm[qt] <= fmaxf(G[qt], Rt + cR[qt]);      // either side
             else passq[qt] = mm[qt] <= G[qt];
             pass |= passq[qt];
         }
+#if MCE_ABLATE == 7 || MCE_ABLATE == 8
+        fold_ctr += 1;
+        if ((fold_ctr & (MCE_ABLATE == 7 ? 3 : 1)) != 0) return;      // (wave-uniform: one compare + branch per group of tiles)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) fold_mm[qt] = __builtin_huge_valf();
+#endif
         if (__any(pass)) {
 #if MCE_STATS
             st_events += 1;

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
     int* const qpk_all = reinterpret_cast<int*>(qd2_all + kHWaves * QN);
     int* const qnx_all = qpk_all + kHWaves * QN;
     int* const head_all = qnx_all + kHWaves * QN;
-    volatile int* const wvote = head_all + kHWaves * QPW;                 // [2] drain votes (chunk parity)
+    volatile int* const wvote = head_all + kHWaves * QPW;                 // [3] drain votes (chunk index mod 3)
     float* const sthr_all = reinterpret_cast<float*>(head_all + kHWaves * QPW + 32);
     int* const redo_all = reinterpret_cast<int*>(sthr_all + kHWaves * QPW);
 
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
     const int64_t qwave0 = (int64_t)qblk * QPB + wave * QPW;     // first query of this wave
 
     whead[lane] = -1;
-    if (tid < 2) wvote[tid] = 0;
+    if (tid < 3) wvote[tid] = 0;
 
     // lane l OWNS wave-local query l: its sorted top-KCAP list lives here
     double own_d[KCAP];
@@ -712,8 +712,14 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
     for (int k = 0; k < ntot; ++k) {
         const int buf = k & 1;
         const int c = cfirst + k;
-        if (qcount >= MCE_PANEL_TRIGGER && lane == 0) wvote[buf] = 1;
+        // drain votes: slot k % 3 collects the votes for chunk k (written before barrier k, read by everybody after it) and is
+        // cleared by thread 0 after barrier k + 1 -- which every wave reaches only after its read -- and voted on again for
+        // chunk k + 3, by waves that have passed barrier k + 2, i.e. after the clear: no write can overtake another.  (Two
+        // slots re-armed right after the read let a late thread 0 wipe the vote of a wave already one chunk ahead.)
+        const int vs = k % 3;
+        if (qcount >= MCE_PANEL_TRIGGER && lane == 0) wvote[vs] = 1;
         dma_barrier();
+        if (tid == 0) wvote[vs == 0 ? 2 : vs - 1] = 0;             // the slot of chunk k - 1: all its readers are behind this barrier
         rt_cur = rt_next;
         if (k + 1 < ntot) {
             stage_async(c + 1, buf ^ 1);
@@ -721,8 +727,7 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
         }
         // (readfirstlane: an LDS load is a divergent value to the compiler, and a drain under a "divergent" branch would make
         //  the queue length a per-lane quantity -- vector compares and exec masks on every use)
-        bool need_drain = __builtin_amdgcn_readfirstlane(wvote[buf]) != 0 || k + 1 == ntot;        // everybody drains at the same chunk; the last chunk ends with the final drain
-        if (tid == 0) wvote[buf ^ 1] = 0;                          // re-arm the other parity (read again only after the next barrier)
+        bool need_drain = __builtin_amdgcn_readfirstlane(wvote[vs]) != 0 || k + 1 == ntot;         // everybody drains at the same chunk; the last chunk ends with the final drain
         const int tlo = (k == 0) ? t_lo - c * CT : 0;
         const int thi = t_hi - c * CT < CT ? t_hi - c * CT : CT;
         const char* const lbuf = stage0 + buf * CHUNK_BYTES + lane * 16;
