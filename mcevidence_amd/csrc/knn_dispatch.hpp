@@ -91,6 +91,8 @@ struct KnnF16Variant {
     int kst, kcap, qt, ct;
     size_t lds_bytes;
     const char* name;
+    knn_f16_launch_fn launch_prune_short;   // PRUNE with prune_short_lc (< kcap) list entries in registers: three waves per SIMD (KST = 1, KCAP = 12), else null
+    int prune_short_lc;
 };
 constexpr int kMaxKST = 4;
 extern const KnnF16Variant g_knn_f16_kcap4[kMaxKST];

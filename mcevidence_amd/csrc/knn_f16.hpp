@@ -113,11 +113,20 @@ constexpr int kHThreads = kHWaves * 64;
 // 5.5 -> 4.0 ms).  Longer lists need 217-253 VGPRs: forced under 168 they spill (K = 9: 197 -> 366 ms), and at
 // two waves per SIMD the smaller batch only costs (197 -> 224 ms), so they keep the larger footprint.
 #ifndef MCE_H_PRUNE_SMALL
-#define MCE_H_PRUNE_SMALL 8      // largest list capacity on the three-wave configuration
+#define MCE_H_PRUNE_SMALL 9      // largest list capacity (entries held in registers) on the three-wave configuration
 #endif
-__host__ __device__ constexpr int f16_prune_batch(int KCAP) { return KCAP <= MCE_H_PRUNE_SMALL ? 4 : 8; }
-__host__ __device__ constexpr int f16_prune_queue(int KCAP) { return KCAP <= MCE_H_PRUNE_SMALL ? 128 : 256; }   // entries are already exact: only the list insertion is deferred
-__host__ __device__ constexpr int f16_prune_trigger(int KCAP) { return KCAP <= MCE_H_PRUNE_SMALL ? 32 : 48; }
+#ifndef MCE_H_PRUNE_B10
+#define MCE_H_PRUNE_B10 2       // tiles per batch with 9 list entries (8 staged-tile registers instead of 16: no scratch at 168 VGPRs)
+#endif
+#ifndef MCE_H_PRUNE_Q10
+#define MCE_H_PRUNE_Q10 128
+#endif
+#ifndef MCE_H_PRUNE_T10
+#define MCE_H_PRUNE_T10 32
+#endif
+__host__ __device__ constexpr int f16_prune_batch(int KCAP) { return KCAP <= 8 ? 4 : (KCAP <= MCE_H_PRUNE_SMALL ? MCE_H_PRUNE_B10 : 8); }
+__host__ __device__ constexpr int f16_prune_queue(int KCAP) { return KCAP <= 8 ? 128 : (KCAP <= MCE_H_PRUNE_SMALL ? MCE_H_PRUNE_Q10 : 256); }   // entries are already exact: only the list insertion is deferred
+__host__ __device__ constexpr int f16_prune_trigger(int KCAP) { return KCAP <= 8 ? 32 : (KCAP <= MCE_H_PRUNE_SMALL ? MCE_H_PRUNE_T10 : 48); }
 #ifndef MCE_H_STAGE_KB
 #define MCE_H_STAGE_KB 48
 #endif
@@ -249,8 +258,12 @@ __host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST, int D, int KCA
 // first pass finds the 16 nearest per (query, reference split) and the second, identical sweep keeps only
 // candidates beyond that split's 16th (lo_d / lo_i = the first pass's lists) and finds the next K - 16;
 // the merge then sees two sorted lists per split.  Two sweeps at fp16 speed instead of one fp64 sweep.
-template <int KST, int KCAP, bool PRUNE = false, bool LOWER = false, int SYM = 0>
-__global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUNE_SMALL ? 3 : MCE_H_PRUNE_WAVES) : (MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ? 4 : 2))) void knn_f16_kernel(
+//   LC (< KCAP, pruned walk only): the lists hold LC entries in registers while the list ARRAYS keep their KCAP rows (the unused
+//   ones are written empty).  K = 9 (C5's kmax = 10) with KCAP = 12 costs 217 VGPRs = two waves per SIMD; nine entries and
+//   batches of two tiles fit the three-wave budget that K <= 8 searches already run under (166 VGPRs, no scratch; ten
+//   entries, or nine with batches of four, spill the staged tiles: 265 vs 196 ms), and the walk is latency-bound.
+template <int KST, int KCAP, bool PRUNE = false, bool LOWER = false, int SYM = 0, int LC = KCAP>
+__global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_SMALL ? 3 : MCE_H_PRUNE_WAVES) : (MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ? 4 : 2))) void knn_f16_kernel(
     const _Float16* __restrict__ Yh, int64_t nchunk_total, int rsplit,
     const _Float16* __restrict__ Xh, const double* __restrict__ qinfo, const double* __restrict__ params,
     const double* __restrict__ X, const double* __restrict__ Y, int64_t nq, int64_t nr, int D,
@@ -263,6 +276,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
 {
     // wg_us (diagnostic, normally null): every workgroup leaves its duration in microseconds (capi.hip: MCE_PRUNE_TIMES)
     const unsigned long long wg_t0 = wg_us ? wall_clock64() : 0ull;
+    static_assert(LC == KCAP || (PRUNE && LC < KCAP), "shorter register lists: pruned walk only");
     static_assert(!(PRUNE && LOWER), "second pass: exhaustive sweep only");
     static_assert(SYM == 0 || (!PRUNE && !LOWER), "symmetric sweep: exhaustive, single pass");
     static_assert(SYM == 0 || kHNL == 1, "symmetric sweep: one list per owner lane");
@@ -282,9 +296,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
     // workgroups let the hardware balance their very uneven walks): [tile slice + pending ids]
     // [queue d2][queue packed][queue next][heads]; workgroup g serves wave g%8 of query block g/8.
     constexpr int LW = PRUNE ? 1 : kHWaves;                       // waves sharing this LDS allocation
-    constexpr int STAGE_BYTES = PRUNE ? f16_prune_slice_bytes(KST, KCAP) : 2 * CT * KST * 1024;
+    constexpr int STAGE_BYTES = PRUNE ? f16_prune_slice_bytes(KST, LC) : 2 * CT * KST * 1024;
     char* const stage0 = lds_raw;
-    constexpr int QN = PRUNE ? f16_prune_queue(KCAP) : kHQueue;   // queue entries per wave
+    constexpr int QN = PRUNE ? f16_prune_queue(LC) : kHQueue;   // queue entries per wave
     double* const qd2_all = reinterpret_cast<double*>(lds_raw + STAGE_BYTES);
     int* const qpk_all = reinterpret_cast<int*>(qd2_all + LW * QN);
     int* const qnx_all = qpk_all + LW * QN;
@@ -347,12 +361,12 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
     for (int nl = 0; nl < kHNL; ++nl) whead[nl * 64 + lane] = -1;
 
     // lane l OWNS wave-local queries nl*64 + l (query ql = qt*32 + column): their sorted top-KCAP lists live here
-    double own_d[kHNL][KCAP];
-    int own_i[kHNL][KCAP];
+    double own_d[kHNL][LC];
+    int own_i[kHNL][LC];
 #pragma unroll
     for (int nl = 0; nl < kHNL; ++nl)
 #pragma unroll
-        for (int k = 0; k < KCAP; ++k) { own_d[nl][k] = INF; own_i[nl][k] = -1; }
+        for (int k = 0; k < LC; ++k) { own_d[nl][k] = INF; own_i[nl][k] = -1; }
 
     if constexpr (SYM == 2) {
         // A block's lists travel from its unit p - 1 to its unit p through the list arrays.  Units are dispatched in
@@ -692,9 +706,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
                 const int j = (PRUNE || SYM >= 2) ? wq[ce] : jsplit0 + (int)((unsigned)wq[ce] & ((1u << kHRelBits) - 1u));
                 cur = on ? wnx[ce] : -1;
                 // ascending list, ties by row; d2 = +inf (idle lane) changes nothing
-                bool c_hi = (d2 < own_d[nl][KCAP - 1]) || (d2 == own_d[nl][KCAP - 1] && j < own_i[nl][KCAP - 1] && d2 < INF);
+                bool c_hi = (d2 < own_d[nl][LC - 1]) || (d2 == own_d[nl][LC - 1] && j < own_i[nl][LC - 1] && d2 < INF);
 #pragma unroll
-                for (int k = KCAP - 1; k >= 1; --k) {
+                for (int k = LC - 1; k >= 1; --k) {
                     const bool c_lo = (d2 < own_d[nl][k - 1]) || (d2 == own_d[nl][k - 1] && j < own_i[nl][k - 1] && d2 < INF);
                     own_d[nl][k] = c_lo ? own_d[nl][k - 1] : (c_hi ? d2 : own_d[nl][k]);
                     own_i[nl][k] = c_lo ? own_i[nl][k - 1] : (c_hi ? j : own_i[nl][k]);
@@ -713,9 +727,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
         double thr_own[kHNL];
 #pragma unroll
         for (int nl = 0; nl < kHNL; ++nl) {
-            thr_own[nl] = own_d[nl][KCAP - 1];
+            thr_own[nl] = own_d[nl][LC - 1];
 #pragma unroll
-            for (int k = 0; k < KCAP - 1; ++k) thr_own[nl] = (k == k_last) ? own_d[nl][k] : thr_own[nl];
+            for (int k = 0; k < LC - 1; ++k) thr_own[nl] = (k == k_last) ? own_d[nl][k] : thr_own[nl];
             thr_own[nl] = fmin(thr_own[nl], seed_thr[nl]);
         }
 #if MCE_STATS
@@ -1249,10 +1263,10 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
         // pass (lane t <-> tile t), collects the tiles within reach and multiplies them in batches
         // of kBatch: the batch's A tiles (1 KB each) go through registers into the wave's private
         // slice of the staging area and are swept from there.
-        constexpr int kBatch = f16_prune_batch(KCAP);
+        constexpr int kBatch = f16_prune_batch(LC);
         constexpr int PCT = kHPruneChunkTiles;               // tiles per list chunk: one per lane
-        constexpr int kPruneDrainTrigger = f16_prune_trigger(KCAP);
-        static_assert(f16_prune_slice_bytes(KST, KCAP) >= kBatch * KST * 1024 + 256, "tile slice");
+        constexpr int kPruneDrainTrigger = f16_prune_trigger(LC);
+        static_assert(f16_prune_slice_bytes(KST, LC) >= kBatch * KST * 1024 + 256, "tile slice");
         const int* const mylist = clist + (int64_t)qblk * list_len;
         const float* const mydist = cdist + (int64_t)qblk * list_len;
         char* const wbuf = stage0;                                          // [kBatch tiles][pending ids]
@@ -1486,9 +1500,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
 #if MCE_SEED_CHECK
 #pragma unroll
     for (int nl = 0; nl < kHNL; ++nl) {
-        double fin = own_d[nl][KCAP - 1];
+        double fin = own_d[nl][LC - 1];
 #pragma unroll
-        for (int k = 0; k < KCAP - 1; ++k) fin = (k == k_last) ? own_d[nl][k] : fin;
+        for (int k = 0; k < LC - 1; ++k) fin = (k == k_last) ? own_d[nl][k] : fin;
         if (qwave0 + nl * 64 + lane < nq && seed_dbg[nl] < INF) {
             double* stat = const_cast<double*>(params);
             unsafeAtomicAdd(stat + 8, 1.0);
@@ -1527,8 +1541,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
             int* const hi_ = const_cast<int*>(lo_i);
 #pragma unroll
             for (int k = 0; k < KCAP; ++k) {
-                hd[((int64_t)(pr_sub - 1) * KCAP + k) * hcols + hc] = own_d[nl][k];
-                hi_[((int64_t)(pr_sub - 1) * KCAP + k) * hcols + hc] = own_i[nl][k];
+                hd[((int64_t)(pr_sub - 1) * KCAP + k) * hcols + hc] = k < LC ? own_d[nl][k < LC ? k : 0] : INF;
+                hi_[((int64_t)(pr_sub - 1) * KCAP + k) * hcols + hc] = k < LC ? own_i[nl][k < LC ? k : 0] : -1;
             }
             continue;
         }
@@ -1536,8 +1550,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (KCAP <= MCE_H_PRUN
         for (int k = 0; k < KCAP; ++k) {
             const int64_t o = ((int64_t)split * KCAP + k) * nq_pad + q;
             MCE_CHK(q >= 0 && q < nq_pad && split >= 0 && qblk >= 0 && qblk < nqblk, 4, q, split, qblk);
-            part_d[o] = own_d[nl][k];
-            part_i[o] = own_i[nl][k];
+            part_d[o] = k < LC ? own_d[nl][k < LC ? k : 0] : INF;           // (rows LC .. KCAP - 1 of the arrays: empty)
+            part_i[o] = k < LC ? own_i[nl][k < LC ? k : 0] : -1;
         }
     }
     if constexpr (SYM == 2) {

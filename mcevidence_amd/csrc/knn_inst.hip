@@ -42,14 +42,14 @@ hipError_t launch_variant(const KnnArgs& a, hipStream_t st)
 #endif
 
 #if MCE_INST_F16
-template <int KST, int KCAP, bool PRUNE, bool LOWER = false, int SYM = 0>
+template <int KST, int KCAP, bool PRUNE, bool LOWER = false, int SYM = 0, int LC = KCAP>
 hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
 {
-    constexpr size_t LDS_MAX = PRUNE ? f16_prune_lds_bytes(KST, 16 * KST - 1, KCAP) : f16_lds_bytes(KST, KCAP, SYM >= 2);
+    constexpr size_t LDS_MAX = PRUNE ? f16_prune_lds_bytes(KST, 16 * KST - 1, LC) : f16_lds_bytes(KST, KCAP, SYM >= 2);
     static_assert(LDS_MAX <= 160 * 1024, "LDS budget");
-    const size_t LDS = PRUNE ? f16_prune_lds_bytes(KST, a.D, KCAP) : LDS_MAX;     // pruned walk: sized by the dimension (more waves per CU)
+    const size_t LDS = PRUNE ? f16_prune_lds_bytes(KST, a.D, LC) : LDS_MAX;     // pruned walk: sized by the dimension (more waves per CU)
     static bool attr_set[kMaxDevices] = {};
-    auto kern = knn_f16_kernel<KST, KCAP, PRUNE, LOWER, SYM>;
+    auto kern = knn_f16_kernel<KST, KCAP, PRUNE, LOWER, SYM, LC>;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= kMaxDevices || !attr_set[dev]) {
@@ -130,11 +130,16 @@ extern const KnnVariant MCE_CAT(g_knn_kcap, MCE_KCAP)[kMaxKS] = {
 #else
 #define MCE_F16_LOWER(KST) nullptr
 #endif
+#if MCE_KCAP == 12
+#define MCE_F16_SHORT(KST) ((KST) == 1 ? &launch_f16_variant<1, MCE_KCAP, true, false, 0, 9> : (knn_f16_launch_fn) nullptr), ((KST) == 1 ? 9 : 0)
+#else
+#define MCE_F16_SHORT(KST) nullptr, 0
+#endif
 #define MCE_F16_VARIANT(KST, PRUNE_FN)                                                                   \
     {&launch_f16_variant<KST, MCE_KCAP, false>, PRUNE_FN, MCE_F16_LOWER(KST), &launch_f16_variant<KST, MCE_KCAP, false, false, 1>, \
      &launch_f16_variant<KST, MCE_KCAP, false, false, 2>, &launch_f16_variant<KST, MCE_KCAP, false, false, 3>, &launch_panel_variant<KST, MCE_KCAP>, panel_lds_bytes(KST), \
      f16_lds_bytes(KST, MCE_KCAP, true), KST, MCE_KCAP, f16_qt(MCE_KCAP), f16_chunk_tiles(KST), \
-     f16_lds_bytes(KST, MCE_KCAP), "knn_f16_kernel<KST=" #KST ",KCAP=" MCE_STR(MCE_KCAP) ">"}
+     f16_lds_bytes(KST, MCE_KCAP), "knn_f16_kernel<KST=" #KST ",KCAP=" MCE_STR(MCE_KCAP) ">", MCE_F16_SHORT(KST)}
 extern const KnnF16Variant MCE_CAT(g_knn_f16_kcap, MCE_KCAP)[kMaxKST] = {
     MCE_F16_VARIANT(1, (&launch_f16_variant<1, MCE_KCAP, true>)), MCE_F16_VARIANT(2, nullptr), MCE_F16_VARIANT(3, nullptr),
     MCE_F16_VARIANT(4, nullptr),
@@ -148,6 +153,9 @@ MCE_F16_INST(1, false, false, 0) MCE_F16_INST(2, false, false, 0) MCE_F16_INST(3
 MCE_F16_INST(1, false, false, 1) MCE_F16_INST(2, false, false, 1) MCE_F16_INST(3, false, false, 1) MCE_F16_INST(4, false, false, 1)
 MCE_F16_INST(1, false, false, 2) MCE_F16_INST(2, false, false, 2) MCE_F16_INST(3, false, false, 2) MCE_F16_INST(4, false, false, 2)
 MCE_F16_INST(1, false, false, 3) MCE_F16_INST(2, false, false, 3) MCE_F16_INST(3, false, false, 3) MCE_F16_INST(4, false, false, 3)
+#if MCE_KCAP == 12
+template __global__ void knn_f16_kernel<1, MCE_KCAP, true, false, 0, 9>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*, int, int, const int*, const double*, const int*, int, SymParams, float*);
+#endif
 #if MCE_KCAP == 16
 MCE_F16_INST(1, false, true, 0) MCE_F16_INST(2, false, true, 0) MCE_F16_INST(3, false, true, 0) MCE_F16_INST(4, false, true, 0)
 #endif
