@@ -19,7 +19,8 @@ constexpr int kThreads = 256;
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-constexpr int kCoordBits = 24;    // coordinate bits in a k-d sort key
+constexpr int kCoordBits = 24;    // coordinate bits in a 64-bit k-d sort key
+constexpr int kMinCoordBits32 = 18;   // ... at least so many in a 32-bit one (sign + 8 exponent + 9 mantissa bits: medians to 2e-3 of the coordinate)
 constexpr int kAlign = 64;        // units (32-row tiles) per aligned group: the list chunk of the pruned walk
 constexpr int kAlignLevels = 6;
 
@@ -36,9 +37,12 @@ int top_tree_levels(int64_t n_units)
 // level, and 15 mantissa bits place a median to 3e-5 of the coordinate -- rows closer than that keep their previous
 // order (stable sort), which only matters below ~30 rows per resolution step (d = 1 with 10^7 rows: the leaf boxes then
 // overlap by a few rows' spacing; the search stays exact either way).
+// Key: unsigned long long with kCoordBits coordinate bits, or -- when node id and coordinate fit -- unsigned with `cbits` of
+// them (half the key bytes and a radix pass less: kd_sort decides).
+template <class Key>
 __global__ __launch_bounds__(kThreads) void kd_key_kernel(const int* __restrict__ perm_in, int64_t n, int64_t n_pad, int unit_rows,
                                                           int n_units, int top_levels, int level, const double* __restrict__ P, int d, int dim,
-                                                          unsigned long long* __restrict__ keys, int* __restrict__ vals)
+                                                          int cbits, Key* __restrict__ keys, int* __restrict__ vals)
 {
     const int64_t pos = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (pos >= n_pad) return;
@@ -69,12 +73,12 @@ __global__ __launch_bounds__(kThreads) void kd_key_kernel(const int* __restrict_
         b = __float_as_uint(c);
         b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
         if (b == 0xFFFFFFFFu) b = 0xFFFFFFFEu;
-        b >>= (32 - kCoordBits);
-        if (b == (0xFFFFFFFFu >> (32 - kCoordBits))) b -= 1u;      // (the largest pattern is the padding rows')
+        b >>= (32 - cbits);
+        if (b == (0xFFFFFFFFu >> (32 - cbits))) b -= 1u;      // (the largest pattern is the padding rows')
     } else {
-        b >>= (32 - kCoordBits);
+        b >>= (32 - cbits);
     }
-    keys[pos] = ((unsigned long long)id << kCoordBits) | b;
+    keys[pos] = (Key)(((Key)id << cbits) | (Key)b);
     vals[pos] = row;
 }
 
@@ -287,7 +291,7 @@ hipError_t sort_pairs(void* tmp, size_t tmp_bytes, const Key* keys_in, Key* keys
     return rocprim::radix_sort_pairs(tmp, tb, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit, st);
 }
 
-size_t sort_tmp_bytes(int64_t n) { return sort_pairs_tmp_bytes<unsigned long long>(n, 64u); }
+size_t sort_tmp_bytes(int64_t n) { return std::max(sort_pairs_tmp_bytes<unsigned long long>(n, 64u), sort_pairs_tmp_bytes<unsigned>(n, 32u)); }
 
 size_t segsort_tmp_bytes(int nqblk, int64_t nchunk)
 {
@@ -317,12 +321,25 @@ hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_ro
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
+    // 32-bit keys where the node id (< 2^Lradix) leaves at least kMinCoordBits32 coordinate bits AND no dimension is split
+    // more than four times by these levels (a dimension split often needs its medians placed finely: d = 1, 2 keep 64 bits)
+    const int cb32 = 32 - Lradix;
+    const bool keys32 = Lradix > 0 && cb32 >= kMinCoordBits32 && (Lradix + d - 1) / d <= 4;
     for (int level = 0; level < Lradix; ++level) {
-        hipLaunchKernelGGL(kd_key_kernel, dim3(blocks), dim3(kThreads), 0, st, level == 0 ? (const int*)nullptr : perm, n, n_pad, unit_rows,
-                           n_units, Ltop, level, P, d, level % d, keys_a, vals_b);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        e = sort_pairs(tmp, tmp_bytes, (const unsigned long long*)keys_a, keys_b, (const int*)vals_b, perm, n_pad, (unsigned)(kCoordBits + level), st);
+        hipError_t e;
+        if (keys32) {
+            unsigned* ka = reinterpret_cast<unsigned*>(keys_a);
+            unsigned* kb = reinterpret_cast<unsigned*>(keys_b);
+            hipLaunchKernelGGL(kd_key_kernel<unsigned>, dim3(blocks), dim3(kThreads), 0, st, level == 0 ? (const int*)nullptr : perm, n, n_pad, unit_rows,
+                               n_units, Ltop, level, P, d, level % d, cb32, ka, vals_b);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            e = sort_pairs(tmp, tmp_bytes, (const unsigned*)ka, kb, (const int*)vals_b, perm, n_pad, (unsigned)(cb32 + level), st);
+        } else {
+            hipLaunchKernelGGL(kd_key_kernel<unsigned long long>, dim3(blocks), dim3(kThreads), 0, st, level == 0 ? (const int*)nullptr : perm, n, n_pad, unit_rows,
+                               n_units, Ltop, level, P, d, level % d, kCoordBits, keys_a, vals_b);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            e = sort_pairs(tmp, tmp_bytes, (const unsigned long long*)keys_a, keys_b, (const int*)vals_b, perm, n_pad, (unsigned)(kCoordBits + level), st);
+        }
         if (e != hipSuccess) return e;
     }
     // ... the last kAlignLevels stay inside a group: one pass through LDS (10 M rows: 6 x 0.72 ms of sorts -> one kernel)
