@@ -599,6 +599,38 @@ def test_pruned_search_is_bit_identical_auto(prune_modes, n, d, K):
     assert _rel(d1[:3000] if sm == capi.SELF_EXCLUDE else capi.knn(Y[:3000], Y, K, self_mode=capi.SELF_EXCLUDE)[0], od) < DIST_RTOL
 
 
+@pytest.mark.parametrize("n,d,K", [(70001, 3, 9), (150000, 6, 9), (90000, 6, 5), (60000, 2, 9)])
+def test_pruned_heavy_waves_and_short_lists_are_bit_identical(prune_modes, n, d, K, monkeypatch):
+    """Round 4's two variations of the pruned walk against the exhaustive sweep, bit for bit: (a) HEAVY waves -- the first
+    waves of the dispatch order served by S workgroups each, lists folded afterwards -- for every S, for a handful of waves,
+    for the library's own count and for as many as the side arrays hold; (b) for K = 9 the instantiation that keeps nine list
+    entries in registers (three waves per SIMD), which the library only takes by itself in launches of 30+ rounds (C5), forced
+    here, with and without heavy waves.  Same buffer as X and Y (auto evidence: the heavy split applies to one set only)."""
+    capi = prune_modes
+    rng = np.random.default_rng(n + 7 * d + K)
+    Y = rng.standard_normal((n, d)) @ (np.eye(d) + 0.3 * rng.standard_normal((d, d)))
+    Y[rng.integers(0, n, 40)] *= 6.0                      # a few far outliers: the waves that hold them are the heavy ones
+    capi.set_prune_mode(capi.PRUNE_OFF)
+    want_d, want_i = capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE)
+    capi.set_prune_mode(capi.PRUNE_FORCE)
+    seen = set()
+    for lists in ((None, "short") if K == 9 else (None,)):
+        for heavy in ("0", None, "5,2", "64,3", "300,8", "100000,4", "7,5"):
+            for name, val in (("MCE_PRUNE_HEAVY", heavy), ("MCE_PRUNE_LISTS", lists)):
+                if val is None:
+                    monkeypatch.delenv(name, raising=False)
+                else:
+                    monkeypatch.setenv(name, val)
+            got_d, got_i = capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE)
+            k = capi.last_kernel()
+            assert "pruned" in k, k
+            seen.add((k.split("heavy=")[1]))
+            assert np.array_equal(got_d, want_d) and np.array_equal(got_i, want_i), (heavy, lists, k)
+    assert any(x.startswith("0x1") for x in seen) and any("x8" in x for x in seen) and any("x5" in x for x in seen)
+    if K == 9:
+        assert any(x.endswith("lists=9") for x in seen) and any(x.endswith("lists=12") for x in seen)
+
+
 @pytest.mark.parametrize("n,d,K", [(5000, 1, 3), (70001, 3, 9), (150000, 6, 10), (40000, 6, 2), (33000, 10, 16)])
 def test_pruned_search_same_buffer_is_bit_identical(prune_modes, n, d, K):
     """queries and references in ONE device buffer (what evidence() passes): the k-d order is shared, the
