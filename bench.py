@@ -12,7 +12,7 @@ bench.py --gpus N ...`: WORLD_SIZE is set, this process is one rank) or plainly 
 starts the N ranks itself as child processes BEFORE anything touches the GPU -- their output, rank 0's JSON line
 included, goes to the parent's stdout -- and exits with the job's code).  One process per GPU, the set replicated on every rank, and per step ONE all-reduce of
 kmax doubles (RCCL): strong scaling.  What a rank computes is the library's choice: auto evidence -- the
-symmetric partition (a contiguous range of the sorted query blocks) or block-cyclic parts of the pruned walk
+symmetric partition (a contiguous range of the sorted query blocks) or every N-th wave of the pruned walk's dispatch order
 (`mce_knn_dotp_part_f64_dev`); cross evidence -- contiguous query rows of s1 against the replicated s2.  Under N > 1 the
 line carries C3 (headline) AND, unless --no-extras, `configs.C2 / C4 / C5` timed the same way (barrier + synchronize
 on both sides, max over ranks), `ranks_seen`, and per rank its device ordinal and its own HIP-event search time.

@@ -172,11 +172,14 @@ int mce_knn_dotp_f64_dev(const double *dX, int64_t nq, const double *dY, int64_t
 
 /* Multi-GPU building block for the auto evidence (queries = references, k0 = 1): the partial sums over
  * part `part` of `nparts` of the queries.  The LIBRARY chooses the partition -- contiguous rows for the
- * exhaustive sweep (the query shard of SURVEY.md section 8e), every nparts-th 512-query block of the k-d
- * order for the pruned walk (spatially compact work units, one shared ordering, statistically equal
- * shares; a row-range shard would go through the much less efficient separate-sets path) -- the parts are disjoint and cover every row, so adding the
+ * exhaustive sweep (the query shard of SURVEY.md section 8e; up to four parts of a set large enough for the symmetric sweep:
+ * ranges of its sorted blocks, see mce_set_sym_mode), every nparts-th WAVE (64 queries: two k-d cells) of the pruned walk's
+ * dispatch order, heaviest first (spatially compact work units, one shared ordering, statistically equal shares; a row-range
+ * shard would go through the much less efficient separate-sets path; the heaviest waves of a part are served by several
+ * workgroups each) -- the parts are disjoint and cover every row, so adding the
  * nparts results gives mce_knn_dotp_f64_dev's dotp up to summation order.  d_w / d_fs: all nr entries.
- * workspace: mce_knn_workspace_bytes(nr, nr, d, kmax-1) + mce_dotp_workspace_bytes(nr, kmax). */
+ * workspace: mce_knn_workspace_bytes(nr, nr, d, kmax-1) + mce_dotp_workspace_bytes(nr, kmax) -- the whole set's, whatever the
+ * part (a row shard that would plan more reference splits than fit takes fewer). */
 int mce_knn_dotp_part_f64_dev(const double *dY, int64_t nr, int32_t d, int32_t kmax, int32_t part, int32_t nparts,
                               const double *d_w, const double *d_fs, double *d_dotp, void *ws, size_t ws_bytes,
                               void *stream);

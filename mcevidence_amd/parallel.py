@@ -154,7 +154,7 @@ def sharded_knn_dotp(X, Y, weight, fs, kmax, k0, want_dist=False, group=None, lo
     """Multi-rank fused kNN + reduction.  Every rank passes the FULL arrays (they are
     replicated host-side, as the reference set must be anyway) and gets the full
     ``dotp`` back.  Auto evidence: the library chooses each rank's share (``part_fn``, default
-    ``_capi.knn_dotp_part``: the symmetric partition for large sets, block-cyclic parts of the pruned walk,
+    ``_capi.knn_dotp_part``: the symmetric partition for large sets, every W-th wave of the pruned walk's dispatch order,
     row shards otherwise); cross evidence: contiguous query rows.  ``local_fn`` / ``part_fn`` let the CPU tests
     substitute the per-rank compute.
     ``verify``: compare a fingerprint of the inputs across the ranks first (``check_replicas``)."""
