@@ -113,3 +113,27 @@ def test_bench_gpus_2_from_a_plain_shell():
         assert np.max(np.abs(np.array(a["lnE"]) - np.array(b["lnE"]))) < LNE_TOL, name
     assert sum(r["query_rows"] for r in two["configs"]["C4"]["per_rank"]) == two["configs"]["C4"]["nq"]      # cross: row shards of s1
     assert "pruned" in two["configs"]["C5"]["kernel"] and "pruned" in one["configs"]["C5"]["kernel"]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_under_the_launcher():
+    """the other way to start it -- `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 --steps K --warmup W`,
+    as the driver's contract spells it: WORLD_SIZE is set, the process is one rank and must NOT spawn again.  Full-size C3,
+    headline only, both ranks on this box's one GPU over gloo: ln E of the all-reduced sums equals the reference's."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MCE_BENCH_BACKEND="gloo", MCE_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--cpu-sample", "0", "--no-extras"], capture_output=True, text=True, env=env, timeout=900, cwd=REPO)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["steps"] == 2 and line["warmup"] == 1
+    assert line["config"]["N"] == 1_000_000 and line["config"]["D"] == 27 and line["max_abs_dlnE_vs_reference"] < LNE_TOL
+    assert "symmetric" in line["roofline"]["kernel"] and len(line["per_rank"]) == 2
