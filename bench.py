@@ -332,6 +332,12 @@ def time_config(ctx, cfg, steps, warmup, mode=0, nsample=0, orc=None):
         res["sampled_rows"] = len(rows)
         res["max_rel_dist_err_sampled_rows_vs_exact_cpu_search"] = float(np.max(np.abs(got - od) / od))
         del dd
+    if "pruned" in kdesc:            # (device counters in the workspace: read before it is freed)
+        try:
+            cf, tf = _capi.last_prune_stats()
+            res["pruned_walk"] = dict(chunk_fraction=round(cf, 5), tile_fraction=round(tf, 5))
+        except Exception:
+            pass
     _capi.set_search_mode(0)
     del Xd, Yd, ws, w, fs
     torch.cuda.empty_cache()
@@ -379,12 +385,6 @@ def extra_configs(ctx, orc, pkg, scale=1.0):
                 lnE = mce.evidence()
                 res["evidence_call_from_host_s"] = round(time.perf_counter() - t0, 4)
                 res["max_abs_dlnE_class_vs_resident_path"] = float(np.max(np.abs(lnE - np.array(res["lnE"]))))
-            if name == "C5":
-                try:
-                    cf, tf = _capi.last_prune_stats()
-                    res["pruned_walk"] = dict(chunk_fraction=round(cf, 5), tile_fraction=round(tf, 5))
-                except Exception:
-                    pass
             res["cpu_baseline"] = sklearn_baseline(cfg, algs, orc)
         out[name] = res
         del cfg
