@@ -30,6 +30,7 @@
 #include <stdint.h>
 
 #include "sym_types.hpp"
+#include "prune.hpp"        // prune_band_floor: the order of the pruned walk's chunk lists
 
 #ifndef MCE_SYM_CHECK
 #define MCE_SYM_CHECK 0    // debugging aid: range checks (device printf) on the indices of the symmetric sweep's global stores
@@ -1344,7 +1345,10 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                         const bool in = idx < list_len;
                         const float cd = in ? mydist[idx] : __builtin_huge_valf();
                         win_c = in ? mylist[idx] : 0;
-                        const bool far = cd > mythr;                   // sorted: once true, true for all later entries
+                        // the list is ordered by BANDS of the bound (prune.hpp): an entry beyond this wave's reach is skipped,
+                        // and the walk ends at the first one whose band FLOOR is -- every later entry is at least that far
+                        const bool far = cd > mythr;
+                        const bool stop = prune_band_floor(cd) > mythr;
                         const float* bb = cbox_r + (int64_t)win_c * (2 * D);
                         float acc[QT];
 #pragma unroll
@@ -1364,7 +1368,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) reach |= !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]);
                         cand = __ballot(in && !far && reach);
-                        e = (__ballot(in && far) != 0) ? list_len : e + 64 * pr_step;
+                        e = (__ballot(in && stop) != 0) ? list_len : e + 64 * pr_step;
                         st_chunks += 1;
                         if (xb_state == 0) {                           // first window of a separate query set
                             float amin = acc[0];

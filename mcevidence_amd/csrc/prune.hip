@@ -5,9 +5,6 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_segmented_radix_sort.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 
 #include <algorithm>
 
@@ -200,26 +197,61 @@ __global__ __launch_bounds__(kThreads) void group_box_kernel(const float* __rest
     gbox[(g * 2 + 1) * d + i] = hi;
 }
 
-// lower bound on the squared distance between any point of query block b and any point of
-// chunk c, rounded DOWN to float (an empty box gives +inf)
-__global__ __launch_bounds__(kThreads) void box_dist_kernel(const float* __restrict__ qbox, int nqblk, const float* __restrict__ rbox,
-                                                            int nchunk, int d, float* __restrict__ out_d, int* __restrict__ out_c)
+// Chunk list of one query block per workgroup: the lower bound on the squared distance between any point of block b and any
+// point of chunk c (box to box, rounded DOWN to float; an empty box gives +inf), and the chunks ordered by BAND of that bound
+// (prune.hpp: prune_band_floor) with a counting sort in LDS -- histogram, scan, scatter; the distances are recomputed for
+// the scatter instead of stored, so any number of chunks fits.  Inside a band the order is whatever the atomics give: the
+// search result does not depend on the order the chunks are visited in (the lists are exact, ties by row), only the
+// stopping rule does, and that one reads band floors.
+constexpr int kBandKeys = 1 << (8 + kPruneBandMantissa);      // exponent + mantissa bits of a non-negative float
+__device__ __forceinline__ float box_dist2(const float* __restrict__ ql, const float* __restrict__ qh, const float* __restrict__ rl,
+                                           const float* __restrict__ rh, int d)
 {
-    const int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (e >= (int64_t)nqblk * nchunk) return;
-    const int b = (int)(e / nchunk);
-    const int c = (int)(e - (int64_t)b * nchunk);
-    const float* ql = qbox + ((int64_t)b * 2) * d;
-    const float* qh = ql + d;
-    const float* rl = rbox + ((int64_t)c * 2) * d;
-    const float* rh = rl + d;
     double s = 0.0;
     for (int i = 0; i < d; ++i) {
         const double g = fmax(0.0, fmax((double)ql[i] - (double)rh[i], (double)rl[i] - (double)qh[i]));     // NaN-free: empty boxes give +inf
         s = fma(g, g, s);
     }
-    out_d[e] = __double2float_rd(s * (1.0 - 1e-12));
-    out_c[e] = c;
+    return __double2float_rd(s * (1.0 - 1e-12));
+}
+__global__ __launch_bounds__(kThreads) void chunk_list_kernel(const float* __restrict__ qbox, const float* __restrict__ rbox, int nchunk, int d,
+                                                              float* __restrict__ out_d, int* __restrict__ out_c)
+{
+    __shared__ int cnt[kBandKeys];
+    __shared__ float qb[2 * kPruneMaxDim];
+    __shared__ int wsum[kThreads / 64];
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < kBandKeys; i += kThreads) cnt[i] = 0;
+    if (threadIdx.x < 2 * d) qb[threadIdx.x] = qbox[(int64_t)b * 2 * d + threadIdx.x];
+    __syncthreads();
+    auto key_of = [](float v) { return (int)(__float_as_uint(v) >> (23 - kPruneBandMantissa)); };       // v >= 0 or +inf: < kBandKeys
+    for (int c = threadIdx.x; c < nchunk; c += kThreads)
+        atomicAdd(&cnt[key_of(box_dist2(qb, qb + d, rbox + (int64_t)c * 2 * d, rbox + (int64_t)c * 2 * d + d, d))], 1);
+    __syncthreads();
+    // exclusive scan of the kBandKeys counters: each thread its kBandKeys / kThreads consecutive ones, then the thread totals
+    constexpr int PER = kBandKeys / kThreads;
+    int loc[PER], tot = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { loc[i] = tot; tot += cnt[threadIdx.x * PER + i]; }
+    int inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if ((threadIdx.x & 63) >= o) inc += v; }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int base = inc - tot;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) cnt[threadIdx.x * PER + i] = base + loc[i];
+    __syncthreads();
+    float* od = out_d + (int64_t)b * nchunk;
+    int* oc = out_c + (int64_t)b * nchunk;
+    for (int c = threadIdx.x; c < nchunk; c += kThreads) {
+        const float v = box_dist2(qb, qb + d, rbox + (int64_t)c * 2 * d, rbox + (int64_t)c * 2 * d + d, d);
+        const int pos = atomicAdd(&cnt[key_of(v)], 1);
+        od[pos] = v;
+        oc[pos] = c;
+    }
 }
 
 // dispatch order of the WAVES (tpw query tiles each: the unit a workgroup of the walk serves): largest box first.  The sparse
@@ -248,18 +280,6 @@ __global__ __launch_bounds__(kThreads) void wave_cost_kernel(const float* __rest
     }
     keys[g] = any ? s : -1.0f;
     vals[g] = g;
-}
-
-struct SegmentOffset {
-    unsigned stride;
-    __host__ __device__ unsigned operator()(unsigned i) const { return i * stride; }
-};
-
-using OffsetIt = rocprim::transform_iterator<rocprim::counting_iterator<unsigned>, SegmentOffset, unsigned>;
-
-OffsetIt offsets(unsigned first, unsigned stride)
-{
-    return rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned>(first), SegmentOffset{stride});
 }
 
 // rocPRIM's radix sort of (key, row) pairs.  Above ~1 M keys it takes its "onesweep" path, which clears its histogram and
@@ -292,15 +312,6 @@ hipError_t sort_pairs(void* tmp, size_t tmp_bytes, const Key* keys_in, Key* keys
 }
 
 size_t sort_tmp_bytes(int64_t n) { return std::max(sort_pairs_tmp_bytes<unsigned long long>(n, 64u), sort_pairs_tmp_bytes<unsigned>(n, 32u)); }
-
-size_t segsort_tmp_bytes(int nqblk, int64_t nchunk)
-{
-    size_t bytes = 0;
-    (void)rocprim::segmented_radix_sort_pairs(nullptr, bytes, (const float*)nullptr, (float*)nullptr, (const int*)nullptr, (int*)nullptr,
-                                              (unsigned)((int64_t)nqblk * nchunk), (unsigned)nqblk, offsets(0, (unsigned)nchunk),
-                                              offsets(1, (unsigned)nchunk), 0u, 32u);
-    return bytes;
-}
 
 // k-d order of P[n, d] in units of unit_rows; final permutation in `perm` ([n_pad])
 hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_rows, int n_units, int* perm, unsigned long long* keys_a,
@@ -376,14 +387,12 @@ int prune_layout(int64_t nq, int64_t nq_pad, int nqblk, int64_t nr, int64_t nr_p
     L.bkey_b = take(nwaves * 4);
     L.bval_a = take(nwaves * 4);
     L.border = take(nwaves * 4);
-    L.list_d_a = take((size_t)pairs * 4);
-    L.list_c_a = take((size_t)pairs * 4);
     L.list_d_b = take((size_t)pairs * 4);
     L.list_c_b = take((size_t)pairs * 4);
     size_t border_tmp = 0;
     (void)rocprim::radix_sort_pairs_desc(nullptr, border_tmp, (const float*)nullptr, (float*)nullptr, (const int*)nullptr, (int*)nullptr,
                                          nwaves, 0u, 32u);
-    L.tmp_bytes = std::max(std::max(sort_tmp_bytes(nmax), segsort_tmp_bytes(nqblk, nchunk)), border_tmp);
+    L.tmp_bytes = std::max(sort_tmp_bytes(nmax), border_tmp);
     L.tmp = take(L.tmp_bytes);
     L.total = off;
     return 0;
@@ -405,8 +414,6 @@ hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t
     float* tboxT_r = reinterpret_cast<float*>(ws + L.tboxT_r);
     float* box_r = reinterpret_cast<float*>(ws + L.box_r);
     float* box_q = reinterpret_cast<float*>(ws + L.box_q);
-    float* list_d_a = reinterpret_cast<float*>(ws + L.list_d_a);
-    int* list_c_a = reinterpret_cast<int*>(ws + L.list_c_a);
     float* list_d_b = reinterpret_cast<float*>(ws + L.list_d_b);
     int* list_c_b = reinterpret_cast<int*>(ws + L.list_c_b);
     void* tmp = ws + L.tmp;
@@ -445,14 +452,9 @@ hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t
     hipLaunchKernelGGL(group_box_kernel, blocks_for((int64_t)nqblk * d), dim3(kThreads), 0, st, out.tbox_q, same_set ? ntile_r : ntile_q, d,
                        qpb / kPruneTileRows, nqblk, box_q);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    const int64_t pairs = (int64_t)nqblk * nchunk;
-    hipLaunchKernelGGL(box_dist_kernel, dim3((unsigned)((pairs + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, box_q, nqblk, box_r,
-                       (int)nchunk, d, list_d_a, list_c_a);
+    static_assert(kBandKeys % kThreads == 0 && kPruneMaxDim * 2 <= kThreads, "chunk_list_kernel geometry");
+    hipLaunchKernelGGL(chunk_list_kernel, dim3((unsigned)nqblk), dim3(kThreads), 0, st, box_q, box_r, (int)nchunk, d, list_d_b, list_c_b);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    size_t tb = L.tmp_bytes;
-    e = rocprim::segmented_radix_sort_pairs(tmp, tb, (const float*)list_d_a, list_d_b, (const int*)list_c_a, list_c_b, (unsigned)pairs,
-                                            (unsigned)nqblk, offsets(0, (unsigned)nchunk), offsets(1, (unsigned)nchunk), 0u, 32u, st);
-    if (e != hipSuccess) return e;
     {
         float* bkey_a = reinterpret_cast<float*>(ws + L.bkey_a);
         float* bkey_b = reinterpret_cast<float*>(ws + L.bkey_b);

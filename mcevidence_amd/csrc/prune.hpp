@@ -38,8 +38,7 @@ struct PruneLayout {
     size_t tboxT_r = 0;                     // float [nchunk][2][d][tiles per chunk]: the kernel's layout
     size_t box_r = 0, box_q = 0;            // float [nchunk][2][d], [nqblk][2][d]
     size_t bkey_a = 0, bkey_b = 0, bval_a = 0, border = 0;   // the walk's waves (block * 8 + wave) by descending box size: [nqblk * 8]
-    size_t list_d_a = 0, list_c_a = 0;      // float / int32 [nqblk * nchunk] unsorted
-    size_t list_d_b = 0, list_c_b = 0;      // sorted
+    size_t list_d_b = 0, list_c_b = 0;      // float / int32 [nqblk * nchunk]: every block's chunks in bands of ascending box distance
     size_t tmp = 0, tmp_bytes = 0;          // rocPRIM scratch
     size_t total = 0;
 };
@@ -47,12 +46,26 @@ struct PruneLayout {
 // pure function of its arguments (host-only size queries)
 int prune_layout(int64_t nq, int64_t nq_pad, int nqblk, int64_t nr, int64_t nr_pad, int64_t nchunk, int d, PruneLayout& L);
 
+// The chunk lists are ordered by BANDS of the lower bound (the float's exponent and its top kPruneBandMantissa mantissa bits:
+// 3 % wide), not entry by entry: prune_band_floor(d) <= d is the same for every entry of a band and never decreases along a
+// list, so the walk may stop at the first entry whose band floor exceeds its reach (knn_f16.hpp) -- and a counting sort by
+// band in one pass replaces a segmented radix sort of nqblk * nchunk pairs.
+constexpr int kPruneBandMantissa = 5;
+__host__ __device__ inline float prune_band_floor(float d2)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(__float_as_uint(d2) & ~((1u << (23 - kPruneBandMantissa)) - 1u));
+#else
+    union { float f; unsigned u; } v; v.f = d2; v.u &= ~((1u << (23 - kPruneBandMantissa)) - 1u); return v.f;
+#endif
+}
+
 struct PruneOut {
     const double* Xs = nullptr;
     const double* Ys = nullptr;
     const int* qperm = nullptr;
     const int* rperm = nullptr;
-    const int* clist = nullptr;             // [nqblk][nchunk] chunk ids, nearest box first
+    const int* clist = nullptr;             // [nqblk][nchunk] chunk ids, in bands of ascending box distance (prune_band_floor)
     const float* cdist = nullptr;           // [nqblk][nchunk] matching lower bounds on the squared distance
     const float* tbox_r = nullptr;          // reference tile boxes, [chunk][2][d][tiles per chunk]
     const float* tbox_q = nullptr;          // query tile boxes
