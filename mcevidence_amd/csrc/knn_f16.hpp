@@ -28,6 +28,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "sym_types.hpp"
 #include "prune.hpp"        // prune_band_floor: the order of the pruned walk's chunk lists
@@ -115,6 +116,9 @@ constexpr int kHThreads = kHWaves * 64;
 // two waves per SIMD the smaller batch only costs (197 -> 224 ms), so they keep the larger footprint.
 #ifndef MCE_H_PRUNE_SMALL
 #define MCE_H_PRUNE_SMALL 9      // largest list capacity (entries held in registers) on the three-wave configuration
+#endif
+#ifndef MCE_H_PRUNE_SMALL_WAVES
+#define MCE_H_PRUNE_SMALL_WAVES 3
 #endif
 #ifndef MCE_H_PRUNE_B10
 #define MCE_H_PRUNE_B10 2       // tiles per batch with 9 list entries (8 staged-tile registers instead of 16: no scratch at 168 VGPRs)
@@ -228,8 +232,15 @@ constexpr int kHPruneChunkTiles = 64; // pruned walk: tiles per list entry ("chu
 // [tile slice + pending ids][queue d2 | row | next][heads][the wave's 64 fp64 query rows][one fp64 reference tile][its caller row numbers]
 __host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST, int D, int KCAP)
 {
+    // (+ slack: the exact evaluation reads the query rows' dimensions 0 .. 7, or 0 .. 15 when d > 8, whatever d is, and
+    //  at d <= 3 and d = 9 the last of those lie past everything else)
+    const int dh = D <= 8 ? 8 : 16;
+    const int past_xq = (kHQT * 32 + 32) * D * 8 + 1024;     // bytes allocated from the start of the query rows
+    const int past_y = 32 * D * 8 + 1024;                    // ... and from the start of the reference tile (read the same way)
+    const int need_x = dh * kHQT * 32 * 8 - past_xq, need_y = dh * 32 * 8 - past_y;
+    const int slack = need_x > need_y ? (need_x > 0 ? need_x : 0) : (need_y > 0 ? need_y : 0);
     return (size_t)f16_prune_slice_bytes(KST, KCAP) + (size_t)f16_prune_queue(KCAP) * 16 + (size_t)kHQT * 32 * 4 + 128 +
-           (size_t)(kHQT * 32 + 32) * D * 8 + 128 + (size_t)kHQT * 32 * 8 + 64 * 8;
+           (size_t)(kHQT * 32 + 32) * D * 8 + 128 + (size_t)kHQT * 32 * 8 + 64 * 8 + (size_t)slack;
 }
 
 // ---------------------------------------------------------------------------
@@ -264,7 +275,7 @@ __host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST, int D, int KCA
 //   batches of two tiles fit the three-wave budget that K <= 8 searches already run under (166 VGPRs, no scratch; ten
 //   entries, or nine with batches of four, spill the staged tiles: 265 vs 196 ms), and the walk is latency-bound.
 template <int KST, int KCAP, bool PRUNE = false, bool LOWER = false, int SYM = 0, int LC = KCAP>
-__global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_SMALL ? 3 : MCE_H_PRUNE_WAVES) : (MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ? 4 : 2))) void knn_f16_kernel(
+__global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_SMALL ? MCE_H_PRUNE_SMALL_WAVES : MCE_H_PRUNE_WAVES) : (MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ? 4 : 2))) void knn_f16_kernel(
     const _Float16* __restrict__ Yh, int64_t nchunk_total, int rsplit,
     const _Float16* __restrict__ Xh, const double* __restrict__ qinfo, const double* __restrict__ params,
     const double* __restrict__ X, const double* __restrict__ Y, int64_t nq, int64_t nr, int D,
@@ -882,6 +893,12 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
     long long gx_iter = 0, gx_cand = 0, gx_useful = 0;
 #endif
     int qorig[QT];
+#ifndef MCE_H_PRUNE_GXB
+#define MCE_H_PRUNE_GXB 4
+#endif
+    // gate_exact: fp64 loads in flight per lane (global -> LDS staging of the tile, LDS reads of the exact evaluation).  One at a
+    // time -- what a loop over the runtime d with its conditions compiles to -- every load waits for the one before.
+    constexpr int GXB = MCE_H_PRUNE_GXB;
     auto gate_exact = [&](const v16f (&acc)[QT], int jb0) {
         bool passq[QT];
         bool pass = false;
@@ -899,18 +916,58 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
             pass |= passq[qt];
         }
         if (!__any(pass)) return;
+        // the passing rows of the lane's column, per query tile -- taken now, so that the accumulators are dead (32
+        // registers free) while the rows are fetched and evaluated
+        unsigned pmq[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            pmq[qt] = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // (0 / 1 and a shift by an inline constant: as a select of 1 << r the compiler keeps the twelve values that
+                //  are no inline constants in registers for the whole walk)
+                unsigned bit = (acc[qt][r] <= G[qt]) ? 1u : 0u;
+                asm("" : "+v"(bit));
+                pmq[qt] |= bit << r;
+                asm("" : "+v"(pmq[qt]));               // (folded in here, not where the mask is first used: sixteen registers otherwise)
+            }
+        }
         {   // the tile's rows (contiguous in the k-d ordered copy) and their caller row numbers
             const int nrow = (nr - jb0 < 32) ? (int)(nr - jb0) : 32;
             const double* yt = Y + (int64_t)jb0 * D;
-            for (int e = lane; e < nrow * D; e += 64) ytile[(e % D) * 32 + e / D] = yt[e];     // [i][row]: conflict-free reads
-            if (lane < 32) yorig[lane] = (lane < nrow) ? rperm[jb0 + lane] : -1;
+            {
+                // (GXB loads at a time -- at most 8 per lane -- then their LDS writes; element e = row * d + i with
+                //  row = floor((e + 0.5) / d) in fp32: e < 512, so the quotient is never within rounding of an integer)
+                const int ne = nrow * D;
+                const int oj = (lane < 32 && lane < nrow) ? rperm[jb0 + (lane & 31)] : -1;
+                const float inv_d = 1.0f / (float)D;
+                int ln = lane;
+                asm volatile("" : "+v"(ln));             // (the eight element numbers and LDS offsets below depend on the lane and d only:
+                                                         //  computed once before the walk they would occupy fifteen registers throughout)
+#pragma unroll
+                for (int h0 = 0; h0 < 8; h0 += GXB) {
+                    if (h0 * 64 < ne) {
+                        double yv[GXB];
+#pragma unroll
+                        for (int u = 0; u < GXB; ++u) {
+                            const int e = ln + (h0 + u) * 64;
+                            yv[u] = yt[e < ne ? e : 0];
+                        }
+#pragma unroll
+                        for (int u = 0; u < GXB; ++u) {
+                            const int e = ln + (h0 + u) * 64;
+                            const int row = (int)(((float)e + 0.5f) * inv_d);
+                            if (e < ne) ytile[(e - row * D) * 32 + row] = yv[u];      // [i][row]: conflict-free reads
+                        }
+                    }
+                }
+                if (lane < 32) yorig[lane] = oj;
+            }
         }
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             if (!__any(passq[qt])) continue;
-            unsigned pm = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) pm |= (acc[qt][r] <= G[qt]) ? (1u << r) : 0u;
+            unsigned pm = pmq[qt];
             const int ql = qt * 32 + (lane & 31);
             const double* xr = xq + ql;                            // xq[i][ql]
             while (__any(pm != 0)) {
@@ -920,19 +977,35 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                 pm &= pm - 1;
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const double* yr = ytile + row;                    // ytile[i][row]
+                // D <= 15: at most two elements per partial sum.  GXB dimensions are read at a time, without
+                // conditions (what lies past dimension d in LDS is whatever follows -- f16_prune_lds_bytes keeps it
+                // inside the allocation -- and its term is replaced by zero: fma(0, 0, a) = a)
                 double sp[8];
+                {
 #pragma unroll
-                for (int sb = 0; sb < 8; ++sb) {
-                    double a0 = 0.0;
+                    for (int g0 = 0; g0 < 8; g0 += GXB) {
+                        double xv[GXB], yv[GXB];
 #pragma unroll
-                    for (int v = 0; v < 2; ++v) {                  // D <= 15: at most two elements per partial sum
-                        const int i = sb + 8 * v;
-                        if (i < D) {
-                            const double t = xr[i * QPW] - yr[i * 32];
-                            a0 = fma(t, t, a0);
+                        for (int u = 0; u < GXB; ++u) { xv[u] = xr[(g0 + u) * QPW]; yv[u] = yr[(g0 + u) * 32]; }
+#pragma unroll
+                        for (int u = 0; u < GXB; ++u) {
+                            const double t = (g0 + u < D) ? xv[u] - yv[u] : 0.0;
+                            sp[g0 + u] = fma(t, t, 0.0);
                         }
                     }
-                    sp[sb] = a0;
+                    if (D > 8) {
+#pragma unroll
+                        for (int g0 = 0; g0 < 8; g0 += GXB) {
+                            double xv[GXB], yv[GXB];
+#pragma unroll
+                            for (int u = 0; u < GXB; ++u) { xv[u] = xr[(8 + g0 + u) * QPW]; yv[u] = yr[(8 + g0 + u) * 32]; }
+#pragma unroll
+                            for (int u = 0; u < GXB; ++u) {
+                                const double t = (8 + g0 + u < D) ? xv[u] - yv[u] : 0.0;
+                                sp[g0 + u] = fma(t, t, sp[g0 + u]);
+                            }
+                        }
+                    }
                 }
                 const double d2 = ((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7]));
                 const int oj = yorig[row];
@@ -1272,7 +1345,119 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
         const float* const mydist = cdist + (int64_t)qblk * list_len;
         char* const wbuf = stage0;                                          // [kBatch tiles][pending ids]
         int* const wl = reinterpret_cast<int*>(wbuf + kBatch * KST * 1024);
-        const float* const qb = tbox_q + (qwave0 / 32) * (int64_t)(2 * D);   // this wave's QT query-tile boxes
+        // This wave's QT query-tile boxes, all in ONE register: lane qt*32 + i holds the lower edge of dimension i, lane
+        // qt*32 + 16 + i the upper.  The box tests read them with v_readlane (constant lanes) where they are needed --
+        // as scalar loads the compiler kept 4 * d pointers alive across the walk, spilled, and waited for every
+        // dimension's loads one after the other.
+        static_assert(QT == 2 && kPruneDims <= 16, "query boxes: one value per lane");
+        int qbv;
+        {
+            const int qi = lane & 15, qh = (lane >> 4) & 1;
+            const float* const qb = tbox_q + (qwave0 / 32) * (int64_t)(2 * D);
+            qbv = __float_as_int(qi < D ? qb[(lane >> 5) * 2 * D + qh * D + qi] : 0.0f);
+        }
+        // (largest coordinate magnitude among this wave's queries: a query's float coordinate is within 2^-24 of that of its fp64 one)
+        float qabs = fabsf(__int_as_float(qbv));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) qabs = fmaxf(qabs, __shfl_xor(qabs, o, 64));
+        const int qabs_bits = __builtin_amdgcn_readfirstlane(__float_as_int(qabs));
+        // squared gap between a reference box (lower edges at p[i * stride], upper at p[(D + i) * stride]) and each query
+        // tile's box.  The loads of eight dimensions are issued together (indices past d clamped, their terms zeroed:
+        // fma(0, 0, acc) = acc, so the sums are those of the one-dimension-at-a-time loop, bit for bit).
+        // (keep: the lane's box stays in blo / bhi for query_reach below)
+        auto box_gap = [&](const float* p, const int stride, float (&acc)[QT], auto keep, float (&blo)[8], float (&bhi)[8]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) acc[qt] = 0.0f;
+            int qv = qbv, Dq = D;
+            // (the lane reads and the clamped offsets stay here: hoisted out of the walk they would only be spilled)
+            asm volatile("" : "+v"(qv), "+s"(Dq));
+#pragma unroll
+            for (int h0 = 0; h0 < kPruneDims; h0 += 8) {
+                if (h0 < D) {
+                    float rlo[8], rhi[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int ii = (h0 + u < Dq) ? h0 + u : h0;
+                        rlo[u] = p[ii * stride];
+                        rhi[u] = p[(Dq + ii) * stride];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = h0 + u;
+                        if (i < kPruneDims) {
+#pragma unroll
+                            for (int qt = 0; qt < QT; ++qt) {
+                                const float qlo = __int_as_float(__builtin_amdgcn_readlane(qv, qt * 32 + i));
+                                const float qhi = __int_as_float(__builtin_amdgcn_readlane(qv, qt * 32 + 16 + i));
+                                const float g = fmaxf(0.0f, fmaxf(qlo - rhi[u], rlo[u] - qhi));
+                                const float gz = (i < Dq) ? g : 0.0f;
+                                acc[qt] = fmaf(gz, gz, acc[qt]);
+                            }
+                        }
+                        if (decltype(keep)::value && h0 == 0) {      // (both known once the loop is unrolled)
+                            // the box, widened by more than the queries' float coordinates can be off (query_reach): 2^-22 of
+                            // the larger of the two magnitudes covers 2^-24 |x| and this subtraction's own rounding
+                            const float mg = fmaf(fmaxf(__int_as_float(qabs_bits), fmaxf(fabsf(rlo[u]), fabsf(rhi[u]))), 0x1p-22f, 1e-37f);
+                            blo[u] = (i < Dq) ? rlo[u] - mg : -__builtin_huge_valf();
+                            bhi[u] = (i < Dq) ? rhi[u] + mg : __builtin_huge_valf();
+                        }
+                    }
+                }
+            }
+        };
+        // Second, sharper test of the tiles whose box is within reach of a query TILE's box: is it within reach of any single
+        // QUERY (its own K-th distance, its own position)?  At d = 6 only one tile in six is (32 queries k-d neighbours of each
+        // other still span a box whose corners no query is near, and the tile's bound is its WORST query's).  Lane = query
+        // here: the tile's box comes out of the lane that tested it (blo / bhi, v_readlane with the tile's lane number, widened
+        // in box_gap by what a float coordinate can be off), the query's coordinates out of LDS as floats, once per chunk; the
+        // gap is then a lower bound like the box test's, and the sum is compared with the same 2^-18 allowance.
+#ifndef MCE_H_PRUNE_QREACH
+#define MCE_H_PRUNE_QREACH 1
+#endif
+        // (compiled for every even number of dimensions DD >= d up to 8, chosen by one uniform switch: with d a run-time bound inside
+        //  the loop every dimension costs two branches and the dimensions wait for each other -- 700 cycles per tile measured,
+        //  against 200 here.  box_gap leaves -inf / +inf in the one dimension that may lie past d: its gap is zero.)
+        auto query_reach_dd = [&](unsigned long long need, const float (&blo)[8], const float (&bhi)[8], auto dd) __attribute__((always_inline)) -> unsigned long long {
+            constexpr int DD = decltype(dd)::value;
+            // (constant offsets from one address; DD - 1 may be d itself, the row after the last: read, and replaced by zero)
+            float xf[DD];
+            const double* xl = xq + lane;
+            asm volatile("" : "+v"(xl));                 // (not sixteen addresses computed before the walk and kept)
+#pragma unroll
+            for (int i = 0; i < DD; ++i) xf[i] = (float)xl[i * QPW];
+            xf[DD - 1] = (DD - 1 < D) ? xf[DD - 1] : 0.0f;
+            const float thrf = (qwave0 + lane < nq) ? __double2float_ru(thrq[lane]) : -1.0f;     // (a padding query reaches nothing)
+            unsigned long long keep = 0;
+            while (need != 0) {
+                const int t = (int)__builtin_ctzll(need);
+                need &= need - 1;
+                float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < DD; i += 2) {
+                    const float lo0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo[i]), t));
+                    const float hi0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi[i]), t));
+                    const float lo1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo[i + 1]), t));
+                    const float hi1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi[i + 1]), t));
+                    const float g0 = fmaxf(0.0f, fmaxf(lo0 - xf[i], xf[i] - hi0));
+                    const float g1 = fmaxf(0.0f, fmaxf(lo1 - xf[i + 1], xf[i + 1] - hi1));
+                    a0 = fmaf(g0, g0, a0);
+                    a1 = fmaf(g1, g1, a1);
+                }
+                if (__ballot(!((a0 + a1) * (1.0f - 0x1p-18f) > thrf)) != 0) keep |= 1ull << t;
+            }
+            return keep;
+        };
+        // (d <= 8 only -- where the pruned walk is chosen at all, capi.hip: kPruneAutoMinRows; sixteen dimensions' worth of
+        //  boxes and coordinates do not fit the registers of the larger list capacities)
+        auto query_reach = [&](unsigned long long need, const float (&blo)[8], const float (&bhi)[8]) __attribute__((always_inline)) -> unsigned long long {
+            switch ((D + 1) >> 1) {
+            case 1: return query_reach_dd(need, blo, bhi, std::integral_constant<int, 2>());
+            case 2: return query_reach_dd(need, blo, bhi, std::integral_constant<int, 4>());
+            case 3: return query_reach_dd(need, blo, bhi, std::integral_constant<int, 6>());
+            case 4: return query_reach_dd(need, blo, bhi, std::integral_constant<int, 8>());
+            default: return need;
+            }
+        };
         int pend = 0;
         int st_tiles = 0, st_chunks = 0;
 #if MCE_PRUNE_PROF
@@ -1350,20 +1535,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                         const bool far = cd > mythr;
                         const bool stop = prune_band_floor(cd) > mythr;
                         const float* bb = cbox_r + (int64_t)win_c * (2 * D);
-                        float acc[QT];
-#pragma unroll
-                        for (int qt = 0; qt < QT; ++qt) acc[qt] = 0.0f;
-#pragma unroll
-                        for (int i = 0; i < kPruneDims; ++i) {
-                            if (i < D) {
-                                const float rlo = bb[i], rhi = bb[D + i];
-#pragma unroll
-                                for (int qt = 0; qt < QT; ++qt) {
-                                    const float g = fmaxf(0.0f, fmaxf(qb[qt * 2 * D + i] - rhi, rlo - qb[qt * 2 * D + D + i]));
-                                    acc[qt] = fmaf(g, g, acc[qt]);
-                                }
-                            }
-                        }
+                        float acc[QT], blo_[8], bhi_[8];
+                        box_gap(bb, 1, acc, std::false_type(), blo_, bhi_);
                         bool reach = false;
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) reach |= !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]);
@@ -1388,20 +1561,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                     const float* cb = tbox_r + (int64_t)c * (2 * D * PCT) + lane;
                     // fp32 is enough for a rigorous bound: a gap fl(a - b) of two floats is within 2^-24
                     // of exact, the sum of <= 15 squares within 2^-19; the comparison gives back 2^-18
-                    float acc[QT];
-#pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) acc[qt] = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < kPruneDims; ++i) {
-                        if (i < D) {
-                            const float rlo = cb[i * PCT], rhi = cb[(D + i) * PCT];
-#pragma unroll
-                            for (int qt = 0; qt < QT; ++qt) {
-                                const float g = fmaxf(0.0f, fmaxf(qb[qt * 2 * D + i] - rhi, rlo - qb[qt * 2 * D + D + i]));
-                                acc[qt] = fmaf(g, g, acc[qt]);
-                            }
-                        }
-                    }
+                    float acc[QT], blo[8], bhi[8];
+                    box_gap(cb, PCT, acc, std::integral_constant<bool, MCE_H_PRUNE_QREACH != 0>(), blo, bhi);
                     if (xb_state == 0) {
                         float amin = acc[0];
 #pragma unroll
@@ -1414,6 +1575,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                         const bool booted = same_order ? (tile_id >= boot_lo && tile_id < boot_hi) : (xb_win0 && ((xb_mask[cur_bsel] >> lane) & 1ull));
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) need |= __ballot(!booted && !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]));
+#if MCE_H_PRUNE_QREACH
+                        if (need != 0) need = query_reach(need, blo, bhi);
+#endif
                     }
                     st_tiles += __builtin_popcountll(need);
                     if (need == 0) continue;

@@ -585,7 +585,8 @@ def _both(capi, fn):
     return a, b
 
 
-@pytest.mark.parametrize("n,d,K", [(5000, 1, 3), (20000, 2, 5), (40000, 3, 1), (60000, 6, 10), (33333, 6, 16), (25000, 9, 4), (20000, 13, 7)])
+@pytest.mark.parametrize("n,d,K", [(5000, 1, 3), (20000, 2, 5), (40000, 3, 1), (60000, 6, 10), (33333, 6, 16), (25000, 9, 4), (20000, 13, 7),
+                                   (45000, 5, 8), (30000, 7, 4), (50000, 8, 12), (64000, 4, 9)])   # (every per-query reach variant: d = 1 .. 8, odd and even)
 def test_pruned_search_is_bit_identical_auto(prune_modes, n, d, K):
     """k-d ordered, box-pruned walk vs the exhaustive sweep: same distances,
     same neighbour rows, same order -- bit for bit -- with the own row excluded, included, ignored."""
