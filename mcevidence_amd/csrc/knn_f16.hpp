@@ -121,7 +121,7 @@ constexpr int kHThreads = kHWaves * 64;
 #define MCE_H_PRUNE_SMALL_WAVES 3
 #endif
 #ifndef MCE_H_PRUNE_B10
-#define MCE_H_PRUNE_B10 2       // tiles per batch with 9 list entries (8 staged-tile registers instead of 16: no scratch at 168 VGPRs)
+#define MCE_H_PRUNE_B10 4       // tiles per batch with 9 list entries
 #endif
 #ifndef MCE_H_PRUNE_Q10
 #define MCE_H_PRUNE_Q10 128
@@ -232,15 +232,10 @@ constexpr int kHPruneChunkTiles = 64; // pruned walk: tiles per list entry ("chu
 // [tile slice + pending ids][queue d2 | row | next][heads][the wave's 64 fp64 query rows][one fp64 reference tile][its caller row numbers]
 __host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST, int D, int KCAP)
 {
-    // (+ slack: the exact evaluation reads the query rows' dimensions 0 .. 7, or 0 .. 15 when d > 8, whatever d is, and
-    //  at d <= 3 and d = 9 the last of those lie past everything else)
-    const int dh = D <= 8 ? 8 : 16;
-    const int past_xq = (kHQT * 32 + 32) * D * 8 + 1024;     // bytes allocated from the start of the query rows
-    const int past_y = 32 * D * 8 + 1024;                    // ... and from the start of the reference tile (read the same way)
-    const int need_x = dh * kHQT * 32 * 8 - past_xq, need_y = dh * 32 * 8 - past_y;
-    const int slack = need_x > need_y ? (need_x > 0 ? need_x : 0) : (need_y > 0 ? need_y : 0);
+    // (the exact evaluation and the per-query reach test may read ONE row past the d rows of the query block / the
+    //  reference tile when d is odd: 512 / 256 bytes that the regions after them always cover)
     return (size_t)f16_prune_slice_bytes(KST, KCAP) + (size_t)f16_prune_queue(KCAP) * 16 + (size_t)kHQT * 32 * 4 + 128 +
-           (size_t)(kHQT * 32 + 32) * D * 8 + 128 + (size_t)kHQT * 32 * 8 + 64 * 8 + (size_t)slack;
+           (size_t)(kHQT * 32 + 32) * D * 8 + 128 + (size_t)kHQT * 32 * 8 + 64 * 8;
 }
 
 // ---------------------------------------------------------------------------
@@ -899,6 +894,43 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
     // gate_exact: fp64 loads in flight per lane (global -> LDS staging of the tile, LDS reads of the exact evaluation).  One at a
     // time -- what a loop over the runtime d with its conditions compiles to -- every load waits for the one before.
     constexpr int GXB = MCE_H_PRUNE_GXB;
+    // partial sums of |x - y|^2 (x: xr[i * QPW], y: yr[i * 32], both LDS), dimension i into sp[i & 7] in ascending order of i --
+    // the sweep's phase A tree.  DD - 1 may be d itself, one row past the data: read (f16_prune_lds_bytes keeps it inside
+    // the allocation) and replaced by zero, fma(0, 0, a) = a.
+    auto exact_sums_dd = [&](const double* xr, const double* yr, double (&sp)[8], auto dd) __attribute__((always_inline)) {
+        constexpr int DD = decltype(dd)::value;
+#pragma unroll
+        for (int sb = 0; sb < 8; ++sb) sp[sb] = 0.0;
+#pragma unroll
+        for (int g0 = 0; g0 < DD; g0 += GXB) {
+            double xv[GXB], yv[GXB];
+#pragma unroll
+            for (int u = 0; u < GXB; ++u)
+                if (g0 + u < DD) { xv[u] = xr[(g0 + u) * QPW]; yv[u] = yr[(g0 + u) * 32]; }
+#pragma unroll
+            for (int u = 0; u < GXB; ++u) {
+                const int i = g0 + u;
+                if (i < DD) {
+                    double t = xv[u] - yv[u];
+                    if (i == DD - 1) t = (i < D) ? t : 0.0;
+                    sp[i & 7] = fma(t, t, sp[i & 7]);
+                }
+            }
+        }
+    };
+    auto exact_sums = [&](const double* xr, const double* yr, double (&sp)[8]) __attribute__((always_inline)) {
+        static_assert(kPruneDims <= 16, "exact_sums: even dimension counts up to 16");
+        switch ((D + 1) >> 1) {
+        case 1: exact_sums_dd(xr, yr, sp, std::integral_constant<int, 2>()); break;
+        case 2: exact_sums_dd(xr, yr, sp, std::integral_constant<int, 4>()); break;
+        case 3: exact_sums_dd(xr, yr, sp, std::integral_constant<int, 6>()); break;
+        case 4: exact_sums_dd(xr, yr, sp, std::integral_constant<int, 8>()); break;
+        case 5: exact_sums_dd(xr, yr, sp, std::integral_constant<int, 10>()); break;
+        case 6: exact_sums_dd(xr, yr, sp, std::integral_constant<int, 12>()); break;
+        case 7: exact_sums_dd(xr, yr, sp, std::integral_constant<int, 14>()); break;
+        default: exact_sums_dd(xr, yr, sp, std::integral_constant<int, 16>()); break;
+        }
+    };
     auto gate_exact = [&](const v16f (&acc)[QT], int jb0) {
         bool passq[QT];
         bool pass = false;
@@ -977,36 +1009,10 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                 pm &= pm - 1;
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const double* yr = ytile + row;                    // ytile[i][row]
-                // D <= 15: at most two elements per partial sum.  GXB dimensions are read at a time, without
-                // conditions (what lies past dimension d in LDS is whatever follows -- f16_prune_lds_bytes keeps it
-                // inside the allocation -- and its term is replaced by zero: fma(0, 0, a) = a)
+                // D <= 15: at most two elements per partial sum (sp[i & 7]); the code for the even dimension count DD >= d is
+                // chosen by a uniform switch (exact_sums): no conditions between the LDS reads, which then go out together.
                 double sp[8];
-                {
-#pragma unroll
-                    for (int g0 = 0; g0 < 8; g0 += GXB) {
-                        double xv[GXB], yv[GXB];
-#pragma unroll
-                        for (int u = 0; u < GXB; ++u) { xv[u] = xr[(g0 + u) * QPW]; yv[u] = yr[(g0 + u) * 32]; }
-#pragma unroll
-                        for (int u = 0; u < GXB; ++u) {
-                            const double t = (g0 + u < D) ? xv[u] - yv[u] : 0.0;
-                            sp[g0 + u] = fma(t, t, 0.0);
-                        }
-                    }
-                    if (D > 8) {
-#pragma unroll
-                        for (int g0 = 0; g0 < 8; g0 += GXB) {
-                            double xv[GXB], yv[GXB];
-#pragma unroll
-                            for (int u = 0; u < GXB; ++u) { xv[u] = xr[(8 + g0 + u) * QPW]; yv[u] = yr[(8 + g0 + u) * 32]; }
-#pragma unroll
-                            for (int u = 0; u < GXB; ++u) {
-                                const double t = (8 + g0 + u < D) ? xv[u] - yv[u] : 0.0;
-                                sp[g0 + u] = fma(t, t, sp[g0 + u]);
-                            }
-                        }
-                    }
-                }
+                exact_sums(xr, yr, sp);
                 const double d2 = ((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7]));
                 const int oj = yorig[row];
                 // (beyond the K-th best of the last drain: can never enter -- the thresholds only shrink)
@@ -1364,8 +1370,15 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
         // squared gap between a reference box (lower edges at p[i * stride], upper at p[(D + i) * stride]) and each query
         // tile's box.  The loads of eight dimensions are issued together (indices past d clamped, their terms zeroed:
         // fma(0, 0, acc) = acc, so the sums are those of the one-dimension-at-a-time loop, bit for bit).
-        // (keep: the lane's box stays in blo / bhi for query_reach below)
-        auto box_gap = [&](const float* p, const int stride, float (&acc)[QT], auto keep, float (&blo)[8], float (&bhi)[8]) __attribute__((always_inline)) {
+#ifndef MCE_H_PRUNE_QREACH
+#define MCE_H_PRUNE_QREACH 1
+#endif
+#define MCE_H_PRUNE_QREACH_ON (MCE_H_PRUNE_QREACH != 0)
+        // (keep: the lane's box, widened, goes to LDS for query_reach below -- the tile slice, idle while tiles are collected)
+        static_assert(!MCE_H_PRUNE_QREACH_ON || kBatch * KST * 1024 >= 64 * 64, "tile slice: room for 64 boxes of 8 dimensions");
+        typedef float v4f_t __attribute__((ext_vector_type(4)));
+        typedef float v2f_t __attribute__((ext_vector_type(2)));
+        auto box_gap = [&](const float* p, const int stride, float (&acc)[QT], auto keep) __attribute__((always_inline)) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) acc[qt] = 0.0f;
             int qv = qbv, Dq = D;
@@ -1394,12 +1407,22 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                                 acc[qt] = fmaf(gz, gz, acc[qt]);
                             }
                         }
-                        if (decltype(keep)::value && h0 == 0) {      // (both known once the loop is unrolled)
-                            // the box, widened by more than the queries' float coordinates can be off (query_reach): 2^-22 of
-                            // the larger of the two magnitudes covers 2^-24 |x| and this subtraction's own rounding
+                    }
+                    if (decltype(keep)::value && h0 == 0) {      // (both known once the loop is unrolled)
+                        // the box, widened by more than the queries' float coordinates can be off (query_reach): 2^-22 of the
+                        // larger of the two magnitudes covers 2^-24 |x| and this subtraction's own rounding; -inf / +inf past
+                        // d (a gap of zero).  64 bytes per tile: (lo, lo, hi, hi) of dimensions 0-1, 2-3, 4-5, 6-7.
+                        float blo[8], bhi[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
                             const float mg = fmaf(fmaxf(__int_as_float(qabs_bits), fmaxf(fabsf(rlo[u]), fabsf(rhi[u]))), 0x1p-22f, 1e-37f);
-                            blo[u] = (i < Dq) ? rlo[u] - mg : -__builtin_huge_valf();
-                            bhi[u] = (i < Dq) ? rhi[u] + mg : __builtin_huge_valf();
+                            blo[u] = (u < Dq) ? rlo[u] - mg : -__builtin_huge_valf();
+                            bhi[u] = (u < Dq) ? rhi[u] + mg : __builtin_huge_valf();
+                        }
+                        v4f_t* bx = reinterpret_cast<v4f_t*>(wbuf) + lane * 4;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (2 * j < Dq) { v4f_t v = {blo[2 * j], blo[2 * j + 1], bhi[2 * j], bhi[2 * j + 1]}; bx[j] = v; }
                         }
                     }
                 }
@@ -1408,53 +1431,58 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
         // Second, sharper test of the tiles whose box is within reach of a query TILE's box: is it within reach of any single
         // QUERY (its own K-th distance, its own position)?  At d = 6 only one tile in six is (32 queries k-d neighbours of each
         // other still span a box whose corners no query is near, and the tile's bound is its WORST query's).  Lane = query
-        // here: the tile's box comes out of the lane that tested it (blo / bhi, v_readlane with the tile's lane number, widened
-        // in box_gap by what a float coordinate can be off), the query's coordinates out of LDS as floats, once per chunk; the
-        // gap is then a lower bound like the box test's, and the sum is compared with the same 2^-18 allowance.
-#ifndef MCE_H_PRUNE_QREACH
-#define MCE_H_PRUNE_QREACH 1
-#endif
+        // here: the tile's box comes out of LDS, where the lane that tested it left it (box_gap: widened by what a float
+        // coordinate can be off), the query's coordinates out of LDS as floats, once per chunk; the gap is then a lower bound
+        // like the box test's, and the sum is compared with the same 2^-18 allowance.
         // (compiled for every even number of dimensions DD >= d up to 8, chosen by one uniform switch: with d a run-time bound inside
         //  the loop every dimension costs two branches and the dimensions wait for each other -- 700 cycles per tile measured,
         //  against 200 here.  box_gap leaves -inf / +inf in the one dimension that may lie past d: its gap is zero.)
-        auto query_reach_dd = [&](unsigned long long need, const float (&blo)[8], const float (&bhi)[8], auto dd) __attribute__((always_inline)) -> unsigned long long {
+        auto query_reach_dd = [&](unsigned long long need, auto dd) __attribute__((always_inline)) -> unsigned long long {
             constexpr int DD = decltype(dd)::value;
             // (constant offsets from one address; DD - 1 may be d itself, the row after the last: read, and replaced by zero)
             float xf[DD];
-            const double* xl = xq + lane;
-            asm volatile("" : "+v"(xl));                 // (not sixteen addresses computed before the walk and kept)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));                 // (not eight addresses computed before the walk and kept)
 #pragma unroll
-            for (int i = 0; i < DD; ++i) xf[i] = (float)xl[i * QPW];
+            for (int i = 0; i < DD; ++i) xf[i] = (float)xq[i * QPW + ln];
             xf[DD - 1] = (DD - 1 < D) ? xf[DD - 1] : 0.0f;
             const float thrf = (qwave0 + lane < nq) ? __double2float_ru(thrq[lane]) : -1.0f;     // (a padding query reaches nothing)
+            const v4f_t* const bx = reinterpret_cast<const v4f_t*>(wbuf);
             unsigned long long keep = 0;
             while (need != 0) {
-                const int t = (int)__builtin_ctzll(need);
+                // two tiles per round (independent chains); an odd last tile is simply tested twice.  Their boxes: the same
+                // address in every lane, one 16-byte LDS read per pair of dimensions -- (lo, lo, hi, hi), as the packed fp32
+                // operations below want them
+                const int t0 = (int)__builtin_ctzll(need);
                 need &= need - 1;
-                float a0 = 0.0f, a1 = 0.0f;
+                const int t1 = need != 0 ? (int)__builtin_ctzll(need) : t0;
+                need &= need - 1;                       // (0 & anything = 0)
+                v4f_t A[DD / 2], B[DD / 2];
 #pragma unroll
-                for (int i = 0; i < DD; i += 2) {
-                    const float lo0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo[i]), t));
-                    const float hi0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi[i]), t));
-                    const float lo1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo[i + 1]), t));
-                    const float hi1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi[i + 1]), t));
-                    const float g0 = fmaxf(0.0f, fmaxf(lo0 - xf[i], xf[i] - hi0));
-                    const float g1 = fmaxf(0.0f, fmaxf(lo1 - xf[i + 1], xf[i + 1] - hi1));
-                    a0 = fmaf(g0, g0, a0);
-                    a1 = fmaf(g1, g1, a1);
+                for (int j = 0; j < DD / 2; ++j) { A[j] = bx[t0 * 4 + j]; B[j] = bx[t1 * 4 + j]; }
+                v2f_t sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
+#pragma unroll
+                for (int j = 0; j < DD / 2; ++j) {
+                    const v2f_t x2 = {xf[2 * j], xf[2 * j + 1]};
+                    const v2f_t ua = A[j].xy - x2, wa = x2 - A[j].zw, ub = B[j].xy - x2, wb = x2 - B[j].zw;
+                    const v2f_t ga = {fmaxf(0.0f, fmaxf(ua.x, wa.x)), fmaxf(0.0f, fmaxf(ua.y, wa.y))};
+                    const v2f_t gb = {fmaxf(0.0f, fmaxf(ub.x, wb.x)), fmaxf(0.0f, fmaxf(ub.y, wb.y))};
+                    sa = ga * ga + sa;
+                    sb = gb * gb + sb;
                 }
-                if (__ballot(!((a0 + a1) * (1.0f - 0x1p-18f) > thrf)) != 0) keep |= 1ull << t;
+                if (__ballot(!((sa.x + sa.y) * (1.0f - 0x1p-18f) > thrf)) != 0) keep |= 1ull << t0;
+                if (__ballot(!((sb.x + sb.y) * (1.0f - 0x1p-18f) > thrf)) != 0) keep |= 1ull << t1;
             }
             return keep;
         };
         // (d <= 8 only -- where the pruned walk is chosen at all, capi.hip: kPruneAutoMinRows; sixteen dimensions' worth of
         //  boxes and coordinates do not fit the registers of the larger list capacities)
-        auto query_reach = [&](unsigned long long need, const float (&blo)[8], const float (&bhi)[8]) __attribute__((always_inline)) -> unsigned long long {
+        auto query_reach = [&](unsigned long long need) __attribute__((always_inline)) -> unsigned long long {
             switch ((D + 1) >> 1) {
-            case 1: return query_reach_dd(need, blo, bhi, std::integral_constant<int, 2>());
-            case 2: return query_reach_dd(need, blo, bhi, std::integral_constant<int, 4>());
-            case 3: return query_reach_dd(need, blo, bhi, std::integral_constant<int, 6>());
-            case 4: return query_reach_dd(need, blo, bhi, std::integral_constant<int, 8>());
+            case 1: return query_reach_dd(need, std::integral_constant<int, 2>());
+            case 2: return query_reach_dd(need, std::integral_constant<int, 4>());
+            case 3: return query_reach_dd(need, std::integral_constant<int, 6>());
+            case 4: return query_reach_dd(need, std::integral_constant<int, 8>());
             default: return need;
             }
         };
@@ -1535,8 +1563,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                         const bool far = cd > mythr;
                         const bool stop = prune_band_floor(cd) > mythr;
                         const float* bb = cbox_r + (int64_t)win_c * (2 * D);
-                        float acc[QT], blo_[8], bhi_[8];
-                        box_gap(bb, 1, acc, std::false_type(), blo_, bhi_);
+                        float acc[QT];
+                        box_gap(bb, 1, acc, std::false_type());
                         bool reach = false;
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) reach |= !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]);
@@ -1561,8 +1589,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                     const float* cb = tbox_r + (int64_t)c * (2 * D * PCT) + lane;
                     // fp32 is enough for a rigorous bound: a gap fl(a - b) of two floats is within 2^-24
                     // of exact, the sum of <= 15 squares within 2^-19; the comparison gives back 2^-18
-                    float acc[QT], blo[8], bhi[8];
-                    box_gap(cb, PCT, acc, std::integral_constant<bool, MCE_H_PRUNE_QREACH != 0>(), blo, bhi);
+                    float acc[QT];
+                    box_gap(cb, PCT, acc, std::integral_constant<bool, MCE_H_PRUNE_QREACH != 0>());
                     if (xb_state == 0) {
                         float amin = acc[0];
 #pragma unroll
@@ -1576,7 +1604,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) need |= __ballot(!booted && !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]));
 #if MCE_H_PRUNE_QREACH
-                        if (need != 0) need = query_reach(need, blo, bhi);
+                        if (need != 0) need = query_reach(need);
 #endif
                     }
                     st_tiles += __builtin_popcountll(need);
