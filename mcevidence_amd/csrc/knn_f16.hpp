@@ -1622,9 +1622,26 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
             MCE_PT(pt_walk);
             if (pend == 0) break;
             // ---- multiply the pending tiles
-            // global -> registers -> the wave's LDS slice (all loads of the batch in flight together).
-            // Not LDS-DMA: a DMA's landing is ordered for ds_read only by vmcnt PLUS a workgroup
-            // barrier, and these waves share no barrier.
+            // global -> the wave's LDS slice by LDS-DMA (all tiles of the batch in flight together, no registers in between).
+            // A DMA's landing is ordered for the ISSUING wave's ds_read by its own vmcnt wait alone (for other waves' reads a
+            // workgroup barrier must follow, dma_barrier above -- these workgroups are one wave).
+#ifndef MCE_H_PRUNE_DMA
+#define MCE_H_PRUNE_DMA 1
+#endif
+#if MCE_H_PRUNE_DMA
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                if (u < pend) {
+                    const int id = __builtin_amdgcn_readfirstlane(wl[u]);
+                    const _Float16* src = Yh + (int64_t)id * (KST * 512) + lane * 8;
+#pragma unroll
+                    for (int ks = 0; ks < KST; ++ks)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ks * 512),
+                                                         (__attribute__((address_space(3))) void*)(wbuf + (u * KST + ks) * 1024), 16, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
             {
                 v8h stg[kBatch][KST];
 #pragma unroll
@@ -1644,6 +1661,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                     }
                 }
             }
+#endif
             MCE_PT(pt_stage);
             {
                 // (no mfma/gate overlap across tiles: measured, the multiply phase is bound by the gate and
