@@ -885,7 +885,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
     // so the distances stay bit-identical.  What is queued is (exact d2, caller row), already linked
     // into its query's chain; drain() is then insertion (phase B) only.
 #if MCE_PRUNE_PROF
-    long long gx_iter = 0, gx_cand = 0, gx_useful = 0;
+    long long gx_iter = 0, gx_cand = 0, gx_useful = 0, gx_stage_t = 0;
 #endif
     int qorig[QT];
 #ifndef MCE_H_PRUNE_GXB
@@ -948,8 +948,29 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
             pass |= passq[qt];
         }
         if (!__any(pass)) return;
-        // the passing rows of the lane's column, per query tile -- taken now, so that the accumulators are dead (32
-        // registers free) while the rows are fetched and evaluated
+        // The tile's rows (contiguous in the k-d ordered copy) and their caller row numbers: the first GXB loads per lane (all
+        // of them at d <= 8) go out now, the masks of passing rows are taken while they are in flight, then the LDS writes.
+        // Element e = row * d + i, row = floor((e + 0.5) / d) in fp32: e < 512, so the quotient is never within rounding of
+        // an integer.
+#if MCE_PRUNE_PROF
+        const long long gx_ts0 = clock64();
+#endif
+        const int nrow = (nr - jb0 < 32) ? (int)(nr - jb0) : 32;
+        const double* yt = Y + (int64_t)jb0 * D;
+        const int ne = nrow * D;
+        const float inv_d = 1.0f / (float)D;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));             // (the eight element numbers and LDS offsets below depend on the lane and d only:
+                                                 //  computed once before the walk they would occupy fifteen registers throughout)
+        const int oj0 = (lane < 32 && lane < nrow) ? rperm[jb0 + (lane & 31)] : -1;
+        double yv0[GXB];
+#pragma unroll
+        for (int u = 0; u < GXB; ++u) {
+            const int e = ln + u * 64;
+            yv0[u] = yt[e < ne ? e : 0];
+        }
+        // the passing rows of the lane's column, per query tile (the accumulators are dead from here: 32 registers free while
+        // the rows are evaluated)
         unsigned pmq[QT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -964,38 +985,33 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                 asm("" : "+v"(pmq[qt]));               // (folded in here, not where the mask is first used: sixteen registers otherwise)
             }
         }
-        {   // the tile's rows (contiguous in the k-d ordered copy) and their caller row numbers
-            const int nrow = (nr - jb0 < 32) ? (int)(nr - jb0) : 32;
-            const double* yt = Y + (int64_t)jb0 * D;
-            {
-                // (GXB loads at a time -- at most 8 per lane -- then their LDS writes; element e = row * d + i with
-                //  row = floor((e + 0.5) / d) in fp32: e < 512, so the quotient is never within rounding of an integer)
-                const int ne = nrow * D;
-                const int oj = (lane < 32 && lane < nrow) ? rperm[jb0 + (lane & 31)] : -1;
-                const float inv_d = 1.0f / (float)D;
-                int ln = lane;
-                asm volatile("" : "+v"(ln));             // (the eight element numbers and LDS offsets below depend on the lane and d only:
-                                                         //  computed once before the walk they would occupy fifteen registers throughout)
 #pragma unroll
-                for (int h0 = 0; h0 < 8; h0 += GXB) {
-                    if (h0 * 64 < ne) {
-                        double yv[GXB];
+        for (int u = 0; u < GXB; ++u) {
+            const int e = ln + u * 64;
+            const int row = (int)(((float)e + 0.5f) * inv_d);
+            if (e < ne) ytile[(e - row * D) * 32 + row] = yv0[u];      // [i][row]: conflict-free reads
+        }
+        if (lane < 32) yorig[lane] = oj0;
 #pragma unroll
-                        for (int u = 0; u < GXB; ++u) {
-                            const int e = ln + (h0 + u) * 64;
-                            yv[u] = yt[e < ne ? e : 0];
-                        }
+        for (int h0 = GXB; h0 < 8; h0 += GXB) {
+            if (h0 * 64 < ne) {
+                double yv[GXB];
 #pragma unroll
-                        for (int u = 0; u < GXB; ++u) {
-                            const int e = ln + (h0 + u) * 64;
-                            const int row = (int)(((float)e + 0.5f) * inv_d);
-                            if (e < ne) ytile[(e - row * D) * 32 + row] = yv[u];      // [i][row]: conflict-free reads
-                        }
-                    }
+                for (int u = 0; u < GXB; ++u) {
+                    const int e = ln + (h0 + u) * 64;
+                    yv[u] = yt[e < ne ? e : 0];
                 }
-                if (lane < 32) yorig[lane] = oj;
+#pragma unroll
+                for (int u = 0; u < GXB; ++u) {
+                    const int e = ln + (h0 + u) * 64;
+                    const int row = (int)(((float)e + 0.5f) * inv_d);
+                    if (e < ne) ytile[(e - row * D) * 32 + row] = yv[u];
+                }
             }
         }
+#if MCE_PRUNE_PROF
+        gx_stage_t += clock64() - gx_ts0;
+#endif
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             if (!__any(passq[qt])) continue;
@@ -1449,29 +1465,43 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
             const float thrf = (qwave0 + lane < nq) ? __double2float_ru(thrq[lane]) : -1.0f;     // (a padding query reaches nothing)
             const v4f_t* const bx = reinterpret_cast<const v4f_t*>(wbuf);
             unsigned long long keep = 0;
+#ifndef MCE_H_PRUNE_QR_TILES
+#define MCE_H_PRUNE_QR_TILES 4
+#endif
+            constexpr int NT = DD >= 8 ? 2 : MCE_H_PRUNE_QR_TILES;      // (eight dimensions x four tiles: 64 registers of boxes -- spills at three waves)
             while (need != 0) {
-                // two tiles per round (independent chains); an odd last tile is simply tested twice.  Their boxes: the same
-                // address in every lane, one 16-byte LDS read per pair of dimensions -- (lo, lo, hi, hi), as the packed fp32
-                // operations below want them
-                const int t0 = (int)__builtin_ctzll(need);
+                // NT tiles per round (independent chains; the last round tests its last tile more than once).  Their boxes:
+                // the same address in every lane, one 16-byte LDS read per pair of dimensions -- (lo, lo, hi, hi), as the
+                // packed fp32 operations below want them
+                int t[NT];
+                t[0] = (int)__builtin_ctzll(need);
                 need &= need - 1;
-                const int t1 = need != 0 ? (int)__builtin_ctzll(need) : t0;
-                need &= need - 1;                       // (0 & anything = 0)
-                v4f_t A[DD / 2], B[DD / 2];
 #pragma unroll
-                for (int j = 0; j < DD / 2; ++j) { A[j] = bx[t0 * 4 + j]; B[j] = bx[t1 * 4 + j]; }
-                v2f_t sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
+                for (int k = 1; k < NT; ++k) {
+                    t[k] = need != 0 ? (int)__builtin_ctzll(need) : t[k - 1];
+                    need &= need - 1;                   // (0 & anything = 0)
+                }
+                v4f_t A[NT][DD / 2];
+#pragma unroll
+                for (int k = 0; k < NT; ++k)
+#pragma unroll
+                    for (int j = 0; j < DD / 2; ++j) A[k][j] = bx[t[k] * 4 + j];
+                v2f_t sm[NT];
+#pragma unroll
+                for (int k = 0; k < NT; ++k) { sm[k].x = 0.0f; sm[k].y = 0.0f; }
 #pragma unroll
                 for (int j = 0; j < DD / 2; ++j) {
                     const v2f_t x2 = {xf[2 * j], xf[2 * j + 1]};
-                    const v2f_t ua = A[j].xy - x2, wa = x2 - A[j].zw, ub = B[j].xy - x2, wb = x2 - B[j].zw;
-                    const v2f_t ga = {fmaxf(0.0f, fmaxf(ua.x, wa.x)), fmaxf(0.0f, fmaxf(ua.y, wa.y))};
-                    const v2f_t gb = {fmaxf(0.0f, fmaxf(ub.x, wb.x)), fmaxf(0.0f, fmaxf(ub.y, wb.y))};
-                    sa = ga * ga + sa;
-                    sb = gb * gb + sb;
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) {
+                        const v2f_t u = A[k][j].xy - x2, w = x2 - A[k][j].zw;
+                        const v2f_t g = {fmaxf(0.0f, fmaxf(u.x, w.x)), fmaxf(0.0f, fmaxf(u.y, w.y))};
+                        sm[k] = g * g + sm[k];
+                    }
                 }
-                if (__ballot(!((sa.x + sa.y) * (1.0f - 0x1p-18f) > thrf)) != 0) keep |= 1ull << t0;
-                if (__ballot(!((sb.x + sb.y) * (1.0f - 0x1p-18f) > thrf)) != 0) keep |= 1ull << t1;
+#pragma unroll
+                for (int k = 0; k < NT; ++k)
+                    if (__ballot(!((sm[k].x + sm[k].y) * (1.0f - 0x1p-18f) > thrf)) != 0) keep |= 1ull << t[k];
             }
             return keep;
         };
@@ -1490,6 +1520,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
         int st_tiles = 0, st_chunks = 0;
 #if MCE_PRUNE_PROF
         long long pt_pass_n = 0, pt_pass_t = 0, pt_nopass_t = 0;
+        long long w2_win = 0, w2_box = 0, w2_qr = 0, w2_nbox = 0, w2_ntile = 0;      // MCE_PRUNE_PROF == 2: the walk phase's parts instead of stage / mul / drain
         long long pt_walk = 0, pt_stage = 0, pt_mul = 0, pt_drain = 0; const long long pt_begin = clock64(); long long pt_t = pt_begin;
 #define MCE_PT(acc) do { const long long n_ = clock64(); acc += n_ - pt_t; pt_t = n_; } while (0)
 #else
@@ -1564,7 +1595,14 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                         const bool stop = prune_band_floor(cd) > mythr;
                         const float* bb = cbox_r + (int64_t)win_c * (2 * D);
                         float acc[QT];
+#if MCE_PRUNE_PROF == 2
+                        const long long tw0_ = clock64();
+#endif
                         box_gap(bb, 1, acc, std::false_type());
+#if MCE_PRUNE_PROF == 2
+                        asm volatile("" :: "v"(acc[0]), "v"(acc[1]));
+                        w2_win += clock64() - tw0_;
+#endif
                         bool reach = false;
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) reach |= !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]);
@@ -1590,7 +1628,14 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                     // fp32 is enough for a rigorous bound: a gap fl(a - b) of two floats is within 2^-24
                     // of exact, the sum of <= 15 squares within 2^-19; the comparison gives back 2^-18
                     float acc[QT];
+#if MCE_PRUNE_PROF == 2
+                    const long long tb0_ = clock64();
+#endif
                     box_gap(cb, PCT, acc, std::integral_constant<bool, MCE_H_PRUNE_QREACH != 0>());
+#if MCE_PRUNE_PROF == 2
+                    asm volatile("" :: "v"(acc[0]), "v"(acc[1]));
+                    w2_box += clock64() - tb0_; w2_nbox += 1;
+#endif
                     if (xb_state == 0) {
                         float amin = acc[0];
 #pragma unroll
@@ -1604,7 +1649,13 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) need |= __ballot(!booted && !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]));
 #if MCE_H_PRUNE_QREACH
+#if MCE_PRUNE_PROF == 2
+                        const long long tq0_ = clock64(); w2_ntile += __builtin_popcountll(need);
+#endif
                         if (need != 0) need = query_reach(need);
+#if MCE_PRUNE_PROF == 2
+                        w2_qr += clock64() - tq0_;
+#endif
 #endif
                     }
                     st_tiles += __builtin_popcountll(need);
@@ -1697,8 +1748,11 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
             unsafeAtomicAdd(stat + HP_STAT_CHUNKS, (double)st_chunks);
             unsafeAtomicAdd(stat + HP_STAT_TILES, (double)st_tiles);
 #if MCE_PRUNE_PROF
+#if MCE_PRUNE_PROF == 2
+            pt_stage = w2_box; pt_mul = w2_qr; pt_drain = w2_win; gx_iter = w2_nbox; pt_pass_n = w2_ntile;
+#endif
             unsafeAtomicAdd(stat + 8, (double)pt_walk); unsafeAtomicAdd(stat + 9, (double)pt_stage); unsafeAtomicAdd(stat + 10, (double)pt_mul);
-            unsafeAtomicAdd(stat + 11, (double)pt_drain); unsafeAtomicAdd(stat + 12, (double)(clock64() - pt_begin)); unsafeAtomicAdd(stat + 13, (double)gx_cand); unsafeAtomicAdd(stat + 9, (double)gx_useful - (double)pt_stage); unsafeAtomicAdd(stat + 14, (double)pt_pass_n); unsafeAtomicAdd(stat + 15, (double)pt_pass_t); unsafeAtomicAdd(stat + 7, (double)pt_nopass_t);
+            unsafeAtomicAdd(stat + 11, (double)pt_drain); unsafeAtomicAdd(stat + 12, (double)(clock64() - pt_begin)); unsafeAtomicAdd(stat + 13, (double)gx_stage_t); unsafeAtomicAdd(stat + 14, (double)pt_pass_n); unsafeAtomicAdd(stat + 15, (double)pt_pass_t); unsafeAtomicAdd(stat + 7, (double)gx_iter);
 #endif
         }
     }
