@@ -604,9 +604,9 @@ def test_pruned_search_is_bit_identical_auto(prune_modes, n, d, K):
 def test_pruned_heavy_waves_and_short_lists_are_bit_identical(prune_modes, n, d, K, monkeypatch):
     """Round 4's two variations of the pruned walk against the exhaustive sweep, bit for bit: (a) HEAVY waves -- the first
     waves of the dispatch order served by S workgroups each, lists folded afterwards -- for every S, for a handful of waves,
-    for the library's own count and for as many as the side arrays hold; (b) for K = 9 the instantiation that keeps nine list
-    entries in registers (three waves per SIMD), which the library only takes by itself in launches of 30+ rounds (C5), forced
-    here, with and without heavy waves.  Same buffer as X and Y (auto evidence: the heavy split applies to one set only)."""
+    for the library's own count and for as many as the side arrays hold; (b) for K = 9 both instantiations -- nine list entries
+    in registers (three waves per SIMD, the library's choice) and twelve (two waves, MCE_PRUNE_LISTS=long) -- with and without
+    heavy waves.  Same buffer as X and Y (auto evidence: the heavy split applies to one set only)."""
     capi = prune_modes
     rng = np.random.default_rng(n + 7 * d + K)
     Y = rng.standard_normal((n, d)) @ (np.eye(d) + 0.3 * rng.standard_normal((d, d)))
@@ -615,7 +615,7 @@ def test_pruned_heavy_waves_and_short_lists_are_bit_identical(prune_modes, n, d,
     want_d, want_i = capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE)
     capi.set_prune_mode(capi.PRUNE_FORCE)
     seen = set()
-    for lists in ((None, "short") if K == 9 else (None,)):
+    for lists in ((None, "long") if K == 9 else (None,)):
         for heavy in ("0", None, "5,2", "64,3", "300,8", "100000,4", "7,5"):
             for name, val in (("MCE_PRUNE_HEAVY", heavy), ("MCE_PRUNE_LISTS", lists)):
                 if val is None:

@@ -2,9 +2,9 @@
 # GPU box: pruned walk vs the automatic exhaustive / symmetric choice around the automatic mode's thresholds
 # (capi.hip: kPruneAutoMinRows), auto evidence, resident data.  usage: tools/prune_crossover.sh -> gpurun_out/prune_crossover.txt
 out=$GRAFT_REPO_ROOT/gpurun_out/prune_crossover.txt; : > $out
-for cfg in "50000 2 4" "50000 3 4" "100000 3 4" "50000 4 4" "100000 4 4" "150000 4 4" "100000 5 4" "150000 5 4" "200000 5 4" "300000 5 4" \
-           "100000 6 4" "150000 6 4" "200000 6 4" "300000 6 4" "100000 6 9" "200000 6 9" "300000 6 9" "300000 7 4" "500000 7 4" "800000 7 4" "500000 7 9" \
-           "1000000 8 4" "2000000 8 4" "1000000 8 9" "2000000 9 4" "4000000 9 4" "4000000 10 4"; do
+for cfg in "30000 2 4" "50000 2 4" "30000 3 4" "50000 3 4" "100000 3 4" "50000 4 4" "100000 4 4" "150000 4 4" "50000 5 4" "100000 5 4" "150000 5 4" "200000 5 4" \
+           "50000 6 4" "100000 6 4" "150000 6 4" "200000 6 4" "300000 6 4" "100000 6 9" "200000 6 9" "300000 6 9" "100000 7 4" "200000 7 4" "300000 7 4" "500000 7 4" \
+           "800000 7 4" "300000 7 9" "500000 7 9" "300000 8 4" "500000 8 4" "1000000 8 4" "2000000 8 4" "500000 8 9" "1000000 8 9"; do
   python tools/prune_bench.py $cfg --full 2>&1 | tail -1 | python -c "
 import sys, json
 r = json.loads(sys.stdin.read())
