@@ -103,17 +103,16 @@ constexpr int kHThreads = kHWaves * 64;
 #define MCE_H_TRIGGER 96
 #endif
 #ifndef MCE_PRUNE_PROF
-#define MCE_PRUNE_PROF 0
-#endif
+#define MCE_PRUNE_PROF 0        // developer builds (tools/build_variant.sh x -DMCE_PRUNE_PROF=n, tools/prune_prof.py): per-wave cycle counts of the
+#endif                          // pruned walk's phases (1), of the walk phase's parts (2), of the drains inside gate_exact (3)
 #ifndef MCE_H_PRUNE_WAVES
 #define MCE_H_PRUNE_WAVES 2     // pruned walk: waves per SIMD the register allocation aims for
 #endif
-// Pruned walk, LDS per wave: tiles multiplied per batch (slice = BATCH KB), queue entries, drain trigger.  The walk
-// is latency-bound and gains from a third wave per SIMD, which needs <= 168 VGPRs AND <= 13.3 KB of LDS per wave.
-// Lists of up to 8 entries get there (144 / 166 VGPRs, no scratch) with half the batch and half the queue:
-// K <= 8 searches run 10-27 % faster (10 M x 6: K = 4 130 -> 100 ms, K = 8 179 -> 142 ms; 4 M x 3, K = 4:
-// 5.5 -> 4.0 ms).  Longer lists need 217-253 VGPRs: forced under 168 they spill (K = 9: 197 -> 366 ms), and at
-// two waves per SIMD the smaller batch only costs (197 -> 224 ms), so they keep the larger footprint.
+// Pruned walk, LDS per wave: tiles multiplied per batch (slice = BATCH KB), queue entries, drain trigger.  A third wave
+// per SIMD needs <= 168 VGPRs AND <= 13.3 KB of LDS per wave: lists of up to 9 entries get there with half the batch and
+// half the queue (round 4: 132 / 156 / 162 VGPRs for 4 / 8 / 9 entries, no scratch, since the tiles are staged by LDS-DMA
+// and the loop-invariant values the compiler parked in registers are computed where they are used) and run 20-30 % faster
+// for it (10 M x 6, K = 9: 96 vs 125 ms); twelve and sixteen entries (182 / 211 VGPRs) stay at two waves.
 #ifndef MCE_H_PRUNE_SMALL
 #define MCE_H_PRUNE_SMALL 9      // largest list capacity (entries held in registers) on the three-wave configuration
 #endif
@@ -266,9 +265,8 @@ __host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST, int D, int KCA
 // candidates beyond that split's 16th (lo_d / lo_i = the first pass's lists) and finds the next K - 16;
 // the merge then sees two sorted lists per split.  Two sweeps at fp16 speed instead of one fp64 sweep.
 //   LC (< KCAP, pruned walk only): the lists hold LC entries in registers while the list ARRAYS keep their KCAP rows (the unused
-//   ones are written empty).  K = 9 (C5's kmax = 10) with KCAP = 12 costs 217 VGPRs = two waves per SIMD; nine entries and
-//   batches of two tiles fit the three-wave budget that K <= 8 searches already run under (166 VGPRs, no scratch; ten
-//   entries, or nine with batches of four, spill the staged tiles: 265 vs 196 ms), and the walk is latency-bound.
+//   ones are written empty).  K = 9 (C5's kmax = 10) with KCAP = 12: nine entries fit the three-wave budget that K <= 8
+//   searches run under, twelve do not (see MCE_H_PRUNE_SMALL above).
 template <int KST, int KCAP, bool PRUNE = false, bool LOWER = false, int SYM = 0, int LC = KCAP>
 __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_SMALL ? MCE_H_PRUNE_SMALL_WAVES : MCE_H_PRUNE_WAVES) : (MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ? 4 : 2))) void knn_f16_kernel(
     const _Float16* __restrict__ Yh, int64_t nchunk_total, int rsplit,
@@ -699,6 +697,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
         st_tA += clock64() - t_d0;
 #endif
         // ---- phase B: every owner lane folds its chain(s) into its register list(s) ----------
+        // (pruned walk: fetching the NEXT chain entry while this one is inserted, and skipping rounds in which no lane's entry
+        //  beats its list's last, was measured: C5 95.4 -> 99.4 ms.)
 #pragma unroll
         for (int nl = 0; nl < kHNL; ++nl) {
             int cur = whead[nl * 64 + lane];
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
     // so the distances stay bit-identical.  What is queued is (exact d2, caller row), already linked
     // into its query's chain; drain() is then insertion (phase B) only.
 #if MCE_PRUNE_PROF
-    long long gx_iter = 0, gx_cand = 0, gx_useful = 0, gx_stage_t = 0;
+    long long gx_iter = 0, gx_cand = 0, gx_useful = 0, gx_stage_t = 0, gx_drain_t = 0, gx_drain_n = 0;
 #endif
     int qorig[QT];
 #ifndef MCE_H_PRUNE_GXB
@@ -1019,7 +1019,11 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
             const int ql = qt * 32 + (lane & 31);
             const double* xr = xq + ql;                            // xq[i][ql]
             while (__any(pm != 0)) {
+#if MCE_PRUNE_PROF == 3
+                if (qcount > QN - 64) { const long long td_ = clock64(); drain(); gx_drain_t += clock64() - td_; gx_drain_n += 1; }
+#else
                 if (qcount > QN - 64) drain();
+#endif
                 const bool has = pm != 0;
                 const int r = has ? __builtin_ctz(pm) : 0;
                 pm &= pm - 1;
@@ -1750,6 +1754,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
 #if MCE_PRUNE_PROF
 #if MCE_PRUNE_PROF == 2
             pt_stage = w2_box; pt_mul = w2_qr; pt_drain = w2_win; gx_iter = w2_nbox; pt_pass_n = w2_ntile;
+#endif
+#if MCE_PRUNE_PROF == 3
+            pt_stage = gx_drain_t; pt_drain = gx_drain_n;      // (drains inside gate_exact's loop: cycles, count)
 #endif
             unsafeAtomicAdd(stat + 8, (double)pt_walk); unsafeAtomicAdd(stat + 9, (double)pt_stage); unsafeAtomicAdd(stat + 10, (double)pt_mul);
             unsafeAtomicAdd(stat + 11, (double)pt_drain); unsafeAtomicAdd(stat + 12, (double)(clock64() - pt_begin)); unsafeAtomicAdd(stat + 13, (double)gx_stage_t); unsafeAtomicAdd(stat + 14, (double)pt_pass_n); unsafeAtomicAdd(stat + 15, (double)pt_pass_t); unsafeAtomicAdd(stat + 7, (double)gx_iter);
