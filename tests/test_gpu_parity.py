@@ -695,6 +695,25 @@ def test_pruned_search_duplicates_clusters_and_ties(prune_modes):
     assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
 
 
+@pytest.mark.parametrize("offset,scale,d,K", [(1.0e5, 1.0, 6, 9), (-3.0e4, 1.0e-2, 3, 4), (1.0e3, 1.0e3, 5, 8), (7.0, 1.0e-6, 2, 9)])
+def test_pruned_search_far_from_the_origin_and_at_odd_scales(prune_modes, offset, scale, d, K):
+    """The walk's box tests and its per-query reach test work on FLOAT coordinates with margins for what the conversion can be off
+    (round 4, knn_f16.hpp: box_gap / query_reach): far from the origin a float's spacing is no longer small against the
+    neighbour distances, so the margins are what keeps the pruning rigorous -- the lists must still be those of the exhaustive
+    sweep, bit for bit (separate query set too: its own k-d order, the cross bootstrap)."""
+    capi = prune_modes
+    rng = np.random.default_rng(int(abs(offset)) + d)
+    Y = (rng.standard_normal((70000, d)) @ (np.eye(d) + 0.3 * rng.standard_normal((d, d)))) * scale + offset
+    Y[:, -1] += np.linspace(0.0, 50.0 * scale, len(Y))        # (one dimension spread out: elongated boxes)
+    (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE))
+    assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+    X = Y[rng.choice(len(Y), 40000, replace=False)] + rng.standard_normal((40000, d)) * (0.1 * scale)
+    (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(X, Y, K, self_mode=capi.SELF_NONE))
+    assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+    od, oi = orc.knn_brute(X[:1000], Y, K, self_mode=0)
+    assert _rel(d1[:1000], od) < DIST_RTOL and np.array_equal(i1[:1000], oi)
+
+
 @pytest.mark.parametrize("k0", [1, 0])
 def test_pruned_fused_reduction_and_class(prune_modes, k0):
     capi = prune_modes
