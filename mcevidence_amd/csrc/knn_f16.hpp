@@ -1602,7 +1602,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
 #if MCE_PRUNE_PROF == 2
                         const long long tw0_ = clock64();
 #endif
-                        box_gap(bb, 1, acc, std::false_type());
+                        box_gap(bb, 1, acc, std::integral_constant<bool, MCE_H_PRUNE_QREACH != 0>());
 #if MCE_PRUNE_PROF == 2
                         asm volatile("" :: "v"(acc[0]), "v"(acc[1]));
                         w2_win += clock64() - tw0_;
@@ -1611,6 +1611,12 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) reach |= !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]);
                         cand = __ballot(in && !far && reach);
+#if MCE_H_PRUNE_QREACH
+                        // (the same per-query test on the window's CHUNK boxes: about half of the chunks whose box is within reach
+                        //  of a query tile's box are within reach of no single query -- their 64 tile boxes are then never fetched.
+                        //  Not in the first window of a separate query set: that one is walked twice, see xb_state.)
+                        if (xb_state != 0 && cand != 0) cand = query_reach(cand);
+#endif
                         e = (__ballot(in && stop) != 0) ? list_len : e + 64 * pr_step;
                         st_chunks += 1;
                         if (xb_state == 0) {                           // first window of a separate query set
