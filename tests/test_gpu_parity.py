@@ -616,7 +616,7 @@ def test_pruned_heavy_waves_and_short_lists_are_bit_identical(prune_modes, n, d,
     capi.set_prune_mode(capi.PRUNE_FORCE)
     seen = set()
     for lists in ((None, "long") if K == 9 else (None,)):
-        for heavy in ("0", None, "5,2", "64,3", "300,8", "100000,4", "7,5"):
+        for heavy in ("0", None, "auto", "5,2", "64,3", "300,8", "100000,4", "7,5"):      # (None: the library's default, off since round 4; "auto": its old rule)
             for name, val in (("MCE_PRUNE_HEAVY", heavy), ("MCE_PRUNE_LISTS", lists)):
                 if val is None:
                     monkeypatch.delenv(name, raising=False)

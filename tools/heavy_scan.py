@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""GPU box: C5 (10M x 6, kmax 10) through the pruned walk, every rank's share of a W-GPU run timed serially (as
+"""GPU box: C5 (10M x 6, kmax 10; HEAVY_SCAN_N rows, HEAVY_SCAN_TAILS=<nu> for Student-t tails) through the pruned walk, every rank's share of a W-GPU run timed serially (as
 tools/predict_scaling.py) for several settings of the heavy-block splitting (MCE_PRUNE_HEAVY="<blocks>,<S>").
 usage: python tools/heavy_scan.py [W ...]  -> gpurun_out/heavy_scan.json"""
 import json, os, sys, time
@@ -12,7 +12,11 @@ from mcevidence_amd.synth import gaussian_chain
 
 worlds = [int(x) for x in sys.argv[1:] if "," not in x and x != "default"] or [1, 8]
 sys_settings = [x for x in sys.argv[1:] if "," in x or x == "default"] or ["0", "default"]
-theta = gaussian_chain(6, 10_000_000, 6, cov="corr")[:, 2:]
+N_ROWS = int(os.environ.get("HEAVY_SCAN_N", "10000000"))
+theta = gaussian_chain(6, N_ROWS, 6, cov="corr")[:, 2:]
+if os.environ.get("HEAVY_SCAN_TAILS"):      # heavy tails: Student-t with that many degrees of freedom (outlier queries reach far)
+    nu = float(os.environ["HEAVY_SCAN_TAILS"])
+    theta = theta / np.sqrt(np.random.default_rng(7).chisquare(nu, size=(len(theta), 1)) / nu)
 cov = np.cov(theta.T); ev, U = np.linalg.eigh(cov)
 X = np.ascontiguousarray((theta @ U) / np.sqrt(ev)); del theta
 n, d = X.shape; kmax = 10
