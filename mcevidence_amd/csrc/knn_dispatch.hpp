@@ -93,6 +93,8 @@ struct KnnF16Variant {
     const char* name;
     knn_f16_launch_fn launch_prune_short;   // PRUNE with prune_short_lc (< kcap) list entries in registers: three waves per SIMD (KST = 1, KCAP = 12), else null
     int prune_short_lc;
+    knn_f16_launch_fn launch_prune_short2;  // the same with prune_short_lc2 entries (> prune_short_lc), else null
+    int prune_short_lc2;
 };
 constexpr int kMaxKST = 4;
 extern const KnnF16Variant g_knn_f16_kcap4[kMaxKST];

@@ -114,7 +114,7 @@ constexpr int kHThreads = kHWaves * 64;
 // and the loop-invariant values the compiler parked in registers are computed where they are used) and run 20-30 % faster
 // for it (10 M x 6, K = 9: 96 vs 125 ms); twelve and sixteen entries (182 / 211 VGPRs) stay at two waves.
 #ifndef MCE_H_PRUNE_SMALL
-#define MCE_H_PRUNE_SMALL 9      // largest list capacity (entries held in registers) on the three-wave configuration
+#define MCE_H_PRUNE_SMALL 10     // largest list capacity (entries held in registers) on the three-wave configuration (eleven spill inside the walk)
 #endif
 #ifndef MCE_H_PRUNE_SMALL_WAVES
 #define MCE_H_PRUNE_SMALL_WAVES 3

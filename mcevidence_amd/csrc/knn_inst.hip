@@ -131,9 +131,10 @@ extern const KnnVariant MCE_CAT(g_knn_kcap, MCE_KCAP)[kMaxKS] = {
 #define MCE_F16_LOWER(KST) nullptr
 #endif
 #if MCE_KCAP == 12
-#define MCE_F16_SHORT(KST) ((KST) == 1 ? &launch_f16_variant<1, MCE_KCAP, true, false, 0, 9> : (knn_f16_launch_fn) nullptr), ((KST) == 1 ? 9 : 0)
+#define MCE_F16_SHORT(KST) ((KST) == 1 ? &launch_f16_variant<1, MCE_KCAP, true, false, 0, 9> : (knn_f16_launch_fn) nullptr), ((KST) == 1 ? 9 : 0), \
+                           ((KST) == 1 ? &launch_f16_variant<1, MCE_KCAP, true, false, 0, 10> : (knn_f16_launch_fn) nullptr), ((KST) == 1 ? 10 : 0)
 #else
-#define MCE_F16_SHORT(KST) nullptr, 0
+#define MCE_F16_SHORT(KST) nullptr, 0, nullptr, 0
 #endif
 #define MCE_F16_VARIANT(KST, PRUNE_FN)                                                                   \
     {&launch_f16_variant<KST, MCE_KCAP, false>, PRUNE_FN, MCE_F16_LOWER(KST), &launch_f16_variant<KST, MCE_KCAP, false, false, 1>, \
@@ -155,6 +156,7 @@ MCE_F16_INST(1, false, false, 2) MCE_F16_INST(2, false, false, 2) MCE_F16_INST(3
 MCE_F16_INST(1, false, false, 3) MCE_F16_INST(2, false, false, 3) MCE_F16_INST(3, false, false, 3) MCE_F16_INST(4, false, false, 3)
 #if MCE_KCAP == 12
 template __global__ void knn_f16_kernel<1, MCE_KCAP, true, false, 0, 9>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*, int, int, const int*, const double*, const int*, int, SymParams, float*);
+template __global__ void knn_f16_kernel<1, MCE_KCAP, true, false, 0, 10>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*, int, int, const int*, const double*, const int*, int, SymParams, float*);
 #endif
 #if MCE_KCAP == 16
 MCE_F16_INST(1, false, true, 0) MCE_F16_INST(2, false, true, 0) MCE_F16_INST(3, false, true, 0) MCE_F16_INST(4, false, true, 0)

@@ -600,13 +600,13 @@ def test_pruned_search_is_bit_identical_auto(prune_modes, n, d, K):
     assert _rel(d1[:3000] if sm == capi.SELF_EXCLUDE else capi.knn(Y[:3000], Y, K, self_mode=capi.SELF_EXCLUDE)[0], od) < DIST_RTOL
 
 
-@pytest.mark.parametrize("n,d,K", [(70001, 3, 9), (150000, 6, 9), (90000, 6, 5), (60000, 2, 9)])
+@pytest.mark.parametrize("n,d,K", [(70001, 3, 9), (150000, 6, 9), (90000, 6, 5), (60000, 2, 9), (80000, 5, 10)])
 def test_pruned_heavy_waves_and_short_lists_are_bit_identical(prune_modes, n, d, K, monkeypatch):
     """Round 4's two variations of the pruned walk against the exhaustive sweep, bit for bit: (a) HEAVY waves -- the first
     waves of the dispatch order served by S workgroups each, lists folded afterwards -- for every S, for a handful of waves,
-    for the library's own count and for as many as the side arrays hold; (b) for K = 9 both instantiations -- nine list entries
-    in registers (three waves per SIMD, the library's choice) and twelve (two waves, MCE_PRUNE_LISTS=long) -- with and without
-    heavy waves.  Same buffer as X and Y (auto evidence: the heavy split applies to one set only)."""
+    for the library's own count and for as many as the side arrays hold; (b) for K = 9 and 10 both instantiations -- K list
+    entries in registers (three waves per SIMD, the library's choice) and twelve (two waves, MCE_PRUNE_LISTS=long) -- with and
+    without heavy waves.  Same buffer as X and Y (auto evidence: the heavy split applies to one set only)."""
     capi = prune_modes
     rng = np.random.default_rng(n + 7 * d + K)
     Y = rng.standard_normal((n, d)) @ (np.eye(d) + 0.3 * rng.standard_normal((d, d)))
@@ -615,7 +615,7 @@ def test_pruned_heavy_waves_and_short_lists_are_bit_identical(prune_modes, n, d,
     want_d, want_i = capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE)
     capi.set_prune_mode(capi.PRUNE_FORCE)
     seen = set()
-    for lists in ((None, "long") if K == 9 else (None,)):
+    for lists in ((None, "long") if K in (9, 10) else (None,)):
         for heavy in ("0", None, "auto", "5,2", "64,3", "300,8", "100000,4", "7,5"):      # (None: the library's default, off since round 4; "auto": its old rule)
             for name, val in (("MCE_PRUNE_HEAVY", heavy), ("MCE_PRUNE_LISTS", lists)):
                 if val is None:
@@ -628,8 +628,8 @@ def test_pruned_heavy_waves_and_short_lists_are_bit_identical(prune_modes, n, d,
             seen.add((k.split("heavy=")[1]))
             assert np.array_equal(got_d, want_d) and np.array_equal(got_i, want_i), (heavy, lists, k)
     assert any(x.startswith("0x1") for x in seen) and any("x8" in x for x in seen) and any("x5" in x for x in seen)
-    if K == 9:
-        assert any(x.endswith("lists=9") for x in seen) and any(x.endswith("lists=12") for x in seen)
+    if K in (9, 10):        # (K = 10: the ten-entry instantiation)
+        assert any(x.endswith("lists=%d" % K) for x in seen) and any(x.endswith("lists=12") for x in seen)
 
 
 @pytest.mark.parametrize("n,d,K", [(5000, 1, 3), (70001, 3, 9), (150000, 6, 10), (40000, 6, 2), (33000, 10, 16)])
