@@ -71,23 +71,26 @@ def source_hash():
     return h.hexdigest()
 
 
-def profile_counters(kernel_desc, library_hash=None):
+def profile_counters(kernel_desc, library_hash=None, tag=""):
     """Counters of the dominant kernel from the newest committed rocprofv3 summary that has it
     (profiles/<round>/pmc_summary.csv: separate --pmc passes; FETCH_SIZE / WRITE_SIZE in KB, FETCH_SIZE doubled per
     MI355X_MICROARCH.md's gfx950 note; kernel_stats.csv: average duration).  {} when no profile of this kernel exists.
-    `stale` = the profile's meta.json names other kernel sources than `library_hash` (or names none)."""
+    `stale` = the profile's meta.json names other kernel sources than `library_hash` (or names none).  `tag`: "_C2" / "_C4" /
+    "_C5" read that config's own passes (pmc_summary_C5.csv, kernel_stats_C5.csv: SQ counters only, no traffic)."""
     m = re.match(r"(\w+)<\w+=(\d+),\w+=(\d+)>", kernel_desc)
     if not m:
         return {}
     name, p1, p2 = m.groups()
-    if name == "knn_f16_kernel" and "panel-kernel" in kernel_desc:
+    if name == "knn_f16_kernel" and "pruned" in kernel_desc:
+        wants = ("%sILi%sELi%sELb1E" % (name, p1, p2),)
+    elif name == "knn_f16_kernel" and "panel-kernel" in kernel_desc:
         wants = ("knn_panel_kernelILi%sELi%sE" % (p1, p2), "knn_panel_kernel<%s, %s>" % (p1, p2))
     elif name == "knn_f16_kernel":
         sy = "2" if " symmetric" in kernel_desc else "0"
         wants = ("%sILi%sELi%sELb0ELb0ELi%sE" % (name, p1, p2, sy),) + (("%sILi%sELi%sELb0ELb0EE" % (name, p1, p2),) if sy == "0" else ())
     else:
         wants = ("%s<%s, %s>" % (name, p1, p2), "%sILi%sELi%sE" % (name, p1, p2))
-    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*", "pmc_summary.csv")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*", "pmc_summary%s.csv" % tag)), reverse=True):
         c = {}
         for ln in open(f):
             col = ln.strip().split(",")
@@ -96,14 +99,19 @@ def profile_counters(kernel_desc, library_hash=None):
                     c[col[-3]] = float(col[-2]) / int(col[-1])          # per dispatch
                 except ValueError:
                     pass
-        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        if tag:
+            if "SQ_INSTS_VALU" not in c:
+                continue
+            out = dict(source=os.path.relpath(f, REPO), traffic=None)
+        elif "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
             continue
-        out = dict(source=os.path.relpath(f, REPO), traffic=(2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
-                   traffic_note="per launch; (2*FETCH_SIZE + WRITE_SIZE) KB, separate --pmc passes")
+        else:
+            out = dict(source=os.path.relpath(f, REPO), traffic=(2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
+                       traffic_note="per launch; (2*FETCH_SIZE + WRITE_SIZE) KB, separate --pmc passes")
         meta = os.path.join(os.path.dirname(f), "meta.json")
         out["profile_source_hash"] = json.load(open(meta)).get("source_hash") if os.path.exists(meta) else None
         out["stale"] = library_hash is not None and out["profile_source_hash"] != library_hash
-        ks = os.path.join(os.path.dirname(f), "kernel_stats.csv")
+        ks = os.path.join(os.path.dirname(f), "kernel_stats%s.csv" % tag)
         avg_ns = None
         if os.path.exists(ks):
             for ln in open(ks):
@@ -123,8 +131,51 @@ def profile_counters(kernel_desc, library_hash=None):
                 out["profile_tflops_from_SQ_INSTS_MFMA"] = round(c["SQ_INSTS_MFMA"] * 32768.0 / (avg_ns * 1e-9) / 1e12, 1)
         if c.get("SQ_WAVE_CYCLES"):
             out["wait_frac"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 3)
+        if c.get("SQ_INSTS_VALU"):
+            out["valu_insts"] = c["SQ_INSTS_VALU"]
         return out
     return {}
+
+
+VALU_ISSUE_PEAK = N_SIMD * PEAK_CLOCK_HZ / 4.0        # one wave64 vector instruction per 4 cycles and SIMD (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1 quad-cycle)
+
+
+def config_roofline(kdesc, stats, nq, nr, d, lib_hash, tag="", prune_stats=None):
+    """`roofline` object of one timed config: what bounds its dominant kernel, what the kernel achieved against that bound over
+    its HIP-event duration, and the same from the committed rocprofv3 passes of that config when they are of this build.
+    Sweeps (fp16 filter, fp64): matrix-core bound -- executed MFMA flops (mce_last_search_stats) / duration against the dense
+    peak.  Pruned walk: its binding resource is vector-instruction ISSUE (a tree walk: box tests, reach tests, list upkeep --
+    ~180 k VALU against ~1 k MFMA per wave): achieved = SQ_INSTS_VALU per launch (committed counters, source-hash guarded) /
+    duration against 1024 SIMDs x 2.4 GHz / 4 cycles per instruction; the MFMA figure rides along as `mfma_frac`."""
+    kms = stats["kernel_ms"]
+    if kms <= 0:
+        return None
+    is64 = kdesc.startswith("knn_mfma")
+    peak = FP64_PEAK_TFLOPS if is64 else F16_PEAK_TFLOPS
+    executed = stats["flops_main"]
+    if "pruned" in kdesc and prune_stats:
+        mk = re.search(r"KST=(\d+)", kdesc)
+        kst = int(mk.group(1)) if mk else 1
+        executed = prune_stats[1] * math.ceil(nq / 32.0) * math.ceil(nr / 32.0) * 32768.0 * kst      # tile fraction x tile pairs x flop per tile
+    tf = executed / (kms * 1e-3) / 1e12 if executed > 0 else None
+    prof = profile_counters(kdesc, lib_hash, tag) if tag else {}
+    stale = bool(prof.get("stale", True))
+    live = (lambda k: None if stale else prof.get(k))
+    if "pruned" in kdesc:
+        vi = live("valu_insts")
+        ach = vi / (kms * 1e-3) / 1e9 if vi else None
+        roof = dict(bound="valu_issue", achieved=(round(ach, 1) if ach else None), peak=round(VALU_ISSUE_PEAK / 1e9, 1), unit="Ginst/s",
+                    frac=(round(ach * 1e9 / VALU_ISSUE_PEAK, 4) if ach else None), traffic=None,
+                    what="k-d pruned walk: bound by vector-instruction issue (box / reach tests, list upkeep), not by the matrix cores; "
+                         "achieved = SQ_INSTS_VALU per launch (committed rocprofv3 pass of this config) / kernel_ms; peak = 1024 SIMDs x 2.4 GHz / 4 cycles",
+                    valu_insts_per_launch=vi, mfma_tflops=(round(tf, 1) if tf else None), mfma_frac=(round(tf / peak, 4) if tf else None))
+    else:
+        roof = dict(bound="mfma", achieved=(round(tf, 2) if tf else None), peak=peak, unit="TFLOP/s", frac=(round(tf / peak, 4) if tf else None),
+                    traffic=None, executed_flops_per_launch=executed)
+    roof.update(kernel_ms=round(kms, 3), kernel=kdesc, counters_stale=stale, counters_source=prof.get("source"),
+                profile_kernel_ms=live("profile_kernel_ms"), valu_per_mfma=live("valu_per_mfma"), mfma_busy_frac=live("mfma_busy_frac"),
+                wait_frac=live("wait_frac"), profile_tflops_from_SQ_INSTS_MFMA=live("profile_tflops_from_SQ_INSTS_MFMA"))
+    return roof
 
 
 def host_info():
@@ -153,12 +204,30 @@ def host_info():
 # ---------------------------------------------------------------------------------------------------------------------
 # self-launch: `python bench.py --gpus N` without a launcher
 # ---------------------------------------------------------------------------------------------------------------------
-def self_launch(argv, gpus):
+RANK_TIMEOUT_S = float(os.environ.get("MCE_BENCH_RANK_TIMEOUT", "900"))
+
+
+def progress(msg):
+    """One line on stderr per phase of a rank of a multi-rank run: what the self-launching parent's watchdog listens for."""
+    if "WORLD_SIZE" in os.environ:
+        sys.stderr.write("[bench rank %s/%s] %s\n" % (os.environ.get("RANK", "0"), os.environ["WORLD_SIZE"], msg))
+        sys.stderr.flush()
+
+
+def self_launch(argv, gpus, timeout_s=None):
     """Start the N ranks as children -- one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment,
     exactly what a launcher would hand them -- and wait.  Runs before torch is imported: this process never touches the GPU,
     and nothing is exec'ed from a process that has.  (Not through `python -m torch.distributed.run`: its argument parser
     rejects script options that abbreviate its own, e.g. `--n`.)  Returns the first non-zero exit code of a rank; the other
-    ranks are then stopped by PID."""
+    ranks are then stopped by PID.
+
+    Watchdog: the ranks' stdout and stderr come through pipes and are relayed line by line; every rank reports its phases on
+    stderr (`progress`).  A rank that has been SILENT for `timeout_s` seconds (MCE_BENCH_RANK_TIMEOUT, default 900: a hung
+    collective, a wedged device) is terminated -- as a child, by PID; nothing is re-exec'ed -- together with the others, the
+    tail of its stderr is printed, and the parent exits with 124."""
+    import collections
+    import threading
+    timeout_s = RANK_TIMEOUT_S if timeout_s is None else timeout_s
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -166,24 +235,52 @@ def self_launch(argv, gpus):
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or gpus) // gpus)))
     base.update(WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    procs = []
+    procs, last, tails, threads = [], [], [], []
+
+    def relay(pipe, sink, r, keep):
+        for ln in iter(pipe.readline, ""):
+            last[r] = time.monotonic()
+            if keep is not None:
+                keep.append(ln)
+            sink.write(ln)
+            sink.flush()
+        pipe.close()
+
     for r in range(gpus):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, bufsize=1)
+        procs.append(p)
+        last.append(time.monotonic())
+        tails.append(collections.deque(maxlen=40))
+        for pipe, sink, keep in ((p.stdout, sys.stdout, None), (p.stderr, sys.stderr, tails[r])):
+            if pipe is not None:
+                t = threading.Thread(target=relay, args=(pipe, sink, r, keep), daemon=True)
+                t.start()
+                threads.append(t)
     rc = 0
-    live = list(procs)
+    live = list(range(gpus))
     while live:
-        for p in list(live):
-            code = p.poll()
+        for r in list(live):
+            code = procs[r].poll()
             if code is None:
+                if rc == 0 and time.monotonic() - last[r] > timeout_s:
+                    rc = 124
+                    sys.stderr.write("bench.py: rank %d silent for %.0f s -- stopping all ranks.  Its last stderr lines:\n%s\n"
+                                     % (r, timeout_s, "".join(tails[r]) or "(none)"))
+                    sys.stderr.flush()
+                    for q in live:
+                        procs[q].terminate()
                 continue
-            live.remove(p)
+            live.remove(r)
             if code != 0 and rc == 0:
                 rc = code
                 for q in live:           # a rank failed: the others would wait for it in the next collective
-                    q.terminate()
+                    procs[q].terminate()
         if live:
             time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=5)
     return rc
 
 
@@ -242,12 +339,14 @@ def golden_lnE(name, cfg):
 class Ctx(object):
     """process-wide bits every timed config needs"""
 
-    def __init__(self, torch, dist, _capi, world, rank, dev):
+    def __init__(self, torch, dist, _capi, world, rank, dev, dist_on=None):
         self.torch, self.dist, self.capi, self.world, self.rank, self.dev = torch, dist, _capi, world, rank, dev
+        # the multi-rank code path (library partition + all-reduce); MCE_BENCH_FORCE_DIST=1 takes it with ONE rank too
+        self.dist_on = (world > 1) if dist_on is None else dist_on
 
     def barrier(self):
         self.torch.cuda.synchronize()
-        if self.world > 1:
+        if self.dist_on:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
@@ -258,6 +357,8 @@ def time_config(ctx, cfg, steps, warmup, mode=0, nsample=0, orc=None):
     mce_knn_dotp_part_f64_dev (the library's partition), cross evidence on the contiguous query rows [S r / W, S (r+1) / W)
     of s1 against the replicated s2.  EXACTLY `steps` timed steps between barrier + synchronize; ms = max over ranks."""
     torch, dist, _capi, world, rank, dev = ctx.torch, ctx.dist, ctx.capi, ctx.world, ctx.rank, ctx.dev
+    dist_on = ctx.dist_on
+    progress("config %s: %d steps + %d warm-up" % (cfg["name"], steps, warmup))
     X, Y, kmax, k0 = cfg["X"], cfg["Y"], cfg["kmax"], cfg["k0"]
     S, d = X.shape
     K = kmax - k0
@@ -275,12 +376,12 @@ def time_config(ctx, cfg, steps, warmup, mode=0, nsample=0, orc=None):
     st = torch.cuda.current_stream().cuda_stream
 
     def step(dist_out=0):
-        if world > 1 and auto:
+        if dist_on and auto:
             _capi.knn_dotp_part_dev(Xd.data_ptr(), nr, d, kmax, rank, world, w.data_ptr(), fs.data_ptr(), out.data_ptr(), ws.data_ptr(), wsb, st)
         else:
             _capi.knn_dotp_dev(Xd.data_ptr(), nq, Yd.data_ptr(), nr, d, kmax, k0, 0, w.data_ptr(), fs.data_ptr(), out.data_ptr(),
                                dist_out, ws.data_ptr(), wsb, st)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(out, op=dist.ReduceOp.SUM)          # the single collective of the path
 
     for _ in range(warmup):
@@ -296,7 +397,7 @@ def time_config(ctx, cfg, steps, warmup, mode=0, nsample=0, orc=None):
     _capi.set_profiling(False)
     kdesc = _capi.last_kernel()
     per_rank = None
-    if world > 1:
+    if dist_on:
         mine = torch.tensor([elapsed, stats["search_ms"], stats["kernel_ms"], float(torch.cuda.current_device()), float(nq)], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -320,7 +421,7 @@ def time_config(ctx, cfg, steps, warmup, mode=0, nsample=0, orc=None):
     if g is not None:
         res["max_abs_dlnE_vs_reference"] = float(np.max(np.abs(lnE - np.array(g["lnE"]))))
         res["reference_wall_s"] = round(g.get("ref_wall_s", 0.0), 1)
-    if nsample and world == 1 and orc is not None:
+    if nsample and not dist_on and orc is not None:
         dd = torch.zeros((nq, K), dtype=torch.float64, device=dev)
         step(dd.data_ptr())
         torch.cuda.synchronize()
@@ -332,12 +433,15 @@ def time_config(ctx, cfg, steps, warmup, mode=0, nsample=0, orc=None):
         res["sampled_rows"] = len(rows)
         res["max_rel_dist_err_sampled_rows_vs_exact_cpu_search"] = float(np.max(np.abs(got - od) / od))
         del dd
+    pstats = None
     if "pruned" in kdesc:            # (device counters in the workspace: read before it is freed)
         try:
-            cf, tf = _capi.last_prune_stats()
-            res["pruned_walk"] = dict(chunk_fraction=round(cf, 5), tile_fraction=round(tf, 5))
+            pstats = _capi.last_prune_stats()
+            res["pruned_walk"] = dict(chunk_fraction=round(pstats[0], 5), tile_fraction=round(pstats[1], 5))
         except Exception:
             pass
+    if cfg["name"] != "C3":          # (the headline's own, fuller object is built in main())
+        res["roofline"] = config_roofline(kdesc, stats, nq, nr, d, _capi.source_hash(), "_" + cfg["name"], pstats)
     _capi.set_search_mode(0)
     del Xd, Yd, ws, w, fs
     torch.cuda.empty_cache()
@@ -373,11 +477,12 @@ def extra_configs(ctx, orc, pkg, scale=1.0):
             ("C4", 4, 1, 1000, (("auto", 1000), ("brute", 20000))),      # the reference's call picks kd_tree at d = 15: ~140 queries/s
             ("C5", 3, 1, 300, (("auto", 20000),)))
     for name, steps, warmup, nsample, algs in plan:
-        cfg = prep_config(name, scale)
         if scale != 1.0:
             nsample, algs = min(nsample, 100), tuple((alg, min(nr, 500)) for alg, nr in algs)
-        res, _, _ = time_config(ctx, cfg, steps, warmup, nsample=nsample if world == 1 else 0, orc=orc)
-        if ctx.rank == 0 and world == 1:
+        progress("preparing config %s" % name)
+        cfg = prep_config(name, scale)
+        res, _, _ = time_config(ctx, cfg, steps, warmup, nsample=0 if ctx.dist_on else nsample, orc=orc)
+        if ctx.rank == 0 and not ctx.dist_on:
             if name == "C4" and "max_abs_dlnE_vs_reference" in res:
                 # ... and ln E through the class (device feeders, from host arrays) for this pair
                 mce = pkg.MCEvidence([cfg["chain"]], kmax=cfg["kmax"], verbose=0).set_split(*cfg["split"])
@@ -416,7 +521,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without a launcher)" % (a.gpus, world, a.gpus))
-    if world > 1:
+    # MCE_BENCH_FORCE_DIST=1: `--gpus 1` takes the multi-rank code path -- a process group of ONE rank (RCCL by default), the
+    # library's partition entry point, the all-reduce per step, the class's part feed -- so that a 1-GPU box exercises every
+    # line an 8-GPU run executes (tests/test_gpu_nccl.py)
+    dist_on = world > 1 or os.environ.get("MCE_BENCH_FORCE_DIST") == "1"
+    if dist_on and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ["MCE_FORCE_DIST"] = "1"              # mcevidence_amd.parallel: a group of one rank counts as distributed
+    if dist_on:
         # (MCE_BENCH_BACKEND=gloo MCE_BENCH_ONE_DEVICE=1: functional check of the N>1 path on a 1-GPU box)
         if os.environ.get("MCE_BENCH_ONE_DEVICE") == "1":
             local = 0
@@ -424,10 +542,12 @@ def main():
             raise SystemExit("bench.py: rank %d wants GPU %d of %d" % (rank, local, torch.cuda.device_count()))
         torch.cuda.set_device(local)
         backend = os.environ.get("MCE_BENCH_BACKEND", "nccl")
+        progress("init_process_group(%s) on device %d" % (backend, local))
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        progress("process group up: %d rank(s)" % dist.get_world_size())
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -436,7 +556,7 @@ def main():
     _capi.set_search_mode(a.mode)
     from mcevidence_amd.synth import gaussian_chain
     import mcevidence_amd as pkg
-    ctx = Ctx(torch, dist, _capi, world, rank, dev)
+    ctx = Ctx(torch, dist, _capi, world, rank, dev, dist_on)
 
     # ---- synthetic chain (config C3 recipe) + host-side feeders (whitening etc.) ----
     n, d, kmax = a.n, a.d, a.kmax
@@ -456,7 +576,8 @@ def main():
     lnE = np.array(head["lnE"])
 
     e2e_ranks = None
-    if world > 1:
+    if dist_on:
+        progress("evidence() from host arrays under the process group")
         # the whole MCEvidence(...).evidence() call from host arrays under the process group: each rank uploads the chain once,
         # whitens on its device, searches its share (mce_evidence_feed_part_f64), ONE all-reduce -- the PCIe-inclusive figure
         mce.evidence()
@@ -473,7 +594,7 @@ def main():
         from oracle import oracle_np as orc                 # checker / CPU baseline only; never inside a timed region
     extras = None
     want_extras = not a.no_extras and a.mode == 0 and ((n, d, kmax) == (1_000_000, 27, 10) or a.extras_scale != 1.0)
-    if want_extras and world > 1:
+    if want_extras and dist_on:
         extras = extra_configs(ctx, orc, pkg, a.extras_scale)   # every rank takes part
 
     out = None
@@ -516,7 +637,7 @@ def main():
         cpu = None
         fp64_mode = None
         e2e = None
-        if world == 1:
+        if not dist_on:
             if a.cpu_sample > 0:
                 rng = np.random.default_rng(0)
                 rows = np.sort(rng.choice(n, size=min(a.cpu_sample, n), replace=False))
@@ -565,12 +686,13 @@ def main():
                    config=dict(workload="C3: auto-evidence, seeded Gaussian chain N=%d D=%d kmax=%d (K=%d true neighbours/query), %s" %
                                (n, d, kmax, K, "one GPU" if world == 1 else "the library's partition over %d GPUs (DESIGN.md 5), one all-reduce of kmax doubles" % world),
                                N=n, D=d, kmax=kmax, ranks=world),
-                   ranks_seen=(dist.get_world_size() if world > 1 else 1), backend=(dist.get_backend() if world > 1 else None),
+                   ranks_seen=(dist.get_world_size() if dist_on else 1), backend=(dist.get_backend() if dist_on else None),
                    per_rank=head.get("per_rank"),
                    max_abs_dlnE_vs_reference=dlnE, lnE=[round(float(x), 10) for x in lnE],
                    roofline=roof, cpu_baseline=cpu, evidence_call_from_host=e2e, configs=extras, fp64_mode=fp64_mode)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
+        progress("done")
         dist.barrier()
         dist.destroy_process_group()
     return out

@@ -237,8 +237,8 @@ size_t mce_knn_workspace_bytes_opt(int64_t nq, int64_t nr, int32_t d, int32_t K,
  * both point sets are put in k-d order on the device (cells of 32 rows) and every wave of 64 queries
  * visits the reference chunks nearest-box-first, multiplies only the 32-row tiles whose box is within
  * reach, and stops once no remaining chunk can hold a neighbour.  Same neighbours, distances and
- * tie-breaks as the exhaustive search.  0 (default): used where it was measured faster -- d <= 3 from
- * 100 k reference rows, d = 4 from 150 k, d = 5 from 200 k, d = 6 from 300 k, d = 7 from 800 k, d = 8 from 3 M (capi.hip: kPruneAutoMinRows),
+ * tie-breaks as the exhaustive search.  0 (default): used where it was measured faster -- d <= 4 from
+ * 100 k reference rows, d = 5 from 125 k, d = 6 from 150 k, d = 7 from 250 k, d = 8 from 500 k (the table is capi.hip: kPruneAutoMinRows),
  * and at least 32 k queries, no fewer than an eighth of the reference rows; 1: never; 2: whenever the shape allows it
  * (d <= 15, K <= 16).  Process-wide default (per call: mce_options). */
 int mce_set_prune_mode(int mode);

@@ -224,7 +224,10 @@ __global__ __launch_bounds__(kThreads) void chunk_list_kernel(const float* __res
     for (int i = threadIdx.x; i < kBandKeys; i += kThreads) cnt[i] = 0;
     if (threadIdx.x < 2 * d) qb[threadIdx.x] = qbox[(int64_t)b * 2 * d + threadIdx.x];
     __syncthreads();
-    auto key_of = [](float v) { return (int)(__float_as_uint(v) >> (23 - kPruneBandMantissa)); };       // v >= 0 or +inf: < kBandKeys
+    // v >= 0 or +inf: < kBandKeys.  A NaN sample makes the box distance NaN (sign bit possibly set): clamped into the last band
+    // (the +inf one) instead of indexing past the histogram.  (The order INSIDE a band is whatever the atomics give -- results
+    // do not depend on it, mce_last_prune_stats' fractions vary by a few 1e-5 from run to run.)
+    auto key_of = [](float v) { return min((int)((__float_as_uint(v) & 0x7fffffffu) >> (23 - kPruneBandMantissa)), kBandKeys - 1); };
     for (int c = threadIdx.x; c < nchunk; c += kThreads)
         atomicAdd(&cnt[key_of(box_dist2(qb, qb + d, rbox + (int64_t)c * 2 * d, rbox + (int64_t)c * 2 * d + d, d))], 1);
     __syncthreads();

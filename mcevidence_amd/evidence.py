@@ -61,9 +61,13 @@ class HipBackend(object):
                 return None
             group = parallel.current_group()
             dev = self.devices[0] if self.devices else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
-            part, jac, _, csum = _capi.evidence_feed_part(S1, S2, ndim, cov_mode, kmax, weight, fs, dist.get_rank(group),
-                                                          dist.get_world_size(group), device=dev, want_checksum=self.verify)
-            return parallel.feed_part_reduce(part, csum, group), jac
+            part, jac, csum, failed = np.zeros(kmax), float("nan"), None, None
+            try:
+                part, jac, _, csum = _capi.evidence_feed_part(S1, S2, ndim, cov_mode, kmax, weight, fs, dist.get_rank(group),
+                                                              dist.get_world_size(group), device=dev, want_checksum=self.verify)
+            except Exception as exc:        # still join the collective (with a failure flag): the other ranks must not hang in it
+                failed = exc
+            return parallel.feed_part_reduce(part, csum, group, failed=failed), jac
         if self.devices not in (None, [0], (0,)):
             return None
         dotp, jac, _ = _capi.evidence_feed(S1, S2, ndim, cov_mode, kmax, weight, fs)

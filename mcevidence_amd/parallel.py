@@ -18,6 +18,21 @@ import numpy as np
 
 
 _GROUP = None      # process group of the evidence computation; None = the default (world) group
+_FORCE = None      # force_distributed(): take the multi-rank code paths in a group of ONE rank too
+
+
+def force_distributed(on=True):
+    """Test / bring-up hook: with ``on`` the multi-rank code paths (part feed, library partition, the all-reduce) are
+    taken whenever a process group exists, also when it has a single rank -- what lets a 1-GPU box run the RCCL
+    collective of the path (``init_process_group("nccl", world_size=1)``).  ``MCE_FORCE_DIST=1`` in the environment
+    does the same; ``on=None`` returns to the environment's choice."""
+    global _FORCE
+    _FORCE = on
+
+
+def _forced():
+    import os
+    return (os.environ.get("MCE_FORCE_DIST") == "1") if _FORCE is None else bool(_FORCE)
 
 
 def set_group(group):
@@ -42,7 +57,7 @@ def is_distributed(group=None):
     group = _GROUP if group is None else group
     if group is not None and dist.get_rank(group) < 0:      # this process is not a member
         return False
-    return dist.get_world_size(group) > 1
+    return dist.get_world_size(group) > 1 or _forced()
 
 
 def shard_bounds(n, world, rank):
@@ -107,25 +122,39 @@ def check_replicas(X, Y, weight, fs, group=None):
             "drawn on rank 0 and broadcast), from the same chains.")
 
 
-def feed_part_reduce(dotp_part, checksum, group=None):
+def feed_part_reduce(dotp_part, checksum, group=None, failed=None):
     """The ONE collective of a multi-rank ``evidence()`` on the device-feeder route: all-reduce(sum) of this rank's
     partial sums, with the comparison of the ranks' input fingerprints riding in the same message.  The 64 bits of the
     checksum travel as four 16-bit pieces p and their squares: every rank holds the same piece iff
     W * sum(p^2) == (sum p)^2 (Cauchy-Schwarz; all exact in fp64 for W <= 1024: both sides < 2^52).  Raises on every rank
-    when the inputs differ."""
+    when the inputs differ.
+
+    ``failed``: the exception this rank's share ended with, if it did (out of memory on a shared GPU, a plan or workspace
+    error).  The rank still takes part -- with zeros and a failure flag in the message's last slot -- so the others do not
+    sit in the collective until its timeout; afterwards the failing rank re-raises its own exception and every other
+    rank raises a RuntimeError naming how many ranks failed."""
     import torch.distributed as dist
     group = _GROUP if group is None else group
     world = dist.get_world_size(group)
     kmax = len(dotp_part)
-    vec = np.zeros(kmax + 8)
-    vec[:kmax] = dotp_part
+    vec = np.zeros(kmax + 9)
+    if failed is None:
+        vec[:kmax] = dotp_part
+    else:
+        vec[kmax + 8] = 1.0
+        checksum = None
     if checksum is not None:
         pieces = [float((int(checksum) >> (16 * i)) & 0xFFFF) for i in range(4)]
         vec[kmax:kmax + 4] = pieces
-        vec[kmax + 4:] = [p * p for p in pieces]
+        vec[kmax + 4:kmax + 8] = [p * p for p in pieces]
     vec = _reduce_partial(vec, group)
+    if failed is not None:
+        raise failed
+    if vec[kmax + 8] != 0.0:
+        raise RuntimeError("mcevidence_amd: the evidence share of %d of the %d ranks of this process group failed "
+                           "(the failing ranks raise their own error)" % (int(vec[kmax + 8]), world))
     if checksum is not None and world <= 1024:
-        s, s2 = vec[kmax:kmax + 4], vec[kmax + 4:]
+        s, s2 = vec[kmax:kmax + 4], vec[kmax + 4:kmax + 8]
         if np.any(world * s2 != s * s):
             raise RuntimeError(
                 "mcevidence_amd: the ranks of this process group hold different samples/weights (fingerprints differ). "

@@ -19,7 +19,9 @@ def test_self_launch_starts_one_rank_per_gpu(monkeypatch):
     started = []
 
     class FakeProc(object):
-        def __init__(self, cmd, env=None):
+        stdout = stderr = None
+
+        def __init__(self, cmd, env=None, **kw):
             self.cmd, self.env, self.code, self.terminated = cmd, env, (3 if env["RANK"] == "2" else 0), False
             started.append(self)
 
@@ -39,12 +41,40 @@ def test_self_launch_starts_one_rank_per_gpu(monkeypatch):
     assert len({p.env["MASTER_PORT"] for p in started}) == 1
 
 
+def test_self_launch_watchdog_stops_a_silent_rank(monkeypatch, capsys):
+    """a rank that says nothing for the time limit (a hung collective, a wedged device) is terminated AS A CHILD together with
+    the others, the tail of its stderr is shown and the parent returns 124 -- nothing is re-exec'ed"""
+    import io
+    import bench
+    started = []
+
+    class Hung(object):
+        def __init__(self, cmd, env=None, **kw):
+            self.rank, self.terminated = int(env["RANK"]), False
+            self.stdout = io.StringIO("")
+            self.stderr = io.StringIO("[bench rank %d/2] init_process_group(nccl) on device %d\n" % (self.rank, self.rank))
+            started.append(self)
+
+        def poll(self):
+            return -15 if self.terminated else None
+
+        def terminate(self):
+            self.terminated = True
+
+    monkeypatch.setattr(bench.subprocess, "Popen", Hung)
+    assert bench.self_launch(["--gpus", "2"], 2, timeout_s=0.3) == 124
+    assert all(p.terminated for p in started)
+    err = capsys.readouterr().err
+    assert "silent for" in err and "init_process_group(nccl)" in err
+
+
 def test_parent_of_a_self_launch_never_imports_torch():
     """`python bench.py --gpus 2` without a launcher: the parent only spawns (nothing that could initialise the GPU is even
     imported); here the ranks are replaced by a stub."""
     code = ("import sys, runpy, subprocess\n"
             "class P(object):\n"
-            "    def __init__(self, cmd, env=None): print('SPAWN', 'torch' in sys.modules, env['RANK'], env['WORLD_SIZE'])\n"
+            "    stdout = stderr = None\n"
+            "    def __init__(self, cmd, env=None, **kw): print('SPAWN', 'torch' in sys.modules, env['RANK'], env['WORLD_SIZE'])\n"
             "    def poll(self): return 0\n"
             "subprocess.Popen = P\n"
             "sys.argv = ['bench.py', '--gpus', '2']\n"

@@ -327,6 +327,10 @@ def _fake_feed_part(S1, S2, d, cov_mode, kmax, w, fs, part, nparts, device=0, wa
     return dotp, float(np.sqrt(np.prod(ev))), ev[::-1].copy(), (int.from_bytes(h.digest(), "little") if want_checksum else None)
 
 
+def _failing_feed_part(*a, **k):
+    raise MemoryError("mce_evidence_feed_part_f64: out of device memory (test)")
+
+
 def _feed_part_worker(rank, world, port, q, split, poison):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -339,7 +343,9 @@ def _feed_part_worker(rank, world, port, q, split, poison):
     from mcevidence_amd.synth import gaussian_chain
     _capi.evidence_feed_part = _fake_feed_part
     chain = gaussian_chain(5, 1400, 4, weights="int", cov="corr")
-    if poison and rank == 1:
+    if poison == "fail" and rank == 1:
+        _capi.evidence_feed_part = _failing_feed_part           # this rank's share raises inside the library call
+    elif poison and rank == 1:
         chain = chain.copy()
         chain[777, 3] = np.nextafter(chain[777, 3], 9.0)         # one bit of one sample differs on one rank
     kw = dict(split=True, s1frac=0.4) if split else {}
@@ -347,14 +353,14 @@ def _feed_part_worker(rank, world, port, q, split, poison):
     assert isinstance(m.backend, pkg.HipBackend)
     try:
         out = ("ok", m.evidence())
-    except RuntimeError as e:
-        out = ("raised", str(e))
+    except (RuntimeError, MemoryError) as e:
+        out = ("raised", type(e).__name__ + ": " + str(e))
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("split,poison", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("split,poison", [(False, False), (True, False), (False, True), (False, "fail")])
 def test_class_under_a_process_group_takes_the_part_feed_and_one_all_reduce(split, poison):
     """MCEvidence(...).evidence() with HipBackend under a 2-rank group: every rank hands the library the whole chain
     (evidence_feed_part: here a CPU stand-in), gets its share of the sums, ONE all-reduce carries sums and input
@@ -369,6 +375,12 @@ def test_class_under_a_process_group_takes_the_part_feed_and_one_all_reduce(spli
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    if poison == "fail":
+        # a rank whose share raises still joins the ONE collective (failure flag): nobody hangs, the failing rank re-raises its own
+        # error, the other one learns that a rank failed
+        assert got[0][0] == got[1][0] == "raised"
+        assert "1 of the 2 ranks" in got[0][1] and got[1][1].startswith("MemoryError")
+        return
     if poison:
         assert got[0][0] == got[1][0] == "raised" and "different samples" in got[0][1]
         return
@@ -392,9 +404,9 @@ def test_feed_part_reduce_checks_fingerprints_exactly():
             tot = np.zeros_like(vec)
             for c in _s:
                 p = [float((c >> (16 * i)) & 0xFFFF) for i in range(4)]
-                tot[-8:-4] += p
-                tot[-4:] += [x * x for x in p]
-            tot[:-8] = vec[:-8] * _w
+                tot[-9:-5] += p
+                tot[-5:-1] += [x * x for x in p]
+            tot[:-9] = vec[:-9] * _w
             return tot
         with um.patch.object(parallel, "_reduce_partial", fake_reduce), um.patch("torch.distributed.get_world_size", lambda g=None: world):
             same = len(set(sums)) == 1
