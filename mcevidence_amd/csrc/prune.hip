@@ -2,6 +2,7 @@
 #include "prune.hpp"
 #include "zero_fill.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -87,22 +88,41 @@ __global__ __launch_bounds__(kThreads) void kd_key_kernel(const int* __restrict_
 // order and the result does not depend on the network; padding rows (-1) and the slots past a partial last group carry the
 // largest keys and stay at the end of their node.
 constexpr int kGroupRows = kAlign * kPruneTileRows;      // 2048
+// Round 5: the group's coordinates are fetched ONCE -- every row's kAlignLevels split coordinates with all loads of a row in
+// flight together (one or two cache lines per row), kept in LDS as floats -- instead of one scattered 8-byte load per row and
+// LEVEL (six passes over rows that lie anywhere in the caller's array: the kernel was bound by those line fetches, 1.41 ms at
+// C5).  What travels through the network is the slot a row was loaded into.
+constexpr size_t kBottomLdsBytes = (size_t)kGroupRows * (8 + 4 + 4 + 4 * kAlignLevels);      // 80 KB
 __global__ __launch_bounds__(kThreads) void kd_bottom_kernel(int* __restrict__ perm, int64_t n_pad, int top_levels, const double* __restrict__ P, int d)
 {
-    __shared__ unsigned long long key[kGroupRows];
-    __shared__ int val[kGroupRows];
+    extern __shared__ __attribute__((aligned(16))) char kb_raw[];
+    unsigned long long* const key = reinterpret_cast<unsigned long long*>(kb_raw);
+    int* const val = reinterpret_cast<int*>(key + kGroupRows);        // the slot the row sits in (rows[], co[])
+    int* const rows = val + kGroupRows;
+    float* const co = reinterpret_cast<float*>(rows + kGroupRows);   // [kAlignLevels][kGroupRows]: coordinate (top_levels + l) % d of slot s
     const int64_t base = (int64_t)blockIdx.x * kGroupRows;
     const int m = (int)(n_pad - base < kGroupRows ? n_pad - base : kGroupRows);
-    for (int i = threadIdx.x; i < kGroupRows; i += kThreads) val[i] = i < m ? perm[base + i] : -2;
+    for (int i = threadIdx.x; i < kGroupRows; i += kThreads) {
+        const int row = i < m ? perm[base + i] : -2;
+        rows[i] = row;
+        val[i] = i;
+        if (row >= 0) {
+            double c[kAlignLevels];
+#pragma unroll
+            for (int l = 0; l < kAlignLevels; ++l) c[l] = P[(int64_t)row * d + (top_levels + l) % d];
+#pragma unroll
+            for (int l = 0; l < kAlignLevels; ++l) co[l * kGroupRows + i] = (float)c[l];
+        }
+    }
     __syncthreads();
     for (int l = 0; l < kAlignLevels; ++l) {
-        const int dim = (top_levels + l) % d;
         const int ns = kGroupRows >> l;                  // node size at this level
         for (int i = threadIdx.x; i < kGroupRows; i += kThreads) {
-            const int row = val[i];
+            const int sl = val[i];
+            const int row = rows[sl];
             unsigned b = 0xFFFFFFFFu;
             if (row >= 0) {
-                b = __float_as_uint((float)P[(int64_t)row * d + dim]);
+                b = __float_as_uint(co[l * kGroupRows + sl]);
                 b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
                 if (b >= 0xFFFFFFFEu) b = 0xFFFFFFFDu;
             } else if (row == -1) {
@@ -126,7 +146,7 @@ __global__ __launch_bounds__(kThreads) void kd_bottom_kernel(int* __restrict__ p
                 __syncthreads();
             }
     }
-    for (int i = threadIdx.x; i < m; i += kThreads) perm[base + i] = val[i];
+    for (int i = threadIdx.x; i < m; i += kThreads) perm[base + i] = rows[val[i]];
 }
 
 __global__ __launch_bounds__(kThreads) void identity_perm_kernel(int64_t n, int64_t n_pad, int* __restrict__ perm)
@@ -214,25 +234,36 @@ __device__ __forceinline__ float box_dist2(const float* __restrict__ ql, const f
     }
     return __double2float_rd(s * (1.0 - 1e-12));
 }
-__global__ __launch_bounds__(kThreads) void chunk_list_kernel(const float* __restrict__ qbox, const float* __restrict__ rbox, int nchunk, int d,
-                                                              float* __restrict__ out_d, int* __restrict__ out_c)
+// Round 5: the scatter goes to LDS and the list leaves the workgroup in coalesced stores (the 4-byte stores to positions
+// scattered over the block's 39 KB of list were the kernel's time: 95 M x 2 of them at C5, 1.33 ms); kListThreads threads, one
+// workgroup per CU (histogram 32 KB + up to kListStage staged entries); longer lists (> 16 M reference rows) are scattered
+// straight to memory as before.
+constexpr int kListThreads = 1024;
+constexpr int kListStage = 8192;
+__host__ __device__ constexpr size_t chunk_list_lds_bytes(int nchunk) { return nchunk <= kListStage ? (size_t)nchunk * 8 : 0; }
+__global__ __launch_bounds__(kListThreads) void chunk_list_kernel(const float* __restrict__ qbox, const float* __restrict__ rbox, int nchunk, int d,
+                                                                  float* __restrict__ out_d, int* __restrict__ out_c)
 {
     __shared__ int cnt[kBandKeys];
     __shared__ float qb[2 * kPruneMaxDim];
-    __shared__ int wsum[kThreads / 64];
+    __shared__ int wsum[kListThreads / 64];
+    extern __shared__ __attribute__((aligned(16))) char cl_raw[];
+    const bool staged = nchunk <= kListStage;
+    float* const sd = reinterpret_cast<float*>(cl_raw);
+    int* const sc = reinterpret_cast<int*>(cl_raw) + nchunk;
     const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < kBandKeys; i += kThreads) cnt[i] = 0;
+    for (int i = threadIdx.x; i < kBandKeys; i += kListThreads) cnt[i] = 0;
     if (threadIdx.x < 2 * d) qb[threadIdx.x] = qbox[(int64_t)b * 2 * d + threadIdx.x];
     __syncthreads();
     // v >= 0 or +inf: < kBandKeys.  A NaN sample makes the box distance NaN (sign bit possibly set): clamped into the last band
     // (the +inf one) instead of indexing past the histogram.  (The order INSIDE a band is whatever the atomics give -- results
     // do not depend on it, mce_last_prune_stats' fractions vary by a few 1e-5 from run to run.)
     auto key_of = [](float v) { return min((int)((__float_as_uint(v) & 0x7fffffffu) >> (23 - kPruneBandMantissa)), kBandKeys - 1); };
-    for (int c = threadIdx.x; c < nchunk; c += kThreads)
+    for (int c = threadIdx.x; c < nchunk; c += kListThreads)
         atomicAdd(&cnt[key_of(box_dist2(qb, qb + d, rbox + (int64_t)c * 2 * d, rbox + (int64_t)c * 2 * d + d, d))], 1);
     __syncthreads();
-    // exclusive scan of the kBandKeys counters: each thread its kBandKeys / kThreads consecutive ones, then the thread totals
-    constexpr int PER = kBandKeys / kThreads;
+    // exclusive scan of the kBandKeys counters: each thread its kBandKeys / kListThreads consecutive ones, then the thread totals
+    constexpr int PER = kBandKeys / kListThreads;
     int loc[PER], tot = 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) { loc[i] = tot; tot += cnt[threadIdx.x * PER + i]; }
@@ -249,12 +280,15 @@ __global__ __launch_bounds__(kThreads) void chunk_list_kernel(const float* __res
     __syncthreads();
     float* od = out_d + (int64_t)b * nchunk;
     int* oc = out_c + (int64_t)b * nchunk;
-    for (int c = threadIdx.x; c < nchunk; c += kThreads) {
+    for (int c = threadIdx.x; c < nchunk; c += kListThreads) {
         const float v = box_dist2(qb, qb + d, rbox + (int64_t)c * 2 * d, rbox + (int64_t)c * 2 * d + d, d);
         const int pos = atomicAdd(&cnt[key_of(v)], 1);
-        od[pos] = v;
-        oc[pos] = c;
+        if (staged) { sd[pos] = v; sc[pos] = c; }
+        else { od[pos] = v; oc[pos] = c; }
     }
+    if (!staged) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nchunk; i += kListThreads) { od[i] = sd[i]; oc[i] = sc[i]; }
 }
 
 // dispatch order of the WAVES (tpw query tiles each: the unit a workgroup of the walk serves): largest box first.  The sparse
@@ -335,22 +369,38 @@ hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_ro
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    // 32-bit keys where the node id (< 2^Lradix) leaves at least kMinCoordBits32 coordinate bits AND no dimension is split
-    // more than four times by these levels (a dimension split often needs its medians placed finely: d = 1, 2 keep 64 bits)
-    const int cb32 = 32 - Lradix;
+    // ONE sort per DIMENSION, not per level (round 5).  The interleaved tree splits dimension l % d at level l: 13 device-wide
+    // sorts for 10 M rows.  But a node of the top levels is a position range, and sorting a node's rows by coordinate j places
+    // ALL of that dimension's split planes inside the node at once (they are ranks); so sort j takes the nodes as they stand
+    // after the dimensions before it (level_j = s_0 + .. + s_{j-1} levels deep, s_k = the number of levels l < Ltop with
+    // l % d == k) and orders each by coordinate j -- d sorts (6 at C5 instead of 13).  A group then lies in the same number
+    // of slabs of every dimension as before, every node still holds exactly its share of the rows, and the cells differ from
+    // the interleaved tree's only in that the later planes of a dimension are quantiles of the node that dimension was sorted
+    // in rather than medians of the smaller cells the other dimensions have cut out of it since.  The search result does not
+    // depend on the order (the lists are exact); C5's walk: 65.9 -> TODO ms, its preparation 12.7 -> TODO ms.
+    // (MCE_KD_TREE=interleaved, tools: the round-4 tree, one sort per level, for same-box comparisons)
+    static const bool interleaved = [] { const char* e = getenv("MCE_KD_TREE"); return e && !strcmp(e, "interleaved"); }();
+    const int nsort = interleaved ? Lradix : std::min(d, Lradix);
+    int level_of[64] = {0};
+    for (int j = 0; j < nsort; ++j) level_of[j + 1] = level_of[j] + (interleaved ? 1 : (Lradix - j + d - 1) / d);
+    const int idbits = nsort > 0 ? level_of[nsort - 1] : 0;        // node id bits of the last sort
+    // 32-bit keys where the node id leaves at least kMinCoordBits32 coordinate bits AND no dimension is split more than four
+    // times by these levels (a dimension split often needs its quantiles placed finely: d = 1, 2 keep 64 bits)
+    const int cb32 = 32 - idbits;
     const bool keys32 = Lradix > 0 && cb32 >= kMinCoordBits32 && (Lradix + d - 1) / d <= 4;
-    for (int level = 0; level < Lradix; ++level) {
+    for (int j = 0; j < nsort; ++j) {
+        const int level = level_of[j];
         hipError_t e;
         if (keys32) {
             unsigned* ka = reinterpret_cast<unsigned*>(keys_a);
             unsigned* kb = reinterpret_cast<unsigned*>(keys_b);
-            hipLaunchKernelGGL(kd_key_kernel<unsigned>, dim3(blocks), dim3(kThreads), 0, st, level == 0 ? (const int*)nullptr : perm, n, n_pad, unit_rows,
-                               n_units, Ltop, level, P, d, level % d, cb32, ka, vals_b);
+            hipLaunchKernelGGL(kd_key_kernel<unsigned>, dim3(blocks), dim3(kThreads), 0, st, j == 0 ? (const int*)nullptr : perm, n, n_pad, unit_rows,
+                               n_units, Ltop, level, P, d, j % d, cb32, ka, vals_b);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             e = sort_pairs(tmp, tmp_bytes, (const unsigned*)ka, kb, (const int*)vals_b, perm, n_pad, (unsigned)(cb32 + level), st);
         } else {
-            hipLaunchKernelGGL(kd_key_kernel<unsigned long long>, dim3(blocks), dim3(kThreads), 0, st, level == 0 ? (const int*)nullptr : perm, n, n_pad, unit_rows,
-                               n_units, Ltop, level, P, d, level % d, kCoordBits, keys_a, vals_b);
+            hipLaunchKernelGGL(kd_key_kernel<unsigned long long>, dim3(blocks), dim3(kThreads), 0, st, j == 0 ? (const int*)nullptr : perm, n, n_pad, unit_rows,
+                               n_units, Ltop, level, P, d, j % d, kCoordBits, keys_a, vals_b);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             e = sort_pairs(tmp, tmp_bytes, (const unsigned long long*)keys_a, keys_b, (const int*)vals_b, perm, n_pad, (unsigned)(kCoordBits + level), st);
         }
@@ -358,7 +408,15 @@ hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_ro
     }
     // ... the last kAlignLevels stay inside a group: one pass through LDS (10 M rows: 6 x 0.72 ms of sorts -> one kernel)
     if (bottom_in_lds && L > Ltop) {
-        hipLaunchKernelGGL(kd_bottom_kernel, dim3((unsigned)((n_pad + kGroupRows - 1) / kGroupRows)), dim3(kThreads), 0, st, perm, n_pad, Ltop, P, d);
+        static bool attr_set[16] = {};          // per device; benign race: idempotent
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 16 || !attr_set[dev]) {
+            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kd_bottom_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBottomLdsBytes);
+            if (ea != hipSuccess) return ea;
+            if (dev < 16) attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(kd_bottom_kernel, dim3((unsigned)((n_pad + kGroupRows - 1) / kGroupRows)), dim3(kThreads), kBottomLdsBytes, st, perm, n_pad, Ltop, P, d);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -455,8 +513,18 @@ hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t
     hipLaunchKernelGGL(group_box_kernel, blocks_for((int64_t)nqblk * d), dim3(kThreads), 0, st, out.tbox_q, same_set ? ntile_r : ntile_q, d,
                        qpb / kPruneTileRows, nqblk, box_q);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    static_assert(kBandKeys % kThreads == 0 && kPruneMaxDim * 2 <= kThreads, "chunk_list_kernel geometry");
-    hipLaunchKernelGGL(chunk_list_kernel, dim3((unsigned)nqblk), dim3(kThreads), 0, st, box_q, box_r, (int)nchunk, d, list_d_b, list_c_b);
+    static_assert(kBandKeys % kListThreads == 0 && kPruneMaxDim * 2 <= kListThreads, "chunk_list_kernel geometry");
+    {
+        static bool attr_set[16] = {};          // per device; benign race: idempotent
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 16 || !attr_set[dev]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(chunk_list_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chunk_list_lds_bytes(kListStage));
+            if (e != hipSuccess) return e;
+            if (dev < 16) attr_set[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(chunk_list_kernel, dim3((unsigned)nqblk), dim3(kListThreads), chunk_list_lds_bytes((int)nchunk), st, box_q, box_r, (int)nchunk, d, list_d_b, list_c_b);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     {
         float* bkey_a = reinterpret_cast<float*>(ws + L.bkey_a);

@@ -97,6 +97,26 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
             sgn = wq < 0.0 ? -1.0 : 1.0;
         }
 
+        if (L == 1 && !REFINE && self_mode != 1) {
+            // ONE list of exact distances per query (pruned walk, symmetric sweep, unsplit exhaustive sweep): it IS the result,
+            // ascending with ties by row -- no merge, and none of the indexed scratch arrays of the general path below (272 B
+            // of private memory per thread; C5's 10 M columns: 2.05 -> TODO ms)
+            for (int k = 0; k < K; ++k) {
+                const int64_t o = (int64_t)k * nq_pad + q;
+                const int i = k < KCAP ? part_i[o] : -1;
+                const double d2 = i >= 0 ? fmax(part_d[o], 0.0) : INF;
+                if (WRITE_DIST) {
+                    dist[qo * (int64_t)ld_out + k] = sqrt(d2);
+                    if (idx) idx[qo * (int64_t)ld_out + k] = (int64_t)i;
+                }
+                if (FUSE_DOTP) {
+                    const double t = sgn * exp(base + 0.5 * (double)D * log(d2));
+#pragma unroll
+                    for (int kk = 0; kk < kMaxK; ++kk)
+                        if (kk == k) term[kk] = t;
+                }
+            }
+        } else {
         unsigned char head[kMaxLists];
         for (int l = 0; l < L; ++l) head[l] = 0;
 
@@ -161,6 +181,7 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
                 for (int kk = 0; kk < kMaxK; ++kk)
                     if (kk == k) term[kk] = t;
             }
+        }
         }
     }
 
