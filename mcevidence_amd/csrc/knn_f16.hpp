@@ -80,7 +80,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #ifndef MCE_H_GEOM
 #define MCE_H_GEOM 0
 #endif
-constexpr int kHWaves = (MCE_H_GEOM == 1 || MCE_H_GEOM == 3) ? 4 : (MCE_H_GEOM == 2 ? 16 : 8);   // GEOM 2: 16 waves (4 per SIMD, <= 128 VGPRs); GEOM 3: 4 waves x 2 tiles, two workgroups per CU
+constexpr int kHWaves = (MCE_H_GEOM == 1 || MCE_H_GEOM == 3) ? 4 : (MCE_H_GEOM == 2 ? 16 : (MCE_H_GEOM == 4 ? 12 : 8));   // GEOM 2: 16 waves (4 per SIMD, <= 128 VGPRs); GEOM 3: 4 waves x 2 tiles, two workgroups per CU; GEOM 4 (tools, round 5): 12 waves (3 per SIMD, <= 168 VGPRs)
 constexpr int kHQT = MCE_H_GEOM == 1 ? 4 : 2;      // 32-query tiles per wave
 constexpr int kHNL = kHQT / 2;                     // top-K lists per owner lane (64 queries per list set)
 constexpr int kHThreads = kHWaves * 64;
@@ -268,7 +268,7 @@ __host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST, int D, int KCA
 //   ones are written empty).  K = 9 (C5's kmax = 10) with KCAP = 12: nine entries fit the three-wave budget that K <= 8
 //   searches run under, twelve do not (see MCE_H_PRUNE_SMALL above).
 template <int KST, int KCAP, bool PRUNE = false, bool LOWER = false, int SYM = 0, int LC = KCAP>
-__global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_SMALL ? MCE_H_PRUNE_SMALL_WAVES : MCE_H_PRUNE_WAVES) : (MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ? 4 : 2))) void knn_f16_kernel(
+__global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_SMALL ? MCE_H_PRUNE_SMALL_WAVES : MCE_H_PRUNE_WAVES) : (MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ? 4 : (MCE_H_GEOM == 4 ? 3 : 2)))) void knn_f16_kernel(
     const _Float16* __restrict__ Yh, int64_t nchunk_total, int rsplit,
     const _Float16* __restrict__ Xh, const double* __restrict__ qinfo, const double* __restrict__ params,
     const double* __restrict__ X, const double* __restrict__ Y, int64_t nq, int64_t nr, int D,

@@ -64,6 +64,10 @@ struct PanelArgs {
 #ifndef MCE_PANEL_TRIGGER
 #define MCE_PANEL_TRIGGER 192                  // a wave with this many queued candidates asks the workgroup to drain (96 -> 192: 35.4 -> 35.1 ms at C3)
 #endif
+#ifndef MCE_PANEL_PRIO
+#define MCE_PANEL_PRIO 0        // tools only: 1 = static s_setprio 1 for the second-dispatched half of the workgroup (waves 4-7: each shares a SIMD with
+                                // wave w - 4 and loses the issue arbitration by age), 2 = for the first half instead
+#endif
 #ifndef MCE_PANEL_ABL
 #define MCE_PANEL_ABL 0         // tools only: 1 = the gates never pass, 2 = no gate at all (results invalid)
 #endif
@@ -709,6 +713,11 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
     st_tPro = clock64() - t_kernel0;
 #endif
     v16f accA[QT], accB[QT];
+#if MCE_PANEL_PRIO == 1
+    if (wave >= kHWaves / 2) __builtin_amdgcn_s_setprio(1);
+#elif MCE_PANEL_PRIO == 2
+    if (wave < kHWaves / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     for (int k = 0; k < ntot; ++k) {
         const int buf = k & 1;
         const int c = cfirst + k;

@@ -88,65 +88,74 @@ __global__ __launch_bounds__(kThreads) void kd_key_kernel(const int* __restrict_
 // order and the result does not depend on the network; padding rows (-1) and the slots past a partial last group carry the
 // largest keys and stay at the end of their node.
 constexpr int kGroupRows = kAlign * kPruneTileRows;      // 2048
-// Round 5: the group's coordinates are fetched ONCE -- every row's kAlignLevels split coordinates with all loads of a row in
-// flight together (one or two cache lines per row), kept in LDS as floats -- instead of one scattered 8-byte load per row and
-// LEVEL (six passes over rows that lie anywhere in the caller's array: the kernel was bound by those line fetches, 1.41 ms at
-// C5).  What travels through the network is the slot a row was loaded into.
-constexpr size_t kBottomLdsBytes = (size_t)kGroupRows * (8 + 4 + 4 + 4 * kAlignLevels);      // 80 KB
+// Round 5: the network runs in REGISTERS three stages at a time.  A thread holds eight slots spaced by the smallest distance
+// j of the group of stages (j, 2j, 4j: all three compare-exchange partners of a slot are then among the thread's own eight),
+// so the 251 stages of the six levels take 102 trips through LDS and as many barriers; only the keys travel (their low half
+// is the slot they started the level in: the rows follow once per level).  Measured at C5: 1.41 -> TODO ms.  (Staging the
+// group's coordinates in LDS instead of re-reading a coordinate per row and level -- 80 KB, two workgroups per CU -- made it
+// SLOWER, 2.0 ms: the kernel is bound by the trips through LDS and the barriers, not by those loads.)
+constexpr int kBottomSlots = kGroupRows + kGroupRows / 32;          // one slot of padding per 32: eight slots a thread apart stay off one bank
+__device__ __forceinline__ int bslot(int i) { return i + (i >> 5); }
 __global__ __launch_bounds__(kThreads) void kd_bottom_kernel(int* __restrict__ perm, int64_t n_pad, int top_levels, const double* __restrict__ P, int d)
 {
-    extern __shared__ __attribute__((aligned(16))) char kb_raw[];
-    unsigned long long* const key = reinterpret_cast<unsigned long long*>(kb_raw);
-    int* const val = reinterpret_cast<int*>(key + kGroupRows);        // the slot the row sits in (rows[], co[])
-    int* const rows = val + kGroupRows;
-    float* const co = reinterpret_cast<float*>(rows + kGroupRows);   // [kAlignLevels][kGroupRows]: coordinate (top_levels + l) % d of slot s
+    static_assert(kGroupRows == 8 * kThreads, "eight slots per thread");
+    __shared__ unsigned long long key[kBottomSlots];
+    __shared__ int val[2][kGroupRows];
     const int64_t base = (int64_t)blockIdx.x * kGroupRows;
     const int m = (int)(n_pad - base < kGroupRows ? n_pad - base : kGroupRows);
-    for (int i = threadIdx.x; i < kGroupRows; i += kThreads) {
-        const int row = i < m ? perm[base + i] : -2;
-        rows[i] = row;
-        val[i] = i;
-        if (row >= 0) {
-            double c[kAlignLevels];
-#pragma unroll
-            for (int l = 0; l < kAlignLevels; ++l) c[l] = P[(int64_t)row * d + (top_levels + l) % d];
-#pragma unroll
-            for (int l = 0; l < kAlignLevels; ++l) co[l * kGroupRows + i] = (float)c[l];
-        }
-    }
+    for (int i = threadIdx.x; i < kGroupRows; i += kThreads) val[0][i] = i < m ? perm[base + i] : -2;
     __syncthreads();
+    int cur = 0;
     for (int l = 0; l < kAlignLevels; ++l) {
+        const int dim = (top_levels + l) % d;
         const int ns = kGroupRows >> l;                  // node size at this level
         for (int i = threadIdx.x; i < kGroupRows; i += kThreads) {
-            const int sl = val[i];
-            const int row = rows[sl];
+            const int row = val[cur][i];
             unsigned b = 0xFFFFFFFFu;
             if (row >= 0) {
-                b = __float_as_uint(co[l * kGroupRows + sl]);
+                b = __float_as_uint((float)P[(int64_t)row * d + dim]);
                 b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
                 if (b >= 0xFFFFFFFEu) b = 0xFFFFFFFDu;
             } else if (row == -1) {
                 b = 0xFFFFFFFEu;                         // padding rows: behind every real row, before the slots that do not exist
             }
-            key[i] = ((unsigned long long)b << 32) | (unsigned)i;
+            key[bslot(i)] = ((unsigned long long)b << 32) | (unsigned)i;
         }
         __syncthreads();
-        for (int k = 2; k <= ns; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int t = threadIdx.x; t < kGroupRows / 2; t += kThreads) {
-                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));        // the lower index of the t-th pair at distance j
-                    const int p2 = i | j;
-                    const bool up = (i & k) == 0 || k == ns;                     // every node ends ascending
-                    const unsigned long long a = key[i], c = key[p2];
-                    if ((a > c) == up) {
-                        key[i] = c; key[p2] = a;
-                        const int va = val[i]; val[i] = val[p2]; val[p2] = va;
-                    }
-                }
+        // bitonic network over the group's slots, run independently on every node (every node ends ascending); keys are
+        // unique, so the result does not depend on the network
+        for (int k = 2; k <= ns; k <<= 1) {
+            int j = k >> 1;
+            while (j >= 1) {
+                const int g = j >= 4 ? 3 : (j == 2 ? 2 : 1);       // stages of this trip: j, j/2, .. (j >> (g - 1))
+                const int q = j >> (g - 1);
+                const int b0 = (threadIdx.x / q) * (8 * q) + (threadIdx.x % q);
+                unsigned long long e[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e[u] = key[bslot(b0 + u * q)];
+#define MCE_CE(A_, B_)                                                                                     \
+                do {                                                                                       \
+                    const bool up_ = (((b0 + (A_) * q) & k) == 0) || k == ns;                              \
+                    const unsigned long long x_ = e[A_], y_ = e[B_];                                       \
+                    const bool sw_ = (x_ > y_) == up_;                                                     \
+                    e[A_] = sw_ ? y_ : x_;                                                                 \
+                    e[B_] = sw_ ? x_ : y_;                                                                 \
+                } while (0)
+                if (g == 3) { MCE_CE(0, 4); MCE_CE(1, 5); MCE_CE(2, 6); MCE_CE(3, 7); }
+                if (g >= 2) { MCE_CE(0, 2); MCE_CE(1, 3); MCE_CE(4, 6); MCE_CE(5, 7); }
+                MCE_CE(0, 1); MCE_CE(2, 3); MCE_CE(4, 5); MCE_CE(6, 7);
+#undef MCE_CE
+#pragma unroll
+                for (int u = 0; u < 8; ++u) key[bslot(b0 + u * q)] = e[u];
                 __syncthreads();
+                j >>= g;
             }
+        }
+        for (int i = threadIdx.x; i < kGroupRows; i += kThreads) val[cur ^ 1][i] = val[cur][(int)(unsigned)key[bslot(i)]];
+        cur ^= 1;
+        __syncthreads();
     }
-    for (int i = threadIdx.x; i < m; i += kThreads) perm[base + i] = rows[val[i]];
+    for (int i = threadIdx.x; i < m; i += kThreads) perm[base + i] = val[cur][i];
 }
 
 __global__ __launch_bounds__(kThreads) void identity_perm_kernel(int64_t n, int64_t n_pad, int* __restrict__ perm)
@@ -234,36 +243,96 @@ __device__ __forceinline__ float box_dist2(const float* __restrict__ ql, const f
     }
     return __double2float_rd(s * (1.0 - 1e-12));
 }
-// Round 5: the scatter goes to LDS and the list leaves the workgroup in coalesced stores (the 4-byte stores to positions
-// scattered over the block's 39 KB of list were the kernel's time: 95 M x 2 of them at C5, 1.33 ms); kListThreads threads, one
-// workgroup per CU (histogram 32 KB + up to kListStage staged entries); longer lists (> 16 M reference rows) are scattered
-// straight to memory as before.
-constexpr int kListThreads = 1024;
+// Round 5 (lists of up to kListStage chunks: 16 M reference rows): every box distance is evaluated ONCE and kept in LDS; the
+// bands are counted in kListBins bins reaching DOWN from the block's largest finite distance (the 8192 possible bands of a
+// float were zeroed, scanned and re-armed per block: most of the kernel's 1.33 ms at C5 -- 19 532 blocks x 4 883 chunks -- was
+// that fixed work, not the distances); what lies more than kListBins - 3 bands (2^31 in the squared distance) below the
+// largest is listed with the bound 0 -- a valid lower bound that keeps the floors ascending; the scatter goes to LDS and the
+// list leaves in coalesced stores.  Longer lists take chunk_list_big_kernel (the round-4 kernel).
 constexpr int kListStage = 8192;
-__host__ __device__ constexpr size_t chunk_list_lds_bytes(int nchunk) { return nchunk <= kListStage ? (size_t)nchunk * 8 : 0; }
-__global__ __launch_bounds__(kListThreads) void chunk_list_kernel(const float* __restrict__ qbox, const float* __restrict__ rbox, int nchunk, int d,
+constexpr int kListBins = 1024;
+__host__ __device__ constexpr size_t chunk_list_lds_bytes(int nchunk) { return (size_t)nchunk * 8; }
+__global__ __launch_bounds__(kThreads) void chunk_list_kernel(const float* __restrict__ qbox, const float* __restrict__ rbox, int nchunk, int d,
+                                                              float* __restrict__ out_d, int* __restrict__ out_c)
+{
+    static_assert(kListBins == 4 * kThreads, "scan: four bins per thread");
+    __shared__ int cnt[kListBins];
+    __shared__ float qb[2 * kPruneMaxDim];
+    __shared__ int wsum[kThreads / 64];
+    __shared__ int wmax[kThreads / 64];
+    extern __shared__ __attribute__((aligned(16))) char cl_raw[];
+    float* const sv = reinterpret_cast<float*>(cl_raw);          // [nchunk] box distances
+    int* const sc = reinterpret_cast<int*>(cl_raw) + nchunk;     // [nchunk] chunk ids in list order
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < kListBins; i += kThreads) cnt[i] = 0;
+    if (threadIdx.x < 2 * d) qb[threadIdx.x] = qbox[(int64_t)b * 2 * d + threadIdx.x];
+    __syncthreads();
+    // band of a distance: v >= 0 or +inf (a NaN sample makes the box distance NaN: taken as +inf)
+    auto band_of = [](float v) { return (int)((__float_as_uint(v) & 0x7fffffffu) >> (23 - kPruneBandMantissa)); };
+    constexpr int kInfBand = 0x7f800000 >> (23 - kPruneBandMantissa);
+    int kmax = 0;
+    for (int c = threadIdx.x; c < nchunk; c += kThreads) {
+        float v = box_dist2(qb, qb + d, rbox + (int64_t)c * 2 * d, rbox + (int64_t)c * 2 * d + d, d);
+        if (!(v < __builtin_huge_valf())) v = __builtin_huge_valf();
+        sv[c] = v;
+        const int k = band_of(v);
+        kmax = (k < kInfBand && k > kmax) ? k : kmax;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int t = __shfl_xor(kmax, o, 64); kmax = t > kmax ? t : kmax; }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = kmax;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) kmax = wmax[w] > kmax ? wmax[w] : kmax;
+    // bins: 0 = bound 0 (exact zeros and everything below the window), 1 .. kListBins - 2 = the bands klo .. kmax, kListBins - 1 = +inf
+    const int klo = kmax - (kListBins - 3);
+    auto bin_of = [&](float v) { const int k = band_of(v); return k >= kInfBand ? kListBins - 1 : (k < klo || v == 0.0f ? 0 : k - klo + 1); };
+    for (int c = threadIdx.x; c < nchunk; c += kThreads) atomicAdd(&cnt[bin_of(sv[c])], 1);
+    __syncthreads();
+    // exclusive scan of the counters: four per thread, then the thread totals
+    int loc[4], tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { loc[i] = tot; tot += cnt[threadIdx.x * 4 + i]; }
+    int inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if ((threadIdx.x & 63) >= o) inc += v; }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int base = inc - tot;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cnt[threadIdx.x * 4 + i] = base + loc[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < nchunk; c += kThreads) sc[atomicAdd(&cnt[bin_of(sv[c])], 1)] = c;
+    __syncthreads();
+    float* od = out_d + (int64_t)b * nchunk;
+    int* oc = out_c + (int64_t)b * nchunk;
+    for (int i = threadIdx.x; i < nchunk; i += kThreads) {
+        const int c = sc[i];
+        const float v = sv[c];
+        oc[i] = c;
+        od[i] = bin_of(v) == 0 ? 0.0f : v;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void chunk_list_big_kernel(const float* __restrict__ qbox, const float* __restrict__ rbox, int nchunk, int d,
                                                                   float* __restrict__ out_d, int* __restrict__ out_c)
 {
     __shared__ int cnt[kBandKeys];
     __shared__ float qb[2 * kPruneMaxDim];
-    __shared__ int wsum[kListThreads / 64];
-    extern __shared__ __attribute__((aligned(16))) char cl_raw[];
-    const bool staged = nchunk <= kListStage;
-    float* const sd = reinterpret_cast<float*>(cl_raw);
-    int* const sc = reinterpret_cast<int*>(cl_raw) + nchunk;
+    __shared__ int wsum[kThreads / 64];
     const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < kBandKeys; i += kListThreads) cnt[i] = 0;
+    for (int i = threadIdx.x; i < kBandKeys; i += kThreads) cnt[i] = 0;
     if (threadIdx.x < 2 * d) qb[threadIdx.x] = qbox[(int64_t)b * 2 * d + threadIdx.x];
     __syncthreads();
     // v >= 0 or +inf: < kBandKeys.  A NaN sample makes the box distance NaN (sign bit possibly set): clamped into the last band
-    // (the +inf one) instead of indexing past the histogram.  (The order INSIDE a band is whatever the atomics give -- results
-    // do not depend on it, mce_last_prune_stats' fractions vary by a few 1e-5 from run to run.)
+    // (the +inf one) instead of indexing past the histogram.
     auto key_of = [](float v) { return min((int)((__float_as_uint(v) & 0x7fffffffu) >> (23 - kPruneBandMantissa)), kBandKeys - 1); };
-    for (int c = threadIdx.x; c < nchunk; c += kListThreads)
+    for (int c = threadIdx.x; c < nchunk; c += kThreads)
         atomicAdd(&cnt[key_of(box_dist2(qb, qb + d, rbox + (int64_t)c * 2 * d, rbox + (int64_t)c * 2 * d + d, d))], 1);
     __syncthreads();
-    // exclusive scan of the kBandKeys counters: each thread its kBandKeys / kListThreads consecutive ones, then the thread totals
-    constexpr int PER = kBandKeys / kListThreads;
+    // exclusive scan of the kBandKeys counters: each thread its kBandKeys / kThreads consecutive ones, then the thread totals
+    constexpr int PER = kBandKeys / kThreads;
     int loc[PER], tot = 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) { loc[i] = tot; tot += cnt[threadIdx.x * PER + i]; }
@@ -280,15 +349,12 @@ __global__ __launch_bounds__(kListThreads) void chunk_list_kernel(const float* _
     __syncthreads();
     float* od = out_d + (int64_t)b * nchunk;
     int* oc = out_c + (int64_t)b * nchunk;
-    for (int c = threadIdx.x; c < nchunk; c += kListThreads) {
+    for (int c = threadIdx.x; c < nchunk; c += kThreads) {
         const float v = box_dist2(qb, qb + d, rbox + (int64_t)c * 2 * d, rbox + (int64_t)c * 2 * d + d, d);
         const int pos = atomicAdd(&cnt[key_of(v)], 1);
-        if (staged) { sd[pos] = v; sc[pos] = c; }
-        else { od[pos] = v; oc[pos] = c; }
+        od[pos] = v;
+        oc[pos] = c;
     }
-    if (!staged) return;
-    __syncthreads();
-    for (int i = threadIdx.x; i < nchunk; i += kListThreads) { od[i] = sd[i]; oc[i] = sc[i]; }
 }
 
 // dispatch order of the WAVES (tpw query tiles each: the unit a workgroup of the walk serves): largest box first.  The sparse
@@ -369,20 +435,28 @@ hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_ro
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    // ONE sort per DIMENSION, not per level (round 5).  The interleaved tree splits dimension l % d at level l: 13 device-wide
-    // sorts for 10 M rows.  But a node of the top levels is a position range, and sorting a node's rows by coordinate j places
-    // ALL of that dimension's split planes inside the node at once (they are ranks); so sort j takes the nodes as they stand
-    // after the dimensions before it (level_j = s_0 + .. + s_{j-1} levels deep, s_k = the number of levels l < Ltop with
-    // l % d == k) and orders each by coordinate j -- d sorts (6 at C5 instead of 13).  A group then lies in the same number
-    // of slabs of every dimension as before, every node still holds exactly its share of the rows, and the cells differ from
-    // the interleaved tree's only in that the later planes of a dimension are quantiles of the node that dimension was sorted
-    // in rather than medians of the smaller cells the other dimensions have cut out of it since.  The search result does not
-    // depend on the order (the lists are exact); C5's walk: 65.9 -> TODO ms, its preparation 12.7 -> TODO ms.
+    // ONE sort per DIMENSION and round, not per level (round 5).  The interleaved tree splits dimension l % d at level l: 13
+    // device-wide sorts for 10 M rows.  But a node of the top levels is a position range, and sorting a node's rows by
+    // coordinate j places ALL the split planes of that dimension inside the node at once (they are ranks).  So the Ltop levels
+    // are taken in two phases: the r = Ltop / d complete rounds of the cycle as ONE sort per dimension (sort j orders the nodes
+    // as they stand after the dimensions before it, j r levels deep, by coordinate j, which settles r levels), then the
+    // Ltop % d levels of the incomplete round one by one, as before -- d + Ltop % d sorts (7 at C5) instead of Ltop (13).
+    // Every branch gets the same number of splits per dimension as in the interleaved tree and every node still holds
+    // exactly its share of the rows; the cells differ only in that the r planes a dimension gets in phase one are
+    // quantiles of the node it was sorted in rather than medians of the smaller cells the other dimensions cut out of it
+    // in between.  (The last, incomplete round must stay last: with 4883 groups most level-12 nodes hold ONE group and do
+    // not split again -- folded into the first phase as a third split of dimension 0, dimension 5 was left with one split
+    // on those branches, the cells came out elongated and the walk multiplied 4 % more tiles: 65.9 -> 67.6 ms.)  The
+    // search result does not depend on the order (the lists are exact).
     // (MCE_KD_TREE=interleaved, tools: the round-4 tree, one sort per level, for same-box comparisons)
     static const bool interleaved = [] { const char* e = getenv("MCE_KD_TREE"); return e && !strcmp(e, "interleaved"); }();
-    const int nsort = interleaved ? Lradix : std::min(d, Lradix);
-    int level_of[64] = {0};
-    for (int j = 0; j < nsort; ++j) level_of[j + 1] = level_of[j] + (interleaved ? 1 : (Lradix - j + d - 1) / d);
+    int sdim[64], level_of[65] = {0}, nsort = 0;
+    {
+        const int rounds = interleaved ? 0 : Lradix / d;
+        if (rounds > 0)
+            for (int j = 0; j < d; ++j) { sdim[nsort] = j; level_of[nsort + 1] = level_of[nsort] + rounds; ++nsort; }
+        for (int l = rounds * d; l < Lradix; ++l) { sdim[nsort] = l % d; level_of[nsort + 1] = level_of[nsort] + 1; ++nsort; }
+    }
     const int idbits = nsort > 0 ? level_of[nsort - 1] : 0;        // node id bits of the last sort
     // 32-bit keys where the node id leaves at least kMinCoordBits32 coordinate bits AND no dimension is split more than four
     // times by these levels (a dimension split often needs its quantiles placed finely: d = 1, 2 keep 64 bits)
@@ -395,12 +469,12 @@ hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_ro
             unsigned* ka = reinterpret_cast<unsigned*>(keys_a);
             unsigned* kb = reinterpret_cast<unsigned*>(keys_b);
             hipLaunchKernelGGL(kd_key_kernel<unsigned>, dim3(blocks), dim3(kThreads), 0, st, j == 0 ? (const int*)nullptr : perm, n, n_pad, unit_rows,
-                               n_units, Ltop, level, P, d, j % d, cb32, ka, vals_b);
+                               n_units, Ltop, level, P, d, sdim[j], cb32, ka, vals_b);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             e = sort_pairs(tmp, tmp_bytes, (const unsigned*)ka, kb, (const int*)vals_b, perm, n_pad, (unsigned)(cb32 + level), st);
         } else {
             hipLaunchKernelGGL(kd_key_kernel<unsigned long long>, dim3(blocks), dim3(kThreads), 0, st, j == 0 ? (const int*)nullptr : perm, n, n_pad, unit_rows,
-                               n_units, Ltop, level, P, d, j % d, kCoordBits, keys_a, vals_b);
+                               n_units, Ltop, level, P, d, sdim[j], kCoordBits, keys_a, vals_b);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             e = sort_pairs(tmp, tmp_bytes, (const unsigned long long*)keys_a, keys_b, (const int*)vals_b, perm, n_pad, (unsigned)(kCoordBits + level), st);
         }
@@ -408,15 +482,7 @@ hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_ro
     }
     // ... the last kAlignLevels stay inside a group: one pass through LDS (10 M rows: 6 x 0.72 ms of sorts -> one kernel)
     if (bottom_in_lds && L > Ltop) {
-        static bool attr_set[16] = {};          // per device; benign race: idempotent
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev >= 16 || !attr_set[dev]) {
-            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kd_bottom_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBottomLdsBytes);
-            if (ea != hipSuccess) return ea;
-            if (dev < 16) attr_set[dev] = true;
-        }
-        hipLaunchKernelGGL(kd_bottom_kernel, dim3((unsigned)((n_pad + kGroupRows - 1) / kGroupRows)), dim3(kThreads), kBottomLdsBytes, st, perm, n_pad, Ltop, P, d);
+        hipLaunchKernelGGL(kd_bottom_kernel, dim3((unsigned)((n_pad + kGroupRows - 1) / kGroupRows)), dim3(kThreads), 0, st, perm, n_pad, Ltop, P, d);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -513,8 +579,8 @@ hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t
     hipLaunchKernelGGL(group_box_kernel, blocks_for((int64_t)nqblk * d), dim3(kThreads), 0, st, out.tbox_q, same_set ? ntile_r : ntile_q, d,
                        qpb / kPruneTileRows, nqblk, box_q);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    static_assert(kBandKeys % kListThreads == 0 && kPruneMaxDim * 2 <= kListThreads, "chunk_list_kernel geometry");
-    {
+    static_assert(kBandKeys % kThreads == 0 && kPruneMaxDim * 2 <= kThreads, "chunk_list_kernel geometry");
+    if (nchunk <= kListStage) {
         static bool attr_set[16] = {};          // per device; benign race: idempotent
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -523,8 +589,10 @@ hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t
             if (e != hipSuccess) return e;
             if (dev < 16) attr_set[dev] = true;
         }
+        hipLaunchKernelGGL(chunk_list_kernel, dim3((unsigned)nqblk), dim3(kThreads), chunk_list_lds_bytes((int)nchunk), st, box_q, box_r, (int)nchunk, d, list_d_b, list_c_b);
+    } else {
+        hipLaunchKernelGGL(chunk_list_big_kernel, dim3((unsigned)nqblk), dim3(kThreads), 0, st, box_q, box_r, (int)nchunk, d, list_d_b, list_c_b);
     }
-    hipLaunchKernelGGL(chunk_list_kernel, dim3((unsigned)nqblk), dim3(kListThreads), chunk_list_lds_bytes((int)nchunk), st, box_q, box_r, (int)nchunk, d, list_d_b, list_c_b);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     {
         float* bkey_a = reinterpret_cast<float*>(ws + L.bkey_a);
