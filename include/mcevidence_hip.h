@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-#define MCE_ABI_VERSION 2     /* 2: per-call options (mce_options, *_opt), mce_last_search_stats */
+#define MCE_ABI_VERSION 2     /* 2: per-call options (mce_options, *_opt), mce_last_search_stats; mce_options.verify and mce_verify_* were
+                               * added compatibly (the field lies in what was reserved[0] = 0) */
 
 #define MCE_OK 0
 #define MCE_ERR_INVALID (-1)   /* bad argument (NULL, d<1, K<1, ...)        -> ValueError  */
@@ -45,6 +46,7 @@ extern "C" {
 #define MCE_ERR_NO_DEVICE (-4) /* no gfx950 device visible                   -> RuntimeError */
 #define MCE_ERR_WORKSPACE (-5) /* caller workspace too small                 -> ValueError  */
 #define MCE_ERR_DIM_RANGE (-6) /* d larger than MCE_MAX_DIM                  -> ValueError  */
+#define MCE_ERR_VERIFY (-7)    /* the re-check of sampled rows disagrees with the search (mce_options.verify) -> RuntimeError */
 
 #define MCE_MAX_K 32    /* neighbours per query handled by the MFMA kernels (fp16 filter: 17..32 in two sweeps) */
 #define MCE_MAX_DIM 63  /* dimensions handled by the MFMA kernels                                */
@@ -219,7 +221,12 @@ typedef struct mce_options {
     int32_t sym_mode;      /* as mce_set_sym_mode    */
     int32_t same_set;      /* workspace queries: 1 = X and Y will be ONE buffer (auto evidence), 0 = they will not (no scratch
                               for the symmetric sweep is reserved: ~1.7 GB at 1 M rows, K = 9), -1 = unknown (reserved) */
-    int32_t reserved[3];   /* 0 */
+    int32_t verify;        /* > 0: after the search, re-check this many query rows (spread over the set) by an independent exact
+                              fp64 scan of ALL reference rows (mce_verify_knn_f64_dev below) and fail with MCE_ERR_VERIFY if a row
+                              disagrees; honoured by the host-pointer entry points (mce_knn_f64[_opt], mce_knn_dotp_f64[_opt],
+                              mce_evidence_feed[_batch]_f64 -- not by a rank's share, *_part_*); 0 / -1: off (the default).
+                              ~2 ms per 1024 rows at 1 M x 27 */
+    int32_t reserved[2];   /* 0 */
 } mce_options;
 int mce_options_push(const mce_options* opt);
 int mce_options_pop(void);
@@ -232,6 +239,23 @@ int mce_knn_dotp_f64_dev_opt(const double* dX, int64_t nq, const double* dY, int
                              int64_t self_offset, const double* d_w, const double* d_fs, double* d_dotp, double* d_dist_out,
                              void* ws, size_t ws_bytes, void* stream, const mce_options* opt);
 size_t mce_knn_workspace_bytes_opt(int64_t nq, int64_t nr, int32_t d, int32_t K, const mce_options* opt);
+
+/* Run-time certificate of a finished search (reference: the result of `nbrs.kneighbors(samples)`, MCEvidence.py:1104, whose
+ * exactness everything downstream rests on).  For `nsample` query rows spread evenly over the set (the pattern shifted by
+ * `seed`) every reference row's squared distance is recomputed by plain fp64 differences -- none of the search's machinery:
+ * no matrix cores, no packed operands, no bounds, no lists -- and counted against the K distances the search reported for
+ * that row (`dist`, [nq][ld] as mce_knn_f64 / dist_out write them): nobody outside the list may be closer than its k-th
+ * entry, and at least k rows must lie within it (relative tolerance 1e-9 on the squared distance).  d <= 128, K <= 32.
+ * _dev: device pointers, the caller's stream, never synchronises; `d_result` (device, 2 ints) receives {rows checked, rows
+ * that failed}; workspace from mce_verify_workspace_bytes.  The host-pointer form uploads, checks, and returns
+ * MCE_ERR_VERIFY (message: how many rows failed) or MCE_OK; `failed` (optional) receives the count. */
+size_t mce_verify_workspace_bytes(int32_t nsample, int32_t K);
+int mce_verify_knn_f64_dev(const double* dX, int64_t nq, const double* dY, int64_t nr, int32_t d, int32_t K, int32_t self_mode,
+                           int64_t self_offset, const double* d_dist, int32_t ld, int32_t nsample, uint64_t seed, int32_t* d_result,
+                           void* ws, size_t ws_bytes, void* stream);
+int mce_verify_knn_f64(const double* X, int64_t nq, const double* Y, int64_t nr, int32_t d, int32_t K, int32_t self_mode,
+                       int64_t self_offset, const double* dist, int32_t ld, int32_t nsample, uint64_t seed, int32_t* failed,
+                       int32_t device);
 
 /* Spatial pruning of the fp16-filter search for low-dimensional, large reference sets (d <= 13):
  * both point sets are put in k-d order on the device (cells of 32 rows) and every wave of 64 queries

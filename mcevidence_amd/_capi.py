@@ -28,6 +28,7 @@ MCE_ERR_HIP = -3
 MCE_ERR_NO_DEVICE = -4
 MCE_ERR_WORKSPACE = -5
 MCE_ERR_DIM_RANGE = -6
+MCE_ERR_VERIFY = -7
 MCE_MAX_K = 32
 MCE_MAX_DIM = 63
 SELF_NONE, SELF_INCLUDE, SELF_EXCLUDE = 0, 1, 2
@@ -69,6 +70,11 @@ SIGNATURES = {
                                               _P, _P, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _c.c_int32]),
     "mce_knn_dotp_part_f64_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _c.c_size_t, _P]),
     "mce_knn_dotp_part_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_int32]),
+    "mce_verify_workspace_bytes": (_c.c_size_t, [_c.c_int32, _c.c_int32]),
+    "mce_verify_knn_f64_dev": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _c.c_int32, _c.c_int32,
+                                          _c.c_uint64, _P, _P, _c.c_size_t, _P]),
+    "mce_verify_knn_f64": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _c.c_int32, _c.c_int32,
+                                      _c.c_uint64, _P, _c.c_int32]),
     "mce_knn_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32]),
     "mce_dotp_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int32]),
     "mce_knn_f64_dev": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _P, _c.c_size_t, _P]),
@@ -190,12 +196,14 @@ def last_kernel_ms():
 
 
 class Options(_c.Structure):
-    """``mce_options``: the search / prune / symmetric modes of ONE call (-1: the process default)."""
+    """``mce_options``: the search / prune / symmetric modes of ONE call (-1: the process default); ``verify`` > 0:
+    re-check that many query rows after the search by an exact fp64 scan of all reference rows (RuntimeError if one
+    disagrees; host-pointer entry points)."""
     _fields_ = [("size", _c.c_int32), ("search_mode", _c.c_int32), ("prune_mode", _c.c_int32), ("sym_mode", _c.c_int32),
-                ("same_set", _c.c_int32), ("reserved", _c.c_int32 * 3)]
+                ("same_set", _c.c_int32), ("verify", _c.c_int32), ("reserved", _c.c_int32 * 2)]
 
-    def __init__(self, search_mode=-1, prune_mode=-1, sym_mode=-1, same_set=-1):
-        super().__init__(_c.sizeof(Options), int(search_mode), int(prune_mode), int(sym_mode), int(same_set))
+    def __init__(self, search_mode=-1, prune_mode=-1, sym_mode=-1, same_set=-1, verify=-1):
+        super().__init__(_c.sizeof(Options), int(search_mode), int(prune_mode), int(sym_mode), int(same_set), int(verify))
 
 
 class options(object):
@@ -281,6 +289,24 @@ def knn(X, Y, K, self_mode=SELF_NONE, self_offset=0, return_index=True, device=0
         check(lib.mce_knn_f64_opt(X.ctypes.data, nq, Y.ctypes.data, nr, d, K, int(self_mode), int(self_offset),
                                   dist.ctypes.data, idx.ctypes.data if idx is not None else None, int(device), _c.addressof(options)))
     return dist, idx
+
+
+def verify_knn(X, Y, dist, self_mode=SELF_NONE, self_offset=0, nsample=1024, seed=0, device=0):
+    """Run-time certificate of a finished search (mce_verify_knn_f64): ``nsample`` query rows spread over X are re-checked
+    against ``dist`` (what ``knn`` returned for them) by an exact fp64 scan of all of Y -- none of the search's machinery.
+    Returns the number of rows that failed (0 = the sample agrees)."""
+    lib = load()
+    X = _f64(X, "X")
+    Y = _f64(Y, "Y")
+    dist = _f64_allow_inf(dist)
+    if X.ndim != 2 or Y.ndim != 2 or X.shape[1] != Y.shape[1] or dist.ndim != 2 or dist.shape[0] != X.shape[0]:
+        raise ValueError("shape mismatch: X %r, Y %r, dist %r" % (X.shape, Y.shape, dist.shape))
+    failed = _c.c_int32(0)
+    rc = lib.mce_verify_knn_f64(X.ctypes.data, X.shape[0], Y.ctypes.data, Y.shape[0], X.shape[1], dist.shape[1], int(self_mode), int(self_offset),
+                                dist.ctypes.data, dist.shape[1], int(nsample), int(seed) & (2 ** 64 - 1), _c.addressof(failed), int(device))
+    if rc not in (MCE_OK, MCE_ERR_VERIFY):
+        check(rc)
+    return int(failed.value)
 
 
 def dotp(dist, w, fs, d, k0, kmax, device=0):

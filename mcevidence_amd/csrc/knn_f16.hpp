@@ -81,7 +81,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #define MCE_H_GEOM 0
 #endif
 constexpr int kHWaves = (MCE_H_GEOM == 1 || MCE_H_GEOM == 3) ? 4 : (MCE_H_GEOM == 2 ? 16 : (MCE_H_GEOM == 4 ? 12 : 8));   // GEOM 2: 16 waves (4 per SIMD, <= 128 VGPRs); GEOM 3: 4 waves x 2 tiles, two workgroups per CU; GEOM 4 (tools, round 5): 12 waves (3 per SIMD, <= 168 VGPRs)
-constexpr int kHQT = MCE_H_GEOM == 1 ? 4 : 2;      // 32-query tiles per wave
+constexpr int kHQT = (MCE_H_GEOM == 1 || MCE_H_GEOM == 5) ? 4 : 2;      // 32-query tiles per wave (GEOM 5, tools, round 5: 8 waves x 4 tiles)
 constexpr int kHNL = kHQT / 2;                     // top-K lists per owner lane (64 queries per list set)
 constexpr int kHThreads = kHWaves * 64;
 #ifndef MCE_H_SETPRIO
@@ -136,7 +136,7 @@ __host__ __device__ constexpr int f16_prune_trigger(int KCAP) { return KCAP <= 8
 #endif
 constexpr int kHQueue = MCE_H_QUEUE;          // candidate queue entries per wave (16 B each in LDS)
 constexpr int kHDrainTrigger = MCE_H_TRIGGER;    // a wave with this many queued candidates asks the workgroup to drain
-constexpr int kHRelBits = MCE_H_GEOM == 1 ? 25 : 26;   // queue entry = query-local (6|7 bits) << kHRelBits | row - first row of the split
+constexpr int kHRelBits = (MCE_H_GEOM == 1 || MCE_H_GEOM == 5) ? 25 : 26;   // queue entry = query-local (6|7 bits) << kHRelBits | row - first row of the split
 constexpr int kHSymRowBits = kHRelBits - 1;            // symmetric sweep: the row field's top bit says "this lane passed the ROW gate"
 constexpr double kHTargetRadius = 200.0;
 constexpr int kPruneDims = 15;                // pruned walk: largest d (KST = 1)
@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
             const int nseed = ((int64_t)(seed_cfg & 0xffff) * 2 <= c_end - c_begin) ? (seed_cfg & 0xffff) : 0;   // chunks (host: f16_seed_cfg)
             if (nseed > 0 && tg > 0 && kneed <= KCAP + 1) {
                 const float FINF = __builtin_huge_valf();
-                static_assert(QT == 2, "wait-state asm names both accumulator tiles");
+                static_assert(QT == 2 || QT == 4, "wait-state asm names the accumulator tiles");
                 float gm[QT], sm[QT][KCAP + 1];         // running group minimum; the KCAP + 1 smallest group minima, ascending
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
@@ -1155,9 +1155,14 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                 // (the minima are inline asm, which the compiler's hazard recogniser does not cover and which -- with
                 //  no branch in this loop to hold them in place -- it schedules right behind the MFMAs that write their
                 //  operands: the wait states are spelled out, tied to the accumulators)
+#if MCE_H_GEOM == 1 || MCE_H_GEOM == 5
+#define MCE_SEED_WAIT(ACC) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(ACC[0]), "+v"(ACC[1]), "+v"(ACC[2]), "+v"(ACC[3]))
+#else
+#define MCE_SEED_WAIT(ACC) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(ACC[0]), "+v"(ACC[1]))
+#endif
 #define MCE_SEED_TILE(ACC, JB, RR)                                                                         \
                 do {                                                                                       \
-                    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(ACC[0]), "+v"(ACC[1]));                       \
+                    MCE_SEED_WAIT(ACC);                                                                    \
                     _Pragma("unroll") for (int qt = 0; qt < QT; ++qt)                                      \
                     {                                                                                      \
                         const v16f& c_ = ACC[qt];                                                          \
@@ -1736,7 +1741,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                 for (int u = 0; u < pend; ++u) {
                     load_a(lbuf + (u * KST) * 1024, a0);
                     mfma_tile(a0, accA);
-                    static_assert(QT == 2, "wait-state asm names both accumulator tiles");
+                    static_assert(QT == 2 || QT == 4, "wait-state asm names the accumulator tiles");
                     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(accA[0]), "+v"(accA[1]));
 #if MCE_PRUNE_PROF
                     const long long q0_ = qcount; const long long tp0 = clock64();

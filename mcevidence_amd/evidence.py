@@ -40,9 +40,19 @@ class HipBackend(object):
 
     name = "hip"
 
-    def __init__(self, devices=None, verify=True):
+    def __init__(self, devices=None, verify=True, recheck_rows=0):
         self.devices = devices
         self.verify = verify        # multi-rank runs: compare a fingerprint of the inputs across the ranks on every call
+        # run-time certificate of the search (mce_options.verify): after every single-process search this many query rows,
+        # spread over the set, are re-checked by an exact fp64 scan of all reference rows that shares nothing with the
+        # search kernels; a disagreement raises RuntimeError.  0 = off (the default); ~2 ms per 1024 rows at 1 M x 27.
+        self.recheck_rows = int(recheck_rows)
+
+    def _scoped(self):
+        """the per-call options of this backend's library calls (thread-scoped: mce_options_push / _pop)"""
+        import contextlib
+        from . import _capi
+        return _capi.options(verify=self.recheck_rows) if self.recheck_rows > 0 else contextlib.nullcontext()
 
     def evidence_feed(self, S1, S2, ndim, cov_mode, kmax, weight, fs):
         """feeders on the device too (get_covariance + diagonalise_chain + the hot path, one upload);
@@ -70,7 +80,8 @@ class HipBackend(object):
             return parallel.feed_part_reduce(part, csum, group, failed=failed), jac
         if self.devices not in (None, [0], (0,)):
             return None
-        dotp, jac, _ = _capi.evidence_feed(S1, S2, ndim, cov_mode, kmax, weight, fs)
+        with self._scoped():
+            dotp, jac, _ = _capi.evidence_feed(S1, S2, ndim, cov_mode, kmax, weight, fs)
         return dotp, jac
 
     def evidence_feed_batch(self, problems):
@@ -83,14 +94,16 @@ class HipBackend(object):
         if parallel.is_distributed():
             return parallel.farm_evidence_feed(problems)
         from . import _capi
-        return [(dotp, jac) for dotp, jac, _ in _capi.evidence_feed_batch(problems, devices=self.devices)]
+        with self._scoped():
+            return [(dotp, jac) for dotp, jac, _ in _capi.evidence_feed_batch(problems, devices=self.devices)]
 
     def knn_dotp(self, X, Y, weight, fs, kmax, k0, want_dist=False):
         from . import parallel
         if parallel.is_distributed():
             return parallel.sharded_knn_dotp(X, Y, weight, fs, kmax, k0, want_dist=want_dist)
         from . import _capi
-        out = _capi.knn_dotp(X, Y, weight, fs, kmax, k0, return_dist=want_dist, devices=self.devices)
+        with self._scoped():
+            out = _capi.knn_dotp(X, Y, weight, fs, kmax, k0, return_dist=want_dist, devices=self.devices)
         return out if want_dist else (out, None)
 
 
