@@ -262,7 +262,7 @@ int mce_verify_knn_f64(const double* X, int64_t nq, const double* Y, int64_t nr,
  * visits the reference chunks nearest-box-first, multiplies only the 32-row tiles whose box is within
  * reach, and stops once no remaining chunk can hold a neighbour.  Same neighbours, distances and
  * tie-breaks as the exhaustive search.  0 (default): used where it was measured faster -- d <= 4 from
- * 100 k reference rows, d = 5 from 125 k, d = 6 from 150 k, d = 7 from 250 k, d = 8 from 500 k (the table is capi.hip: kPruneAutoMinRows),
+ * 100 k reference rows, d = 5 from 125 k, d = 6 from 150 k, d = 7 from 250 k, d = 8 from 500 k (the table is capi_common.hpp: kPruneAutoMinRows),
  * and at least 32 k queries, no fewer than an eighth of the reference rows; 1: never; 2: whenever the shape allows it
  * (d <= 15, K <= 16).  Process-wide default (per call: mce_options). */
 int mce_set_prune_mode(int mode);

@@ -1,0 +1,302 @@
+// capi_plan.hpp -- part of capi.hip: the planner.  Plan = which kernel, which geometry, which scratch; make_plan() is a pure
+// function of the sizes, the modes in force on this thread and the planner hints (no device work).
+#pragma once
+namespace {
+
+using mce::kMaxDevices;
+constexpr int kAssumedCUs = 256;   // MI355X; only steers the reference-split heuristic
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Pruned walk over ONE set (auto evidence), heavy waves: the walk's workgroups (one wave of 64 queries each) are dispatched
+// largest box first, and the first of them -- sparse cells of the k-d order, waves holding a far outlier -- walk their chunk
+// list 10-30x longer than the average (C5, measured with MCE_PRUNE_TIMES: mean 2.4 ms, 1 in 1000 over 18 ms, one at 81 ms
+// of a 200 ms launch).  A launch of many rounds of workgroups hides that (heaviest first); a rank of an 8-GPU run (25 ms of
+// walks) or a one-GPU search of 1 M rows does not.  In a launch of fewer than kPruneHeavyMaxRounds rounds (2048 waves in
+// flight) the first waves of the order (kPruneHeavyCount of a launch of up to kPruneHeavyFullRounds rounds, fewer of a
+// longer one: run_search) are therefore served by kPruneHeavySplit workgroups each, every one on every S-th window of the
+// list (knn_f16.hpp; MCE_PRUNE_HEAVY="<waves>,<S>" overrides, "0" = off; a split wave costs ~1.6x the work of a whole one:
+// bootstrap per sub-wave, looser bounds).
+// The side lists are sized for 1 / kPruneHeavyMaxShare of all waves at kPruneHeavyMaxSplit.
+// Since the per-query reach test (knn_f16.hpp: query_reach -- a far outlier no longer sets the reach of its whole wave) the
+// slowest wave of C5 takes 3.5 ms against a mean of 1.25 (was 81 against 2.4), and splitting only costs: one rank of eight
+// 8.8 ms of walk without, 9.7 with (4 M rows with Student-t tails, nu = 3: 24.1 vs 25.2).  OFF by default now
+// (kPruneHeavyDefault); MCE_PRUNE_HEAVY="<waves>,<S>" still sets it, "auto" restores the rule below.
+constexpr bool kPruneHeavyDefault = false;
+constexpr int kPruneHeavyMinBlocks = 64, kPruneHeavyCount = 700, kPruneHeavyMaxShare = 16, kPruneHeavyMinCount = 32, kPruneHeavyMaxRounds = 60;
+constexpr double kPruneHeavyFullRounds = 10.0;
+constexpr int kPruneHeavySplit = 4, kPruneHeavyMaxSplit = 8;
+constexpr int kPruneWaveQueries = mce::kHQT * 32;     // list columns per workgroup of the walk
+// side lists for split waves are part of a plan only when the split can happen (44 % of the list arrays: ~630 MB at C5)
+bool prune_heavy_enabled()
+{
+    if (t_no_heavy) return false;
+    const char* e = getenv("MCE_PRUNE_HEAVY");
+    return kPruneHeavyDefault || (e && *e && strcmp(e, "0") != 0);
+}
+static_assert(mce::kPruneWavesPerBlock == mce::kHWaves, "prune.hip orders kHWaves waves per query block");
+
+struct Plan {
+    const mce::KnnVariant* v = nullptr;
+    const mce::KnnF16Variant* vh = nullptr;   // non-null: fp16-filter path
+    bool generic = false;                     // plain exact kernel (d > 63 or K > 32)
+    int KST = 0;
+    size_t off_yh = 0, off_xh = 0, off_qinfo = 0, off_params = 0;
+    int KS = 0, KCAP = 0, QT = 0, CT = 0;
+    int64_t nchunk = 0;      // reference chunks (CT tiles of 16 rows)
+    int64_t nrow_pad = 0;    // padded reference rows
+    int nqblk = 0;
+    int64_t nq_pad = 0;
+    int rsplit = 1;
+    int L = 4;
+    size_t off_yf = 0, off_pd = 0, off_pi = 0, off_center = 0, off_msum = 0, total = 0;
+    double cost = 0.0;                        // the split model's estimate for this plan (cycles per SIMD; exhaustive kernels)
+    bool twopass = false;                     // fp16 filter, 16 < K <= 32: two sweeps of 16-entry lists (knn_f16.hpp, LOWER)
+    bool prune = false;                       // fp16 filter walking k-d ordered chunk lists (prune.hpp)
+    int part = 0, nparts = 1;                 // pruned walk over the waves part, part + nparts, ... of the dispatch order only; symmetric sweep: the
+                                              // contiguous range of sorted blocks [sym_qb_lo, sym_qb_hi) (one rank's share)
+    int sym_qb_lo = 0, sym_qb_hi = 0;         // set by run_search when the symmetric sweep ran
+    int64_t pl_nr = 0;                        // reference rows the plan was made for
+    mce::PruneLayout pl;
+    size_t off_prune = 0;
+    size_t off_heavy = 0;                     // pruned walk over one set: side lists of the heavy waves' extra sub-waves (knn_f16.hpp)
+    int heavy_max = 0;                        // ... room for this many waves at kPruneHeavyMaxSplit sub-waves
+    bool sym = false;                         // workspace holds the symmetric sweep's scratch (run_search decides: X and Y must be one buffer)
+    bool sym_active = false;                  // set by run_search: the lists are in sorted-row order, one split
+    mce::SymLayout sl;
+    size_t off_sym = 0;
+};
+
+const mce::KnnVariant* variant_for(int KS, int kcap_idx)
+{
+    switch (kcap_idx) {
+        case 0: return &mce::g_knn_kcap4[KS - 1];
+        case 1: return &mce::g_knn_kcap8[KS - 1];
+        case 2: return &mce::g_knn_kcap12[KS - 1];
+        case 3: return &mce::g_knn_kcap16[KS - 1];
+        case 4: return &mce::g_knn_kcap24[KS - 1];
+        default: return &mce::g_knn_kcap32[KS - 1];
+    }
+}
+
+// Validates (nq, nr, d, K, self_mode) and lays out the workspace.  Pure function of its
+// arguments so mce_knn_workspace_bytes() and the launcher always agree.
+// Seed phase of the exhaustive fp16 sweep for splits of (at least) `cps` chunks: chunks | group tiles << 16, 0 = none
+// (knn_f16.hpp: f16_seed_cfg).  MCE_F16_SEED_ROWS / MCE_F16_SEED_SHARE / MCE_F16_SEED_TG override (tests, tuning).
+// Small splits: a quarter of the chunks (then half) in smaller groups, as long as they hold twice the K groups a bound
+// needs.  Without a seed phase a query accepts ~K ln(n/K) candidates before its list settles; measured (fused call, none ->
+// seeded): 32 k x 6, K = 3: 0.61 -> 0.33 ms; 100 k x 6 (C2): 1.23 -> 0.90; 65 k x 27, K = 9: 1.51 -> 0.96; 131 k x 27: 2.60 ->
+// 1.93; 197 k x 27: 5.35 -> 4.10; from ~400 k rows the row budget binds as before.
+int sweep_seed_cfg(int64_t cps, int CT, int kneed)
+{
+    const Tuning t = read_tuning();
+    if (t.f16_seed_rows >= 0 || t.f16_seed_share >= 0 || t.f16_seed_tg >= 0)
+        return mce::f16_seed_cfg(cps, CT, kneed, t.f16_seed_rows >= 0 ? t.f16_seed_rows : MCE_H_SEED_ROWS, t.f16_seed_share >= 0 ? t.f16_seed_share : MCE_H_SEED_SHARE,
+                                 t.f16_seed_tg >= 0 ? t.f16_seed_tg : MCE_H_SEED_TG);
+    for (int share = MCE_H_SEED_SHARE; share >= 2; share /= 2)
+        for (int tg = MCE_H_SEED_TG; tg >= 2; tg /= 2)
+            if (const int cfg = mce::f16_seed_cfg(cps, CT, kneed, MCE_H_SEED_ROWS, share, tg)) return cfg;
+    return 0;
+}
+
+int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, Plan& p)
+{
+    if (nq < 0 || nr < 1 || d < 1 || K < 1) return fail(MCE_ERR_INVALID, "invalid sizes nq=%lld nr=%lld d=%d K=%d", (long long)nq, (long long)nr, d, K);
+    if (self_mode < 0 || self_mode > 2) return fail(MCE_ERR_INVALID, "invalid self_mode %d", self_mode);
+    if (d > mce::kGenMaxDim) return fail(MCE_ERR_DIM_RANGE, "d=%d exceeds the supported maximum %d", d, mce::kGenMaxDim);
+    if (K > mce::kGenMaxK) return fail(MCE_ERR_K_RANGE, "K=%d exceeds the supported maximum %d", K, mce::kGenMaxK);
+    const int64_t usable = (self_mode == MCE_SELF_EXCLUDE) ? nr - 1 : nr;
+    if (K > usable)   // sklearn raises ValueError("Expected n_neighbors <= n_samples_fit")
+        return fail(MCE_ERR_K_RANGE, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", K, (long long)usable);
+    if (nr >= (int64_t)1 << 31) return fail(MCE_ERR_INVALID, "nr=%lld exceeds 2^31-1 reference rows", (long long)nr);
+
+    if (d > MCE_MAX_DIM || K > MCE_MAX_K) {
+        // outside the MFMA kernels' register budgets: plain exact kernel, lists [1][K][nq_pad]
+        p.generic = true;
+        p.v = nullptr;
+        p.vh = nullptr;
+        p.KCAP = K;
+        p.rsplit = 1;
+        p.L = 1;
+        p.nqblk = (int)std::max<int64_t>(1, (nq + mce::kGenThreads - 1) / mce::kGenThreads);
+        p.nq_pad = (int64_t)p.nqblk * mce::kGenThreads;
+        size_t off = 0;
+        p.off_pd = off;
+        off = align_up(off + (size_t)K * (size_t)p.nq_pad * sizeof(double), 256);
+        p.off_pi = off;
+        off = align_up(off + (size_t)K * (size_t)p.nq_pad * sizeof(int), 256);
+        p.off_center = off;      // (generic plans: scratch for the distance matrix of the fused path)
+        off = align_up(off + (size_t)nq * K * sizeof(double), 256);
+        p.off_msum = off;
+        p.total = off + 256;
+        return MCE_OK;
+    }
+    p.KS = (d + 1 + 3) / 4;
+    int ki = 0;
+    while (ki < mce::kNumKcap - 1 && mce::kKcapList[ki] < K) ++ki;
+    p.KCAP = mce::kKcapList[ki];
+    const bool f16 = (eff_search_mode() != 1) && mce::f16_supported(d, K);
+    int qpb, rows_per_tile;
+    if (f16) {
+        if (K > 16) {                          // 16 nearest per reference split first, then the next K - 16 beyond them
+            p.twopass = true;
+            ki = 3;
+            p.KCAP = 16;
+        }
+        p.KST = mce::f16_ksteps(d);
+        const mce::KnnF16Variant* tab = ki == 0 ? mce::g_knn_f16_kcap4 : ki == 1 ? mce::g_knn_f16_kcap8
+                                        : ki == 2 ? mce::g_knn_f16_kcap12 : mce::g_knn_f16_kcap16;
+        p.vh = &tab[p.KST - 1];
+        p.v = nullptr;
+        p.QT = p.vh->qt;
+        p.CT = p.vh->ct;
+        qpb = mce::f16_qpb(p.KCAP);
+        rows_per_tile = 32;
+    } else {
+        p.v = variant_for(p.KS, ki);
+        p.vh = nullptr;
+        p.QT = p.v->qt;
+        p.CT = p.v->ct;
+        qpb = mce::queries_per_block(p.QT);
+        rows_per_tile = 16;
+    }
+    p.nqblk = (int)std::max<int64_t>(1, (nq + qpb - 1) / qpb);
+    p.nq_pad = (int64_t)p.nqblk * qpb;
+    const int64_t rows_per_chunk = (int64_t)p.CT * rows_per_tile;
+    p.nchunk = (nr + rows_per_chunk - 1) / rows_per_chunk;
+    p.nrow_pad = p.nchunk * rows_per_chunk;
+
+    if (f16 && !p.twopass && p.KST == 1 && d <= mce::kPruneMaxDim && p.vh->launch_prune && nq > 0 &&
+        p.nrow_pad <= ((int64_t)1 << mce::kHRelBits) && (int64_t)p.nqblk * p.nchunk <= mce::kPruneMaxPairs) {
+        const int pm = eff_prune_mode();
+        // (the k-d ordering costs ~4 ms per million reference rows whatever the number of queries, and sparse
+        // query sets make large query tiles: measured at 2 M x 6, separate sets, the walk wins from nq ~ nr/10)
+        p.prune = pm == 2 || (pm == 0 && kPruneAutoMinRows[d] > 0 && nr >= kPruneAutoMinRows[d] && nq >= kPruneAutoMinQueries &&
+                                           nq >= nr / 8);
+    }
+    if (p.prune) {
+        // no chunk staging in this mode: a "chunk" is just a list entry of 64 tiles (one per lane) = an aligned
+        // k-d subtree of 2048 rows
+        p.CT = mce::kHPruneChunkTiles;
+        p.nchunk = (nr + p.CT * 32 - 1) / (p.CT * 32);
+        p.nrow_pad = p.nchunk * p.CT * 32;
+        if (p.nrow_pad > ((int64_t)1 << mce::kHRelBits)) p.prune = false;
+        if (!p.prune) {
+            p.CT = p.vh->ct;
+            p.nchunk = (nr + rows_per_chunk - 1) / rows_per_chunk;
+            p.nrow_pad = p.nchunk * rows_per_chunk;
+        }
+    }
+    // reference split r: more workgroups fill the chip and trim the last partial round
+    // (one 512-thread workgroup per CU), but every split re-pays the list warm-up: a query
+    // accepts ~K(1+ln(n/K)) candidates while streaming n references, each a serialised
+    // whole-wave insertion.  Model (cycles per SIMD, fitted on MI355X):
+    //   fp64 sweep : block(r) = 256*KS*tiles16(r)      + 1000 * 32   * K (1 + ln(n_r/K))
+    //   fp16 filter: block(r) = 64*QT*KST*tiles32(r)   +  300 * 32QT * K (1 + ln(n_r/K))
+    //   total(r)   = ceil(nqblk*r / CUs) * block(r),   n_r = nr/r
+    int best_r = 1;
+    double best_c = 1e300;
+    const int rmax = (int)std::min<int64_t>(p.twopass ? mce::kMaxLists / 2 : mce::kMaxLists, p.nchunk);
+    const int rmin = f16 ? (int)((nr + ((int64_t)1 << mce::kHRelBits) - 1) >> mce::kHRelBits) : 1;   // queue entries hold 26-bit row offsets
+    if (rmin > rmax) return fail(MCE_ERR_INVALID, "reference set too large for the fp16-filter path (nr=%lld)", (long long)nr);
+    for (int r = std::max(1, rmin); r <= rmax; ++r) {
+        const double n_r = (double)nr / r;
+        const double lnf = 1.0 + std::log(std::max(1.0, n_r / K));
+        const double block = f16 ? 64.0 * p.QT * p.KST * (n_r / 32.0) + 300.0 * 32.0 * p.QT * K * lnf
+                                 : 256.0 * p.KS * (n_r / 16.0) + 1000.0 * 32.0 * K * lnf;
+        const double rounds = std::ceil((double)p.nqblk * r / kAssumedCUs);
+        const double c = rounds * block;
+        if (c < best_c * 0.98) { best_c = c; best_r = r; }   // need >2% gain to take a bigger split
+    }
+    // Searches of at most one round of workgroups (up to ~130 k queries): the sweep of such a set is mostly candidate
+    // handling, which a seed phase cuts by half or more and which parallelises over the splits -- take the largest split
+    // count that still fits one round AND leaves every split enough chunks for a seed phase (tools/_tmp scans, fused call,
+    // model's choice -> this: 8 k x 6, K = 3: 0.41 -> 0.20 ms; 16 k x 6: 0.47 -> 0.23; 12 k x 27, K = 9: 0.75 -> 0.41; 16 k x 45:
+    // 1.04 -> 0.47; from 24 k rows both agree).  Nothing seeded: the model's choice.
+    if (f16 && !p.twopass && p.nqblk <= kAssumedCUs) {
+        const int kneed = K + 1;      // (whatever the self mode: the workspace query does not know it, and the layout depends on r)
+        for (int r = std::min(rmax, kAssumedCUs / p.nqblk); r >= std::max(1, rmin); --r)
+            if (sweep_seed_cfg(p.nchunk / r, p.CT, kneed)) { best_r = r; break; }
+    }
+    if (const int r = read_tuning().rsplit) {          // tuning
+        if (r >= std::max(1, rmin) && r <= rmax) best_r = r;
+    }
+    if (p.prune) best_r = 1;                  // every workgroup walks its own chunk list
+    p.rsplit = best_r;
+    {   // the model's cost of the split count actually taken (the overrides above may have left its minimum)
+        const double n_r = (double)nr / best_r;
+        const double lnf = 1.0 + std::log(std::max(1.0, n_r / K));
+        const double block = f16 ? 64.0 * p.QT * p.KST * (n_r / 32.0) + 300.0 * 32.0 * p.QT * K * lnf : 256.0 * p.KS * (n_r / 16.0) + 1000.0 * 32.0 * K * lnf;
+        best_c = std::ceil((double)p.nqblk * best_r / kAssumedCUs) * block;
+    }
+    p.cost = best_c;
+    // the workspace layout for the split count taken; a part of a search that was handed the WHOLE search's workspace
+    // (mce_knn_dotp_part_f64_dev: a row shard plans more reference splits than the whole set would, and every split has its
+    // own lists) takes fewer splits until it fits (t_plan_cap)
+    auto layout = [&]() {
+    p.L = p.twopass ? 2 * p.rsplit : p.rsplit;
+
+    size_t off = 0;
+    p.off_yf = off;
+    if (f16) {
+        p.off_yh = off;
+        off = align_up(off + (size_t)p.nrow_pad * (size_t)(16 * p.KST) * 2, 256);
+        p.off_xh = off;
+        off = align_up(off + (size_t)p.nq_pad * (size_t)(16 * p.KST) * 2, 256);
+        p.off_qinfo = off;
+        off = align_up(off + (size_t)p.nq_pad * 2 * sizeof(double), 256);
+        p.off_params = off;
+        off = align_up(off + (size_t)mce::HP_COUNT * sizeof(double), 256);
+    } else {
+        off = align_up(off + (size_t)p.nrow_pad * (size_t)(4 * p.KS) * sizeof(double), 256);
+    }
+    // symmetric sweep: auto-evidence searches (the caller passes ONE buffer as X and Y; only the sizes are known here)
+    if (f16 && !p.twopass && !p.prune && nq == nr && p.vh->launch_sym && p.nqblk >= 2 && p.nrow_pad <= ((int64_t)1 << mce::kHSymRowBits)) {
+        const int sm = eff_sym_mode();
+        p.sym = sm == 2 || (sm == 0 && p.nqblk >= kSymAutoMinBlocks[p.KST] * ((p.KST == 1 && p.KCAP == 16) ? 2 : 1));     // (1M x 15, K = 16: 62.3 vs 62.7 ms)
+        // the symmetric sweep needs queries and references to be ONE buffer: known from the pointers (host entry points, and
+        // the *_dev ones at call time) or said by the caller of a workspace query (mce_options.same_set); unknown: reserve
+        if (g_same_set_hint == 0 || (g_same_set_hint < 0 && t_opt.same_set == 0)) p.sym = false;
+    }
+    const int l_alloc = p.L;
+    p.off_pd = off;
+    off = align_up(off + (size_t)l_alloc * p.KCAP * (size_t)p.nq_pad * sizeof(double), 256);
+    p.off_pi = off;
+    off = align_up(off + (size_t)l_alloc * p.KCAP * (size_t)p.nq_pad * sizeof(int), 256);
+    p.off_center = off;
+    off = align_up(off + (size_t)3 * mce::kMaxDimPad * sizeof(double), 256);      // centre | box(Y) | box(X)
+    p.off_msum = off;
+    off = align_up(off + (size_t)mce::kMeanBlocks * mce::kStatStride * sizeof(double), 256);
+    if (p.prune) {
+        mce::prune_layout(nq, p.nq_pad, p.nqblk, nr, p.nrow_pad, p.nchunk, d, p.pl);
+        p.pl_nr = nr;
+        p.off_prune = off;
+        off = align_up(off + p.pl.total, 256);
+        if (nq == nr && p.nqblk >= kPruneHeavyMinBlocks && prune_heavy_enabled()) {
+            p.heavy_max = std::max(p.nqblk * mce::kHWaves / kPruneHeavyMaxShare, kPruneHeavyMinCount);       // waves
+            p.off_heavy = off;
+            off = align_up(off + (size_t)p.heavy_max * kPruneWaveQueries * (kPruneHeavyMaxSplit - 1) * p.KCAP * (sizeof(double) + sizeof(int)), 256);
+        }
+    }
+    if (p.sym) {
+        mce::sym_layout(nr, p.nq_pad, p.nqblk, d, p.KCAP, mce::f16_qpb(p.KCAP), sym_bucket_per_row(K), p.sl);
+        p.off_sym = off;
+        off = align_up(off + p.sl.total, 256);
+    }
+    p.total = off;
+    };
+    layout();
+    while (t_plan_cap && p.total > t_plan_cap && p.rsplit > std::max(1, rmin)) {
+        p.rsplit -= 1;
+        layout();
+    }
+    return MCE_OK;
+}
+
+size_t dotp_ws_bytes(int64_t nq, int32_t kmax)
+{
+    const int64_t nb = (nq + mce::kRedThreads - 1) / mce::kRedThreads;
+    return align_up((size_t)std::max<int64_t>(nb, 1) * (size_t)kmax * sizeof(double), 256);
+}
+
+}  // namespace

@@ -1,0 +1,405 @@
+// capi_search.hpp -- part of capi_search.hpp: run_search() (pack + the search launches of a plan; leaves the lists in the workspace)
+// and launch_merge() (list merge, optional distance output, fused volume / weight reduction).  Reference: MCEvidence.py:1093-1117.
+#pragma once
+namespace {
+
+double ln_unit_ball(int d) { return 0.5 * d * std::log(M_PI) - std::lgamma(1.0 + 0.5 * d); }
+
+// pack + search; leaves the lane/split lists in the workspace
+int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t nr, int32_t d, int32_t K,
+               int32_t self_mode, int64_t self_offset, char* ws, hipStream_t st)
+{
+    p.sym_active = false;
+    double* pd = reinterpret_cast<double*>(ws + p.off_pd);
+    int* pi = reinterpret_cast<int*>(ws + p.off_pi);
+    if (p.generic) {
+        const size_t lds = (size_t)mce::kGenTileRows * d * sizeof(double);
+        hipLaunchKernelGGL(mce::knn_generic_kernel, dim3((unsigned)p.nqblk), dim3(mce::kGenThreads), lds, st, dX, nq, dY, nr, (int)d,
+                           (int)K, p.nq_pad, (self_mode == MCE_SELF_EXCLUDE) ? 1 : 0, self_offset, pd, pi);
+        MCE_HIP(hipGetLastError());
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "knn_generic_kernel grid=%d block=%d lds=%zu", p.nqblk, mce::kGenThreads, lds);
+        return MCE_OK;
+    }
+    double* center = reinterpret_cast<double*>(ws + p.off_center);
+    double* msum = reinterpret_cast<double*>(ws + p.off_msum);
+    double* box_y = center + mce::kMaxDimPad;
+    double* box_x = center + 2 * mce::kMaxDimPad;
+    hipLaunchKernelGGL(mce::col_stats_partial_kernel, dim3(mce::kMeanBlocks), dim3(mce::kMeanThreads), 0, st, dY, nr, (int)d, msum);
+    MCE_HIP(hipGetLastError());
+    hipLaunchKernelGGL(mce::col_stats_final_kernel, dim3(1), dim3(64), 0, st, msum, nr, (int)d, center, box_y);
+    MCE_HIP(hipGetLastError());
+    const bool prof = g_prof_on && g_ev_used < 1024;
+    // bracket of the whole search: closed by the caller-visible end of run_search (SearchBracket's destructor)
+    struct SearchBracket {
+        hipStream_t st; bool on;
+        SearchBracket(hipStream_t s, bool o) : st(s), on(o)
+        {
+            if (!on) return;
+            if (g_evs_used == g_evs_pool.size()) {
+                hipEvent_t e0, e1;
+                if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { on = false; return; }
+                g_evs_pool.emplace_back(e0, e1);
+            }
+            (void)hipEventRecord(g_evs_pool[g_evs_used].first, st);
+        }
+        ~SearchBracket() { if (on) { (void)hipEventRecord(g_evs_pool[g_evs_used].second, st); ++g_evs_used; } }
+    } search_bracket(st, prof && g_evs_used < 1024);
+    g_last_flops_main = g_last_flops_all = 0.0;
+    auto prof_begin = [&]() -> int {
+        if (!prof) return MCE_OK;
+        if (g_ev_used == g_ev_pool.size()) {
+            hipEvent_t e0, e1;
+            MCE_HIP(hipEventCreate(&e0));
+            MCE_HIP(hipEventCreate(&e1));
+            g_ev_pool.emplace_back(e0, e1);
+        }
+        MCE_HIP(hipEventRecord(g_ev_pool[g_ev_used].first, st));
+        return MCE_OK;
+    };
+    auto prof_end = [&]() -> int {
+        if (!prof) return MCE_OK;
+        MCE_HIP(hipEventRecord(g_ev_pool[g_ev_used].second, st));
+        ++g_ev_used;
+        if (!g_in_tail) ++g_ev_calls;
+        return MCE_OK;
+    };
+    const int threads = 256;
+    if (p.vh) {
+        // ---- fp16 filter + exact fp64 refine ------------------------------------
+        _Float16* yh = reinterpret_cast<_Float16*>(ws + p.off_yh);
+        _Float16* xh = reinterpret_cast<_Float16*>(ws + p.off_xh);
+        double* qinfo = reinterpret_cast<double*>(ws + p.off_qinfo);
+        double* params = reinterpret_cast<double*>(ws + p.off_params);
+        MCE_HIP(mce::zero_async(params, mce::HP_COUNT * sizeof(double), st));
+        // queries that are literally rows of the reference buffer are inside its bounding box already
+        bool separate_queries = !(dX >= dY && dX + (size_t)nq * d <= dY + (size_t)nr * d);
+        const double* sX = dX;     // the rows the search reads: the caller's, or their k-d ordered copies
+        const double* sY = dY;
+        mce::PruneOut po;
+        const bool use_sym = p.sym && dX == dY && nq == nr && self_offset == 0 && g_split_depth == 0;
+        if (use_sym) {
+            // rows by distance from the mean: a 32-row tile then holds rows of nearly equal K-th neighbour distance
+            MCE_HIP(mce::sym_prepare(dY, nr, (int)d, center, p.nq_pad, ws + p.off_sym, p.sl, st));
+            sX = sY = reinterpret_cast<const double*>(ws + p.off_sym + p.sl.Ys);
+            separate_queries = false;
+        }
+        if (p.prune) {
+            const bool same_set = (dX == dY && nq == nr);
+            MCE_HIP(mce::prune_prepare(dX, nq, dY, nr, (int)d, same_set, mce::f16_qpb(p.KCAP), p.CT * 32, p.nq_pad, p.nqblk, p.nrow_pad,
+                                       p.nchunk, ws + p.off_prune, p.pl, st, po));
+            sX = po.Xs;
+            sY = po.Ys;
+            separate_queries = separate_queries && !same_set;
+        }
+        if (separate_queries) {
+            hipLaunchKernelGGL(mce::col_stats_partial_kernel, dim3(mce::kMeanBlocks), dim3(mce::kMeanThreads), 0, st, dX, nq, (int)d, msum);
+            MCE_HIP(hipGetLastError());
+            hipLaunchKernelGGL(mce::f16_box_about_kernel, dim3(1), dim3(64), 0, st, msum, (int)d, center, box_x);
+            MCE_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(mce::f16_scale_kernel, dim3(1), dim3(64), 0, st, box_y, separate_queries ? box_x : (const double*)nullptr, params);
+        MCE_HIP(hipGetLastError());
+        {
+            const int64_t rows_per_block = 4 * (64 / (2 * p.KST));          // 4 waves x R rows
+            const int64_t pack_blocks = std::min<int64_t>((p.nrow_pad + rows_per_block - 1) / rows_per_block, 2048);   // grid-stride
+            hipLaunchKernelGGL(mce::f16_pack_refs_kernel, dim3((unsigned)pack_blocks), dim3(256), 0, st,
+                               sY, nr, (int)d, p.KST, p.nrow_pad, center, params, yh);
+            MCE_HIP(hipGetLastError());
+            hipLaunchKernelGGL(mce::f16_pack_queries_kernel, dim3((unsigned)((p.nq_pad + rows_per_block - 1) / rows_per_block)), dim3(256), 0, st,
+                               sX, nq, p.nq_pad, (int)d, p.KST, center, params, xh, qinfo);
+            MCE_HIP(hipGetLastError());
+        }
+        mce::KnnF16Args a;
+        a.Yh = yh; a.nchunk_total = p.nchunk; a.rsplit = p.rsplit; a.Xh = xh; a.qinfo = qinfo; a.params = params;
+        a.X = sX; a.Y = sY; a.nq = nq; a.nr = nr; a.D = d; a.nq_pad = p.nq_pad; a.nqblk = p.nqblk;
+        a.self_exclude = (self_mode == MCE_SELF_EXCLUDE) ? 1 : 0;
+        a.self_offset = self_offset; a.ksel = K; a.part_d = pd; a.part_i = pi;
+        if (p.prune) {
+            a.clist = po.clist; a.cdist = po.cdist; a.list_len = (int)p.nchunk; a.rperm = po.rperm; a.qperm = po.qperm;
+            a.tbox_r = po.tbox_r; a.tbox_q = po.tbox_q; a.cbox_r = po.cbox_r; a.border = po.border;
+            // (a part of a multi-GPU run: every nparts-th WAVE of the dispatch order)
+            const int nw_total = p.nqblk * mce::kHWaves;
+            if (p.nparts > 1) { a.qblk0 = p.part; a.qblk_stride = p.nparts; a.nqblk_run = (nw_total - p.part + p.nparts - 1) / p.nparts; }
+            // heavy waves (the first of this launch's dispatch order): several workgroups each, lists folded afterwards
+            const int nblk_run = a.nqblk_run ? a.nqblk_run : nw_total;       // waves of this launch
+            int hv_n = 0, hv_S = 1;
+            if (p.heavy_max > 0 && dX == dY && nq == nr) {
+                // how many: the waves that would run longer than a fraction of the launch.  Measured at C5 (1 wave in 100 takes
+                // 3.4x the mean, 1 in 1000 7.5x, 1 in 10 000 13x): ~700 of a 10-round launch, fewer of a longer one (it hides
+                // longer waves) -- 1 / 2 / 4 / 8 GPUs: 0 / 184 / 367 / 700 waves per rank
+                const double rounds = (double)nblk_run / 2048.0;
+                const char* hv_env = getenv("MCE_PRUNE_HEAVY");
+                if ((kPruneHeavyDefault || (hv_env && !strcmp(hv_env, "auto"))) && rounds < kPruneHeavyMaxRounds) {
+                    const double f = std::min(1.0, kPruneHeavyFullRounds / std::max(rounds, 1.0));
+                    hv_n = std::min(std::max((int)(kPruneHeavyCount * f), kPruneHeavyMinCount), std::min(p.heavy_max, nblk_run));
+                    hv_S = kPruneHeavySplit;
+                }
+                if (const char* e = hv_env) {
+                    int n_ = hv_n, s_ = kPruneHeavySplit;
+                    if (sscanf(e, "%d,%d", &n_, &s_) >= 1) { hv_n = std::min(std::max(n_, 0), std::min(p.heavy_max, nblk_run)); hv_S = std::min(std::max(s_, 1), kPruneHeavyMaxSplit); }
+                }
+                if (hv_n == 0 || hv_S == 1) { hv_n = 0; hv_S = 1; }
+            }
+            double* hv_d = reinterpret_cast<double*>(ws + p.off_heavy);
+            int* hv_i = reinterpret_cast<int*>(hv_d + (size_t)p.heavy_max * kPruneWaveQueries * (kPruneHeavyMaxSplit - 1) * p.KCAP);
+            a.seed_cfg = hv_n | (hv_S << 24);
+            a.lo_d = hv_n ? hv_d : nullptr;
+            a.lo_i = hv_n ? hv_i : nullptr;
+            // MCE_PRUNE_TIMES=<file> (diagnostic): the duration of every workgroup of the walk, by position in the dispatch
+            // order -- where the tail of a launch is (tools/heavy_scan.py)
+            const char* times_file = getenv("MCE_PRUNE_TIMES");
+            const size_t n_wg = (size_t)(nblk_run + hv_n * (hv_S - 1));
+            DevBuf wg_times;
+            if (times_file && *times_file) { MCE_HIP(wg_times.alloc(n_wg * sizeof(float))); a.wg_us = wg_times.as<float>(); }
+            int rc = prof_begin();
+            if (rc != MCE_OK) return rc;
+            // K <= 9 with 12-row list arrays: the instantiation that keeps nine entries in registers runs three waves per SIMD
+            // instead of two (knn_f16.hpp, LC): C5 on one GPU 95.9 vs 124.7 ms.  MCE_PRUNE_LISTS=long / short: comparisons.
+            const char* force_lists = getenv("MCE_PRUNE_LISTS");
+            // (K = 10 likewise with ten entries: 10 M x 6 105.7 -> 83 ms; eleven spill inside the walk)
+            mce::knn_f16_launch_fn short_fn = nullptr;
+            int short_lc = 0;
+            if (p.vh->launch_prune_short && K <= p.vh->prune_short_lc) { short_fn = p.vh->launch_prune_short; short_lc = p.vh->prune_short_lc; }
+            else if (p.vh->launch_prune_short2 && K <= p.vh->prune_short_lc2) { short_fn = p.vh->launch_prune_short2; short_lc = p.vh->prune_short_lc2; }
+            const bool short_lists = short_fn && !(force_lists && !strcmp(force_lists, "long"));
+            MCE_HIP(short_lists ? short_fn(a, st) : p.vh->launch_prune(a, st));
+            rc = prof_end();
+            if (rc != MCE_OK) return rc;
+            if (a.wg_us) {
+                std::vector<float> us(n_wg);
+                MCE_HIP(hipStreamSynchronize(st));
+                MCE_HIP(hipMemcpy(us.data(), a.wg_us, n_wg * sizeof(float), hipMemcpyDeviceToHost));
+                if (FILE* f = fopen(times_file, "wb")) {
+                    const int hdr[4] = {(int)n_wg, hv_n, hv_S, 1};
+                    fwrite(hdr, sizeof(int), 4, f);
+                    fwrite(us.data(), sizeof(float), n_wg, f);
+                    fclose(f);
+                }
+            }
+            if (hv_n) {
+                const unsigned fb = (unsigned)(((int64_t)hv_n * kPruneWaveQueries + mce::kRedThreads - 1) / mce::kRedThreads);
+                hipLaunchKernelGGL(mce::prune_heavy_fold_kernel, dim3(fb), dim3(mce::kRedThreads), 0, st, pd, pi, p.nq_pad, p.KCAP, hv_d, hv_i, hv_n, hv_S,
+                                   kPruneWaveQueries, po.border, a.qblk0, a.qblk_stride);
+                MCE_HIP(hipGetLastError());
+            }
+            g_last_params = params;
+            g_last_flops_main = g_last_flops_all = -1.0;        // (tiles multiplied: a device counter, mce_last_prune_stats)
+            g_last_prune_geom[0] = p.nqblk; g_last_prune_geom[1] = (double)p.nchunk; g_last_prune_geom[2] = p.CT;
+            snprintf(g_last_kernel, sizeof(g_last_kernel), "%s pruned grid=%d block=64 lds=%zu qt=%d ct=%d chunks=%lld heavy=%dx%d lists=%d", p.vh->name,
+                     nblk_run + hv_n * (hv_S - 1), mce::f16_prune_lds_bytes(p.KST, d, short_lists ? short_lc : p.KCAP), p.QT, p.CT, (long long)p.nchunk, hv_n,
+                     hv_S, short_lists ? short_lc : p.KCAP);
+            return MCE_OK;
+        }
+        // seed phase: the host picks the group size; MCE_F16_SEED_ROWS / MCE_F16_SEED_SHARE override (tests, tuning)
+        // (the kernel balances the splits to within one chunk: size the seed phase for the smallest)
+        auto seed_cfg = [&](int ksel) { return sweep_seed_cfg(p.nchunk / p.rsplit, p.CT, ksel + a.self_exclude); };
+        if (use_sym) {
+            char* const sw = ws + p.off_sym;
+            a.rsplit = 1;
+            a.rperm = reinterpret_cast<const int*>(sw + p.sl.perm);
+            a.sym.thr = reinterpret_cast<unsigned long long*>(sw + p.sl.thr);
+            a.sym.rrow = reinterpret_cast<unsigned*>(sw + p.sl.rrow);
+            a.sym.rtile = reinterpret_cast<float*>(sw + p.sl.rtile);
+            a.sym.slots = reinterpret_cast<unsigned long long*>(sw + p.sl.slots);
+            a.sym.bucket_cnt = reinterpret_cast<int*>(sw + p.sl.bucket_cnt);
+            a.sym.bucket_flag = reinterpret_cast<int*>(sw + p.sl.bucket_flag);
+            a.sym.bucket = reinterpret_cast<mce::SymEntry*>(sw + p.sl.bucket);
+            a.sym.cap = p.sl.cap;
+            a.sym.done = reinterpret_cast<int*>(sw + p.sl.done);
+            // panel = the packed rows one L2 (4 MB per XCD) serves to the units running at the same time; MCE_SYM_PANEL: chunks (tuning)
+            const Tuning tun = read_tuning();
+            a.sym.panel = tun.sym_panel > 0 ? tun.sym_panel : kSymPanelChunks[p.KST];
+            // prepass: every row's bound before any block runs (the seed phase as its own launch)
+            // about 32 k rows (one k-step: 64 k), at most half of the chunks (tools/_tmp-style scans, fused call, share 8 -> 2:
+            // 49 k x 27 1.51 -> 1.32 ms, 98 k 2.18 -> 2.03, 131 k 2.58 -> 2.47, from 197 k rows the same; 393 k x 15 7.04 -> 6.88)
+            const int seed_rows = tun.sym_seed_rows > 0 ? tun.sym_seed_rows : (p.KST == 1 ? 65536 : 32768);
+            const int seed_share = tun.sym_seed_share;
+            a.seed_cfg = mce::f16_seed_cfg(p.nchunk, p.CT, K + a.self_exclude, seed_rows, seed_share, MCE_H_SEED_TG);
+            // tiny sets (forced mode): smaller groups, so that half of the chunks still hold twice the K groups a bound needs --
+            // without any bound every pair would go through the row side (20 k x 27: 10.8 ms instead of 0.8)
+            for (int tg = MCE_H_SEED_TG / 2; a.seed_cfg == 0 && tg >= 1; tg /= 2)
+                a.seed_cfg = mce::f16_seed_cfg(p.nchunk, p.CT, K + a.self_exclude, seed_rows, seed_share, tg);
+            if (a.seed_cfg) {
+                a.seed_cfg |= ((tun.sym_seed_mode >= 0 ? tun.sym_seed_mode : kSymSeedMode[p.KST]) & 3) << 28;
+            }
+            // One rank's share of a multi-GPU partition: the contiguous range of sorted blocks [qb_lo, qb_hi).  Their tiles
+            // carry the row-side gate; everybody else's rows are swept column side only (sym_types.hpp, PanelGeom) -- no
+            // exchange between the ranks, each ends with complete lists for its own rows.  Only they need a prepass bound.
+            const int qb_lo = p.nparts > 1 ? (int)((int64_t)p.nqblk * p.part / p.nparts) : 0;
+            const int qb_hi = p.nparts > 1 ? (int)((int64_t)p.nqblk * (p.part + 1) / p.nparts) : p.nqblk;
+            p.sym_qb_lo = qb_lo;
+            p.sym_qb_hi = qb_hi;
+            a.qblk0 = qb_lo;
+            a.nqblk_run = qb_hi - qb_lo;
+            if (qb_hi > qb_lo) MCE_HIP(p.vh->launch_sym_pre(a, st));
+            a.qblk0 = 0;
+            a.nqblk_run = 0;
+            const int seed_used = a.seed_cfg;
+            a.seed_cfg = 0;
+            int rc = prof_begin();             // (the bracket of mce_last_kernel_ms(): the dominant kernel, as for the other searches)
+            if (rc != MCE_OK) return rc;
+            const bool panel_kernel = !tun.sym_kernel_f16 || p.nparts > 1;
+            if (panel_kernel) {
+                mce::PanelArgs pa;
+                pa.Yh = yh; pa.Xh = xh; pa.qinfo = qinfo; pa.params = params; pa.X = sX; pa.Y = sY; pa.rperm = a.rperm;
+                pa.part_d = pd; pa.part_i = pi; pa.nq = nq; pa.nr = nr; pa.nq_pad = p.nq_pad; pa.self_offset = 0;
+                pa.D = d; pa.ksel = K; pa.self_exclude = a.self_exclude; pa.spin_limit = tun.spin_limit;
+                pa.sym = a.sym;
+                pa.debug = tun.panel_debug;
+                pa.geom.qb_lo = qb_lo; pa.geom.qb_hi = qb_hi; pa.geom.tpb = mce::kHWaves * mce::kHQT; pa.geom.ct = p.CT;
+                pa.geom.tpp = a.sym.panel * p.CT; pa.geom.sym_on = 1;
+                pa.geom.ntiles = (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1);
+                MCE_HIP(p.vh->launch_panel(pa, st));
+            } else {
+                MCE_HIP(p.vh->launch_sym(a, st));
+            }
+            rc = prof_end();
+            if (rc != MCE_OK) return rc;
+            MCE_HIP(p.vh->launch_sym_repair(a, st));      // blocks whose bucket overflowed (normally none: every workgroup exits at once)
+            {
+                const dim3 g((unsigned)std::max(1, qb_hi - qb_lo)), b(mce::kSymMergeThreads);
+                static_assert(mce::kSymMergeThreads == mce::f16_qpb(4), "one merge block per query block");
+                switch (p.KCAP) {
+                    case 4: hipLaunchKernelGGL(mce::sym_merge_kernel<4>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
+                    case 8: hipLaunchKernelGGL(mce::sym_merge_kernel<8>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
+                    case 12: hipLaunchKernelGGL(mce::sym_merge_kernel<12>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
+                    default: hipLaunchKernelGGL(mce::sym_merge_kernel<16>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
+                }
+                MCE_HIP(hipGetLastError());
+            }
+            p.sym_active = true;
+            p.L = 1;
+            int sym_units = mce::sym_unit_count(p.nqblk, mce::kHWaves * mce::kHQT, a.sym.panel * p.CT, (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1));
+            if (panel_kernel) {
+                mce::PanelGeom g;
+                g.qb_lo = qb_lo; g.qb_hi = qb_hi; g.tpb = mce::kHWaves * mce::kHQT; g.ct = p.CT; g.tpp = a.sym.panel * p.CT; g.sym_on = 1;
+                g.ntiles = (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1);
+                sym_units = mce::panel_unit_count(g);
+                // executed MFMA flops: every unit's tiles x 16 query tiles x (32 x 32 x 16 KST) multiply-adds -- a figure for
+                // mce_last_search_stats(), counted only while profiling is on (the loop is O(units x panels): seconds of host
+                // time per search near the row limit)
+                double tiles = 0.0;
+                for (int u = 0; g_prof_on && u < sym_units; ++u) {
+                    int pp, aa, lo, hi;
+                    mce::panel_unit_decode(u, g, pp, aa);
+                    mce::panel_unit_tiles(pp, aa, g, lo, hi);
+                    tiles += hi - lo;
+                }
+                g_last_flops_main = tiles * 16.0 * 1024.0 * 32.0 * p.KST;
+            } else {
+                const double nb = p.nqblk, tpb = mce::kHWaves * mce::kHQT, T = (double)((nr + 31) / 32);
+                double tiles = 0.0;
+                for (int b = 0; b < p.nqblk; ++b) tiles += std::min(tpb * (b + 1), T);
+                (void)nb;
+                g_last_flops_main = tiles * 16.0 * 1024.0 * 32.0 * p.KST;
+            }
+            g_last_flops_all = g_last_flops_main + (double)(seed_used & 0xffff) * p.CT * (double)(qb_hi - qb_lo) * 16.0 * 1024.0 * 32.0 * p.KST;
+            snprintf(g_last_kernel, sizeof(g_last_kernel), "%s symmetric%s grid=%d block=%d lds=%zu qt=%d ct=%d panel=%d seed=%dx%d/%d bucket=%d", p.vh->name, panel_kernel ? " panel-kernel" : "",
+                     sym_units,
+                     mce::kHThreads, panel_kernel ? p.vh->lds_bytes_panel : p.vh->lds_bytes_sym, p.QT, p.CT, a.sym.panel, seed_used & 0xffff, (seed_used >> 16) & 0xfff, (seed_used >> 28) & 3, p.sl.cap);
+            return MCE_OK;
+        }
+        int rc = prof_begin();
+        if (rc != MCE_OK) return rc;
+        if (p.twopass) {
+            // lists [2*rsplit][16][nq_pad]: pass 1 fills splits 0..rsplit-1 with each split's 16 nearest, pass 2 the
+            // next K - 16 beyond them into rsplit..2*rsplit-1; the merge takes the K best of all
+            a.ksel = 16;
+            a.seed_cfg = seed_cfg(16);
+            MCE_HIP(p.vh->launch(a, st));
+            a.lo_d = pd;
+            a.lo_i = pi;
+            a.part_d = pd + (size_t)p.rsplit * p.KCAP * (size_t)p.nq_pad;
+            a.part_i = pi + (size_t)p.rsplit * p.KCAP * (size_t)p.nq_pad;
+            a.ksel = K - 16;
+            a.seed_cfg = 0;
+            MCE_HIP(p.vh->launch_lower(a, st));
+        } else {
+            a.seed_cfg = seed_cfg(K);
+            MCE_HIP(p.vh->launch(a, st));
+        }
+        rc = prof_end();
+        if (rc != MCE_OK) return rc;
+        const int seed_first = p.twopass ? seed_cfg(16) : a.seed_cfg;
+        g_last_flops_main = (double)p.nqblk * ((double)p.nchunk + (double)(seed_first & 0xffff) * p.rsplit) * p.CT * 16.0 * 1024.0 * 32.0 * p.KST +
+                            (p.twopass ? (double)p.nqblk * (double)p.nchunk * p.CT * 16.0 * 1024.0 * 32.0 * p.KST : 0.0);
+        g_last_flops_all = g_last_flops_main;
+        char seed_txt[48] = "";
+        if (seed_first) snprintf(seed_txt, sizeof(seed_txt), " seed=%dx%d", seed_first & 0xffff, seed_first >> 16);   // chunks x tiles per group
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d%s%s", p.vh->name,
+                 p.nqblk * p.rsplit, mce::kHThreads, p.vh->lds_bytes, p.QT, p.CT, p.rsplit, p.twopass ? " two passes" : "", seed_txt);
+        return MCE_OK;
+    }
+    // ---- fp64 MFMA sweep ----------------------------------------------------------
+    double* yf = reinterpret_cast<double*>(ws + p.off_yf);
+    hipLaunchKernelGGL(mce::pack_refs_kernel, dim3((unsigned)((p.nrow_pad + threads - 1) / threads)), dim3(threads), 0, st, dY, nr,
+                       (int)d, p.KS, p.nrow_pad, center, yf);
+    MCE_HIP(hipGetLastError());
+    mce::KnnArgs a;
+    a.Yf = yf;
+    a.nchunk_total = p.nchunk;
+    a.rsplit = p.rsplit;
+    a.X = dX;
+    a.center = center;
+    a.nq = nq;
+    a.D = d;
+    a.nq_pad = p.nq_pad;
+    a.nqblk = p.nqblk;
+    a.self_exclude = (self_mode == MCE_SELF_EXCLUDE) ? 1 : 0;
+    a.self_offset = self_offset;
+    a.ksel = K;
+    a.part_d = pd;
+    a.part_i = pi;
+    int rc = prof_begin();
+    if (rc != MCE_OK) return rc;
+    MCE_HIP(p.v->launch(a, st));
+    rc = prof_end();
+    if (rc != MCE_OK) return rc;
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d", p.v->name,
+             p.nqblk * p.rsplit, mce::kThreads, p.v->lds_bytes, p.QT, p.CT, p.rsplit);
+    g_last_flops_main = g_last_flops_all = (double)p.nq_pad * (double)p.nrow_pad * 2.0 * 4.0 * p.KS;
+    return MCE_OK;
+}
+
+// merge (+ optional distance output, + optional fused reduction) of the per-split lists
+int launch_merge(const Plan& p, bool write_dist, bool fuse, const double* dX, const double* dY, int64_t nq, int32_t d, int K,
+                 int self_mode, int64_t self_offset, double* d_dist, int64_t* d_idx, int k0, int kmax,
+                 const double* d_w, const double* d_fs, double* partial, char* ws, hipStream_t st)
+{
+    const bool same_set = (dX == dY && nq == p.pl_nr);
+    // a part of a pruned search: only the list columns of its query blocks were filled; the merge threads
+    // enumerate those columns compactly
+    // (a part of a pruned walk takes every nparts-th WAVE of the dispatch order: its list columns come in runs of 64)
+    const bool wave_parts = p.prune && p.nparts > 1 && !p.sym_active;
+    const int qpb = wave_parts ? kPruneWaveQueries : (p.vh ? mce::f16_qpb(p.KCAP) : 1);
+    const int nunits = wave_parts ? p.nqblk * mce::kHWaves : p.nqblk;
+    int64_t ncol = nq;
+    int64_t col0 = 0, col1 = INT64_MAX;
+    if (p.sym_active && p.nparts > 1) {         // one rank's blocks of a symmetric partition: a contiguous range of list columns
+        col0 = (int64_t)p.sym_qb_lo * qpb;
+        col1 = std::min<int64_t>((int64_t)p.sym_qb_hi * qpb, nq);
+        ncol = std::max<int64_t>(col1 - col0, 0);
+    } else if (p.nparts > 1) ncol = (int64_t)((nunits - p.part + p.nparts - 1) / p.nparts) * qpb;
+    const unsigned blocks = (unsigned)std::max<int64_t>((ncol + mce::kRedThreads - 1) / mce::kRedThreads, 1);
+    const double* pd = reinterpret_cast<const double*>(ws + p.off_pd);
+    const int* pi = reinterpret_cast<const int*>(ws + p.off_pi);
+    const bool refine = p.vh == nullptr && !p.generic;   // fp64 sweep keys are GEMM-form: refine; the others are exact
+    const double lnc = fuse ? ln_unit_ball(d) : 0.0;
+    // pruned search: list column q is the q-th query in k-d order; its caller row is qperm[q]
+    const int* qperm = nullptr;
+    if (p.prune) qperm = reinterpret_cast<const int*>(ws + p.off_prune + (same_set ? p.pl.perm_r : p.pl.perm_q));
+    if (p.sym_active) qperm = reinterpret_cast<const int*>(ws + p.off_sym + p.sl.perm);     // list column = sorted position
+    const int* border = p.prune ? reinterpret_cast<const int*>(ws + p.off_prune + p.pl.border) : nullptr;
+#define MCE_MERGE(W, F, R)                                                                                          \
+    hipLaunchKernelGGL((mce::merge_lists_kernel<W, F, R>), dim3(blocks), dim3(mce::kRedThreads), 0, st, pd, pi, p.L,  \
+                       p.KCAP, nq, p.nq_pad, dX, dY, (int)d, K, self_mode, self_offset, d_dist, d_idx, K, k0, kmax, \
+                       d_w, d_fs, lnc, partial, qperm, p.part, p.nparts, qpb, border, nunits, col0, col1)
+    if (write_dist && !fuse) { if (refine) MCE_MERGE(true, false, true); else MCE_MERGE(true, false, false); }
+    else if (write_dist && fuse) { if (refine) MCE_MERGE(true, true, true); else MCE_MERGE(true, true, false); }
+    else { if (refine) MCE_MERGE(false, true, true); else MCE_MERGE(false, true, false); }
+#undef MCE_MERGE
+    MCE_HIP(hipGetLastError());
+    return MCE_OK;
+}
+
+}  // namespace

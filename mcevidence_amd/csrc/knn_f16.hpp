@@ -94,7 +94,7 @@ constexpr int kHThreads = kHWaves * 64;
 #define MCE_H_SEED_ROWS 24576  // seed phase: reference rows swept twice (0 = no seed phase; 16 k - 48 k rows: within 1 % at 0.1 - 1 M rows) ...
 #endif
 #ifndef MCE_H_SEED_SHARE
-#define MCE_H_SEED_SHARE 4     // ... at most 1/4 of the split's chunks (binds below ~65 k rows per split; capi.hip: seed_cfg) ...
+#define MCE_H_SEED_SHARE 4     // ... at most 1/4 of the split's chunks (binds below ~65 k rows per split; capi_search.hpp: seed_cfg) ...
 #endif
 #ifndef MCE_H_SEED_TG
 #define MCE_H_SEED_TG 8        // ... in groups of 8 tiles (256 rows)
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
     if constexpr (SYM >= 2) {
         if (SYM == 3 && sym.bucket_flag[qblk] == 0) return;      // repair launch: only the blocks whose bucket overflowed
     }
-    // balanced splits (sizes differ by at most one chunk: the host sizes the seed phase for the smallest, capi.hip: seed_cfg)
+    // balanced splits (sizes differ by at most one chunk: the host sizes the seed phase for the smallest, capi_search.hpp: seed_cfg)
     const int64_t c_begin = (int64_t)split * nchunk_total / rsplit;
     const int64_t c_end = (int64_t)(split + 1) * nchunk_total / rsplit;
 
@@ -1514,7 +1514,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
             }
             return keep;
         };
-        // (d <= 8 only -- where the pruned walk is chosen at all, capi.hip: kPruneAutoMinRows; sixteen dimensions' worth of
+        // (d <= 8 only -- where the pruned walk is chosen at all, capi_common.hpp: kPruneAutoMinRows; sixteen dimensions' worth of
         //  boxes and coordinates do not fit the registers of the larger list capacities)
         auto query_reach = [&](unsigned long long need) __attribute__((always_inline)) -> unsigned long long {
             switch ((D + 1) >> 1) {

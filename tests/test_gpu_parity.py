@@ -1021,7 +1021,7 @@ def test_partial_sums_add_up(prune_modes, n, d, kmax, pruned):
     """mce_knn_dotp_part_f64: the parts (library-chosen: row ranges for the sweep, k-d cells for the pruned
     walk) are disjoint and complete -- their sums add up to the one-call result -- for any number of parts.
     (100 k x 6, kmax 17: a row shard of that set plans more reference splits -- each with its own 16-entry lists -- than the
-    whole set does and would not fit the whole set's workspace: the library then takes fewer splits, capi.hip: t_plan_cap;
+    whole set does and would not fit the whole set's workspace: the library then takes fewer splits, capi_common.hpp: t_plan_cap;
     before round 4 parts 4 and 8 of this shape failed with MCE_ERR_WORKSPACE.)"""
     capi = prune_modes
     capi.set_prune_mode(capi.PRUNE_FORCE if pruned else capi.PRUNE_OFF)

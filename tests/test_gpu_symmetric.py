@@ -441,7 +441,7 @@ def test_symmetric_partition_parts_add_up_to_the_whole(sym, n, d, kmax, W):
     parts = []
     for r in range(W):
         parts.append(capi.knn_dotp_part(Y, w, fs, kmax, r, W))
-        # up to four ranks the symmetric partition, beyond that query shards (capi.hip: kSymPartitionMaxParts)
+        # up to four ranks the symmetric partition, beyond that query shards (capi_common.hpp: kSymPartitionMaxParts)
         assert ("panel-kernel" in capi.last_kernel()) == (W <= 4), capi.last_kernel()
     total = np.sum(parts, axis=0)
     assert np.allclose(total[1:], whole[1:], rtol=1e-12, atol=0), (total, whole)

@@ -96,7 +96,7 @@ int main(int argc, char** argv)
     }
     const int npanel_units = panel_unit_count(pa.geom);
     hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
-    const int seed_mode = getenv("SEED_MODE") ? atoi(getenv("SEED_MODE")) : (KST >= 2 ? 1 : 0);      // as capi.hip: kSymSeedMode
+    const int seed_mode = getenv("SEED_MODE") ? atoi(getenv("SEED_MODE")) : (KST >= 2 ? 1 : 0);      // as capi_common.hpp: kSymSeedMode
     const int seed_cfg0 = f16_seed_cfg(nchunk, CT, KSEL + 1, seed_rows, 8, MCE_H_SEED_TG);
     const int seed_cfg = seed_cfg0 ? (seed_cfg0 | (seed_mode << 28)) : 0;
     for (int r = 0; r < reps; ++r) {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: pruned walk vs the automatic exhaustive / symmetric choice around the automatic mode's thresholds
-# (capi.hip: kPruneAutoMinRows), auto evidence, resident data.  usage: tools/prune_crossover.sh -> gpurun_out/prune_crossover.txt
+# (capi_common.hpp: kPruneAutoMinRows), auto evidence, resident data.  usage: tools/prune_crossover.sh -> gpurun_out/prune_crossover.txt
 out=$GRAFT_REPO_ROOT/gpurun_out/prune_crossover.txt; : > $out
 for cfg in "30000 2 4" "50000 2 4" "30000 3 4" "50000 3 4" "100000 3 4" "50000 4 4" "100000 4 4" "150000 4 4" "50000 5 4" "100000 5 4" "150000 5 4" "200000 5 4" \
            "50000 6 4" "100000 6 4" "150000 6 4" "200000 6 4" "300000 6 4" "100000 6 9" "200000 6 9" "300000 6 9" "100000 7 4" "200000 7 4" "300000 7 4" "500000 7 4" \
