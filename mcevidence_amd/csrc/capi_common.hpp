@@ -55,13 +55,14 @@ std::atomic<int> g_prune_mode{0};
 //   MCE_F16_SEED_ROWS / _SHARE / _TG     seed phase of the exhaustive sweep: rows (24576), share (4), tiles per group (8)
 //   MCE_RSPLIT=n                 reference splits of the exhaustive sweep (the model's choice)
 //   MCE_TAIL_SPLIT=0             keep a search with a nearly empty last round of workgroups in one launch
+//   MCE_WIDE=0                   exhaustive one-k-step sweep: two query tiles per wave also where four would be taken (A/B)
 //   MCE_PANEL_DEBUG=bits         knn_panel.hpp test hooks (8: every candidate through the redo list, 16: waves give up waiting)
 //   MCE_FEED_WAVE_BYTES=n        batched feed: bytes of host data per upload wave (tests: force several waves)
 //   MCE_FEED_UPLOAD=async        batched feed: uploads on the job's stream (read once)
 //   MCE_PRUNE_PROF=1             print the pruned walk's per-wave cycle breakdown (builds with -DMCE_PRUNE_PROF)
 // ---------------------------------------------------------------------------------------------------------------------
 struct Tuning {
-    bool sym_kernel_f16 = false, tail_split = true, prune_prof = false;
+    bool sym_kernel_f16 = false, tail_split = true, prune_prof = false, wide = true;
     int spin_limit = 1 << 21, sym_bucket = 0, sym_panel = 0, sym_seed_rows = 0, sym_seed_share = 2, sym_seed_mode = -1;
     int f16_seed_rows = -1, f16_seed_share = -1, f16_seed_tg = -1, rsplit = 0, panel_debug = 0;
     size_t feed_wave_bytes = 0;
@@ -83,6 +84,7 @@ Tuning read_tuning()
     t.f16_seed_tg = num("MCE_F16_SEED_TG", -1);
     t.rsplit = num("MCE_RSPLIT", 0);
     t.tail_split = num("MCE_TAIL_SPLIT", 1) != 0;
+    t.wide = num("MCE_WIDE", 1) != 0;
     t.panel_debug = num("MCE_PANEL_DEBUG", 0);
     t.prune_prof = getenv("MCE_PRUNE_PROF") != nullptr;
     if ((e = getenv("MCE_FEED_WAVE_BYTES"))) t.feed_wave_bytes = (size_t)std::strtoull(e, nullptr, 10);

@@ -27,6 +27,7 @@ constexpr int kPruneHeavyMinBlocks = 64, kPruneHeavyCount = 700, kPruneHeavyMaxS
 constexpr double kPruneHeavyFullRounds = 10.0;
 constexpr int kPruneHeavySplit = 4, kPruneHeavyMaxSplit = 8;
 constexpr int kPruneWaveQueries = mce::kHQT * 32;     // list columns per workgroup of the walk
+constexpr int kWideMinBlocks = 4 * kAssumedCUs;       // query blocks from which the exhaustive one-k-step sweep takes its wide form (make_plan)
 // side lists for split waves are part of a plan only when the split can happen (44 % of the list arrays: ~630 MB at C5)
 bool prune_heavy_enabled()
 {
@@ -52,6 +53,7 @@ struct Plan {
     size_t off_yf = 0, off_pd = 0, off_pi = 0, off_center = 0, off_msum = 0, total = 0;
     double cost = 0.0;                        // the split model's estimate for this plan (cycles per SIMD; exhaustive kernels)
     bool twopass = false;                     // fp16 filter, 16 < K <= 32: two sweeps of 16-entry lists (knn_f16.hpp, LOWER)
+    bool wide_ok = false;                     // the exhaustive sweep may run four query tiles per wave (knn_f16.hpp, QTT = 4): nqblk is even
     bool prune = false;                       // fp16 filter walking k-d ordered chunk lists (prune.hpp)
     int part = 0, nparts = 1;                 // pruned walk over the waves part, part + nparts, ... of the dispatch order only; symmetric sweep: the
                                               // contiguous range of sorted blocks [sym_qb_lo, sym_qb_hi) (one rank's share)
@@ -161,6 +163,12 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
         rows_per_tile = 16;
     }
     p.nqblk = (int)std::max<int64_t>(1, (nq + qpb - 1) / qpb);
+    // One-k-step sweeps of short lists over many queries: four query tiles per wave, a workgroup = TWO query blocks (knn_f16.hpp,
+    // QTT = 4: C4 41.5 -> 37.7 ms).  From kWideMinBlocks blocks: the chip then still gets two full rounds of the wider workgroups
+    // (C2's 196 blocks would leave 60 % of the CUs idle).  Decided on the sizes alone, so that the workspace query and the call
+    // agree; which sweep runs (pruned walk, symmetric, exhaustive) is settled later -- only the exhaustive one has a wide form.
+    p.wide_ok = f16 && !p.twopass && p.KST == 1 && p.vh->launch_wide && p.nqblk >= kWideMinBlocks && nr <= ((int64_t)1 << 25) && read_tuning().wide;
+    if (p.wide_ok && (p.nqblk & 1)) p.nqblk += 1;
     p.nq_pad = (int64_t)p.nqblk * qpb;
     const int64_t rows_per_chunk = (int64_t)p.CT * rows_per_tile;
     p.nchunk = (nr + rows_per_chunk - 1) / rows_per_chunk;

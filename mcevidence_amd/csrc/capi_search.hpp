@@ -316,7 +316,8 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             MCE_HIP(p.vh->launch_lower(a, st));
         } else {
             a.seed_cfg = seed_cfg(K);
-            MCE_HIP(p.vh->launch(a, st));
+            if (p.wide_ok) MCE_HIP(p.vh->launch_wide(a, st));       // four query tiles per wave: a workgroup = two query blocks
+            else MCE_HIP(p.vh->launch(a, st));
         }
         rc = prof_end();
         if (rc != MCE_OK) return rc;
@@ -326,8 +327,10 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
         g_last_flops_all = g_last_flops_main;
         char seed_txt[48] = "";
         if (seed_first) snprintf(seed_txt, sizeof(seed_txt), " seed=%dx%d", seed_first & 0xffff, seed_first >> 16);   // chunks x tiles per group
-        snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d%s%s", p.vh->name,
-                 p.nqblk * p.rsplit, mce::kHThreads, p.vh->lds_bytes, p.QT, p.CT, p.rsplit, p.twopass ? " two passes" : "", seed_txt);
+        const bool wide = p.wide_ok && !p.twopass;
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d%s%s%s", p.vh->name,
+                 (wide ? p.nqblk / 2 : p.nqblk) * p.rsplit, mce::kHThreads, wide ? p.vh->lds_bytes_wide : p.vh->lds_bytes, wide ? 2 * p.QT : p.QT, p.CT, p.rsplit,
+                 p.twopass ? " two passes" : "", seed_txt, wide ? " wide" : "");
         return MCE_OK;
     }
     // ---- fp64 MFMA sweep ----------------------------------------------------------

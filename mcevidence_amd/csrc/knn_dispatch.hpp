@@ -95,6 +95,8 @@ struct KnnF16Variant {
     int prune_short_lc;
     knn_f16_launch_fn launch_prune_short2;  // the same with prune_short_lc2 entries (> prune_short_lc), else null
     int prune_short_lc2;
+    knn_f16_launch_fn launch_wide;          // the exhaustive sweep with FOUR query tiles per wave (a workgroup = two query blocks; KST = 1, KCAP = 4), else null
+    size_t lds_bytes_wide;
 };
 constexpr int kMaxKST = 4;
 extern const KnnF16Variant g_knn_f16_kcap4[kMaxKST];

@@ -168,12 +168,12 @@ inline int f16_seed_cfg(int64_t cps, int CT, int kneed, int rows = MCE_H_SEED_RO
     if (chunks * CT / tg < 2 * (int64_t)kneed) return 0;
     return (int)chunks | (tg << 16);       // (bits 28-29: where the chunks are, set by the caller -- see the seed phase)
 }
-__host__ __device__ constexpr size_t f16_lds_bytes(int KST, int KCAP, bool sym = false)
+__host__ __device__ constexpr size_t f16_lds_bytes(int KST, int KCAP, bool sym = false, int qt = kHQT)
 {
     return (size_t)2 * f16_chunk_tiles(KST) * KST * 1024             // staging
            + (size_t)kHWaves * kHQueue * 16                            // queues: packed(4) + next(4) + d2(8)
-           + (size_t)kHWaves * kHQT * 32 * 4 + 128                     // chain heads + votes + block thresholds (pruned walk)
-           + (sym ? (size_t)kHWaves * kHQT * 32 * 8 : 0);              // symmetric sweep: K-th bound per query as of the last drain
+           + (size_t)kHWaves * qt * 32 * 4 + 128                       // chain heads + votes + block thresholds (pruned walk)
+           + (sym ? (size_t)kHWaves * qt * 32 * 8 : 0);                // symmetric sweep: K-th bound per query as of the last drain
 }
 
 // ---------------------------------------------------------------------------
@@ -267,7 +267,12 @@ __host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST, int D, int KCA
 //   LC (< KCAP, pruned walk only): the lists hold LC entries in registers while the list ARRAYS keep their KCAP rows (the unused
 //   ones are written empty).  K = 9 (C5's kmax = 10) with KCAP = 12: nine entries fit the three-wave budget that K <= 8
 //   searches run under, twelve do not (see MCE_H_PRUNE_SMALL above).
-template <int KST, int KCAP, bool PRUNE = false, bool LOWER = false, int SYM = 0, int LC = KCAP>
+//   QTT (round 5): 32-query tiles per wave.  2 everywhere but in the WIDE form of the exhaustive one-k-step sweep (QTT = 4, KST = 1,
+//   KCAP = 4: a workgroup serves 1024 queries, i.e. two of the plan's 512-query blocks): every A fragment read from LDS then feeds
+//   four MFMAs instead of two and the gate of one query tile runs under the MFMAs of the other three -- C4 (1 M x 1 M x 15, K = 4)
+//   41.5 -> 37.7 ms on one box (tools/r05_exp2.sh; the gate-never-passes stream 34.8 -> 31.7).  Longer lists or a second k-step
+//   do not fit the register file at four tiles (they spill); twelve waves of two tiles -- three per SIMD -- are SLOWER (42.7 ms).
+template <int KST, int KCAP, bool PRUNE = false, bool LOWER = false, int SYM = 0, int LC = KCAP, int QTT = kHQT>
 __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_SMALL ? MCE_H_PRUNE_SMALL_WAVES : MCE_H_PRUNE_WAVES) : (MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ? 4 : (MCE_H_GEOM == 4 ? 3 : 2)))) void knn_f16_kernel(
     const _Float16* __restrict__ Yh, int64_t nchunk_total, int rsplit,
     const _Float16* __restrict__ Xh, const double* __restrict__ qinfo, const double* __restrict__ params,
@@ -284,8 +289,11 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
     static_assert(LC == KCAP || (PRUNE && LC < KCAP), "shorter register lists: pruned walk only");
     static_assert(!(PRUNE && LOWER), "second pass: exhaustive sweep only");
     static_assert(SYM == 0 || (!PRUNE && !LOWER), "symmetric sweep: exhaustive, single pass");
-    static_assert(SYM == 0 || kHNL == 1, "symmetric sweep: one list per owner lane");
-    constexpr int QT = f16_qt(KCAP);
+    static_assert(QTT == 2 || (QTT == 4 && !PRUNE && !LOWER && SYM == 0), "four query tiles: the plain exhaustive sweep only");
+    constexpr int QT = QTT;
+    constexpr int NL = QT / 2;                           // top-K lists per owner lane
+    constexpr int RELB = QT == 4 ? 25 : kHRelBits;       // queue entry = query-local (6 | 7 bits) << RELB | row - first row of the split
+    static_assert(SYM == 0 || NL == 1, "symmetric sweep: one list per owner lane");
     constexpr int QPW = QT * 32;                         // queries per wave
     constexpr int QPB = kHWaves * QPW;
     constexpr int CT = f16_chunk_tiles(KST);
@@ -358,18 +366,18 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
     double* const thrq = reinterpret_cast<double*>(yorig + 32);      // current exact K-th squared distance per wave-local query
     double* const sthr = xq + lwave * QPW;                      // SYM: K-th bound of every wave-local query as of the last drain (same LDS region as xq; never both)
     float mythr = __builtin_huge_valf();                        // PRUNE: largest K-th squared distance among this wave's queries (rounded up)
-    float Tq[kHQT];                                             // PRUNE: the same per 32-query tile (wave-uniform)
+    float Tq[QT];                                             // PRUNE: the same per 32-query tile (wave-uniform)
 #pragma unroll
-    for (int qt = 0; qt < kHQT; ++qt) Tq[qt] = __builtin_huge_valf();
+    for (int qt = 0; qt < QT; ++qt) Tq[qt] = __builtin_huge_valf();
     const int jsplit0 = SYM ? 0 : (int)(c_begin * (CT * 32));   // first reference row of this split (SYM: queue entries hold absolute rows)
 #pragma unroll
-    for (int nl = 0; nl < kHNL; ++nl) whead[nl * 64 + lane] = -1;
+    for (int nl = 0; nl < NL; ++nl) whead[nl * 64 + lane] = -1;
 
     // lane l OWNS wave-local queries nl*64 + l (query ql = qt*32 + column): their sorted top-KCAP lists live here
-    double own_d[kHNL][LC];
-    int own_i[kHNL][LC];
+    double own_d[NL][LC];
+    int own_i[NL][LC];
 #pragma unroll
-    for (int nl = 0; nl < kHNL; ++nl)
+    for (int nl = 0; nl < NL; ++nl)
 #pragma unroll
         for (int k = 0; k < LC; ++k) { own_d[nl][k] = INF; own_i[nl][k] = -1; }
 
@@ -390,16 +398,16 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
         }
     }
     // upper bound on the final K-th squared distance of the owned queries, known before the sweep (seed phase below)
-    double seed_thr[kHNL];
+    double seed_thr[NL];
 #pragma unroll
-    for (int nl = 0; nl < kHNL; ++nl) seed_thr[nl] = INF;
+    for (int nl = 0; nl < NL; ++nl) seed_thr[nl] = INF;
 #ifndef MCE_SEED_CHECK
 #define MCE_SEED_CHECK 0
 #endif
 #if MCE_SEED_CHECK
-    double seed_dbg[kHNL];
+    double seed_dbg[NL];
 #pragma unroll
-    for (int nl = 0; nl < kHNL; ++nl) seed_dbg[nl] = INF;
+    for (int nl = 0; nl < NL; ++nl) seed_dbg[nl] = INF;
 #endif
 
     const int64_t qwave0 = (int64_t)qblk * QPB + wave * QPW;     // first query of this wave
@@ -512,7 +520,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
 #ifndef MCE_H_NPASS_WIDE
 #define MCE_H_NPASS_WIDE 1      // D > 31 (16 loads per lane and pass): more in flight spills (3: 160-300 bytes of scratch per lane)
 #endif
-        constexpr int NPASS = KST > 2 ? MCE_H_NPASS_WIDE : MCE_H_NPASS;            // 8*NPASS pairs in flight; 8 (D <= 32) or 16 (D <= 63) loads per lane and pass
+        constexpr int NPASS = (KST > 2 || QT == 4) ? MCE_H_NPASS_WIDE : MCE_H_NPASS;            // 8*NPASS pairs in flight; 8 (D <= 32) or 16 (D <= 63) loads per lane and pass (four query tiles: one pass -- registers)
         constexpr int EPL = KST > 2 ? 8 : 4;        // elements per lane: 4 covers D <= 32, 8 covers D <= 63
         for (int b0 = 0; b0 < qcount; b0 += NPASS * 8) {
             int qlp[NPASS], ep[NPASS];
@@ -527,8 +535,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                 const bool valid = e < qcount;
                 if (valid) {
                     const unsigned ent = (unsigned)wq[e];
-                    ql = (int)(ent >> kHRelBits);
-                    j = jsplit0 + (int)(ent & ((1u << (SYM >= 2 ? kHSymRowBits : kHRelBits)) - 1u));
+                    ql = (int)(ent >> RELB);
+                    j = jsplit0 + (int)(ent & ((1u << (SYM >= 2 ? kHSymRowBits : RELB)) - 1u));
                 }
                 qlp[u] = ql;
                 const int64_t q = qwave0 + ql;
@@ -564,7 +572,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                         const int64_t o = ((int64_t)split * KCAP + (KCAP - 1)) * nq_pad + qwave0 + qlp[u];
                         const double ld = lo_d[o];
                         const int li = lo_i[o];
-                        const int j = jsplit0 + (int)((unsigned)wq[ep[u]] & ((1u << kHRelBits) - 1u));
+                        const int j = jsplit0 + (int)((unsigned)wq[ep[u]] & ((1u << RELB) - 1u));
                         ok = a0 > ld || (a0 == ld && j > li);       // (list not full: ld = +inf, nothing is left)
                     }
                 }
@@ -653,7 +661,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                 const int e = e0 + lane;
                 const bool valid = e < qcount;
                 const unsigned ent = valid ? (unsigned)wq[e] : 0u;
-                const int ql = (int)(ent >> kHRelBits);
+                const int ql = (int)(ent >> RELB);
                 const int j = jsplit0 + (int)(ent & ((1u << kHSymRowBits) - 1u));
                 const bool rowflag = (ent >> kHSymRowBits) & 1u;        // the lane passed the row gate on this tile: only then can the pair matter to row j
                 const double d2 = valid ? wqd[e] : -1.0;
@@ -700,7 +708,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
         // (pruned walk: fetching the NEXT chain entry while this one is inserted, and skipping rounds in which no lane's entry
         //  beats its list's last, was measured: C5 95.4 -> 99.4 ms.)
 #pragma unroll
-        for (int nl = 0; nl < kHNL; ++nl) {
+        for (int nl = 0; nl < NL; ++nl) {
             int cur = whead[nl * 64 + lane];
             whead[nl * 64 + lane] = -1;
             while (__any(cur >= 0)) {
@@ -710,7 +718,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                 const bool on = cur >= 0;
                 const int ce = on ? cur : 0;
                 const double d2 = on ? wqd[ce] : INF;
-                const int j = (PRUNE || SYM >= 2) ? wq[ce] : jsplit0 + (int)((unsigned)wq[ce] & ((1u << kHRelBits) - 1u));
+                const int j = (PRUNE || SYM >= 2) ? wq[ce] : jsplit0 + (int)((unsigned)wq[ce] & ((1u << RELB) - 1u));
                 cur = on ? wnx[ce] : -1;
                 // ascending list, ties by row; d2 = +inf (idle lane) changes nothing
                 bool c_hi = (d2 < own_d[nl][LC - 1]) || (d2 == own_d[nl][LC - 1] && j < own_i[nl][LC - 1] && d2 < INF);
@@ -731,9 +739,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
         qcount = 0;
         // ---- refresh the gates: lane l needs the K-th best of queries ql = qt*32 + (l&31),
         // owned by lane ql & 63 in list ql >> 6
-        double thr_own[kHNL];
+        double thr_own[NL];
 #pragma unroll
-        for (int nl = 0; nl < kHNL; ++nl) {
+        for (int nl = 0; nl < NL; ++nl) {
             thr_own[nl] = own_d[nl][LC - 1];
 #pragma unroll
             for (int k = 0; k < LC - 1; ++k) thr_own[nl] = (k == k_last) ? own_d[nl][k] : thr_own[nl];
@@ -781,7 +789,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
         for (int qt = 0; qt < QT; ++qt) G[qt] = gate_of(__shfl(thr_own[qt >> 1], (qt & 1) * 32 + (lane & 31), 64), qt);
         if constexpr (PRUNE) {
 #pragma unroll
-            for (int nl = 0; nl < kHNL; ++nl) thrq[nl * 64 + lane] = thr_own[nl];
+            for (int nl = 0; nl < NL; ++nl) thrq[nl * 64 + lane] = thr_own[nl];
             mythr = 0.0f;
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
@@ -865,7 +873,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                         const int slot = qcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
                         unsigned rel = (unsigned)(jrel0 + (r & 3) + 8 * (r >> 2));
                         if constexpr (SYM == 2) rel |= (mm[qt] <= Rt + cR[qt]) ? (1u << kHSymRowBits) : 0u;      // (lane-level: most events are column-side only)
-                        wq[slot] = (int)(((unsigned)(qt * 32 + (lane & 31)) << kHRelBits) | rel);
+                        wq[slot] = (int)(((unsigned)(qt * 32 + (lane & 31)) << RELB) | rel);
                     }
                     qcount += __builtin_popcountll(m);
                     m = __ballot(pm != 0);
@@ -1060,7 +1068,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
             qorig[qt] = q < nq ? qperm[q] : -1;
         }
 #pragma unroll
-        for (int nl = 0; nl < kHNL; ++nl) thrq[nl * 64 + lane] = INF;
+        for (int nl = 0; nl < NL; ++nl) thrq[nl * 64 + lane] = INF;
         for (int e = lane; e < QPW * D; e += 64) {
             const int64_t q = qwave0 + e / D;
             xq[(e % D) * QPW + e / D] = q < nq ? X[q * (int64_t)D + (e % D)] : 0.0;
@@ -1155,11 +1163,11 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                 // (the minima are inline asm, which the compiler's hazard recogniser does not cover and which -- with
                 //  no branch in this loop to hold them in place -- it schedules right behind the MFMAs that write their
                 //  operands: the wait states are spelled out, tied to the accumulators)
-#if MCE_H_GEOM == 1 || MCE_H_GEOM == 5
-#define MCE_SEED_WAIT(ACC) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(ACC[0]), "+v"(ACC[1]), "+v"(ACC[2]), "+v"(ACC[3]))
-#else
-#define MCE_SEED_WAIT(ACC) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(ACC[0]), "+v"(ACC[1]))
-#endif
+#define MCE_SEED_WAIT(ACC)                                                                                 \
+                do {                                                                                       \
+                    if constexpr (QT == 4) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(ACC[0]), "+v"(ACC[1]), "+v"(ACC[QT - 2]), "+v"(ACC[QT - 1])); \
+                    else asm volatile("s_nop 15\n\ts_nop 3" : "+v"(ACC[0]), "+v"(ACC[1]));                 \
+                } while (0)
 #define MCE_SEED_TILE(ACC, JB, RR)                                                                         \
                 do {                                                                                       \
                     MCE_SEED_WAIT(ACC);                                                                    \
@@ -1212,7 +1220,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                     for (int r = 0; r < 16; ++r) accB[qt][r] = __builtin_nanf("");
                 // owner lane l holds query nl*64 + l = tile 2 nl + (l >> 5), column l & 31 -- its own column
 #pragma unroll
-                for (int nl = 0; nl < kHNL; ++nl) {
+                for (int nl = 0; nl < NL; ++nl) {
                     float u0 = sm[2 * nl][KCAP], u1 = sm[2 * nl + 1][KCAP];
 #pragma unroll
                     for (int k = 0; k < KCAP; ++k) {
@@ -1785,7 +1793,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
 #endif
 #if MCE_SEED_CHECK
 #pragma unroll
-    for (int nl = 0; nl < kHNL; ++nl) {
+    for (int nl = 0; nl < NL; ++nl) {
         double fin = own_d[nl][LC - 1];
 #pragma unroll
         for (int k = 0; k < LC - 1; ++k) fin = (k == k_last) ? own_d[nl][k] : fin;
@@ -1817,7 +1825,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
 #endif
     // ---- write the lists: lane l owns wave-local queries nl*64 + l (coalesced over lanes) ----
 #pragma unroll
-    for (int nl = 0; nl < kHNL; ++nl) {
+    for (int nl = 0; nl < NL; ++nl) {
         const int64_t q = qwave0 + nl * 64 + lane;
         if (PRUNE && pr_sub > 0) {
             // a heavy block's extra sub-wave: its lists go to the side arrays, column = position among the heavy blocks

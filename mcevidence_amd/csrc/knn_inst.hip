@@ -42,14 +42,17 @@ hipError_t launch_variant(const KnnArgs& a, hipStream_t st)
 #endif
 
 #if MCE_INST_F16
-template <int KST, int KCAP, bool PRUNE, bool LOWER = false, int SYM = 0, int LC = KCAP>
+template <int KST, int KCAP, bool PRUNE, bool LOWER = false, int SYM = 0, int LC = KCAP, int QTT = kHQT>
 hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
 {
-    constexpr size_t LDS_MAX = PRUNE ? f16_prune_lds_bytes(KST, 16 * KST - 1, LC) : f16_lds_bytes(KST, KCAP, SYM >= 2);
+    constexpr size_t LDS_MAX = PRUNE ? f16_prune_lds_bytes(KST, 16 * KST - 1, LC) : f16_lds_bytes(KST, KCAP, SYM >= 2, QTT);
     static_assert(LDS_MAX <= 160 * 1024, "LDS budget");
     const size_t LDS = PRUNE ? f16_prune_lds_bytes(KST, a.D, LC) : LDS_MAX;     // pruned walk: sized by the dimension (more waves per CU)
     static bool attr_set[kMaxDevices] = {};
-    auto kern = knn_f16_kernel<KST, KCAP, PRUNE, LOWER, SYM, LC>;
+    auto kern = knn_f16_kernel<KST, KCAP, PRUNE, LOWER, SYM, LC, QTT>;
+    // (QTT = 4, the wide exhaustive sweep: a workgroup serves QTT / kHQT of the plan's query blocks -- the plan keeps their number a
+    //  multiple of that)
+    constexpr int WB = QTT / kHQT;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= kMaxDevices || !attr_set[dev]) {
@@ -64,9 +67,9 @@ hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
     // (pruned walk: nqblk_run counts WAVES of the dispatch order -- 0: all nqblk * 8 of them)
     const dim3 grid((unsigned)(PRUNE ? (a.nqblk_run ? a.nqblk_run : a.nqblk * kHWaves) + hv_n * (hv_S - 1)
                                : SYM == 2 ? sym_unit_count(a.nqblk, kHWaves * kHQT, a.sym.panel * f16_chunk_tiles(KST), ntiles_even)
-                               : SYM == 1 ? (a.nqblk_run ? a.nqblk_run : a.nqblk) : a.nqblk * a.rsplit));
+                               : SYM == 1 ? (a.nqblk_run ? a.nqblk_run : a.nqblk) : (a.nqblk / WB) * a.rsplit));
     hipLaunchKernelGGL(kern, grid, dim3(PRUNE ? 64 : kHThreads), LDS, st, static_cast<const _Float16*>(a.Yh), a.nchunk_total, a.rsplit,
-                       static_cast<const _Float16*>(a.Xh), a.qinfo, a.params, a.X, a.Y, a.nq, a.nr, a.D, a.nq_pad, a.nqblk,
+                       static_cast<const _Float16*>(a.Xh), a.qinfo, a.params, a.X, a.Y, a.nq, a.nr, a.D, a.nq_pad, a.nqblk / WB,
                        a.self_exclude, a.self_offset, a.ksel, a.part_d, a.part_i, a.clist, a.cdist, a.list_len, a.rperm, a.qperm, a.tbox_r, a.tbox_q, a.cbox_r, a.qblk0, a.qblk_stride, a.border, a.lo_d, a.lo_i, a.seed_cfg, a.sym, a.wg_us);
     return hipGetLastError();
 }
@@ -136,11 +139,16 @@ extern const KnnVariant MCE_CAT(g_knn_kcap, MCE_KCAP)[kMaxKS] = {
 #else
 #define MCE_F16_SHORT(KST) nullptr, 0, nullptr, 0
 #endif
+#if MCE_KCAP == 4
+#define MCE_F16_WIDE(KST) ((KST) == 1 ? &launch_f16_variant<1, MCE_KCAP, false, false, 0, MCE_KCAP, 4> : (knn_f16_launch_fn) nullptr), ((KST) == 1 ? f16_lds_bytes(1, MCE_KCAP, false, 4) : 0)
+#else
+#define MCE_F16_WIDE(KST) nullptr, 0
+#endif
 #define MCE_F16_VARIANT(KST, PRUNE_FN)                                                                   \
     {&launch_f16_variant<KST, MCE_KCAP, false>, PRUNE_FN, MCE_F16_LOWER(KST), &launch_f16_variant<KST, MCE_KCAP, false, false, 1>, \
      &launch_f16_variant<KST, MCE_KCAP, false, false, 2>, &launch_f16_variant<KST, MCE_KCAP, false, false, 3>, &launch_panel_variant<KST, MCE_KCAP>, panel_lds_bytes(KST), \
      f16_lds_bytes(KST, MCE_KCAP, true), KST, MCE_KCAP, f16_qt(MCE_KCAP), f16_chunk_tiles(KST), \
-     f16_lds_bytes(KST, MCE_KCAP), "knn_f16_kernel<KST=" #KST ",KCAP=" MCE_STR(MCE_KCAP) ">", MCE_F16_SHORT(KST)}
+     f16_lds_bytes(KST, MCE_KCAP), "knn_f16_kernel<KST=" #KST ",KCAP=" MCE_STR(MCE_KCAP) ">", MCE_F16_SHORT(KST), MCE_F16_WIDE(KST)}
 extern const KnnF16Variant MCE_CAT(g_knn_f16_kcap, MCE_KCAP)[kMaxKST] = {
     MCE_F16_VARIANT(1, (&launch_f16_variant<1, MCE_KCAP, true>)), MCE_F16_VARIANT(2, nullptr), MCE_F16_VARIANT(3, nullptr),
     MCE_F16_VARIANT(4, nullptr),
@@ -160,6 +168,9 @@ template __global__ void knn_f16_kernel<1, MCE_KCAP, true, false, 0, 10>(const _
 #endif
 #if MCE_KCAP == 16
 MCE_F16_INST(1, false, true, 0) MCE_F16_INST(2, false, true, 0) MCE_F16_INST(3, false, true, 0) MCE_F16_INST(4, false, true, 0)
+#endif
+#if MCE_KCAP == 4
+template __global__ void knn_f16_kernel<1, MCE_KCAP, false, false, 0, MCE_KCAP, 4>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*, int, int, const int*, const double*, const int*, int, SymParams, float*);
 #endif
 #endif
 #if MCE_INST_PANEL

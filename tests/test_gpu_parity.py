@@ -219,6 +219,50 @@ def test_trailing_round_split_is_bit_identical(nq, nr, d, K, same, monkeypatch):
         _capi.set_prune_mode(0)
 
 
+@pytest.mark.parametrize("nq,nr,d,K,same", [(525724, 30000, 15, 4, False), (600000, 600000, 6, 3, True), (530000, 20000, 1, 1, False), (524289, 45000, 10, 2, False)])
+def test_wide_sweep_is_bit_identical(nq, nr, d, K, same, monkeypatch):
+    """Round 5: one-k-step sweeps of short lists over 1024 or more query blocks run FOUR query tiles per wave (a workgroup =
+    two query blocks; knn_f16.hpp, QTT = 4).  Neighbours, distances and the fused sums must equal the two-tile kernel's
+    (MCE_WIDE=0) to the bit -- odd block counts (padded to even), self-exclusion on one buffer, d = 1 -- and the oracle's on
+    sampled rows."""
+    from mcevidence_amd import _capi
+    _capi.set_search_mode(_capi.MODE_AUTO)
+    _capi.set_prune_mode(_capi.PRUNE_OFF)
+    sym_before = _capi.get_sym_mode()
+    _capi.set_sym_mode(_capi.SYM_OFF)
+    try:
+        rng = np.random.default_rng(nq + d)
+        Y = rng.standard_normal((nr, d))
+        X = Y if same else rng.standard_normal((nq, d))
+        if same:
+            Y[rng.integers(0, nr, 50)] = Y[rng.integers(0, nr, 50)]          # exact duplicates: ties
+        w = rng.integers(1, 5, size=nq).astype(float)
+        fs = -rng.random(nq)
+        sm = _capi.SELF_EXCLUDE if same else _capi.SELF_NONE
+        k0 = 1 if same else 0
+        out = {}
+        for flag in ("0", "1"):
+            monkeypatch.setenv("MCE_WIDE", flag)
+            dist, idx = _capi.knn(X, Y, K, self_mode=sm)
+            kern = _capi.last_kernel()
+            dotp = _capi.knn_dotp(X, Y, w, fs, K + k0, k0)
+            out[flag] = (dist, idx, dotp, kern)
+        assert " wide" not in out["0"][3] and " wide" in out["1"][3] and "qt=4" in out["1"][3], (out["0"][3], out["1"][3])
+        assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
+        assert np.array_equal(out["0"][2], out["1"][2])
+        rows = np.sort(rng.choice(nq, size=400, replace=False))
+        rows[-1] = nq - 1                                                     # the last row of the last (half-filled) workgroup
+        od, oi = orc.knn_brute(X[rows], Y, K + k0)
+        if k0:
+            od, oi = od[:, 1:], oi[:, 1:]
+        assert _rel(out["1"][0][rows], od) < DIST_RTOL
+        if not same:
+            assert np.array_equal(out["1"][1][rows], oi)
+    finally:
+        _capi.set_sym_mode(sym_before)
+        _capi.set_prune_mode(_capi.PRUNE_AUTO)
+
+
 def test_knn_large_offsets_are_stable(capi):
     """un-whitened data far from the origin: GEMM-form cancellation stays within tolerance."""
     rng = np.random.default_rng(5)
