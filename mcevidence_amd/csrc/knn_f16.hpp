@@ -33,20 +33,10 @@
 #include "sym_types.hpp"
 #include "prune.hpp"        // prune_band_floor: the order of the pruned walk's chunk lists
 
-#ifndef MCE_SYM_CHECK
-#define MCE_SYM_CHECK 0    // debugging aid: range checks (device printf) on the indices of the symmetric sweep's global stores
-#endif
-#if MCE_SYM_CHECK
-#define MCE_CHK(cond, code, a, b, c) do { if (!(cond)) { printf("SYMCHK %d blk %d tid %d: %lld %lld %lld\n", code, (int)blockIdx.x, (int)threadIdx.x, (long long)(a), (long long)(b), (long long)(c)); } } while (0)
-#else
-#define MCE_CHK(cond, code, a, b, c) do {} while (0)
-#endif
-#ifndef MCE_STATS
-#define MCE_STATS 0    // tools/knn_f16_bench.hip only: per-wave clock64/event counters appended to `params`
-#endif
 #ifndef MCE_ABLATE
-#define MCE_ABLATE 0   // tools/knn_f16_bench.hip only: 1 = gate never passes, 2 = no gate at all, 3 = 1 + no barriers, 5 = 1 + no LDS reads, 6 = 2 + 5,
-                       // 7 / 8 = 1 + the FAST path of a two-level gate: the lane minima of 4 / 2 consecutive tiles folded, one compare + branch per group (results invalid)
+#define MCE_ABLATE 0   // tools/knn_f16_bench.hip only: 1 = the gate never passes (no candidates), 2 = no gate at all (results invalid).  The other
+                       // ablation builds of rounds 1-4 (no barriers, no LDS reads, two-level gate folding: profiles/r04_final/kst1_ablation.txt)
+                       // are closed and gone from the source.
 #endif
 
 namespace mce {
@@ -74,19 +64,14 @@ __device__ __forceinline__ float min3f(float a, float b, float c)
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-// Workgroup geometry.  MCE_H_GEOM 0 (shipped): 8 waves (2 per SIMD) x 2 query tiles.  Kept for the
-// record, both measured SLOWER at C3 (tools/knn_f16_bench.hip): 1 = 4 waves (one per SIMD, 512
-// registers) x 4 query tiles: sweep 83 ms vs 56 ms; 2 = 16 waves (4 per SIMD, 128 VGPRs): spills.
-#ifndef MCE_H_GEOM
-#define MCE_H_GEOM 0
-#endif
-constexpr int kHWaves = (MCE_H_GEOM == 1 || MCE_H_GEOM == 3) ? 4 : (MCE_H_GEOM == 2 ? 16 : (MCE_H_GEOM == 4 ? 12 : 8));   // GEOM 2: 16 waves (4 per SIMD, <= 128 VGPRs); GEOM 3: 4 waves x 2 tiles, two workgroups per CU; GEOM 4 (tools, round 5): 12 waves (3 per SIMD, <= 168 VGPRs)
-constexpr int kHQT = (MCE_H_GEOM == 1 || MCE_H_GEOM == 5) ? 4 : 2;      // 32-query tiles per wave (GEOM 5, tools, round 5: 8 waves x 4 tiles)
+// Workgroup geometry: 8 waves (2 per SIMD) x 2 query tiles.  Measured and dropped (the builds are gone from this file, the
+// numbers are in DESIGN.md / profiles/): 4 waves x 4 tiles, one wave per SIMD (83 vs 56 ms at C3, round 1); 16 waves, four per
+// SIMD (spills); 12 waves, three per SIMD, at one k-step and K <= 4 (42.7 vs 41.3 ms at C4, round 5).  What did pay at one
+// k-step and K <= 4 is 8 waves x FOUR tiles: the kernel's QTT parameter.
+constexpr int kHWaves = 8;      // waves per workgroup (two per SIMD)
+constexpr int kHQT = 2;         // 32-query tiles per wave (the wide exhaustive sweep: four -- template parameter QTT of the kernel)
 constexpr int kHNL = kHQT / 2;                     // top-K lists per owner lane (64 queries per list set)
 constexpr int kHThreads = kHWaves * 64;
-#ifndef MCE_H_SETPRIO
-#define MCE_H_SETPRIO 0
-#endif
 #ifndef MCE_H_QUEUE
 #define MCE_H_QUEUE 448
 #endif
@@ -136,7 +121,7 @@ __host__ __device__ constexpr int f16_prune_trigger(int KCAP) { return KCAP <= 8
 #endif
 constexpr int kHQueue = MCE_H_QUEUE;          // candidate queue entries per wave (16 B each in LDS)
 constexpr int kHDrainTrigger = MCE_H_TRIGGER;    // a wave with this many queued candidates asks the workgroup to drain
-constexpr int kHRelBits = (MCE_H_GEOM == 1 || MCE_H_GEOM == 5) ? 25 : 26;   // queue entry = query-local (6|7 bits) << kHRelBits | row - first row of the split
+constexpr int kHRelBits = 26;   // queue entry = query-local (6|7 bits) << kHRelBits | row - first row of the split
 constexpr int kHSymRowBits = kHRelBits - 1;            // symmetric sweep: the row field's top bit says "this lane passed the ROW gate"
 constexpr double kHTargetRadius = 200.0;
 constexpr int kPruneDims = 15;                // pruned walk: largest d (KST = 1)
@@ -273,7 +258,7 @@ __host__ __device__ constexpr size_t f16_prune_lds_bytes(int KST, int D, int KCA
 //   41.5 -> 37.7 ms on one box (tools/r05_exp2.sh; the gate-never-passes stream 34.8 -> 31.7).  Longer lists or a second k-step
 //   do not fit the register file at four tiles (they spill); twelve waves of two tiles -- three per SIMD -- are SLOWER (42.7 ms).
 template <int KST, int KCAP, bool PRUNE = false, bool LOWER = false, int SYM = 0, int LC = KCAP, int QTT = kHQT>
-__global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_SMALL ? MCE_H_PRUNE_SMALL_WAVES : MCE_H_PRUNE_WAVES) : (MCE_H_GEOM == 1 ? 1 : (MCE_H_GEOM == 2 ? 4 : (MCE_H_GEOM == 4 ? 3 : 2)))) void knn_f16_kernel(
+__global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_SMALL ? MCE_H_PRUNE_SMALL_WAVES : MCE_H_PRUNE_WAVES) : 2) void knn_f16_kernel(
     const _Float16* __restrict__ Yh, int64_t nchunk_total, int rsplit,
     const _Float16* __restrict__ Xh, const double* __restrict__ qinfo, const double* __restrict__ params,
     const double* __restrict__ X, const double* __restrict__ Y, int64_t nq, int64_t nr, int D,
@@ -317,11 +302,6 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
     int* const qnx_all = qpk_all + LW * QN;
     int* const head_all = qnx_all + LW * QN;
 
-#if MCE_STATS
-    const long long t_kernel0 = clock64();
-    long long st_drains = 0, st_enq = 0, st_steps = 0, st_events = 0, st_tA = 0, st_tD = 0, st_tB = 0;
-    long long st_tR = 0, st_tE = 0, st_rtest = 0, st_rapp = 0, st_cas = 0, st_linked = 0, st_tP = 0, st_tPro = 0;      // SYM: phase R / event cycles, row-side tested / appended / slot replacements, chain links, publish cycles
-#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int lwave = PRUNE ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);                  // index into the LDS regions
@@ -341,7 +321,6 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
     // (sym_unit_count): the units running at the same time stream the same few MB of packed rows through L2
     int sym_a = 0, sym_p = 0;
     if constexpr (SYM == 2) sym_unit_decode((int)blockIdx.x, nqblk, kHWaves * kHQT, sym.panel * f16_chunk_tiles(KST), sym_p, sym_a);
-    if constexpr (SYM == 2) MCE_CHK(sym_a >= 0 && sym_a < nqblk && sym_p >= 0, 5, sym_a, sym_p, nqblk);
     // (SYM == 1, the prepass: the blocks qblk0, qblk0 + 1, ... of the launch -- one rank's share of a multi-GPU partition)
     const int qblk = PRUNE ? pr_gw / kHWaves : (SYM == 2 ? sym_a : (SYM == 1 ? qblk0 + (int)blockIdx.x : (int)(blockIdx.x % nqblk)));
     const int split = PRUNE ? 0 : (SYM >= 2 ? 0 : (int)(blockIdx.x / nqblk));
@@ -401,14 +380,6 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
     double seed_thr[NL];
 #pragma unroll
     for (int nl = 0; nl < NL; ++nl) seed_thr[nl] = INF;
-#ifndef MCE_SEED_CHECK
-#define MCE_SEED_CHECK 0
-#endif
-#if MCE_SEED_CHECK
-    double seed_dbg[NL];
-#pragma unroll
-    for (int nl = 0; nl < NL; ++nl) seed_dbg[nl] = INF;
-#endif
 
     const int64_t qwave0 = (int64_t)qblk * QPB + wave * QPW;     // first query of this wave
 
@@ -422,7 +393,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks)
             b[qt][ks] = *reinterpret_cast<const v8h*>(Xh + q * (int64_t)(16 * KST) + 16 * ks + 8 * (lane >> 5));
-        G[qt] = (q < nq && MCE_ABLATE != 1 && MCE_ABLATE != 3 && MCE_ABLATE != 5 && MCE_ABLATE != 7 && MCE_ABLATE != 8) ? __builtin_huge_valf() : -__builtin_huge_valf();     // padding queries never pass
+        G[qt] = (q < nq && MCE_ABLATE != 1) ? __builtin_huge_valf() : -__builtin_huge_valf();     // padding queries never pass
     }
     // SYM: c_i = eps_i - |x^_i|^2 of the lane's query (rounded up): the row-side gate is  min A <= R_tile + c_i
     float cR[QT];
@@ -446,7 +417,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
     // and keeping them in registers would cost 6 VGPRs per query tile in the sweep.
     auto gate_of = [&](double thr, int qt) __attribute__((always_inline)) -> float {
         const int64_t q = qwave0 + qt * 32 + (lane & 31);
-        if (!(q < nq) || MCE_ABLATE == 1 || MCE_ABLATE == 3 || MCE_ABLATE == 5 || MCE_ABLATE == 7 || MCE_ABLATE == 8) return -__builtin_huge_valf();
+        if (!(q < nq) || MCE_ABLATE == 1) return -__builtin_huge_valf();
         if (!(thr < INF)) return __builtin_huge_valf();
         const double ex = qinfo[2 * q], xn = qinfo[2 * q + 1];
         const double r = sqrt(xn) + params[HP_YHATMAX];
@@ -477,16 +448,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
     auto load_a = [&](const char* lp, v8h (&a)[KST]) {
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks) a[ks] = *reinterpret_cast<const v8h*>(lp + ks * 1024);
-#if MCE_ABLATE == 5 || MCE_ABLATE == 6      // ablation: no LDS reads in the sweep (results invalid)
-#pragma unroll
-        for (int ks = 0; ks < KST; ++ks) a[ks] = b[0][ks];
-#endif
     };
     // one 32-row tile: QT chains of KST MFMAs
     auto mfma_tile = [&](const v8h (&a)[KST], v16f (&acc)[QT]) {
-#if MCE_H_SETPRIO
-        __builtin_amdgcn_s_setprio(1);      // the wave in its MFMA burst wins issue arbitration; its SIMD partner gates meanwhile
-#endif
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             v16f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -496,18 +460,11 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
         for (int ks = 1; ks < KST; ++ks)
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], b[qt][ks], acc[qt], 0, 0, 0);
-#if MCE_H_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
     };
 
     int qcount = 0;   // wave-uniform number of queued candidates
 
     auto drain = [&]() __attribute__((always_inline)) {
-#if MCE_STATS
-        const long long t_d0 = clock64();
-        st_drains += 1; st_enq += qcount;
-#endif
         if constexpr (!PRUNE) {     // (pruned walk: entries arrive evaluated and linked, see gate_exact)
         // ---- phase A: exact distances + chain links.  8 lanes share one queued pair and read
         // the two rows in 64-byte segments (a row is fetched once, not once per element).  The
@@ -583,9 +540,6 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                         wqd[ep[u]] = ok ? a0 : -1.0;
                         if (ok && !(a0 > sthr[qlp[u]])) {
                             wnx[ep[u]] = atomicExch(&whead[qlp[u]], ep[u]);
-#if MCE_STATS
-                            st_linked += 1;
-#endif
                         }
                     }
                 } else if (ok && sub == 0) {
@@ -602,15 +556,11 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
             // on j's K-th distance, published for everybody -- and into the bucket of j's block.  Then the entry's
             // packed word is replaced by the caller's row number of j, which is what the lists carry.
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#if MCE_STATS
-            const long long t_r0 = clock64();
-#endif
             // one candidate distance d2 for sorted row `row`: replace the largest of the row's K slots if d2 is
             // smaller (compare-and-swap; lock-free, any number of writers) and publish the new K-th as the row's
             // bound.  Returns false if K slots hold strictly smaller distances (the candidate cannot be among the K).
             auto slot_insert = [&](int row, double d2) __attribute__((always_inline)) -> bool {
                 unsigned long long* const sl = sym.slots + (int64_t)row * KCAP;
-                MCE_CHK(row >= 0 && row < nr, 1, row, nr, 0);
                 for (;;) {
                     double vmax = -1.0, v2 = -1.0;
                     int imax = 0;
@@ -627,9 +577,6 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                     unsigned long long expect = (unsigned long long)__double_as_longlong(vmax);
                     if (__hip_atomic_compare_exchange_strong(sl + imax, &expect, (unsigned long long)__double_as_longlong(d2), __ATOMIC_RELAXED,
                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-#if MCE_STATS
-                        st_cas += 1;
-#endif
                         const double nk = fmax(v2, d2);              // the K-th smallest after the replacement, from a snapshot: an upper bound
                         if (nk < INF) {
                             const unsigned long long nb = (unsigned long long)__double_as_longlong(nk);
@@ -637,11 +584,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                             if (nb < ob) {
                                 const unsigned rb = __float_as_uint(sym_row_gate(nk, qinfo[2 * (int64_t)row], params, KST));
                                 const unsigned orb = __hip_atomic_fetch_min(sym.rrow + row, rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if defined(MCE_SYM_ABL) && MCE_SYM_ABL == 6
-                                if (false) {
-#else
                                 if (rb < orb) {
-#endif
                                     // the tile's largest R_j, from a snapshot (each value >= its current one): safe to store
                                     const unsigned* const rt = sym.rrow + (int64_t)(row >> 5) * 32;
                                     unsigned m = 0;
@@ -669,17 +612,10 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                 const int oj = ok ? rperm[j] : -1;
                 const int jb = j / QPB;
                 bool rs = ok && SYM == 2 && jb != qblk && rowflag;
-#if defined(MCE_SYM_ABL) && (MCE_SYM_ABL == 3 || MCE_SYM_ABL == 5)
-                rs = false;                  // ablation: no row-side bookkeeping at all (results invalid)
-#endif
-#if MCE_STATS
-                st_rtest += __builtin_popcountll(__ballot(rs));
-#endif
                 if (rs) rs = d2 <= __longlong_as_double((long long)__hip_atomic_load(sym.thr + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 if (rs) rs = slot_insert(j, d2);
                 if (rs) {
                     const int slot = atomicAdd(sym.bucket_cnt + jb, 1);
-                    MCE_CHK(slot >= 0 && jb >= 0 && jb < nqblk && j >= 0 && j < nr, 2, slot, jb, j);
                     if ((unsigned)slot < (unsigned)sym.cap) {      // (unsigned: a count that is not a count ends in the repair pass, not in a wild store)
                         SymEntry en;
                         en.d2 = d2;
@@ -691,19 +627,10 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                     }
                 }
                 if (valid) wq[e] = oj;
-#if MCE_STATS
-                st_rapp += __builtin_popcountll(__ballot(rs));
-#endif
             }
-#if MCE_STATS
-            st_tR += clock64() - t_r0;
-#endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         }
-#if MCE_STATS
-        st_tA += clock64() - t_d0;
-#endif
         // ---- phase B: every owner lane folds its chain(s) into its register list(s) ----------
         // (pruned walk: fetching the NEXT chain entry while this one is inserted, and skipping rounds in which no lane's entry
         //  beats its list's last, was measured: C5 95.4 -> 99.4 ms.)
@@ -712,9 +639,6 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
             int cur = whead[nl * 64 + lane];
             whead[nl * 64 + lane] = -1;
             while (__any(cur >= 0)) {
-#if MCE_STATS
-                st_steps += 1;
-#endif
                 const bool on = cur >= 0;
                 const int ce = on ? cur : 0;
                 const double d2 = on ? wqd[ce] : INF;
@@ -733,9 +657,6 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                 own_i[nl][0] = c_hi ? j : own_i[nl][0];
             }
         }
-#if MCE_STATS
-        st_tD += clock64() - t_d0;
-#endif
         qcount = 0;
         // ---- refresh the gates: lane l needs the K-th best of queries ql = qt*32 + (l&31),
         // owned by lane ql & 63 in list ql >> 6
@@ -747,19 +668,10 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
             for (int k = 0; k < LC - 1; ++k) thr_own[nl] = (k == k_last) ? own_d[nl][k] : thr_own[nl];
             thr_own[nl] = fmin(thr_own[nl], seed_thr[nl]);
         }
-#if MCE_STATS
-        const long long t_p0 = clock64();
-#endif
-#if defined(MCE_SYM_ABL) && (MCE_SYM_ABL == 4 || MCE_SYM_ABL == 5)
-        if constexpr (SYM >= 2) { sthr[lane] = thr_own[0]; seed_thr[0] = thr_own[0]; }      // ablation: nothing published (results invalid)
-        if constexpr (false) {
-#else
         if constexpr (SYM >= 2) {
-#endif
             // publish: thr[q] takes this list's K-th bound and gives back what the row side knows (the K-th of q's
             // slots); the row-side gate constants follow, and the maximum over each 32-row tile (= half a wave)
             const int64_t q = qwave0 + lane;
-            MCE_CHK(q >= 0 && q < nq_pad, 3, q, nq_pad, qblk);
             double t = thr_own[0];
             float R = 0.0f;
             if (q < nq) {
@@ -782,9 +694,6 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
             for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
             if ((lane & 31) == 0 && SYM == 2) __hip_atomic_store(sym.rtile + ((qwave0 + lane) >> 5), m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-#if MCE_STATS
-        st_tP += clock64() - t_p0;
-#endif
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) G[qt] = gate_of(__shfl(thr_own[qt >> 1], (qt & 1) * 32 + (lane & 31), 64), qt);
         if constexpr (PRUNE) {
@@ -806,14 +715,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
     // gate + enqueue for one finished tile; jb0 = first reference row of the tile.
     // C layout of 32x32 f32: lane l -> query column l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5)
     // SYM: Rt = the tile's row-side gate constant (wave-uniform; -inf: column side only)
-#if MCE_ABLATE == 7 || MCE_ABLATE == 8
-    float fold_mm[QT];
-    int fold_ctr = 0;
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) fold_mm[qt] = __builtin_huge_valf();
-#endif
     auto process = [&](const v16f (&acc)[QT], int jb0, float Rt) __attribute__((always_inline)) {
-#if MCE_ABLATE == 2 || MCE_ABLATE == 6
+#if MCE_ABLATE == 2
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) asm volatile("" ::"v"(acc[qt]));
@@ -833,27 +736,12 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
             float m4 = min3f(c[12], c[13], c[14]);
             m0 = min3f(m0, m1, m2);
             m3 = min3f(m3, m4, c[15]);
-#if MCE_ABLATE == 7 || MCE_ABLATE == 8
-            mm[qt] = min3f(m0, m3, fold_mm[qt]);           // the group's running minimum rides in the tree's free third input
-            fold_mm[qt] = mm[qt];
-#else
             mm[qt] = min3f(m0, m3, m3);
-#endif
             if constexpr (SYM == 2) passq[qt] = mm[qt] <= fmaxf(G[qt], Rt + cR[qt]);      // either side
             else passq[qt] = mm[qt] <= G[qt];
             pass |= passq[qt];
         }
-#if MCE_ABLATE == 7 || MCE_ABLATE == 8
-        fold_ctr += 1;
-        if ((fold_ctr & (MCE_ABLATE == 7 ? 3 : 1)) != 0) return;      // (wave-uniform: one compare + branch per group of tiles)
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) fold_mm[qt] = __builtin_huge_valf();
-#endif
         if (__any(pass)) {
-#if MCE_STATS
-            st_events += 1;
-            const long long t_e0 = clock64();
-#endif
             const int jrel0 = jb0 - jsplit0 + 4 * (lane >> 5);
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
@@ -879,9 +767,6 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                     m = __ballot(pm != 0);
                 }
             }
-#if MCE_STATS
-            st_tE += clock64() - t_e0;
-#endif
         }
     };
 
@@ -1239,11 +1124,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                         const double eps = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 1e-9) + params[HP_RHO] + 1e-30;
                         const double h2 = fmax((double)a_up + xn + eps, 0.0);
                         const double dd = sqrt(h2) * (1.0 + 1e-12) + ga;
-#if MCE_SEED_CHECK      // tools/knn_f16_bench.hip: compute the bound, do not use it, compare with the final K-th distance
-                        seed_dbg[nl] = dd * dd * (1.0 + 1e-12) / s2 * (1.0 + 1e-12);
-#else
                         seed_thr[nl] = dd * dd * (1.0 + 1e-12) / s2 * (1.0 + 1e-12);
-#endif
                     }
                 }
 #pragma unroll
@@ -1307,16 +1188,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
             auto rt_load = [&](int c, int tlo, int thi) -> float {
                 const int t = c * CT + lane;
                 const bool en = SYM == 2 && lane >= tlo && lane < thi && t / TPB != qblk;
-#ifndef MCE_SYM_ABL
-#define MCE_SYM_ABL 0      // tools/knn_sym_bench.hip only: 1 = no row side at all (results invalid), 2 = plain (L2-cached) load of the tile constants
-#endif
-#if MCE_SYM_ABL == 1
-                return -__builtin_huge_valf();
-#elif MCE_SYM_ABL == 2
-                return en ? sym.rtile[t] : -__builtin_huge_valf();
-#else
                 return en ? __hip_atomic_load(sym.rtile + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -__builtin_huge_valf();
-#endif
             };
             float rt_cur = -__builtin_huge_valf(), rt_next = -__builtin_huge_valf();
             int c0 = 0, tlo0 = 0, thi0 = 0;
@@ -1325,9 +1197,6 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                 stage_async(c0, 0);
                 rt_next = rt_load(c0, tlo0, thi0);
             }
-#if MCE_STATS
-            st_tPro = clock64() - t_kernel0;
-#endif
             for (int k = 0; k < ntot; ++k) {
                 const int buf = k & 1;
                 if (qcount >= kHDrainTrigger && lane == 0) wvote[buf] = 1;
@@ -1351,17 +1220,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
         for (int64_t c = c_begin; c < c_end; ++c) {
             const int buf = (int)((c - c_begin) & 1);
             if (qcount >= kHDrainTrigger && lane == 0) wvote[buf] = 1;
-#if MCE_STATS
-            const long long t_b0 = clock64();
-#endif
-#if MCE_ABLATE != 3
             dma_barrier();
-#else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ablation: no barrier (results invalid)
-#endif
-#if MCE_STATS
-            st_tB += clock64() - t_b0;
-#endif
             if ((c + 1) < c_end) stage_async(c + 1, buf ^ 1);
             const bool all_drain = wvote[buf] != 0;
             if (tid == 0) wvote[buf ^ 1] = 0;          // re-arm the other parity (read again only after the next barrier)
@@ -1783,46 +1642,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
         }
     }
 #undef MCE_SWEEP_CHUNK
-#if MCE_STATS
-    const long long t_epi0 = clock64();
-#endif
     if constexpr (!PRUNE && SYM != 1) process(accB, jbB, rB);
     if constexpr (SYM != 1) drain();
-#if MCE_STATS
-    const long long t_epi1 = clock64();
-#endif
-#if MCE_SEED_CHECK
-#pragma unroll
-    for (int nl = 0; nl < NL; ++nl) {
-        double fin = own_d[nl][LC - 1];
-#pragma unroll
-        for (int k = 0; k < LC - 1; ++k) fin = (k == k_last) ? own_d[nl][k] : fin;
-        if (qwave0 + nl * 64 + lane < nq && seed_dbg[nl] < INF) {
-            double* stat = const_cast<double*>(params);
-            unsafeAtomicAdd(stat + 8, 1.0);
-            if (fin > seed_dbg[nl]) unsafeAtomicAdd(stat + 9, 1.0);
-            unsafeAtomicAdd(stat + 10, seed_dbg[nl]);
-            unsafeAtomicAdd(stat + 11, fin);
-        }
-    }
-#endif
 
-#if MCE_STATS
-    for (int o_ = 32; o_ >= 1; o_ >>= 1) {         // per-lane counters -> wave totals
-        st_cas += __shfl_xor((int)st_cas, o_, 64);
-        st_linked += __shfl_xor((int)st_linked, o_, 64);
-    }
-    if (lane == 0) {
-        double* o = const_cast<double*>(params) + 16 + ((int64_t)blockIdx.x * kHWaves + wave) * 8;
-        o[0] = (double)st_drains; o[1] = (double)st_enq; o[2] = (double)st_steps; o[3] = (double)st_events;
-        o[4] = (double)st_tA; o[5] = (double)st_tD; o[6] = (double)(clock64() - t_kernel0); o[7] = (double)st_tB;
-        if constexpr (SYM >= 2) {      // (the harness sizes `params` for 16 values per wave)
-            double* o2 = const_cast<double*>(params) + 16 + ((int64_t)gridDim.x * kHWaves) * 8 + ((int64_t)blockIdx.x * kHWaves + wave) * 8;
-            o2[0] = (double)st_tR; o2[1] = (double)st_tE; o2[2] = (double)st_rtest; o2[3] = (double)st_rapp; o2[4] = (double)st_cas; o2[5] = (double)st_linked; o2[6] = (double)st_tP; o2[7] = (double)st_tPro;
-            o[7] = (double)(t_epi1 - t_epi0);      // (no barrier-wait timer in this mode: the final process + drain instead)
-        }
-    }
-#endif
     // ---- write the lists: lane l owns wave-local queries nl*64 + l (coalesced over lanes) ----
 #pragma unroll
     for (int nl = 0; nl < NL; ++nl) {
@@ -1843,7 +1665,6 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
 #pragma unroll
         for (int k = 0; k < KCAP; ++k) {
             const int64_t o = ((int64_t)split * KCAP + k) * nq_pad + q;
-            MCE_CHK(q >= 0 && q < nq_pad && split >= 0 && qblk >= 0 && qblk < nqblk, 4, q, split, qblk);
             part_d[o] = k < LC ? own_d[nl][k < LC ? k : 0] : INF;           // (rows LC .. KCAP - 1 of the arrays: empty)
             part_i[o] = k < LC ? own_i[nl][k < LC ? k : 0] : -1;
         }

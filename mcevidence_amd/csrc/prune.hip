@@ -39,7 +39,7 @@ int top_tree_levels(int64_t n_units)
 // them (half the key bytes and a radix pass less: kd_sort decides).
 template <class Key>
 __global__ __launch_bounds__(kThreads) void kd_key_kernel(const int* __restrict__ perm_in, int64_t n, int64_t n_pad, int unit_rows,
-                                                          int n_units, int top_levels, int level, const double* __restrict__ P, int d, int dim,
+                                                          int n_units, int top_levels, int level, const float* __restrict__ Cf, int d, int dim,
                                                           int cbits, Key* __restrict__ keys, int* __restrict__ vals)
 {
     const int64_t pos = (int64_t)blockIdx.x * kThreads + threadIdx.x;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kThreads) void kd_key_kernel(const int* __restrict_
     for (int half = kAlign >> 1; l < level; ++l, half >>= 1) id = 2 * id + ((u & half) ? 1u : 0u);
     unsigned b = 0xFFFFFFFFu;
     if (row >= 0) {
-        const float c = (float)P[(int64_t)row * d + dim];
+        const float c = Cf[(int64_t)dim * n + row];          // (float) of the row's coordinate: coords_f32_kernel
         b = __float_as_uint(c);
         b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
         if (b == 0xFFFFFFFFu) b = 0xFFFFFFFEu;
@@ -96,7 +96,7 @@ constexpr int kGroupRows = kAlign * kPruneTileRows;      // 2048
 // SLOWER, 2.0 ms: the kernel is bound by the trips through LDS and the barriers, not by those loads.)
 constexpr int kBottomSlots = kGroupRows + kGroupRows / 32;          // one slot of padding per 32: eight slots a thread apart stay off one bank
 __device__ __forceinline__ int bslot(int i) { return i + (i >> 5); }
-__global__ __launch_bounds__(kThreads) void kd_bottom_kernel(int* __restrict__ perm, int64_t n_pad, int top_levels, const double* __restrict__ P, int d)
+__global__ __launch_bounds__(kThreads) void kd_bottom_kernel(int* __restrict__ perm, int64_t n, int64_t n_pad, int top_levels, const float* __restrict__ Cf, int d)
 {
     static_assert(kGroupRows == 8 * kThreads, "eight slots per thread");
     __shared__ unsigned long long key[kBottomSlots];
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kThreads) void kd_bottom_kernel(int* __restrict__ p
             const int row = val[cur][i];
             unsigned b = 0xFFFFFFFFu;
             if (row >= 0) {
-                b = __float_as_uint((float)P[(int64_t)row * d + dim]);
+                b = __float_as_uint(Cf[(int64_t)dim * n + row]);
                 b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
                 if (b >= 0xFFFFFFFEu) b = 0xFFFFFFFDu;
             } else if (row == -1) {
@@ -156,6 +156,21 @@ __global__ __launch_bounds__(kThreads) void kd_bottom_kernel(int* __restrict__ p
         __syncthreads();
     }
     for (int i = threadIdx.x; i < m; i += kThreads) perm[base + i] = val[cur][i];
+}
+
+// Cf[i][row] = (float)P[row][i]: the coordinates the k-d keys are made of, one plane per dimension (round 5).  Every sort of the
+// top levels and every level of the bottom kernel reads ONE coordinate of every row in an order that is random in the caller's
+// array: from the row-major fp64 rows that is a 64-byte line per 8 useful bytes (10 M x 6: 0.19 ms per pass, 13 passes); from a
+// 40 MB plane of floats the same gather mostly hits the L2 / the Infinity Cache.  Same float, same keys, same order.
+__global__ __launch_bounds__(kThreads) void coords_f32_kernel(const double* __restrict__ P, int64_t n, int d, float* __restrict__ Cf)
+{
+    __shared__ float t[kThreads][kPruneMaxDim + 1];
+    const int64_t r0 = (int64_t)blockIdx.x * kThreads;
+    const int rows = (int)(n - r0 < kThreads ? n - r0 : kThreads);
+    for (int e = threadIdx.x; e < rows * d; e += kThreads) t[e / d][e % d] = (float)P[r0 * d + e];        // coalesced read of the block's rows
+    __syncthreads();
+    if ((int)threadIdx.x < rows)
+        for (int i = 0; i < d; ++i) Cf[(int64_t)i * n + r0 + threadIdx.x] = t[threadIdx.x][i];
 }
 
 __global__ __launch_bounds__(kThreads) void identity_perm_kernel(int64_t n, int64_t n_pad, int* __restrict__ perm)
@@ -418,8 +433,13 @@ size_t sort_tmp_bytes(int64_t n) { return std::max(sort_pairs_tmp_bytes<unsigned
 
 // k-d order of P[n, d] in units of unit_rows; final permutation in `perm` ([n_pad])
 hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_rows, int n_units, int* perm, unsigned long long* keys_a,
-                   unsigned long long* keys_b, int* vals_b, void* tmp, size_t tmp_bytes, hipStream_t st)
+                   unsigned long long* keys_b, int* vals_b, float* Cf, void* tmp, size_t tmp_bytes, hipStream_t st)
 {
+    hipLaunchKernelGGL(coords_f32_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, P, n, d, Cf);
+    {
+        const hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) return e0;
+    }
     const int Ltop = top_tree_levels(n_units);
     const int L = Ltop + (n_units > 1 ? kAlignLevels : 0);
     const unsigned blocks = (unsigned)((n_pad + kThreads - 1) / kThreads);
@@ -469,12 +489,12 @@ hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_ro
             unsigned* ka = reinterpret_cast<unsigned*>(keys_a);
             unsigned* kb = reinterpret_cast<unsigned*>(keys_b);
             hipLaunchKernelGGL(kd_key_kernel<unsigned>, dim3(blocks), dim3(kThreads), 0, st, j == 0 ? (const int*)nullptr : perm, n, n_pad, unit_rows,
-                               n_units, Ltop, level, P, d, sdim[j], cb32, ka, vals_b);
+                               n_units, Ltop, level, Cf, d, sdim[j], cb32, ka, vals_b);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             e = sort_pairs(tmp, tmp_bytes, (const unsigned*)ka, kb, (const int*)vals_b, perm, n_pad, (unsigned)(cb32 + level), st);
         } else {
             hipLaunchKernelGGL(kd_key_kernel<unsigned long long>, dim3(blocks), dim3(kThreads), 0, st, j == 0 ? (const int*)nullptr : perm, n, n_pad, unit_rows,
-                               n_units, Ltop, level, P, d, sdim[j], kCoordBits, keys_a, vals_b);
+                               n_units, Ltop, level, Cf, d, sdim[j], kCoordBits, keys_a, vals_b);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             e = sort_pairs(tmp, tmp_bytes, (const unsigned long long*)keys_a, keys_b, (const int*)vals_b, perm, n_pad, (unsigned)(kCoordBits + level), st);
         }
@@ -482,7 +502,7 @@ hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_ro
     }
     // ... the last kAlignLevels stay inside a group: one pass through LDS (10 M rows: 6 x 0.72 ms of sorts -> one kernel)
     if (bottom_in_lds && L > Ltop) {
-        hipLaunchKernelGGL(kd_bottom_kernel, dim3((unsigned)((n_pad + kGroupRows - 1) / kGroupRows)), dim3(kThreads), 0, st, perm, n_pad, Ltop, P, d);
+        hipLaunchKernelGGL(kd_bottom_kernel, dim3((unsigned)((n_pad + kGroupRows - 1) / kGroupRows)), dim3(kThreads), 0, st, perm, n, n_pad, Ltop, Cf, d);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -504,6 +524,9 @@ int prune_layout(int64_t nq, int64_t nq_pad, int nqblk, int64_t nr, int64_t nr_p
     L.vals_b = take((size_t)nmax * 4);
     L.Ys = take((size_t)nr * d * 8);
     L.Xs = take((size_t)nq * d * 8);
+    // float planes of the coordinates while a set is being sorted (kd_sort): they live in the Xs region where it is large enough
+    // (it is written only after the last sort), else in room of their own
+    L.cf32 = (size_t)nq * d * 8 >= (size_t)std::max(nq, nr) * d * 4 ? L.Xs : take((size_t)std::max(nq, nr) * d * 4);
     L.tbox_r = take((size_t)(nr_pad / kPruneTileRows) * 2 * d * 4);
     L.tbox_q = take((size_t)(nq_pad / kPruneTileRows) * 2 * d * 4);
     L.tboxT_r = take((size_t)(nr_pad / kPruneTileRows) * 2 * d * 4);
@@ -536,6 +559,7 @@ hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t
     int* vals_b = reinterpret_cast<int*>(ws + L.vals_b);
     double* Ys = reinterpret_cast<double*>(ws + L.Ys);
     double* Xs = reinterpret_cast<double*>(ws + L.Xs);
+    float* cf32 = reinterpret_cast<float*>(ws + L.cf32);
     float* tbox_r = reinterpret_cast<float*>(ws + L.tbox_r);
     float* tbox_q = reinterpret_cast<float*>(ws + L.tbox_q);
     float* tboxT_r = reinterpret_cast<float*>(ws + L.tboxT_r);
@@ -548,7 +572,7 @@ hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t
     auto blocks_for = [](int64_t n) { return dim3((unsigned)((n + kThreads - 1) / kThreads)); };
 
     // references: k-d order down to single 32-row tiles, reordered copy, tile and chunk boxes
-    hipError_t e = kd_sort(dY, nr, nr_pad, d, kPruneTileRows, (int)ntile_r, perm_r, keys_a, keys_b, vals_b, tmp, L.tmp_bytes, st);
+    hipError_t e = kd_sort(dY, nr, nr_pad, d, kPruneTileRows, (int)ntile_r, perm_r, keys_a, keys_b, vals_b, cf32, tmp, L.tmp_bytes, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gather_rows_kernel, blocks_for(nr * d), dim3(kThreads), 0, st, dY, perm_r, nr, d, Ys);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -561,7 +585,7 @@ hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t
         out.qperm = perm_r;          // query tile t IS reference tile t
         out.tbox_q = tbox_r;
     } else {
-        e = kd_sort(dX, nq, nq_pad, d, kPruneTileRows, (int)ntile_q, perm_q, keys_a, keys_b, vals_b, tmp, L.tmp_bytes, st);
+        e = kd_sort(dX, nq, nq_pad, d, kPruneTileRows, (int)ntile_q, perm_q, keys_a, keys_b, vals_b, cf32, tmp, L.tmp_bytes, st);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(gather_rows_kernel, blocks_for(nq * d), dim3(kThreads), 0, st, dX, perm_q, nq, d, Xs);
         if ((e = hipGetLastError()) != hipSuccess) return e;

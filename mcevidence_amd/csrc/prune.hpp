@@ -34,6 +34,7 @@ struct PruneLayout {
     size_t keys_a = 0, keys_b = 0;          // uint64 [max(nr_pad, nq_pad)] sort keys (ping-pong)
     size_t vals_b = 0;                      // int32 [max(nr_pad, nq_pad)]
     size_t Ys = 0, Xs = 0;                  // double [nr * d], [nq * d] reordered rows
+    size_t cf32 = 0;                        // float [d][n]: the coordinates of the set being sorted, one plane per dimension (aliases Xs where that is large enough)
     size_t tbox_r = 0, tbox_q = 0;          // float [tiles][2][d] (lo | hi), rounded outward
     size_t tboxT_r = 0;                     // float [nchunk][2][d][tiles per chunk]: the kernel's layout
     size_t box_r = 0, box_q = 0;            // float [nchunk][2][d], [nqblk][2][d]
