@@ -259,7 +259,8 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
         off = align_up(off + (size_t)p.nrow_pad * (size_t)(4 * p.KS) * sizeof(double), 256);
     }
     // symmetric sweep: auto-evidence searches (the caller passes ONE buffer as X and Y; only the sizes are known here)
-    if (f16 && !p.twopass && !p.prune && nq == nr && p.vh->launch_sym && p.nqblk >= 2 && p.nrow_pad <= ((int64_t)1 << mce::kHSymRowBits)) {
+    // (16 < K <= 32: two symmetric passes over 16-entry lists -- capi_search.hpp -- where the list capacity has the second-pass kernels)
+    if (f16 && (!p.twopass || p.vh->launch_panel_lower) && !p.prune && nq == nr && p.vh->launch_sym && p.nqblk >= 2 && p.nrow_pad <= ((int64_t)1 << mce::kHSymRowBits)) {
         const int sm = eff_sym_mode();
         p.sym = sm == 2 || (sm == 0 && p.nqblk >= kSymAutoMinBlocks[p.KST] * ((p.KST == 1 && p.KCAP == 16) ? 2 : 1));     // (1M x 15, K = 16: 62.3 vs 62.7 ms)
         // the symmetric sweep needs queries and references to be ONE buffer: known from the pointers (host entry points, and
@@ -287,7 +288,7 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
         }
     }
     if (p.sym) {
-        mce::sym_layout(nr, p.nq_pad, p.nqblk, d, p.KCAP, mce::f16_qpb(p.KCAP), sym_bucket_per_row(K), p.sl);
+        mce::sym_layout(nr, p.nq_pad, p.nqblk, d, p.KCAP, mce::f16_qpb(p.KCAP), sym_bucket_per_row(std::min<int>(K, p.KCAP)), p.sl);      // (two passes: each fills lists of KCAP)
         p.off_sym = off;
         off = align_up(off + p.sl.total, 256);
     }

@@ -214,14 +214,15 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             // 49 k x 27 1.51 -> 1.32 ms, 98 k 2.18 -> 2.03, 131 k 2.58 -> 2.47, from 197 k rows the same; 393 k x 15 7.04 -> 6.88)
             const int seed_rows = tun.sym_seed_rows > 0 ? tun.sym_seed_rows : (p.KST == 1 ? 65536 : 32768);
             const int seed_share = tun.sym_seed_share;
-            a.seed_cfg = mce::f16_seed_cfg(p.nchunk, p.CT, K + a.self_exclude, seed_rows, seed_share, MCE_H_SEED_TG);
-            // tiny sets (forced mode): smaller groups, so that half of the chunks still hold twice the K groups a bound needs --
-            // without any bound every pair would go through the row side (20 k x 27: 10.8 ms instead of 0.8)
-            for (int tg = MCE_H_SEED_TG / 2; a.seed_cfg == 0 && tg >= 1; tg /= 2)
-                a.seed_cfg = mce::f16_seed_cfg(p.nchunk, p.CT, K + a.self_exclude, seed_rows, seed_share, tg);
-            if (a.seed_cfg) {
-                a.seed_cfg |= ((tun.sym_seed_mode >= 0 ? tun.sym_seed_mode : kSymSeedMode[p.KST]) & 3) << 28;
-            }
+            auto sym_seed_for = [&](int kk) {
+                int cfg = mce::f16_seed_cfg(p.nchunk, p.CT, kk + a.self_exclude, seed_rows, seed_share, MCE_H_SEED_TG);
+                // tiny sets (forced mode): smaller groups, so that half of the chunks still hold twice the K groups a bound needs --
+                // without any bound every pair would go through the row side (20 k x 27: 10.8 ms instead of 0.8)
+                for (int tg = MCE_H_SEED_TG / 2; cfg == 0 && tg >= 1; tg /= 2)
+                    cfg = mce::f16_seed_cfg(p.nchunk, p.CT, kk + a.self_exclude, seed_rows, seed_share, tg);
+                if (cfg) cfg |= ((tun.sym_seed_mode >= 0 ? tun.sym_seed_mode : kSymSeedMode[p.KST]) & 3) << 28;
+                return cfg;
+            };
             // One rank's share of a multi-GPU partition: the contiguous range of sorted blocks [qb_lo, qb_hi).  Their tiles
             // carry the row-side gate; everybody else's rows are swept column side only (sym_types.hpp, PanelGeom) -- no
             // exchange between the ranks, each ends with complete lists for its own rows.  Only they need a prepass bound.
@@ -229,51 +230,79 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             const int qb_hi = p.nparts > 1 ? (int)((int64_t)p.nqblk * (p.part + 1) / p.nparts) : p.nqblk;
             p.sym_qb_lo = qb_lo;
             p.sym_qb_hi = qb_hi;
-            a.qblk0 = qb_lo;
-            a.nqblk_run = qb_hi - qb_lo;
-            if (qb_hi > qb_lo) MCE_HIP(p.vh->launch_sym_pre(a, st));
-            a.qblk0 = 0;
-            a.nqblk_run = 0;
-            const int seed_used = a.seed_cfg;
-            a.seed_cfg = 0;
-            int rc = prof_begin();             // (the bracket of mce_last_kernel_ms(): the dominant kernel, as for the other searches)
-            if (rc != MCE_OK) return rc;
-            const bool panel_kernel = !tun.sym_kernel_f16 || p.nparts > 1;
-            if (panel_kernel) {
-                mce::PanelArgs pa;
-                pa.Yh = yh; pa.Xh = xh; pa.qinfo = qinfo; pa.params = params; pa.X = sX; pa.Y = sY; pa.rperm = a.rperm;
-                pa.part_d = pd; pa.part_i = pi; pa.nq = nq; pa.nr = nr; pa.nq_pad = p.nq_pad; pa.self_offset = 0;
-                pa.D = d; pa.ksel = K; pa.self_exclude = a.self_exclude; pa.spin_limit = tun.spin_limit;
-                pa.sym = a.sym;
-                pa.debug = tun.panel_debug;
-                pa.geom.qb_lo = qb_lo; pa.geom.qb_hi = qb_hi; pa.geom.tpb = mce::kHWaves * mce::kHQT; pa.geom.ct = p.CT;
-                pa.geom.tpp = a.sym.panel * p.CT; pa.geom.sym_on = 1;
-                pa.geom.ntiles = (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1);
-                MCE_HIP(p.vh->launch_panel(pa, st));
-            } else {
-                MCE_HIP(p.vh->launch_sym(a, st));
-            }
-            rc = prof_end();
-            if (rc != MCE_OK) return rc;
-            MCE_HIP(p.vh->launch_sym_repair(a, st));      // blocks whose bucket overflowed (normally none: every workgroup exits at once)
-            {
-                const dim3 g((unsigned)std::max(1, qb_hi - qb_lo)), b(mce::kSymMergeThreads);
-                static_assert(mce::kSymMergeThreads == mce::f16_qpb(4), "one merge block per query block");
-                switch (p.KCAP) {
-                    case 4: hipLaunchKernelGGL(mce::sym_merge_kernel<4>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
-                    case 8: hipLaunchKernelGGL(mce::sym_merge_kernel<8>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
-                    case 12: hipLaunchKernelGGL(mce::sym_merge_kernel<12>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
-                    default: hipLaunchKernelGGL(mce::sym_merge_kernel<16>, g, b, 0, st, pd, pi, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
+            const bool panel_kernel = !tun.sym_kernel_f16 || p.nparts > 1 || p.twopass;
+            mce::PanelGeom geom;
+            geom.qb_lo = qb_lo; geom.qb_hi = qb_hi; geom.tpb = mce::kHWaves * mce::kHQT; geom.ct = p.CT; geom.tpp = a.sym.panel * p.CT; geom.sym_on = 1;
+            geom.ntiles = (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1);
+            // 16 < K <= 32 (round 5): TWO symmetric passes over 16-entry lists, as the exhaustive sweep does it (knn_f16.hpp, LOWER) --
+            // the first finds every row's 16 nearest (lists A), the second the next K - 16 beyond them (lists B: knn_panel.hpp,
+            // LOWER); the merge takes the K best of A and B.  The second pass needs bounds on the K-th distance: a prepass
+            // whose seed phase tracks K + 1 <= 33 group minima.
+            const int npass = p.twopass ? 2 : 1;
+            const size_t list_set = (size_t)p.KCAP * (size_t)p.nq_pad;
+            int seed_used = 0;
+            for (int pass = 0; pass < npass; ++pass) {
+                const bool lower = pass == 1;
+                const int Kp = !p.twopass ? K : (lower ? K - 16 : 16);          // neighbours this pass's lists are to hold
+                double* const pdp = pd + (lower ? list_set : 0);
+                int* const pip = pi + (lower ? list_set : 0);
+                if (lower) {
+                    MCE_HIP(mce::zero_async(a.sym.bucket_cnt, (size_t)3 * p.nqblk * sizeof(int), st));      // counts | flags | done
+                    a.sym.slot_stride = p.KCAP;
                 }
-                MCE_HIP(hipGetLastError());
+                // prepass: every row's bound on the distance of the LAST neighbour wanted (K-th: both passes of a two-pass search
+                // publish bounds on what the row will finally hold) before any block runs (the seed phase as its own launch);
+                // about 32 k rows (one k-step: 64 k), at most half of the chunks (tools/_tmp-style scans, fused call, share 8 -> 2:
+                // 49 k x 27 1.51 -> 1.32 ms, 98 k 2.18 -> 2.03, 131 k 2.58 -> 2.47, from 197 k rows the same; 393 k x 15 7.04 -> 6.88)
+                a.ksel = lower ? K : Kp;
+                a.seed_cfg = sym_seed_for(a.ksel);
+                a.part_d = pdp;
+                a.part_i = pip;
+                a.qblk0 = qb_lo;
+                a.nqblk_run = qb_hi - qb_lo;
+                if (qb_hi > qb_lo) MCE_HIP((lower ? p.vh->launch_sym_pre32 : p.vh->launch_sym_pre)(a, st));
+                a.qblk0 = 0;
+                a.nqblk_run = 0;
+                if (pass == 0) seed_used = a.seed_cfg;
+                a.seed_cfg = 0;
+                a.ksel = Kp;
+                a.lo_d = lower ? pd : nullptr;
+                a.lo_i = lower ? pi : nullptr;
+                int rc = pass == 0 ? prof_begin() : MCE_OK;             // (the bracket of mce_last_kernel_ms(): the dominant kernel, as for the other searches)
+                if (rc != MCE_OK) return rc;
+                if (panel_kernel) {
+                    mce::PanelArgs pa;
+                    pa.Yh = yh; pa.Xh = xh; pa.qinfo = qinfo; pa.params = params; pa.X = sX; pa.Y = sY; pa.rperm = a.rperm;
+                    pa.part_d = pdp; pa.part_i = pip; pa.nq = nq; pa.nr = nr; pa.nq_pad = p.nq_pad; pa.self_offset = 0;
+                    pa.D = d; pa.ksel = Kp; pa.self_exclude = a.self_exclude; pa.spin_limit = tun.spin_limit;
+                    pa.sym = a.sym;
+                    pa.debug = tun.panel_debug;
+                    pa.geom = geom;
+                    pa.lo_d = a.lo_d; pa.lo_i = a.lo_i;
+                    MCE_HIP((lower ? p.vh->launch_panel_lower : p.vh->launch_panel)(pa, st));
+                } else {
+                    MCE_HIP(p.vh->launch_sym(a, st));
+                }
+                rc = pass == 0 ? prof_end() : MCE_OK;
+                if (rc != MCE_OK) return rc;
+                MCE_HIP((lower ? p.vh->launch_sym_repair_lower : p.vh->launch_sym_repair)(a, st));      // blocks whose bucket overflowed (normally none: every workgroup exits at once)
+                {
+                    const dim3 g((unsigned)std::max(1, qb_hi - qb_lo)), b(mce::kSymMergeThreads);
+                    static_assert(mce::kSymMergeThreads == mce::f16_qpb(4), "one merge block per query block");
+                    switch (p.KCAP) {
+                        case 4: hipLaunchKernelGGL(mce::sym_merge_kernel<4>, g, b, 0, st, pdp, pip, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
+                        case 8: hipLaunchKernelGGL(mce::sym_merge_kernel<8>, g, b, 0, st, pdp, pip, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
+                        case 12: hipLaunchKernelGGL(mce::sym_merge_kernel<12>, g, b, 0, st, pdp, pip, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
+                        default: hipLaunchKernelGGL(mce::sym_merge_kernel<16>, g, b, 0, st, pdp, pip, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
+                    }
+                    MCE_HIP(hipGetLastError());
+                }
             }
             p.sym_active = true;
-            p.L = 1;
+            p.L = npass;
             int sym_units = mce::sym_unit_count(p.nqblk, mce::kHWaves * mce::kHQT, a.sym.panel * p.CT, (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1));
             if (panel_kernel) {
-                mce::PanelGeom g;
-                g.qb_lo = qb_lo; g.qb_hi = qb_hi; g.tpb = mce::kHWaves * mce::kHQT; g.ct = p.CT; g.tpp = a.sym.panel * p.CT; g.sym_on = 1;
-                g.ntiles = (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1);
+                const mce::PanelGeom& g = geom;
                 sym_units = mce::panel_unit_count(g);
                 // executed MFMA flops: every unit's tiles x 16 query tiles x (32 x 32 x 16 KST) multiply-adds -- a figure for
                 // mce_last_search_stats(), counted only while profiling is on (the loop is O(units x panels): seconds of host
@@ -285,7 +314,7 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
                     mce::panel_unit_tiles(pp, aa, g, lo, hi);
                     tiles += hi - lo;
                 }
-                g_last_flops_main = tiles * 16.0 * 1024.0 * 32.0 * p.KST;
+                g_last_flops_main = tiles * 16.0 * 1024.0 * 32.0 * p.KST;        // (a two-pass search: the first pass's sweep, which the event bracket times)
             } else {
                 const double nb = p.nqblk, tpb = mce::kHWaves * mce::kHQT, T = (double)((nr + 31) / 32);
                 double tiles = 0.0;
@@ -294,8 +323,8 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
                 g_last_flops_main = tiles * 16.0 * 1024.0 * 32.0 * p.KST;
             }
             g_last_flops_all = g_last_flops_main + (double)(seed_used & 0xffff) * p.CT * (double)(qb_hi - qb_lo) * 16.0 * 1024.0 * 32.0 * p.KST;
-            snprintf(g_last_kernel, sizeof(g_last_kernel), "%s symmetric%s grid=%d block=%d lds=%zu qt=%d ct=%d panel=%d seed=%dx%d/%d bucket=%d", p.vh->name, panel_kernel ? " panel-kernel" : "",
-                     sym_units,
+            snprintf(g_last_kernel, sizeof(g_last_kernel), "%s symmetric%s%s grid=%d block=%d lds=%zu qt=%d ct=%d panel=%d seed=%dx%d/%d bucket=%d", p.vh->name, panel_kernel ? " panel-kernel" : "",
+                     p.twopass ? " two passes" : "", sym_units,
                      mce::kHThreads, panel_kernel ? p.vh->lds_bytes_panel : p.vh->lds_bytes_sym, p.QT, p.CT, a.sym.panel, seed_used & 0xffff, (seed_used >> 16) & 0xfff, (seed_used >> 28) & 3, p.sl.cap);
             return MCE_OK;
         }

@@ -97,6 +97,11 @@ struct KnnF16Variant {
     int prune_short_lc2;
     knn_f16_launch_fn launch_wide;          // the exhaustive sweep with FOUR query tiles per wave (a workgroup = two query blocks; KST = 1, KCAP = 4), else null
     size_t lds_bytes_wide;
+    // second pass of a SYMMETRIC search for 16 < K <= 32 neighbours (KCAP = 16 only, else null): the LOWER panel sweep, its repair
+    // launch (SYM = 3, LOWER) and a prepass whose seed phase tracks 33 group minima (a bound on the 32nd neighbour)
+    knn_panel_launch_fn launch_panel_lower;
+    knn_f16_launch_fn launch_sym_repair_lower;
+    knn_f16_launch_fn launch_sym_pre32;
 };
 constexpr int kMaxKST = 4;
 extern const KnnF16Variant g_knn_f16_kcap4[kMaxKST];

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
     const unsigned long long wg_t0 = wg_us ? wall_clock64() : 0ull;
     static_assert(LC == KCAP || (PRUNE && LC < KCAP), "shorter register lists: pruned walk only");
     static_assert(!(PRUNE && LOWER), "second pass: exhaustive sweep only");
-    static_assert(SYM == 0 || (!PRUNE && !LOWER), "symmetric sweep: exhaustive, single pass");
+    static_assert(SYM == 0 || (!PRUNE && (!LOWER || SYM == 3)), "symmetric sweep: exhaustive; second pass: the repair launch only (the sweep itself: knn_panel.hpp)");
     static_assert(QTT == 2 || (QTT == 4 && !PRUNE && !LOWER && SYM == 0), "four query tiles: the plain exhaustive sweep only");
     constexpr int QT = QTT;
     constexpr int NL = QT / 2;                           // top-K lists per owner lane
@@ -529,7 +529,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                         const int64_t o = ((int64_t)split * KCAP + (KCAP - 1)) * nq_pad + qwave0 + qlp[u];
                         const double ld = lo_d[o];
                         const int li = lo_i[o];
-                        const int j = jsplit0 + (int)((unsigned)wq[ep[u]] & ((1u << RELB) - 1u));
+                        int j = jsplit0 + (int)((unsigned)wq[ep[u]] & ((1u << (SYM >= 2 ? kHSymRowBits : RELB)) - 1u));
+                        if constexpr (SYM >= 2) j = rperm ? rperm[j] : j;       // (the lists of a symmetric search carry the caller's rows)
                         ok = a0 > ld || (a0 == ld && j > li);       // (list not full: ld = +inf, nothing is left)
                     }
                 }
@@ -1141,7 +1142,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                 sym.thr[q] = (unsigned long long)__double_as_longlong(seed_thr[0]);
                 R = sym_row_gate(seed_thr[0], qinfo[2 * q], params, KST);
                 sym.rrow[q] = __float_as_uint(R);
-                for (int k = 0; k < KCAP; ++k) sym.slots[q * KCAP + k] = 0x7FF0000000000000ull;
+                const int sstride = sym.slot_stride ? sym.slot_stride : KCAP;
+                for (int k = 0; k < sstride; ++k) sym.slots[q * sstride + k] = 0x7FF0000000000000ull;
             } else {
                 sym.thr[q] = 0x7FF0000000000000ull;
                 sym.rrow[q] = 0u;

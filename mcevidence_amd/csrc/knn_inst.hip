@@ -76,14 +76,14 @@ hipError_t launch_f16_variant(const KnnF16Args& a, hipStream_t st)
 #endif
 
 #if MCE_INST_F16 || MCE_INST_PANEL
-template <int KST, int KCAP>
+template <int KST, int KCAP, bool LOWER = false>
 hipError_t launch_panel_variant(const PanelArgs& a, hipStream_t st)
 #if MCE_INST_PANEL
 {
     constexpr size_t LDS = panel_lds_bytes(KST);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set[kMaxDevices] = {};
-    auto kern = knn_panel_kernel<KST, KCAP>;
+    auto kern = knn_panel_kernel<KST, KCAP, LOWER>;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= kMaxDevices || !attr_set[dev]) {
@@ -100,12 +100,24 @@ template hipError_t launch_panel_variant<1, MCE_KCAP>(const PanelArgs&, hipStrea
 template hipError_t launch_panel_variant<2, MCE_KCAP>(const PanelArgs&, hipStream_t);
 template hipError_t launch_panel_variant<3, MCE_KCAP>(const PanelArgs&, hipStream_t);
 template hipError_t launch_panel_variant<4, MCE_KCAP>(const PanelArgs&, hipStream_t);
+#if MCE_KCAP == 16
+template hipError_t launch_panel_variant<1, MCE_KCAP, true>(const PanelArgs&, hipStream_t);
+template hipError_t launch_panel_variant<2, MCE_KCAP, true>(const PanelArgs&, hipStream_t);
+template hipError_t launch_panel_variant<3, MCE_KCAP, true>(const PanelArgs&, hipStream_t);
+template hipError_t launch_panel_variant<4, MCE_KCAP, true>(const PanelArgs&, hipStream_t);
+#endif
 #else
 ;     // defined in this list capacity's panel object (MCE_INST_PART = 3)
 extern template hipError_t launch_panel_variant<1, MCE_KCAP>(const PanelArgs&, hipStream_t);
 extern template hipError_t launch_panel_variant<2, MCE_KCAP>(const PanelArgs&, hipStream_t);
 extern template hipError_t launch_panel_variant<3, MCE_KCAP>(const PanelArgs&, hipStream_t);
 extern template hipError_t launch_panel_variant<4, MCE_KCAP>(const PanelArgs&, hipStream_t);
+#if MCE_KCAP == 16
+extern template hipError_t launch_panel_variant<1, MCE_KCAP, true>(const PanelArgs&, hipStream_t);
+extern template hipError_t launch_panel_variant<2, MCE_KCAP, true>(const PanelArgs&, hipStream_t);
+extern template hipError_t launch_panel_variant<3, MCE_KCAP, true>(const PanelArgs&, hipStream_t);
+extern template hipError_t launch_panel_variant<4, MCE_KCAP, true>(const PanelArgs&, hipStream_t);
+#endif
 #endif
 #endif
 
@@ -130,8 +142,11 @@ extern const KnnVariant MCE_CAT(g_knn_kcap, MCE_KCAP)[kMaxKS] = {
 #if MCE_INST_F16
 #if MCE_KCAP == 16
 #define MCE_F16_LOWER(KST) (&launch_f16_variant<KST, MCE_KCAP, false, true>)
+// symmetric second pass (16 < K <= 32): the sweep on the LOWER panel kernel, its repair launch, and a prepass that tracks 33 group minima
+#define MCE_F16_SYM_LOWER(KST) &launch_panel_variant<KST, MCE_KCAP, true>, &launch_f16_variant<KST, MCE_KCAP, false, true, 3>, &launch_f16_variant<KST, 32, false, false, 1>
 #else
 #define MCE_F16_LOWER(KST) nullptr
+#define MCE_F16_SYM_LOWER(KST) nullptr, nullptr, nullptr
 #endif
 #if MCE_KCAP == 12
 #define MCE_F16_SHORT(KST) ((KST) == 1 ? &launch_f16_variant<1, MCE_KCAP, true, false, 0, 9> : (knn_f16_launch_fn) nullptr), ((KST) == 1 ? 9 : 0), \
@@ -148,7 +163,7 @@ extern const KnnVariant MCE_CAT(g_knn_kcap, MCE_KCAP)[kMaxKS] = {
     {&launch_f16_variant<KST, MCE_KCAP, false>, PRUNE_FN, MCE_F16_LOWER(KST), &launch_f16_variant<KST, MCE_KCAP, false, false, 1>, \
      &launch_f16_variant<KST, MCE_KCAP, false, false, 2>, &launch_f16_variant<KST, MCE_KCAP, false, false, 3>, &launch_panel_variant<KST, MCE_KCAP>, panel_lds_bytes(KST), \
      f16_lds_bytes(KST, MCE_KCAP, true), KST, MCE_KCAP, f16_qt(MCE_KCAP), f16_chunk_tiles(KST), \
-     f16_lds_bytes(KST, MCE_KCAP), "knn_f16_kernel<KST=" #KST ",KCAP=" MCE_STR(MCE_KCAP) ">", MCE_F16_SHORT(KST), MCE_F16_WIDE(KST)}
+     f16_lds_bytes(KST, MCE_KCAP), "knn_f16_kernel<KST=" #KST ",KCAP=" MCE_STR(MCE_KCAP) ">", MCE_F16_SHORT(KST), MCE_F16_WIDE(KST), MCE_F16_SYM_LOWER(KST)}
 extern const KnnF16Variant MCE_CAT(g_knn_f16_kcap, MCE_KCAP)[kMaxKST] = {
     MCE_F16_VARIANT(1, (&launch_f16_variant<1, MCE_KCAP, true>)), MCE_F16_VARIANT(2, nullptr), MCE_F16_VARIANT(3, nullptr),
     MCE_F16_VARIANT(4, nullptr),
@@ -168,6 +183,9 @@ template __global__ void knn_f16_kernel<1, MCE_KCAP, true, false, 0, 10>(const _
 #endif
 #if MCE_KCAP == 16
 MCE_F16_INST(1, false, true, 0) MCE_F16_INST(2, false, true, 0) MCE_F16_INST(3, false, true, 0) MCE_F16_INST(4, false, true, 0)
+MCE_F16_INST(1, false, true, 3) MCE_F16_INST(2, false, true, 3) MCE_F16_INST(3, false, true, 3) MCE_F16_INST(4, false, true, 3)
+#define MCE_F16_INST32(KST) template __global__ void knn_f16_kernel<KST, 32, false, false, 1>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*, int, int, const int*, const double*, const int*, int, SymParams, float*);
+MCE_F16_INST32(1) MCE_F16_INST32(2) MCE_F16_INST32(3) MCE_F16_INST32(4)
 #endif
 #if MCE_KCAP == 4
 template __global__ void knn_f16_kernel<1, MCE_KCAP, false, false, 0, MCE_KCAP, 4>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*, int, int, const int*, const double*, const int*, int, SymParams, float*);
@@ -178,6 +196,12 @@ template __global__ void knn_panel_kernel<1, MCE_KCAP>(PanelArgs);
 template __global__ void knn_panel_kernel<2, MCE_KCAP>(PanelArgs);
 template __global__ void knn_panel_kernel<3, MCE_KCAP>(PanelArgs);
 template __global__ void knn_panel_kernel<4, MCE_KCAP>(PanelArgs);
+#if MCE_KCAP == 16
+template __global__ void knn_panel_kernel<1, MCE_KCAP, true>(PanelArgs);
+template __global__ void knn_panel_kernel<2, MCE_KCAP, true>(PanelArgs);
+template __global__ void knn_panel_kernel<3, MCE_KCAP, true>(PanelArgs);
+template __global__ void knn_panel_kernel<4, MCE_KCAP, true>(PanelArgs);
+#endif
 #endif
 #if MCE_INST_F64
 #define MCE_INST(KS) template __global__ void knn_mfma_kernel<KS, MCE_KCAP>(const double*, int64_t, int, const double*, const double*, int64_t, int, int64_t, int, int, int64_t, int, double*, int*);

@@ -44,13 +44,12 @@ struct PanelArgs {
                                  // second unit give up waiting at once
     SymParams sym;               // .done, .panel always; the row-side state only with geom.sym_on
     PanelGeom geom;
+    const double* lo_d = nullptr;   // LOWER (second pass of a search for 16 < K <= 32 neighbours): the FIRST pass's lists, [KCAP][nq_pad] in the
+    const int* lo_i = nullptr;      // same column order -- every row's own 16 nearest; this pass keeps only what lies beyond a row's 16th
 };
 
 #ifndef MCE_PANEL_STATS
 #define MCE_PANEL_STATS 0       // tools/knn_sym_bench.hip: per-wave cycle / event counters appended to `params`
-#endif
-#ifndef MCE_PANEL_EVT
-#define MCE_PANEL_EVT 1         // how a tile with a candidate finds it: 1 = through the gate's first-level minima (9 compares), 0 = groups of four (16)
 #endif
 #ifndef MCE_PANEL_NPASS
 #define MCE_PANEL_NPASS 3       // drain, phase A: 8 * NPASS pairs in flight per trip
@@ -63,10 +62,6 @@ struct PanelArgs {
 #endif
 #ifndef MCE_PANEL_TRIGGER
 #define MCE_PANEL_TRIGGER 192                  // a wave with this many queued candidates asks the workgroup to drain (96 -> 192: 35.4 -> 35.1 ms at C3)
-#endif
-#ifndef MCE_PANEL_PRIO
-#define MCE_PANEL_PRIO 0        // tools only: 1 = static s_setprio 1 for the second-dispatched half of the workgroup (waves 4-7: each shares a SIMD with
-                                // wave w - 4 and loses the issue arbitration by age), 2 = for the first half instead
 #endif
 #ifndef MCE_PANEL_ABL
 #define MCE_PANEL_ABL 0         // tools only: 1 = the gates never pass, 2 = no gate at all (results invalid)
@@ -102,7 +97,13 @@ __device__ __forceinline__ float vmaxf(float a, float b)       // v_max_f32 with
     return r;
 }
 
-template <int KST, int KCAP>
+// LOWER (round 5): the second pass of a symmetric search for 16 < K <= 32 neighbours.  The first pass (this kernel, K = 16) left every
+// row's 16 nearest in lo_d / lo_i; this one finds the next K - 16: a pair (i, j) counts for row i only if (d2, caller row of j) lies
+// lexicographically beyond the 16th entry of i's first list -- checked where the exact distance is known: column side in phase A,
+// row side (the same test with the roles exchanged, against j's first list) in phase R.  Thresholds, slots and published bounds
+// then speak of the (K - 16)-th entry beyond the cut, i.e. of the K-th neighbour; the prepass that seeds them bounds the K-th
+// distance (capi_search.hpp).  The first 16 still pass the fp16 gate and are evaluated again -- the price of lists that hold 16.
+template <int KST, int KCAP, bool LOWER = false>
 __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_by_value)
 {
     static_assert(kHQT == 2 && kHNL == 1, "8 waves x 2 query tiles, one list per owner lane");
@@ -376,7 +377,18 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
                     // query's list (K-th bound of the last drain) joins its chain
                     if (sub == 0 && ep[u] < qcount) {
                         wqd[ep[u]] = okp[u] ? a0 : -1.0;
-                        if (okp[u] && !(a0 > (double)sthr[qlp[u]])) wnx[ep[u]] = atomicExch(&whead[qlp[u]], ep[u]);
+                        bool col = okp[u] && !(a0 > (double)sthr[qlp[u]]);
+                        if constexpr (LOWER) {
+                            if (col) {       // beyond the 16th entry of the query's first list?  (list not full: +inf, nothing is left)
+                                const int64_t o = (int64_t)(KCAP - 1) * a->nq_pad + qwave0 + qlp[u];
+                                const double ld = gptr(a->lo_d)[o];
+                                const int li = gptr(a->lo_i)[o];
+                                const int jr = (int)((unsigned)wq[ep[u]] & ((1u << kHSymRowBits) - 1u));
+                                const int jc = rperm ? rperm[jr] : jr;
+                                col = a0 > ld || (a0 == ld && jc > li);
+                            }
+                        }
+                        if (col) wnx[ep[u]] = atomicExch(&whead[qlp[u]], ep[u]);
                     }
                 }
             }
@@ -455,6 +467,15 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
                 if (rs) {
                     const int jb = j / QPB;
                     rs = d2 <= __longlong_as_double((long long)__hip_atomic_load(sp_thr + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if constexpr (LOWER) {
+                        if (rs) {       // beyond the 16th entry of row j's first list?  (what j is offered is the QUERY's row)
+                            const int64_t o = (int64_t)(KCAP - 1) * a->nq_pad + j;
+                            const double ld = gptr(a->lo_d)[o];
+                            const int li = gptr(a->lo_i)[o];
+                            const int sc = rperm ? rperm[qwave0 + ql] : (int)(qwave0 + ql);
+                            rs = d2 > ld || (d2 == ld && sc > li);
+                        }
+                    }
                     if (rs) rs = slot_insert(j, d2);
                     if (rs) {
                         const int slot = __hip_atomic_fetch_add(sp_bucket_cnt + jb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -547,9 +568,10 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
     // ---- a tile with a candidate ------------------------------------------------------------------------------------
     // c: the 16 accumulators of query tile qt (C layout of 32x32 f32: lane l -> query column l & 31, rows
     // (r & 3) + 8 (r >> 2) + 4 (l >> 5)); gq: the lane's gate; rowflag: the lane passed the ROW gate; jb0: first reference
-    // row of the tile; todo: the accumulators still to be looked at (a redo passes what is left).  Accumulator by
-    // accumulator, in groups of four: a wave-wide compare each, scalar branches over the empty ones; the lanes under the
-    // gate append (query, row) to the wave's queue.  Returns the accumulators NOT handled because the queue was full.
+    // row of the tile; todo: the accumulators still to be looked at (a redo passes what is left).  Wave-wide compares, scalar
+    // branches over the empty ones; the lanes under the gate append (query, row) to the wave's queue.  Returns the accumulators
+    // NOT handled because the queue was full.  (Static s_setprio for either half of the workgroup -- MI355X_MICROARCH.md, two
+    // waves per SIMD, item 4 -- was measured in round 5: 36.9-37.1 ms either way against 36.7-37.3, nothing.)
     auto event = [&](const v16f& c, const float (&l1)[5], const int qt, const float gq, const bool rowflag, const int jb0, const unsigned todo, const int qlimit) __attribute__((always_inline)) -> unsigned {
         (void)l1;
         const unsigned wbase = (lanew[qt] + (unsigned)jb0) | (rowflag ? (1u << kHSymRowBits) : 0u);
@@ -564,7 +586,6 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
                 qcount += __builtin_popcountll(S_);                                                                       \
             }                                                                                                             \
         }
-#if MCE_PANEL_EVT == 1
         // the gate's own first-level minima say which triples of accumulators hold something: 6 wave-wide compares, then 3
         // for each triple that does (usually one) -- 9 instead of 16
         {
@@ -582,22 +603,6 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
 #undef MCE_TRIPLE
             MCE_HIT(15, p15, s15)
         }
-#else
-#pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("" : "+v"(g));      // the compares of the later groups stay behind this point: four live masks, not sixteen
-#endif
-            const bool p0 = c[4 * grp + 0] <= g, p1 = c[4 * grp + 1] <= g, p2 = c[4 * grp + 2] <= g, p3 = c[4 * grp + 3] <= g;
-            const unsigned long long s0 = __ballot(p0), s1 = __ballot(p1), s2 = __ballot(p2), s3 = __ballot(p3);
-            if ((s0 | s1 | s2 | s3) != 0) {
-                MCE_HIT(4 * grp + 0, p0, s0)
-                MCE_HIT(4 * grp + 1, p1, s1)
-                MCE_HIT(4 * grp + 2, p2, s2)
-                MCE_HIT(4 * grp + 3, p3, s3)
-            }
-        }
-#endif
 #undef MCE_HIT
         return rem;
     };
@@ -713,11 +718,6 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
     st_tPro = clock64() - t_kernel0;
 #endif
     v16f accA[QT], accB[QT];
-#if MCE_PANEL_PRIO == 1
-    if (wave >= kHWaves / 2) __builtin_amdgcn_s_setprio(1);
-#elif MCE_PANEL_PRIO == 2
-    if (wave < kHWaves / 2) __builtin_amdgcn_s_setprio(1);
-#endif
     for (int k = 0; k < ntot; ++k) {
         const int buf = k & 1;
         const int c = cfirst + k;

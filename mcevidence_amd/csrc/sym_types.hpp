@@ -17,6 +17,7 @@ struct SymParams {
     int cap = 0;
     int* done = nullptr;                   // [nqblk] units of the block finished so far (its lists are handed from unit to unit)
     int panel = 0;                         // chunks per panel of reference rows (a unit = one block's queries x one panel)
+    int slot_stride = 0;                   // slots per row in `slots` when it differs from the kernel's KCAP (0: KCAP) -- the prepass of a second pass
 };
 
 #if defined(__HIPCC__)

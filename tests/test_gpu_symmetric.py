@@ -56,6 +56,56 @@ def test_symmetric_sweep_is_bit_identical(sym, n, d, K):
     assert _rel(g[-m:], od) < DIST_RTOL and np.array_equal(gi[-m:], oi)
 
 
+@pytest.mark.parametrize("n,d,K", [(700, 27, 17), (5000, 6, 24), (20000, 27, 24), (33333, 15, 32), (12345, 31, 20), (9000, 45, 19), (70001, 27, 21), (150000, 6, 17)])
+def test_symmetric_two_pass_search_is_bit_identical(sym, n, d, K):
+    """Round 5: 16 < K <= 32 on the symmetric sweep -- two symmetric passes over 16-entry lists (the second, knn_panel.hpp LOWER,
+    keeps what lies beyond every row's 16th neighbour; its prepass bounds the K-th distance with 33 group minima) -- against
+    the exhaustive two-pass search: same distances, same rows, same order, all self modes; and against the oracle."""
+    capi = sym
+    Y = _data(n, d, n + d + K)
+    for sm in (capi.SELF_EXCLUDE, capi.SELF_INCLUDE, capi.SELF_NONE):
+        (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(Y, Y, K, self_mode=sm))
+        assert "two passes" in capi.last_kernel(), capi.last_kernel()
+        assert np.array_equal(d0, d1) and np.array_equal(i0, i1), (sm, np.argwhere(d0 != d1)[:5], np.argwhere(i0 != i1)[:5])
+    m = min(n, 1500)
+    od, oi = orc.knn_brute(Y[-m:], Y, K, self_mode=2, self_offset=n - m)
+    g, gi = capi.knn(Y, Y, K, self_mode=capi.SELF_EXCLUDE)
+    assert _rel(g[-m:], od) < DIST_RTOL and np.array_equal(gi[-m:], oi)
+    # the fused reduction over two lists per row
+    rng = np.random.default_rng(K)
+    w = rng.integers(1, 4, n).astype(float)
+    fs = -rng.random(n)
+    a, b = _both(capi, lambda: capi.knn_dotp(Y, None, w, fs, K + 1, 1))
+    assert np.array_equal(a, b)
+
+
+def test_symmetric_two_pass_ties_overflow_and_give_up(sym, monkeypatch):
+    """the second pass under the conditions that break things: exact ties across the cut (a lattice: many rows at the 16th
+    distance -- the cut is lexicographic in (distance, caller row)), duplicates, buckets far too small (the LOWER repair
+    launch) and units that give up waiting for their block's previous unit"""
+    capi = sym
+    grid = np.stack(np.meshgrid(*[np.arange(10.0)] * 4), -1).reshape(-1, 4)     # 10 000 lattice points
+    for K in (17, 24, 32):
+        (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(grid, grid, K, self_mode=capi.SELF_EXCLUDE))
+        assert np.array_equal(d0, d1) and np.array_equal(i0, i1), K
+    rng = np.random.default_rng(4)
+    base = rng.standard_normal((2500, 5))
+    Y = np.ascontiguousarray(np.concatenate([base, base, base[:900], rng.standard_normal((3000, 5))])[rng.permutation(8900)])
+    (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(Y, Y, 20, self_mode=capi.SELF_EXCLUDE))
+    assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+    Z = _data(30000, 12, 5)
+    want = capi.knn(Z, Z, 22, self_mode=capi.SELF_EXCLUDE)
+    capi.set_sym_mode(capi.SYM_FORCE)
+    for name, val in (("MCE_SYM_BUCKET", "2"), ("MCE_SYM_SPIN_LIMIT", "0"), ("MCE_PANEL_DEBUG", "16"), ("MCE_PANEL_DEBUG", "8")):
+        monkeypatch.setenv(name, val)
+        if name == "MCE_SYM_SPIN_LIMIT":
+            monkeypatch.setenv("MCE_SYM_PANEL", "4")            # many units per block
+        got = capi.knn(Z, Z, 22, self_mode=capi.SELF_EXCLUDE)
+        assert "symmetric" in capi.last_kernel() and "two passes" in capi.last_kernel()
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), name
+        monkeypatch.delenv(name)
+
+
 def _rel(a, b):
     return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300) * (b != 0)) if a.size else 0.0
 

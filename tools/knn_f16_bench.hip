@@ -74,23 +74,5 @@ int main(int argc, char** argv)
         }
         printf("K-th entries: %lld not finite, checksum %.17g\n", bad, sum);
     }
-#if MCE_SEED_CHECK
-    {
-        double hp[16];
-        CK(hipMemcpy(hp, params, sizeof(hp), hipMemcpyDeviceToHost));
-        printf("seed check (all reps): %.0f queries seeded, %.0f violated; mean bound %.6g vs mean final K-th %.6g\n", hp[8], hp[9], hp[10] / hp[8], hp[11] / hp[8]);
-    }
-#endif
-#if MCE_STATS
-    {
-        const size_t nw = (size_t)nqblk * rsplit * 8;
-        std::vector<double> hs(nw * 8);
-        CK(hipMemcpy(hs.data(), (char*)params + 128, nw * 64, hipMemcpyDeviceToHost));
-        double m[8] = {0};
-        for (size_t w = 0; w < nw; ++w) for (int k = 0; k < 8; ++k) m[k] += hs[w * 8 + k] / nw;
-        printf("per wave (mean): drains %.1f  enq %.0f (per query %.1f)  chain-steps %.1f  event_tiles %.0f | cycles: phaseA %.3g  drain %.3g  barrier-wait %.3g  kernel %.3g\n",
-               m[0], m[1], m[1] / 64, m[2], m[3], m[4], m[5], m[7], m[6]);
-    }
-#endif
     return 0;
 }

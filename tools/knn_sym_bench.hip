@@ -1,8 +1,8 @@
 // knn_sym_bench.hip -- developer microbench for the symmetric sweep (knn_f16_kernel<.., SYM>): prepass + sweep with the
 // per-wave statistics on; not part of the product.  Rows are sorted by distance from the mean on the host.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DMCE_STATS=1 -mllvm -amdgpu-sched-strategy=max-ilp tools/knn_sym_bench.hip -o tools/knn_bench_sym
-// -DPANEL=1 (default): the sweep runs on knn_panel_kernel (knn_panel.hpp; statistics with -DMCE_PANEL_STATS=1); -DPANEL=0: on the
-// SYM = 2 instantiation of knn_f16_kernel (statistics with -DMCE_STATS=1).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/knn_sym_bench.hip -o tools/knn_bench_sym
+// -DPANEL=1 (default): the sweep runs on knn_panel_kernel (knn_panel.hpp; per-wave statistics with -DMCE_PANEL_STATS=1; -DMCE_PANEL_ABL=1 / 2:
+// gates never pass / no gate); -DPANEL=0: on the SYM = 2 instantiation of knn_f16_kernel (the round-2 kernel; its statistics build is gone).
 #ifndef PANEL
 #define PANEL 1
 #endif
@@ -148,28 +148,6 @@ int main(int argc, char** argv)
         printf("per wave and unit (mean): drains %.1f  enq %.0f  redo tiles %.2f  event (tile, query tile)s %.0f | cycles: events %.3g (%.1f %%)  drains %.3g (%.1f %%)  prologue %.3g (%.1f %%)  kernel %.3g\n",
                m[0], m[1], m[2], m[3], m[4], 100 * m[4] / m[6], m[5], 100 * m[5] / m[6], m[7], 100 * m[7] / m[6], m[6]);
         printf("   per event %.0f cycles, per drain %.0f cycles, per queued pair %.1f drain cycles; enq per query (whole search) %.1f\n", m[4] / (m[3] > 0 ? m[3] : 1), m[5] / (m[0] > 0 ? m[0] : 1), m[5] / (m[1] > 0 ? m[1] : 1), m[1] * nw / 64.0 / n * 64.0 / 64.0);
-    }
-#endif
-#if MCE_STATS && !PANEL
-    {
-        const size_t nw = (size_t)nunits * 8;
-        std::vector<double> hs(nw * 16);
-        CK(hipMemcpy(hs.data(), (char*)params + 128, nw * 128, hipMemcpyDeviceToHost));
-        double m[16] = {0};
-        for (size_t w = 0; w < nw; ++w) for (int k = 0; k < 8; ++k) { m[k] += hs[w * 8 + k] / nw; m[8 + k] += hs[nw * 8 + w * 8 + k] / nw; }
-        printf("per wave (mean): drains %.1f  enq %.0f (per query %.1f)  chain-steps %.1f  event_tiles %.0f | cycles: phaseA %.3g  drain(all) %.3g  barrier-wait %.3g  kernel %.3g\n",
-               m[0], m[1], m[1] / 64, m[2], m[3], m[4], m[5], m[7], m[6]);
-        printf("   sym: phaseR %.3g  events %.3g  publish %.3g cycles | row-side tested %.0f (per query %.1f)  appended %.0f (%.1f)  slot replacements %.0f (%.1f)  chain links %.0f (%.1f)\n",
-               m[8], m[9], m[14], m[10], m[10] / 64, m[11], m[11] / 64, m[12], m[12] / 64, m[13], m[13] / 64);
-        // by dispatch position: tenths of the blocks
-        for (int part = 0; part < 10; part += 1) {
-            const size_t b0 = (nw / 8) * part / 10, b1 = (nw / 8) * (part + 1) / 10;
-            double a[16] = {0}; size_t c = 0;
-            for (size_t b = b0; b < b1; ++b) for (int w = 0; w < 8; ++w) { for (int k = 0; k < 8; ++k) { a[k] += hs[(b * 8 + w) * 8 + k]; a[8 + k] += hs[nw * 8 + (b * 8 + w) * 8 + k]; } ++c; }
-            for (int k = 0; k < 16; ++k) a[k] /= c;
-            printf("   units %5zu..%5zu: kernel %.3g cyc (prologue %.3g, final drain %.3g) | drains %.1f enq/q %.1f events %.0f | phaseA+R %.3g (R %.3g) drain(all) %.3g events %.3g publish %.3g | row tested/q %.1f appended/q %.1f links/q %.1f\n",
-                   b0, b1, a[6], a[15], a[7], a[0], a[1] / 64, a[3], a[4], a[8], a[5], a[9], a[14], a[10] / 64, a[11] / 64, a[13] / 64);
-        }
     }
 #endif
     return 0;
