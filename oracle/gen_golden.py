@@ -15,7 +15,7 @@ SURVEY.md section 8c) and records, for seeded synthetic chains made by
   * a few sampled rows of the whitened samples and of DkNN.
 
 Outputs are data only (JSON/NPZ under tests/golden/).  No reference source is
-copied.  Usage:  python oracle/gen_golden.py [--small] [--medium] [--big] [--sym] [--host] [--c4 [--c4-n N]] [--c5 [--c5-n N]]
+copied.  Usage:  python oracle/gen_golden.py [--small] [--medium] [--big] [--sym] [--sym2] [--host] [--c4 [--c4-n N]] [--c5 [--c5-n N]]
 """
 from __future__ import annotations
 
@@ -186,6 +186,12 @@ SYM_CASES = [
     ("auto_n135000_d27_k10_corr", dict(seed=21, n=135_000, d=27, cov="corr"), dict(kmax=10), {}, None),
     ("auto_n70000_d45_k6", dict(seed=22, n=70_000, d=45), dict(kmax=6), {}, None),
     ("auto_n140000_d20_k5_corr_intw", dict(seed=23, n=140_000, d=20, cov="corr", weights="int"), dict(kmax=5), {}, None),
+]
+
+
+# 16 < K <= 32 neighbours at a size where the symmetric sweep is the automatic choice (two symmetric passes, round 5)
+SYM2_CASES = [
+    ("auto_n140000_d20_k21_corr", dict(seed=24, n=140_000, d=20, cov="corr"), dict(kmax=21), {}, None),
 ]
 
 
@@ -436,6 +442,7 @@ def main():
     ap.add_argument("--medium", action="store_true")
     ap.add_argument("--big", action="store_true")
     ap.add_argument("--sym", action="store_true")
+    ap.add_argument("--sym2", action="store_true")
     ap.add_argument("--host", action="store_true")
     ap.add_argument("--c4", action="store_true", help="BASELINE configs[3] at full size: hours of kd_tree on 8 cores")
     ap.add_argument("--c4-n", type=int, default=1_000_000, help="rows per chain for --c4 (smaller: a quick harness check)")
@@ -454,6 +461,8 @@ def main():
         gen_inmemory(ref, BIG_CASES, "big")
     if a.sym:
         gen_inmemory(ref, SYM_CASES, "sym")
+    if a.sym2:
+        gen_inmemory(ref, SYM2_CASES, "sym2")
     if a.host:
         gen_host_pins(ref)
     if a.c4:

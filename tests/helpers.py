@@ -25,7 +25,7 @@ DIST_RTOL = 1e-10
 
 def load_golden():
     out = {}
-    for tag in ("small", "medium", "big", "sym", "c4_n20000", "c4", "c5_n200000", "c5"):
+    for tag in ("small", "medium", "big", "sym", "sym2", "c4_n20000", "c4", "c5_n200000", "c5"):
         jp = os.path.join(GOLD, "evidence_%s.json" % tag)
         if not os.path.exists(jp):
             continue

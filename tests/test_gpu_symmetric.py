@@ -106,6 +106,19 @@ def test_symmetric_two_pass_ties_overflow_and_give_up(sym, monkeypatch):
         monkeypatch.delenv(name)
 
 
+def test_symmetric_two_pass_reproduces_the_reference_at_kmax_21(sym):
+    """the reference's own ln E for k = 1 .. 20 (kmax = 21: tests/golden/evidence_sym2.json, 140 k x 20) through the class; the
+    automatic mode takes the symmetric sweep in two passes at this size"""
+    from helpers import build_mce
+    from mcevidence_amd import _capi
+    case = G["auto_n140000_d20_k21_corr"]
+    _capi.set_sym_mode(_capi.SYM_AUTO)
+    lnE = build_mce(case).evidence(**case["ev"])
+    k = _capi.last_kernel()
+    assert "symmetric" in k and "two passes" in k, k
+    assert lnE.shape == (20,) and np.max(np.abs(lnE - np.array(case["lnE"]))) < LNE_TOL
+
+
 def _rel(a, b):
     return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300) * (b != 0)) if a.size else 0.0
 
