@@ -13,8 +13,8 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
     double* pd = reinterpret_cast<double*>(ws + p.off_pd);
     int* pi = reinterpret_cast<int*>(ws + p.off_pi);
     if (p.generic) {
-        const size_t lds = (size_t)mce::kGenTileRows * d * sizeof(double);
-        hipLaunchKernelGGL(mce::knn_generic_kernel, dim3((unsigned)p.nqblk), dim3(mce::kGenThreads), lds, st, dX, nq, dY, nr, (int)d,
+        const size_t lds = mce::generic_lds_bytes();        // (static in the kernel; reported in mce_last_kernel())
+        hipLaunchKernelGGL(mce::knn_generic_kernel, dim3((unsigned)p.nqblk), dim3(mce::kGenThreads), 0, st, dX, nq, dY, nr, (int)d,
                            (int)K, p.nq_pad, (self_mode == MCE_SELF_EXCLUDE) ? 1 : 0, self_offset, pd, pi);
         MCE_HIP(hipGetLastError());
         snprintf(g_last_kernel, sizeof(g_last_kernel), "knn_generic_kernel grid=%d block=%d lds=%zu", p.nqblk, mce::kGenThreads, lds);
