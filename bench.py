@@ -504,7 +504,7 @@ def main():
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--d", type=int, default=27)
     ap.add_argument("--kmax", type=int, default=10)
-    ap.add_argument("--cpu-sample", type=int, default=20000, help="queries timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=100000, help="queries timed on the CPU baseline (0 = skip): ~12 s of the reference's sklearn call on a 256-thread host")
     ap.add_argument("--mode", type=int, default=0, help="0 auto (fp16 filter + fp64 refine), 1 fp64 MFMA sweep")
     ap.add_argument("--no-extras", action="store_true", help="headline only: skip the C2/C4/C5 and fp64-mode sections")
     ap.add_argument("--extras-scale", type=float, default=1.0, help="rows of the C2/C4/C5 sections x this factor (functional checks; 1 = BASELINE.json sizes)")

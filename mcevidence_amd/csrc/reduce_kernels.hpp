@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
         if (L == 1 && !REFINE && self_mode != 1) {
             // ONE list of exact distances per query (pruned walk, symmetric sweep, unsplit exhaustive sweep): it IS the result,
             // ascending with ties by row -- no merge, and none of the indexed scratch arrays of the general path below (272 B
-            // of private memory per thread; C5's 10 M columns: 2.05 -> TODO ms)
+            // of private memory per thread; C5's 10 M columns: 2.05 -> 0.79 ms)
             for (int k = 0; k < K; ++k) {
                 const int64_t o = (int64_t)k * nq_pad + q;
                 const int i = k < KCAP ? part_i[o] : -1;

@@ -15,6 +15,9 @@
 #ifndef BKSEL
 #define BKSEL 9
 #endif
+#ifndef BQT
+#define BQT 2      // query tiles per wave (4: the wide form of the exhaustive sweep)
+#endif
 using namespace mce;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 int main(int argc, char** argv)
@@ -27,7 +30,7 @@ int main(int argc, char** argv)
     constexpr int D = DIM;
     constexpr int KST = f16_ksteps(D);
     constexpr int CT = f16_chunk_tiles(KST);
-    const int qpb = f16_qpb(BKCAP);
+    const int qpb = kHWaves * BQT * 32;
     const int nqblk = (int)((n + qpb - 1) / qpb);
     const int64_t nq_pad = (int64_t)nqblk * qpb;
     const int64_t nchunk = (n + CT * 32 - 1) / (CT * 32);
@@ -50,8 +53,8 @@ int main(int argc, char** argv)
     f16_pack_refs_kernel<<<(unsigned)std::min<int64_t>((nrow_pad + rpb - 1) / rpb, 2048), 256>>>(X, n, D, KST, nrow_pad, center, params, Yh);
     f16_pack_queries_kernel<<<(unsigned)((nq_pad + rpb - 1) / rpb), 256>>>(X, n, nq_pad, D, KST, center, params, Xh, qinfo);
     CK(hipDeviceSynchronize());
-    constexpr size_t LDS = f16_lds_bytes(KST, BKCAP);
-    auto kern = knn_f16_kernel<KST, BKCAP>;
+    constexpr size_t LDS = f16_lds_bytes(KST, BKCAP, false, BQT);
+    auto kern = knn_f16_kernel<KST, BKCAP, false, false, 0, BKCAP, BQT>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int r = 0; r < reps; ++r) {
@@ -62,7 +65,7 @@ int main(int argc, char** argv)
                                                 f16_seed_cfg((nchunk + rsplit - 1) / rsplit, CT, BKSEL + 1, seed_rows, MCE_H_SEED_SHARE, seed_tg), SymParams(), (float*)nullptr);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        printf("D=%d KST=%d BKCAP=%d K=%d CT=%d ablate=%d lds=%zu n=%lld rsplit=%d grid=%d: %.2f ms  %.3f Mq/s  %.1f TF(f16 flops)\n", D, KST, BKCAP, BKSEL, CT, MCE_ABLATE, LDS,
+        printf("D=%d KST=%d BKCAP=%d K=%d QT=%d CT=%d ablate=%d lds=%zu n=%lld rsplit=%d grid=%d: %.2f ms  %.3f Mq/s  %.1f TF(f16 flops)\n", D, KST, BKCAP, BKSEL, BQT, CT, MCE_ABLATE, LDS,
                (long long)n, rsplit, nqblk * rsplit, ms, n / ms / 1e3, (double)n * n * 32.0 * KST / ms / 1e9);
     }
     {   // sanity of the lists: K-th entries finite, and a checksum to compare builds / seed settings
