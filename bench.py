@@ -84,7 +84,7 @@ def profile_counters(kernel_desc, library_hash=None, tag=""):
     if name == "knn_f16_kernel" and "pruned" in kernel_desc:
         wants = ("%sILi%sELi%sELb1E" % (name, p1, p2),)
     elif name == "knn_f16_kernel" and "panel-kernel" in kernel_desc:
-        wants = ("knn_panel_kernelILi%sELi%sE" % (p1, p2), "knn_panel_kernel<%s, %s>" % (p1, p2))
+        wants = ("knn_panel_kernelILi%sELi%sE" % (p1, p2), "knn_panel_kernel<%s, %s," % (p1, p2), "knn_panel_kernel<%s, %s>" % (p1, p2))
     elif name == "knn_f16_kernel":
         sy = "2" if " symmetric" in kernel_desc else "0"
         wants = ("%sILi%sELi%sELb0ELb0ELi%sE" % (name, p1, p2, sy),) + (("%sILi%sELi%sELb0ELb0EE" % (name, p1, p2),) if sy == "0" else ())

@@ -27,7 +27,8 @@ constexpr int kPruneHeavyMinBlocks = 64, kPruneHeavyCount = 700, kPruneHeavyMaxS
 constexpr double kPruneHeavyFullRounds = 10.0;
 constexpr int kPruneHeavySplit = 4, kPruneHeavyMaxSplit = 8;
 constexpr int kPruneWaveQueries = mce::kHQT * 32;     // list columns per workgroup of the walk
-constexpr int kWideMinBlocks = 4 * kAssumedCUs;       // query blocks from which the exhaustive one-k-step sweep takes its wide form (make_plan)
+constexpr int kWideMinBlocks = 480;                    // query blocks from which the exhaustive one-k-step sweep takes its wide form (make_plan):
+                                                       // ~one full round of the wider workgroups (two ranks' and four ranks' shards of C4: 977, 489 blocks)
 // side lists for split waves are part of a plan only when the split can happen (44 % of the list arrays: ~630 MB at C5)
 bool prune_heavy_enabled()
 {
@@ -164,7 +165,7 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     }
     p.nqblk = (int)std::max<int64_t>(1, (nq + qpb - 1) / qpb);
     // One-k-step sweeps of short lists over many queries: four query tiles per wave, a workgroup = TWO query blocks (knn_f16.hpp,
-    // QTT = 4: C4 41.5 -> 37.7 ms).  From kWideMinBlocks blocks: the chip then still gets two full rounds of the wider workgroups
+    // QTT = 4: C4 41.5 -> 37.7 ms).  From kWideMinBlocks blocks: the chip then still gets about a full round of the wider workgroups
     // (C2's 196 blocks would leave 60 % of the CUs idle).  Decided on the sizes alone, so that the workspace query and the call
     // agree; which sweep runs (pruned walk, symmetric, exhaustive) is settled later -- only the exhaustive one has a wide form.
     p.wide_ok = f16 && !p.twopass && p.KST == 1 && p.vh->launch_wide && p.nqblk >= kWideMinBlocks && nr <= ((int64_t)1 << 25) && read_tuning().wide;

@@ -219,9 +219,10 @@ def test_trailing_round_split_is_bit_identical(nq, nr, d, K, same, monkeypatch):
         _capi.set_prune_mode(0)
 
 
-@pytest.mark.parametrize("nq,nr,d,K,same", [(525724, 30000, 15, 4, False), (600000, 600000, 6, 3, True), (530000, 20000, 1, 1, False), (524289, 45000, 10, 2, False)])
+@pytest.mark.parametrize("nq,nr,d,K,same", [(525724, 30000, 15, 4, False), (600000, 600000, 6, 3, True), (530000, 20000, 1, 1, False), (524289, 45000, 10, 2, False),
+                                            (246000, 60000, 15, 4, False)])        # (481 blocks: just over the threshold, padded to 482)
 def test_wide_sweep_is_bit_identical(nq, nr, d, K, same, monkeypatch):
-    """Round 5: one-k-step sweeps of short lists over 1024 or more query blocks run FOUR query tiles per wave (a workgroup =
+    """Round 5: one-k-step sweeps of short lists over 480 or more query blocks run FOUR query tiles per wave (a workgroup =
     two query blocks; knn_f16.hpp, QTT = 4).  Neighbours, distances and the fused sums must equal the two-tile kernel's
     (MCE_WIDE=0) to the bit -- odd block counts (padded to even), self-exclusion on one buffer, d = 1 -- and the oracle's on
     sampled rows."""
