@@ -189,6 +189,28 @@ int mce_knn_dotp_part_f64_dev(const double *dY, int64_t nr, int32_t d, int32_t k
 int mce_knn_dotp_part_f64(const double *Y, int64_t nr, int32_t d, int32_t kmax, int32_t part, int32_t nparts,
                           const double *w, const double *fs, double *dotp, int32_t device);
 
+/* The ALL-PAIRS-ONCE partition of the same sums (round 5; optional -- parallel.py takes it when MCE_PAIRS_ONCE=1): where one GPU
+ * would run the one-pass symmetric sweep (mce_pairs_once_blocks > 0), W ranks can multiply every pair of rows once per NODE
+ * instead of once per side: rank r owns the sorted 512-row blocks r, r + W, ... and runs the single-GPU units of those blocks
+ * (a block against every block below it, both gates on), and ships the candidates it found for rows it does not own to their owners.  Three calls on one workspace (sized as for
+ * mce_knn_dotp_part_f64_dev), the collectives between them are the caller's (no RCCL dependency in this library):
+ *   sweep   -> d_counts[nparts]: 16-byte candidates for every rank (own entry 0); d_flags[blocks]: blocks of other ranks whose
+ *              candidates did not fit here (the owner searches such a block again: all-reduce the flags with MAX);
+ *   export  -> d_send: the candidates, densely, ordered by destination rank (sum of d_counts entries of 16 bytes);
+ *              exchange them (all_to_all with the counts as split sizes);
+ *   finish  <- d_recv / nrecv: what arrived; d_flags: the reduced flags; -> d_dotp[kmax]: the sums over this rank's own rows
+ *              (NaN if an entry arrived for a row the rank does not own: ranks that disagree about the partition).
+ * Adding the nparts results gives mce_knn_dotp_f64_dev's dotp up to summation order.  Replaces the same reference lines as
+ * mce_knn_dotp_f64_dev (MCEvidence.py:1093-1117) for one rank's rows. */
+int32_t mce_pairs_once_blocks(int64_t nr, int32_t d, int32_t kmax);
+int mce_pairs_once_sweep_dev(const double *dY, int64_t nr, int32_t d, int32_t kmax, int32_t part, int32_t nparts,
+                             int64_t *d_counts, int32_t *d_flags, void *ws, size_t ws_bytes, void *stream);
+int mce_pairs_once_export_dev(int64_t nr, int32_t d, int32_t kmax, int32_t part, int32_t nparts, void *d_send, void *ws,
+                              size_t ws_bytes, void *stream);
+int mce_pairs_once_finish_dev(const double *dY, int64_t nr, int32_t d, int32_t kmax, int32_t part, int32_t nparts,
+                              const double *d_w, const double *d_fs, const void *d_recv, int64_t nrecv,
+                              const int32_t *d_flags, double *d_dotp, void *ws, size_t ws_bytes, void *stream);
+
 /* Name of the dominant kernel last launched by this thread and its launch
  * geometry (for bench.py / profiles): "knn_mfma_f64<KS=7,KCAP=12>" etc. */
 const char *mce_last_kernel(void);

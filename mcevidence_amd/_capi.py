@@ -70,6 +70,11 @@ SIGNATURES = {
                                               _P, _P, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _c.c_int32]),
     "mce_knn_dotp_part_f64_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _c.c_size_t, _P]),
     "mce_knn_dotp_part_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_int32]),
+    "mce_pairs_once_blocks": (_c.c_int32, [_c.c_int64, _c.c_int32, _c.c_int32]),
+    "mce_pairs_once_sweep_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_size_t, _P]),
+    "mce_pairs_once_export_dev": (_c.c_int, [_c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _c.c_size_t, _P]),
+    "mce_pairs_once_finish_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_int64, _P, _P, _P,
+                                             _c.c_size_t, _P]),
     "mce_verify_workspace_bytes": (_c.c_size_t, [_c.c_int32, _c.c_int32]),
     "mce_verify_knn_f64_dev": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int64, _P, _c.c_int32, _c.c_int32,
                                           _c.c_uint64, _P, _P, _c.c_size_t, _P]),
@@ -516,6 +521,25 @@ def dotp_dev(d_dist, nq, ld, k0, kmax, d, d_w, d_fs, d_dotp, ws, ws_bytes, strea
 
 def knn_dotp_part_dev(dY, nr, d, kmax, part, nparts, d_w, d_fs, d_dotp, ws, ws_bytes, stream=0):
     check(load().mce_knn_dotp_part_f64_dev(dY, nr, d, kmax, part, nparts, d_w, d_fs, d_dotp, ws, ws_bytes, stream or None))
+
+
+def pairs_once_blocks(nr, d, kmax):
+    """Sorted 512-row blocks of the all-pairs-once partition for this shape (the length of its flags array); 0: the shape
+    does not take the one-pass symmetric sweep and the partition does not exist (``mce_pairs_once_blocks``)."""
+    return int(load().mce_pairs_once_blocks(int(nr), int(d), int(kmax)))
+
+
+def pairs_once_sweep_dev(dY, nr, d, kmax, part, nparts, d_counts, d_flags, ws, ws_bytes, stream=0):
+    check(load().mce_pairs_once_sweep_dev(dY, nr, d, kmax, part, nparts, d_counts, d_flags, ws, ws_bytes, stream or None))
+
+
+def pairs_once_export_dev(nr, d, kmax, part, nparts, d_send, ws, ws_bytes, stream=0):
+    check(load().mce_pairs_once_export_dev(nr, d, kmax, part, nparts, d_send or None, ws, ws_bytes, stream or None))
+
+
+def pairs_once_finish_dev(dY, nr, d, kmax, part, nparts, d_w, d_fs, d_recv, nrecv, d_flags, d_dotp, ws, ws_bytes, stream=0):
+    check(load().mce_pairs_once_finish_dev(dY, nr, d, kmax, part, nparts, d_w, d_fs, d_recv or None, nrecv, d_flags, d_dotp, ws, ws_bytes,
+                                           stream or None))
 
 
 def knn_dotp_dev(dX, nq, dY, nr, d, kmax, k0, self_offset, d_w, d_fs, d_dotp, d_dist_out, ws, ws_bytes, stream=0):

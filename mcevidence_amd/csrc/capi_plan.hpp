@@ -59,6 +59,7 @@ struct Plan {
     int part = 0, nparts = 1;                 // pruned walk over the waves part, part + nparts, ... of the dispatch order only; symmetric sweep: the
                                               // contiguous range of sorted blocks [sym_qb_lo, sym_qb_hi) (one rank's share)
     int sym_qb_lo = 0, sym_qb_hi = 0;         // set by run_search when the symmetric sweep ran
+    bool apo = false;                         // symmetric sweep as one rank's share of the all-pairs-once partition (capi_apo.hpp): run_search stops after the sweep
     int64_t pl_nr = 0;                        // reference rows the plan was made for
     mce::PruneLayout pl;
     size_t off_prune = 0;

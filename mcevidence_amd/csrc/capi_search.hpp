@@ -5,6 +5,23 @@ namespace {
 
 double ln_unit_ball(int d) { return 0.5 * d * std::log(M_PI) - std::lgamma(1.0 + 0.5 * d); }
 
+// the row-side candidates of the blocks [qb_lo, qb_hi) -- their buckets -- folded into their lists
+// (the blocks qb_lo, qb_lo + stride, ... below qb_hi)
+hipError_t launch_sym_merge(int KCAP, double* pd, int* pi, int64_t nq_pad, const mce::SymParams& sym, int qb_lo, int qb_hi, hipStream_t st, int stride = 1)
+{
+    const int nb = qb_hi > qb_lo ? (qb_hi - qb_lo + stride - 1) / stride : 0;
+    if (nb <= 0) return hipSuccess;
+    const dim3 g((unsigned)nb), b(mce::kSymMergeThreads);
+    static_assert(mce::kSymMergeThreads == mce::f16_qpb(4), "one merge block per query block");
+    switch (KCAP) {
+        case 4: hipLaunchKernelGGL(mce::sym_merge_kernel<4>, g, b, 0, st, pd, pi, nq_pad, sym.bucket_cnt, sym.bucket_flag, sym.bucket, sym.cap, qb_lo, stride); break;
+        case 8: hipLaunchKernelGGL(mce::sym_merge_kernel<8>, g, b, 0, st, pd, pi, nq_pad, sym.bucket_cnt, sym.bucket_flag, sym.bucket, sym.cap, qb_lo, stride); break;
+        case 12: hipLaunchKernelGGL(mce::sym_merge_kernel<12>, g, b, 0, st, pd, pi, nq_pad, sym.bucket_cnt, sym.bucket_flag, sym.bucket, sym.cap, qb_lo, stride); break;
+        default: hipLaunchKernelGGL(mce::sym_merge_kernel<16>, g, b, 0, st, pd, pi, nq_pad, sym.bucket_cnt, sym.bucket_flag, sym.bucket, sym.cap, qb_lo, stride); break;
+    }
+    return hipGetLastError();
+}
+
 // pack + search; leaves the lane/split lists in the workspace
 int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t nr, int32_t d, int32_t K,
                int32_t self_mode, int64_t self_offset, char* ws, hipStream_t st)
@@ -226,14 +243,20 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             // One rank's share of a multi-GPU partition: the contiguous range of sorted blocks [qb_lo, qb_hi).  Their tiles
             // carry the row-side gate; everybody else's rows are swept column side only (sym_types.hpp, PanelGeom) -- no
             // exchange between the ranks, each ends with complete lists for its own rows.  Only they need a prepass bound.
-            const int qb_lo = p.nparts > 1 ? (int)((int64_t)p.nqblk * p.part / p.nparts) : 0;
-            const int qb_hi = p.nparts > 1 ? (int)((int64_t)p.nqblk * (p.part + 1) / p.nparts) : p.nqblk;
+            // (the all-pairs-once partition, p.apo: every nparts-th block instead -- the geometry's stride, below; the prepass then
+            //  covers all blocks: a rank handles the rows of every lower block on the row side)
+            const int qb_lo = p.nparts > 1 && !p.apo ? (int)((int64_t)p.nqblk * p.part / p.nparts) : 0;
+            const int qb_hi = p.nparts > 1 && !p.apo ? (int)((int64_t)p.nqblk * (p.part + 1) / p.nparts) : p.nqblk;
             p.sym_qb_lo = qb_lo;
             p.sym_qb_hi = qb_hi;
             const bool panel_kernel = !tun.sym_kernel_f16 || p.nparts > 1 || p.twopass;
             mce::PanelGeom geom;
             geom.qb_lo = qb_lo; geom.qb_hi = qb_hi; geom.tpb = mce::kHWaves * mce::kHQT; geom.ct = p.CT; geom.tpp = a.sym.panel * p.CT; geom.sym_on = 1;
             geom.ntiles = (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1);
+            // the all-pairs-once partition (capi_apo.hpp; sym_types.hpp): the single-GPU units of the blocks part, part + nparts, ...;
+            // this call ends with the sweep -- repair and merge follow the exchange of the row-side candidates
+            const bool apo = p.apo && p.nparts > 1 && !p.twopass && panel_kernel;
+            if (apo) { geom.blk_first = p.part; geom.blk_stride = p.nparts; }
             // 16 < K <= 32 (round 5): TWO symmetric passes over 16-entry lists, as the exhaustive sweep does it (knn_f16.hpp, LOWER) --
             // the first finds every row's 16 nearest (lists A), the second the next K - 16 beyond them (lists B: knn_panel.hpp,
             // LOWER); the merge takes the K best of A and B.  The second pass needs bounds on the K-th distance: a prepass
@@ -285,18 +308,9 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
                 }
                 rc = pass == 0 ? prof_end() : MCE_OK;
                 if (rc != MCE_OK) return rc;
+                if (apo) break;             // (repair and merge: pairs_once_finish, after the exchange)
                 MCE_HIP((lower ? p.vh->launch_sym_repair_lower : p.vh->launch_sym_repair)(a, st));      // blocks whose bucket overflowed (normally none: every workgroup exits at once)
-                {
-                    const dim3 g((unsigned)std::max(1, qb_hi - qb_lo)), b(mce::kSymMergeThreads);
-                    static_assert(mce::kSymMergeThreads == mce::f16_qpb(4), "one merge block per query block");
-                    switch (p.KCAP) {
-                        case 4: hipLaunchKernelGGL(mce::sym_merge_kernel<4>, g, b, 0, st, pdp, pip, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
-                        case 8: hipLaunchKernelGGL(mce::sym_merge_kernel<8>, g, b, 0, st, pdp, pip, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
-                        case 12: hipLaunchKernelGGL(mce::sym_merge_kernel<12>, g, b, 0, st, pdp, pip, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
-                        default: hipLaunchKernelGGL(mce::sym_merge_kernel<16>, g, b, 0, st, pdp, pip, p.nq_pad, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.bucket, a.sym.cap, qb_lo); break;
-                    }
-                    MCE_HIP(hipGetLastError());
-                }
+                MCE_HIP(launch_sym_merge(p.KCAP, pdp, pip, p.nq_pad, a.sym, qb_lo, qb_hi, st));
             }
             p.sym_active = true;
             p.L = npass;
@@ -323,8 +337,8 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
                 g_last_flops_main = tiles * 16.0 * 1024.0 * 32.0 * p.KST;
             }
             g_last_flops_all = g_last_flops_main + (double)(seed_used & 0xffff) * p.CT * (double)(qb_hi - qb_lo) * 16.0 * 1024.0 * 32.0 * p.KST;
-            snprintf(g_last_kernel, sizeof(g_last_kernel), "%s symmetric%s%s grid=%d block=%d lds=%zu qt=%d ct=%d panel=%d seed=%dx%d/%d bucket=%d", p.vh->name, panel_kernel ? " panel-kernel" : "",
-                     p.twopass ? " two passes" : "", sym_units,
+            snprintf(g_last_kernel, sizeof(g_last_kernel), "%s symmetric%s%s%s grid=%d block=%d lds=%zu qt=%d ct=%d panel=%d seed=%dx%d/%d bucket=%d", p.vh->name, panel_kernel ? " panel-kernel" : "",
+                     p.twopass ? " two passes" : "", geom.blk_stride > 1 ? " pairs-once" : "", sym_units,
                      mce::kHThreads, panel_kernel ? p.vh->lds_bytes_panel : p.vh->lds_bytes_sym, p.QT, p.CT, a.sym.panel, seed_used & 0xffff, (seed_used >> 16) & 0xfff, (seed_used >> 28) & 3, p.sl.cap);
             return MCE_OK;
         }
@@ -407,7 +421,13 @@ int launch_merge(const Plan& p, bool write_dist, bool fuse, const double* dX, co
     const int nunits = wave_parts ? p.nqblk * mce::kHWaves : p.nqblk;
     int64_t ncol = nq;
     int64_t col0 = 0, col1 = INT64_MAX;
-    if (p.sym_active && p.nparts > 1) {         // one rank's blocks of a symmetric partition: a contiguous range of list columns
+    const int* border = p.prune ? reinterpret_cast<const int*>(ws + p.off_prune + p.pl.border) : nullptr;
+    if (p.sym_active && p.nparts > 1 && p.apo) {
+        // the all-pairs-once partition: every nparts-th block of list columns, enumerated through the identity table the
+        // finish call left in the `done` array (the kernel's border path)
+        ncol = (int64_t)((nunits - p.part + p.nparts - 1) / p.nparts) * qpb;
+        border = reinterpret_cast<const int*>(ws + p.off_sym + p.sl.done);
+    } else if (p.sym_active && p.nparts > 1) {         // one rank's blocks of a symmetric partition: a contiguous range of list columns
         col0 = (int64_t)p.sym_qb_lo * qpb;
         col1 = std::min<int64_t>((int64_t)p.sym_qb_hi * qpb, nq);
         ncol = std::max<int64_t>(col1 - col0, 0);
@@ -421,7 +441,6 @@ int launch_merge(const Plan& p, bool write_dist, bool fuse, const double* dX, co
     const int* qperm = nullptr;
     if (p.prune) qperm = reinterpret_cast<const int*>(ws + p.off_prune + (same_set ? p.pl.perm_r : p.pl.perm_q));
     if (p.sym_active) qperm = reinterpret_cast<const int*>(ws + p.off_sym + p.sl.perm);     // list column = sorted position
-    const int* border = p.prune ? reinterpret_cast<const int*>(ws + p.off_prune + p.pl.border) : nullptr;
 #define MCE_MERGE(W, F, R)                                                                                          \
     hipLaunchKernelGGL((mce::merge_lists_kernel<W, F, R>), dim3(blocks), dim3(mce::kRedThreads), 0, st, pd, pi, p.L,  \
                        p.KCAP, nq, p.nq_pad, dX, dY, (int)d, K, self_mode, self_offset, d_dist, d_idx, K, k0, kmax, \

@@ -157,6 +157,7 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
         PanelGeom g;
         g.qb_lo = a->geom.qb_lo; g.qb_hi = a->geom.qb_hi; g.tpb = a->geom.tpb; g.tpp = a->geom.tpp;
         g.ct = a->geom.ct; g.ntiles = a->geom.ntiles; g.sym_on = a->geom.sym_on;
+        g.blk_first = a->geom.blk_first; g.blk_stride = a->geom.blk_stride;       // (one rank's blocks of the all-pairs-once partition)
         panel_unit_decode((int)blockIdx.x, g, sym_p, qblk);
         panel_unit_tiles(sym_p, qblk, g, t_lo, t_hi);
         useq = panel_unit_seq(sym_p, qblk, g);

@@ -248,13 +248,13 @@ constexpr int kSymMergeBatch = 2048;
 template <int KCAP>
 __global__ __launch_bounds__(kSymMergeThreads) void sym_merge_kernel(double* __restrict__ part_d, int* __restrict__ part_i, int64_t nq_pad,
                                                                      const int* __restrict__ bucket_cnt, const int* __restrict__ bucket_flag,
-                                                                     const SymEntry* __restrict__ bucket, int cap, int b0)
+                                                                     const SymEntry* __restrict__ bucket, int cap, int b0, int bstride)
 {
     __shared__ double e_d[kSymMergeBatch];
     __shared__ int e_i[kSymMergeBatch];
     __shared__ int e_nx[kSymMergeBatch];
     __shared__ int head[kSymMergeThreads];
-    const int b = b0 + blockIdx.x, t = threadIdx.x;      // (b0: first block of the launch -- one rank's range of a partition)
+    const int b = b0 + bstride * blockIdx.x, t = threadIdx.x;      // (b0, bstride: the launch's blocks -- one rank's range of a partition: stride 1; its every W-th block: W)
     if (bucket_flag[b]) return;
     int n = bucket_cnt[b];
     if (n <= 0) return;

@@ -80,6 +80,8 @@ struct PanelGeom {
     int ct = 0;                    // tiles per chunk
     int ntiles = 0;                // 32-row tiles holding reference rows, rounded up to even
     int sym_on = 0;
+    int blk_first = 0, blk_stride = 0;   // blk_stride = W > 1: only the blocks blk_first, blk_first + W, ... of [qb_lo, qb_hi) have units (one rank's share of
+                                   // the all-pairs-once partition, below); needs qb_lo = 0 and sym_on = 1
 };
 MCE_HD inline int panel_r1(const PanelGeom& g) { return g.sym_on ? (g.tpb * g.qb_hi < g.ntiles ? g.tpb * g.qb_hi : g.ntiles) : g.ntiles; }
 MCE_HD inline int panel_r2(const PanelGeom& g) { return g.sym_on ? g.tpb * g.qb_hi : g.ntiles; }
@@ -98,18 +100,36 @@ MCE_HD inline int panel_amin(const PanelGeom& g, int p)
     const int amin = (int)(((int64_t)p * g.tpp) / g.tpb);
     return amin > g.qb_lo ? amin : g.qb_lo;
 }
+// The all-pairs-once partition of auto evidence over W ranks (round 5; capi_apo.hpp): rank r owns the sorted blocks r, r + W,
+// r + 2W, ... and runs exactly the single-GPU units of THOSE blocks -- block a sweeps the tiles [0, tpb (a + 1)) with both
+// gates on -- so every pair of blocks {a, b}, b < a, is multiplied once per NODE, by the owner of a, from the side of the
+// rows farther from the mean (the orientation the symmetric sweep is built for: the row side then belongs to the denser
+// rows, whose bounds are tight).  The row-side candidates it finds for rows of blocks it does not own travel to their
+// owners afterwards.  Work per block grows with a; the cyclic ownership balances it to within one block's share.
+// number of blocks with units among [amin, qb_hi)
+MCE_HD inline int panel_nown(const PanelGeom& g, int amin)
+{
+    if (g.blk_stride <= 1) return g.qb_hi - amin;
+    const int total = g.qb_hi > g.blk_first ? (g.qb_hi - g.blk_first + g.blk_stride - 1) / g.blk_stride : 0;
+    const int skip = amin <= g.blk_first ? 0 : (amin - g.blk_first + g.blk_stride - 1) / g.blk_stride;
+    return total > skip ? total - skip : 0;
+}
 MCE_HD inline int panel_unit_count(const PanelGeom& g)
 {
     int total = 0;
     const int np = panel_n1(g) + panel_n2(g);
-    for (int p = 0; p < np; ++p) total += g.qb_hi - panel_amin(g, p);
+    for (int p = 0; p < np; ++p) total += panel_nown(g, panel_amin(g, p));
     return total;
 }
 MCE_HD inline void panel_unit_decode(int u, const PanelGeom& g, int& p, int& a)
 {
     for (p = 0;; ++p) {
-        const int cnt = g.qb_hi - panel_amin(g, p);
-        if (u < cnt) { a = g.qb_hi - 1 - u; return; }
+        const int cnt = panel_nown(g, panel_amin(g, p));
+        if (u < cnt) {
+            // (from the last block with units down)
+            a = g.blk_stride <= 1 ? g.qb_hi - 1 - u : g.blk_first + g.blk_stride * (panel_nown(g, 0) - 1 - u);
+            return;
+        }
         u -= cnt;
     }
 }

@@ -179,6 +179,119 @@ def symmetric_partition_rows(Y, world, rank, block=512):
     return order[lo * block: min(hi * block, n)]
 
 
+def pairs_once_enabled():
+    """``MCE_PAIRS_ONCE=1``: auto evidence of a set large enough for the symmetric sweep takes the all-pairs-once partition
+    (``pairs_once_knn_dotp``) instead of the exchange-free one."""
+    import os
+    return os.environ.get("MCE_PAIRS_ONCE") == "1"
+
+
+def _exchange_rows(send, in_splits, out_splits, group):
+    """all_to_all of rows of a [n, 2] float64 tensor (16-byte candidates), ``in_splits[s]`` rows to rank s, ``out_splits[s]``
+    from it.  RCCL moves device tensors; any other backend goes through the host."""
+    import torch
+    import torch.distributed as dist
+    nccl = dist.get_backend(group) == "nccl"
+    src = send if nccl else send.cpu()
+    recv = torch.empty((int(sum(out_splits)), 2), dtype=torch.float64, device=src.device)
+    dist.all_to_all_single(recv, src, [int(v) for v in out_splits], [int(v) for v in in_splits], group=group)
+    return recv if nccl else recv.to(send.device)
+
+
+class _HipPairsOnce:
+    """The three library calls of the all-pairs-once partition on this rank's GPU (device tensors through torch)."""
+
+    def __init__(self, Y, weight, fs, kmax):
+        import torch
+        from . import _capi
+        self.capi, self.torch = _capi, torch
+        self.n, self.d = Y.shape
+        self.kmax = int(kmax)
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        self.Y = torch.from_numpy(Y).to(self.dev)
+        self.w = torch.from_numpy(np.ascontiguousarray(weight, dtype=np.float64)).to(self.dev)
+        self.fs = torch.from_numpy(np.ascontiguousarray(fs, dtype=np.float64)).to(self.dev)
+        self.wsb = _capi.knn_workspace_bytes(self.n, self.n, self.d, self.kmax - 1) + _capi.dotp_workspace_bytes(self.n, self.kmax)
+        self.ws = torch.empty(self.wsb, dtype=torch.uint8, device=self.dev)
+        self.st = torch.cuda.current_stream().cuda_stream
+
+    def blocks(self):
+        return self.capi.pairs_once_blocks(self.n, self.d, self.kmax)
+
+    def sweep(self, rank, world, nblk):
+        torch = self.torch
+        self.rank, self.world = rank, world
+        counts = torch.zeros(world, dtype=torch.int64, device=self.dev)
+        flags = torch.zeros(nblk, dtype=torch.int32, device=self.dev)
+        self.capi.pairs_once_sweep_dev(self.Y.data_ptr(), self.n, self.d, self.kmax, rank, world, counts.data_ptr(), flags.data_ptr(),
+                                       self.ws.data_ptr(), self.wsb, self.st)
+        return counts, flags
+
+    def export(self, total):
+        send = self.torch.empty((max(total, 1), 2), dtype=self.torch.float64, device=self.dev)
+        self.capi.pairs_once_export_dev(self.n, self.d, self.kmax, self.rank, self.world, send.data_ptr() if total else 0, self.ws.data_ptr(),
+                                        self.wsb, self.st)
+        return send[:total]
+
+    def finish(self, recv, flags):
+        out = self.torch.zeros(self.kmax, dtype=self.torch.float64, device=self.dev)
+        recv = recv.to(self.dev).contiguous()
+        flags = flags.to(self.dev).contiguous()
+        nrecv = int(recv.shape[0])
+        self.capi.pairs_once_finish_dev(self.Y.data_ptr(), self.n, self.d, self.kmax, self.rank, self.world, self.w.data_ptr(), self.fs.data_ptr(),
+                                        recv.data_ptr() if nrecv else 0, nrecv, flags.data_ptr(), out.data_ptr(), self.ws.data_ptr(), self.wsb, self.st)
+        return out.cpu().numpy()
+
+
+def pairs_once_knn_dotp(Y, weight, fs, kmax, group=None, stats=None, impl=None):
+    """Auto evidence over the ranks with every pair of rows multiplied ONCE PER NODE (``include/mcevidence_hip.h``:
+    ``mce_pairs_once_*``): this rank runs the single-GPU units of every W-th sorted block (a block against
+    all blocks below it, both gates on), the candidates found for other ranks' rows travel to their owners in ONE all_to_all (16 bytes
+    each; its split sizes in an all_gather of W counts, the overflow flags in an all_reduce(MAX)), every rank folds what it
+    receives into its own lists and sums its own rows' terms; the usual all-reduce(sum) of ``kmax`` doubles ends the call.
+    Returns the full ``dotp``.  ``stats``: a dict that receives the counts (entries sent / received, bytes).
+    ``impl``: the per-rank compute (default: the HIP library; the CPU tests pass a host restatement)."""
+    import torch
+    import torch.distributed as dist
+    group = _GROUP if group is None else group
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    if impl is None:
+        impl = _HipPairsOnce(Y, weight, fs, kmax)
+    nblk = impl.blocks()
+    if nblk < world or world < 2:
+        raise ValueError("pairs-once partition: not applicable to %d x %d, kmax %d on %d ranks" % (Y.shape[0], Y.shape[1], kmax, world))
+    nccl = dist.get_backend(group) == "nccl"
+    counts, flags = impl.sweep(rank, world, nblk)
+    cdev = counts.device if nccl else torch.device("cpu")
+    # split sizes: every rank's counts to everybody (W x W integers); overflow flags: MAX over the ranks
+    mine = counts.to(cdev)
+    table = [torch.zeros(world, dtype=torch.int64, device=cdev) for _ in range(world)]
+    dist.all_gather(table, mine, group=group)
+    fl = flags.to(cdev)
+    dist.all_reduce(fl, op=dist.ReduceOp.MAX, group=group)
+    in_splits = [int(v) for v in mine.tolist()]
+    out_splits = [int(table[s][rank]) for s in range(world)]
+    if in_splits[rank] != 0:
+        raise RuntimeError("pairs-once partition: a rank has candidates addressed to itself")
+    send = impl.export(sum(in_splits))
+    recv = _exchange_rows(send, in_splits, out_splits, group)
+    part = impl.finish(recv, fl)
+    if stats is not None:
+        stats.update(sent=int(sum(in_splits)), received=int(recv.shape[0]), bytes_sent=16 * int(sum(in_splits)), blocks=nblk, flagged=int(fl.sum().item()))
+    failed = None if np.all(np.isfinite(part)) else 1.0
+    vec = np.zeros(int(kmax) + 1)
+    if failed is None:
+        vec[:int(kmax)] = part
+    else:
+        vec[int(kmax)] = 1.0
+    vec = _reduce_partial(vec, group)
+    if vec[int(kmax)] != 0.0:
+        raise RuntimeError("mcevidence_amd: pairs-once partition: the ranks disagree about who owns which rows (%d of %d)" % (int(vec[int(kmax)]), world))
+    return vec[:int(kmax)]
+
+
 def sharded_knn_dotp(X, Y, weight, fs, kmax, k0, want_dist=False, group=None, local_fn=None, verify=True, part_fn=None):
     """Multi-rank fused kNN + reduction.  Every rank passes the FULL arrays (they are
     replicated host-side, as the reference set must be anyway) and gets the full
@@ -204,6 +317,8 @@ def sharded_knn_dotp(X, Y, weight, fs, kmax, k0, want_dist=False, group=None, lo
         if part_fn is None:
             from . import _capi
             dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
+            if pairs_once_enabled() and world >= 2 and _capi.pairs_once_blocks(X.shape[0], X.shape[1], kmax) >= world:
+                return pairs_once_knn_dotp(X, weight, fs, kmax, group), None
             part = _capi.knn_dotp_part(X, weight, fs, kmax, rank, world, device=dev)
         else:
             part = part_fn(X, weight, fs, kmax, rank, world)

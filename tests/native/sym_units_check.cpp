@@ -86,5 +86,47 @@ int main()
                                     }
                             }
     printf("ok %ld panel units\n", pchecked);
+    // ---- the all-pairs-once partition (PanelGeom.blk_stride): over all ranks every block appears on exactly one rank, with the
+    // single-GPU units of that block -- tiles [0, min(tpb (a + 1), ntiles)) -- handed over in sequence
+    long schecked = 0;
+    for (int nqblk = 2; nqblk <= 61; nqblk += (nqblk < 12 ? 1 : 7))
+        for (int ct : {12, 48})
+            for (int panel : {1, 3, 96})
+                for (int W = 2; W <= 9; ++W)
+                    for (int cut = 0; cut < 2; ++cut) {
+                        const int ntiles = 16 * nqblk - (cut ? 6 : 0);
+                        std::vector<int> owner_seen(nqblk, -1), next_lo(nqblk, 0), seq(nqblk, 0);
+                        long units_all = 0;
+                        for (int r = 0; r < W; ++r) {
+                            mce::PanelGeom g;
+                            g.tpb = 16; g.ct = ct; g.tpp = panel * ct; g.ntiles = ntiles; g.sym_on = 1;
+                            g.qb_lo = 0; g.qb_hi = nqblk; g.blk_first = r; g.blk_stride = W;
+                            const int n = mce::panel_unit_count(g);
+                            units_all += n;
+                            int lp = 0, la = 1 << 30;
+                            for (int u = 0; u < n; ++u) {
+                                int p, a, lo, hi;
+                                mce::panel_unit_decode(u, g, p, a);
+                                mce::panel_unit_tiles(p, a, g, lo, hi);
+                                if (a < 0 || a >= nqblk || a % W != r) { printf("stride: unit %d of rank %d/%d is block %d\n", u, r, W, a); return 1; }
+                                if (p != lp) la = 1 << 30;
+                                if (p < lp || a >= la) { printf("stride: order broken at unit %d\n", u); return 1; }
+                                lp = p; la = a;
+                                if (hi <= lo || lo != next_lo[a] || (lo & 1) || (hi & 1)) { printf("stride: block %d unit %d range [%d,%d), expected lo %d (W %d r %d nqblk %d tpp %d)\n", a, u, lo, hi, next_lo[a], W, r, nqblk, g.tpp); return 1; }
+                                if (mce::panel_unit_seq(p, a, g) != seq[a]) { printf("stride: block %d seq\n", a); return 1; }
+                                next_lo[a] = hi; seq[a] += 1; owner_seen[a] = r;
+                                ++schecked;
+                            }
+                        }
+                        for (int a = 0; a < nqblk; ++a) {
+                            const int want = 16 * (a + 1) < ntiles ? 16 * (a + 1) : ntiles;
+                            if (owner_seen[a] != a % W || next_lo[a] != want) { printf("stride: block %d owner %d covered to %d, expected %d (W %d nqblk %d)\n", a, owner_seen[a], next_lo[a], want, W, nqblk); return 1; }
+                        }
+                        // the ranks' units together are the single-GPU launch
+                        mce::PanelGeom g1;
+                        g1.tpb = 16; g1.ct = ct; g1.tpp = panel * ct; g1.ntiles = ntiles; g1.sym_on = 1; g1.qb_lo = 0; g1.qb_hi = nqblk;
+                        if (units_all != mce::panel_unit_count(g1)) { printf("stride: %ld units over the ranks, %d on one GPU\n", units_all, mce::panel_unit_count(g1)); return 1; }
+                    }
+    printf("ok %ld strided units\n", schecked);
     return 0;
 }

@@ -295,6 +295,126 @@ def test_symmetric_partition_over_ranks_equals_the_single_rank_sum(world):
     assert max(sizes) - min(sizes) <= 512 + 511                          # whole blocks; the last one is partial
 
 
+class _HostPairsOnce:
+    """Host restatement of one rank's share of the all-pairs-once partition (include/mcevidence_hip.h: mce_pairs_once_*;
+    csrc/sym_types.hpp: PanelGeom.blk_stride) for the CPU test of parallel.pairs_once_knn_dotp's collectives: rows sorted by
+    their distance from the mean, blocks of B rows, rank r owns the blocks r, r + W, r + 2W, ...; it multiplies each of its
+    blocks a against the blocks 0..a (itself included).  Every multiplied pair (i, j) is a candidate for i (kept here) and
+    for j (kept here if j is this rank's, shipped to j's owner otherwise) -- entries {d2, caller row of the other, sorted row}."""
+    ENTRY = np.dtype([("d2", "f8"), ("src", "i4"), ("row", "i4")])
+    B = 64
+
+    def __init__(self, Y, w, fs, kmax):
+        self.Y, self.w, self.fs, self.kmax = Y, w, fs, kmax
+        n = Y.shape[0]
+        key = ((Y - Y.mean(axis=0)) ** 2).sum(axis=1).astype(np.float32)
+        self.order = np.argsort(key, kind="stable")                       # sorted position -> caller's row
+        self.nblk = (n + self.B - 1) // self.B
+
+    def blocks(self):
+        return self.nblk
+
+    def _own(self, b):
+        return b % self.world == self.rank
+
+    def _pairs_of_blocks(self):
+        """(query block a, tile block b) this rank multiplies; a == b: the block against itself"""
+        return [(a, b) for a in range(self.rank, self.nblk, self.world) for b in range(a + 1)]
+
+    def sweep(self, rank, world, nblk):
+        self.rank, self.world = rank, world
+        n, B = self.Y.shape[0], self.B
+        Ys = self.Y[self.order]
+        self.mine = {}                     # sorted row -> list of (d2, caller row of the neighbour)
+        ship = [[] for _ in range(world)]
+        for a, b in self._pairs_of_blocks():
+            ia = np.arange(a * B, min((a + 1) * B, n)); jb = np.arange(b * B, min((b + 1) * B, n))
+            d2 = ((Ys[ia][:, None, :] - Ys[jb][None, :, :]) ** 2).sum(-1)
+            for x, i in enumerate(ia):
+                for y, j in enumerate(jb):
+                    if i == j or (a == b and j > i):
+                        continue                    # a block against itself: every pair once, from the larger row's side
+                    self.mine.setdefault(int(i), []).append((d2[x, y], int(self.order[j])))
+                    if self._own(b):
+                        self.mine.setdefault(int(j), []).append((d2[x, y], int(self.order[i])))
+                    else:
+                        ship[b % world].append((d2[x, y], int(self.order[i]), int(j)))
+        self.ship = ship
+        counts = torch.tensor([len(v) for v in ship], dtype=torch.int64)
+        return counts, torch.zeros(nblk, dtype=torch.int32)
+
+    def export(self, total):
+        ent = np.zeros(total, dtype=self.ENTRY)
+        k = 0
+        for dest in self.ship:
+            for d2, src, row in dest:
+                ent[k] = (d2, src, row); k += 1
+        assert k == total
+        return torch.from_numpy(ent.view(np.float64).reshape(-1, 2).copy())
+
+    def finish(self, recv, flags):
+        ent = recv.numpy().copy().reshape(-1).view(self.ENTRY)
+        n, B, K = self.Y.shape[0], self.B, self.kmax - 1
+        for e in ent:
+            assert 0 <= e["row"] < n and self._own(int(e["row"]) // B)
+            self.mine.setdefault(int(e["row"]), []).append((float(e["d2"]), int(e["src"])))
+        rows = np.concatenate([np.arange(b * B, min((b + 1) * B, n)) for b in range(self.rank, self.nblk, self.world)] + [np.zeros(0, dtype=int)])
+        full = np.zeros((len(rows), self.kmax))
+        for x, i in enumerate(rows):
+            c = sorted(self.mine.get(int(i), []))
+            assert len(c) >= K and len({src for _, src in c}) == len(c)          # every pair once: no neighbour twice
+            full[x, 1:] = np.sqrt([v for v, _ in c[:K]])
+        cr = self.order[rows]
+        return orc.dotp_literal(full, self.w[cr], self.fs[cr], self.Y.shape[1], 1, self.kmax) if len(rows) else np.zeros(self.kmax)
+
+
+def _pairs_once_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mcevidence_amd import parallel
+    rng = np.random.default_rng(11)
+    n, d, kmax = 700, 5, 4                                               # 11 blocks of 64
+    Y = rng.standard_normal((n, d)) * (1.0 + rng.random((1, d)))
+    w = rng.integers(1, 4, n).astype(float)
+    fs = -rng.random(n)
+    stats = {}
+    dotp = parallel.pairs_once_knn_dotp(Y, w, fs, kmax, stats=stats, impl=_HostPairsOnce(Y, w, fs, kmax))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (stats["sent"], stats["received"]))
+    if rank == 0:
+        q.put((dotp, gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_pairs_once_partition_collectives_over_gloo(world):
+    """parallel.pairs_once_knn_dotp's control flow on CPU, the library's three calls replaced by a host restatement of the
+    partition: all_gather of the counts, all_reduce(MAX) of the flags, all_to_all_single of the 16-byte candidates with the
+    counts as split sizes, all_reduce(sum) of the sums.  Every row ends with each of its neighbours exactly once, and the
+    result equals the single-process sum -- odd and even world sizes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pairs_once_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    dotp, traffic = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(11)
+    n, d, kmax = 700, 5, 4
+    Y = rng.standard_normal((n, d)) * (1.0 + rng.random((1, d)))
+    w = rng.integers(1, 4, n).astype(float)
+    fs = -rng.random(n)
+    one = _part_oracle(Y, w, fs, kmax, 0, 1)
+    assert np.allclose(dotp[1:], one[1:], rtol=1e-12, atol=0)
+    assert sum(s for s, _ in traffic) == sum(r for _, r in traffic) > 0
+
+
 def test_replica_fingerprint_sees_every_row():
     from mcevidence_amd.parallel import replica_fingerprint
     rng = np.random.default_rng(3)

@@ -514,6 +514,155 @@ def test_symmetric_partition_parts_add_up_to_the_whole(sym, n, d, kmax, W):
         assert np.allclose(total[1:], orc.dotp_literal(full, w, fs, d, 1, kmax)[1:], rtol=1e-10, atol=0)
 
 
+def _tools():
+    import os, sys
+    t = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if t not in sys.path:
+        sys.path.insert(0, t)
+    import pairs_once_emulate
+    return pairs_once_emulate
+
+
+@pytest.mark.parametrize("n,d,kmax,W", [(40000, 27, 10, 2), (30001, 6, 5, 3), (150000, 20, 6, 4), (70001, 27, 10, 8), (33000, 15, 17, 5), (5000, 15, 3, 4),
+                                        (20000, 27, 10, 6), (9000, 40, 5, 7)])
+def test_pairs_once_partition_parts_add_up_to_the_whole(sym, n, d, kmax, W):
+    """mce_pairs_once_*: every pair of rows multiplied once per NODE -- rank r runs the single-GPU units of the sorted blocks
+    r, r + W, ... (block a against the tiles of the blocks 0..a, both gates on) and ships the candidates it found for rows it
+    does not own to their owners.  All W shares computed one after the other on this GPU, each in its own workspace, the
+    exchange done with device copies (tools/pairs_once_emulate.py): the results add up to the single-rank sum, which equals
+    the oracle's -- odd and even W, sizes that are not whole blocks, ranks of one or two blocks."""
+    capi = sym
+    rng = np.random.default_rng(n + W)
+    Y = _data(n, d, n + 3 * W)
+    w = rng.integers(1, 6, n).astype(np.float64)
+    fs = -0.5 * rng.random(n) * 5.0
+    capi.set_sym_mode(capi.SYM_OFF)
+    whole = capi.knn_dotp(Y, None, w, fs, kmax, 1)
+    assert "symmetric" not in capi.last_kernel()
+    assert capi.pairs_once_blocks(n, d, kmax) == 0            # (the exhaustive sweep was asked for: no partition of the symmetric one)
+    capi.set_sym_mode(capi.SYM_FORCE)
+    assert capi.pairs_once_blocks(n, d, kmax) == (n + 511) // 512
+    r = _tools().emulate(Y, w, fs, kmax, W)
+    assert "pairs-once" in r["kernel"] and "panel-kernel" in r["kernel"], r["kernel"]
+    assert sum(r["candidates_sent"]) == sum(r["candidates_received"]) > 0 and r["flagged_blocks"] == 0
+    assert np.allclose(r["dotp"][1:], whole[1:], rtol=1e-12, atol=0), (r["dotp"], whole)
+    if n <= 40000:
+        od, _ = orc.knn_brute(Y, Y, kmax - 1, self_mode=2)
+        full = np.zeros((n, kmax)); full[:, 1:] = od
+        assert np.allclose(r["dotp"][1:], orc.dotp_literal(full, w, fs, d, 1, kmax)[1:], rtol=1e-10, atol=0)
+
+
+def test_pairs_once_partition_overflow_and_give_up(sym, monkeypatch):
+    """Buckets that overflow on ANOTHER rank (MCE_SYM_BUCKET=1: a block's bucket holds 512 candidates) reach the owner as
+    flags -- MAX over the ranks -- and the owner searches those blocks again exhaustively; units that give up waiting
+    (MCE_SYM_SPIN_LIMIT=0) flag their own block.  The sums do not change."""
+    capi = sym
+    n, d, kmax, W = 60000, 20, 7, 3
+    rng = np.random.default_rng(5)
+    Y = _data(n, d, 11)
+    w = rng.integers(1, 4, n).astype(np.float64)
+    fs = -rng.random(n)
+    capi.set_sym_mode(capi.SYM_OFF)
+    whole = capi.knn_dotp(Y, None, w, fs, kmax, 1)
+    capi.set_sym_mode(capi.SYM_FORCE)
+    monkeypatch.setenv("MCE_SYM_BUCKET", "1")
+    r = _tools().emulate(Y, w, fs, kmax, W)
+    assert r["flagged_blocks"] > 0
+    assert np.allclose(r["dotp"][1:], whole[1:], rtol=1e-12, atol=0)
+    monkeypatch.delenv("MCE_SYM_BUCKET")
+    monkeypatch.setenv("MCE_SYM_PANEL", "2")
+    monkeypatch.setenv("MCE_SYM_SPIN_LIMIT", "0")
+    r = _tools().emulate(Y, w, fs, kmax, W)
+    assert np.allclose(r["dotp"][1:], whole[1:], rtol=1e-12, atol=0)
+
+
+def test_pairs_once_partition_refuses_what_it_cannot_do(sym):
+    capi = sym
+    import torch
+    capi.set_sym_mode(capi.SYM_FORCE)
+    assert capi.pairs_once_blocks(30000, 20, 19) == 0          # K = 18 > 16: two passes -- not partitioned this way
+    n, d, kmax = 30000, 20, 6
+    Y = torch.from_numpy(_data(n, d, 3)).cuda()
+    wsb = capi.knn_workspace_bytes(n, n, d, kmax - 1) + capi.dotp_workspace_bytes(n, kmax)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(4, dtype=torch.int64, device="cuda"); fl = torch.zeros(capi.pairs_once_blocks(n, d, kmax), dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):
+        capi.pairs_once_sweep_dev(Y.data_ptr(), n, d, kmax, 0, 1, cnt.data_ptr(), fl.data_ptr(), ws.data_ptr(), wsb, 0)         # one rank: nothing to exchange
+    with pytest.raises(ValueError):
+        capi.pairs_once_sweep_dev(Y.data_ptr(), n, d, kmax, 2, 2, cnt.data_ptr(), fl.data_ptr(), ws.data_ptr(), wsb, 0)
+    with pytest.raises(ValueError):
+        capi.pairs_once_sweep_dev(Y.data_ptr(), n, d, kmax, 0, 2, cnt.data_ptr(), fl.data_ptr(), ws.data_ptr(), wsb - 4096, 0)
+    # an entry for a row the rank does not own poisons the result instead of being dropped silently
+    capi.pairs_once_sweep_dev(Y.data_ptr(), n, d, kmax, 0, 2, cnt.data_ptr(), fl.data_ptr(), ws.data_ptr(), wsb, 0)
+    w = torch.ones(n, dtype=torch.float64, device="cuda"); fs = torch.zeros(n, dtype=torch.float64, device="cuda")
+    out = torch.zeros(kmax, dtype=torch.float64, device="cuda")
+    bad = torch.zeros((1, 2), dtype=torch.float64, device="cuda")
+    bad.view(torch.int32)[0, 2] = 5; bad.view(torch.int32)[0, 3] = 512 + 7       # {d2 = 0, src = 5, row = 519}: block 1 is rank 1's
+    capi.pairs_once_finish_dev(Y.data_ptr(), n, d, kmax, 0, 2, w.data_ptr(), fs.data_ptr(), bad.data_ptr(), 1, fl.data_ptr(), out.data_ptr(), ws.data_ptr(), wsb, 0)
+    torch.cuda.synchronize()
+    assert torch.isnan(out).all()
+
+
+def _pairs_once_rank(rank, world, port, q, n, d, kmax):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MCE_PAIRS_ONCE="1")
+    torch.cuda.set_device(0)                                 # one GPU on the test box: the ranks share it
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mcevidence_amd import _capi, parallel
+    _capi.set_prune_mode(_capi.PRUNE_OFF)
+    _capi.set_sym_mode(_capi.SYM_FORCE)
+    rng = np.random.default_rng(n)
+    Y = _data(n, d, n + 1)
+    w = rng.integers(1, 6, n).astype(np.float64)
+    fs = -0.5 * rng.random(n) * 5.0
+    stats = {}
+    direct = parallel.pairs_once_knn_dotp(Y, w, fs, kmax, stats=stats)
+    dotp, _ = parallel.sharded_knn_dotp(Y, None, w, fs, kmax, 1)             # MCE_PAIRS_ONCE=1: the same route
+    q.put((rank, direct, dotp, stats, _capi.last_kernel()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pairs_once_partition_over_gloo_ranks(sym, world):
+    """parallel.pairs_once_knn_dotp under a gloo group whose ranks share the box's one GPU: sweep -> all_gather of the counts,
+    all_reduce(MAX) of the flags -> export -> all_to_all_single of the candidates -> finish -> all_reduce(sum): every rank
+    returns the single-process sums (1e-12); parallel.sharded_knn_dotp takes the same route under MCE_PAIRS_ONCE=1."""
+    import socket
+    import torch.multiprocessing as mp
+    capi = sym
+    n, d, kmax = 90000, 27, 10
+    rng = np.random.default_rng(n)
+    Y = _data(n, d, n + 1)
+    w = rng.integers(1, 6, n).astype(np.float64)
+    fs = -0.5 * rng.random(n) * 5.0
+    capi.set_sym_mode(capi.SYM_OFF)
+    whole = capi.knn_dotp(Y, None, w, fs, kmax, 1)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pairs_once_rank, args=(r, world, port, q, n, d, kmax)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r: rest for r, *rest in (q.get(timeout=600) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sent = recv = 0
+    for r in range(world):
+        direct, dotp, stats, kernel = got[r]
+        assert np.allclose(direct[1:], whole[1:], rtol=1e-12, atol=0) and np.allclose(dotp[1:], whole[1:], rtol=1e-12, atol=0)
+        assert np.array_equal(direct, got[0][0])                          # the all-reduce hands every rank the same sums
+        assert "pairs-once" in kernel
+        sent += stats["sent"]; recv += stats["received"]
+    assert sent == recv > 0
+
+
 def test_unit_that_gives_up_waiting_is_repaired(sym, monkeypatch):
     """The wait of a unit for its block's previous unit is bounded (knn_panel.hpp).  With the bound at 0 every wait that
     is not already satisfied gives up at once: the unit starts from empty lists, flags its block, and the repair launch

@@ -1,0 +1,145 @@
+#!/usr/bin/env python
+"""GPU box (ONE GPU): the all-pairs-once partition of auto evidence (include/mcevidence_hip.h: mce_pairs_once_*), emulated --
+the W ranks' shares run SERIALLY on this one GPU, each in its own workspace, and the exchange between them (all_to_all of the
+row-side candidates, MAX of the overflow flags) is done with device copies.  Per rank: sweep / export / finish timed with
+resident data; the predicted step = the slowest rank's sweep + export + finish + the exchange priced at the candidates' bytes
+over one xGMI link.  PREDICTED, not measured (no multi-GPU box is reachable).  Checks that the W results add up to the
+single-GPU sums.
+
+usage: python tools/pairs_once_emulate.py [C3] [--worlds 2,4,8] [--reps 3] -> gpurun_out/pairs_once_emulated.json
+       (tests/test_gpu_symmetric.py imports emulate())"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+XGMI_LINK_GBS = 50.0       # one direction of one link, conservatively (MI355X_MICROARCH.md: ~153 GB/s per link pair peak; RCCL all_to_all sees less)
+COLLECTIVE_LATENCY_MS = 0.06      # all_gather of the counts + all_reduce of the flags + all_to_all launch, ~20 us each
+
+
+def emulate(Y, weight, fs, kmax, W, reps=1):
+    """-> dict(dotp[kmax] summed over the ranks, per-rank times in ms, candidates sent per rank, flagged blocks)"""
+    import torch
+    from mcevidence_amd import _capi
+    dev = torch.device("cuda")
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    n, d = Y.shape
+    nblk = _capi.pairs_once_blocks(n, d, kmax)
+    if nblk < W:
+        raise ValueError("pairs-once partition not applicable: %d blocks, %d ranks" % (nblk, W))
+    Yd = torch.from_numpy(Y).to(dev)
+    wd = torch.from_numpy(np.ascontiguousarray(weight, dtype=np.float64)).to(dev)
+    fd = torch.from_numpy(np.ascontiguousarray(fs, dtype=np.float64)).to(dev)
+    wsb = _capi.knn_workspace_bytes(n, n, d, kmax - 1) + _capi.dotp_workspace_bytes(n, kmax)
+    ws = [torch.empty(wsb, dtype=torch.uint8, device=dev) for _ in range(W)]
+    best = None
+    for _ in range(reps):
+        counts = [torch.zeros(W, dtype=torch.int64, device=dev) for _ in range(W)]
+        flags = [torch.zeros(nblk, dtype=torch.int32, device=dev) for _ in range(W)]
+        t_sweep, t_export, t_finish, kern = [], [], [], []
+        for r in range(W):
+            _capi.set_profiling(True)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            _capi.pairs_once_sweep_dev(Yd.data_ptr(), n, d, kmax, r, W, counts[r].data_ptr(), flags[r].data_ptr(), ws[r].data_ptr(), wsb, 0)
+            torch.cuda.synchronize(); t_sweep.append((time.perf_counter() - t0) * 1e3)
+            kern.append(_capi.last_kernel_ms()); _capi.set_profiling(False)
+        kernel = _capi.last_kernel()
+        cnt = [c.cpu().numpy() for c in counts]
+        send = []
+        for r in range(W):
+            tot = int(cnt[r].sum())
+            buf = torch.empty((max(tot, 1), 2), dtype=torch.float64, device=dev)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            _capi.pairs_once_export_dev(n, d, kmax, r, W, buf.data_ptr() if tot else 0, ws[r].data_ptr(), wsb, 0)
+            torch.cuda.synchronize(); t_export.append((time.perf_counter() - t0) * 1e3)
+            send.append(buf[:tot])
+        # the exchange: rank r receives, from every rank s, the slice of s's send buffer meant for r
+        allflags = torch.stack(flags).max(dim=0).values.contiguous()
+        total = np.zeros(kmax)
+        recv_n = []
+        for r in range(W):
+            pieces = []
+            for s in range(W):
+                off = int(cnt[s][:r].sum())
+                pieces.append(send[s][off:off + int(cnt[s][r])])
+            recv = torch.cat(pieces).contiguous() if pieces else torch.empty((0, 2), dtype=torch.float64, device=dev)
+            out = torch.zeros(kmax, dtype=torch.float64, device=dev)
+            nrecv = int(recv.shape[0]); recv_n.append(nrecv)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            _capi.pairs_once_finish_dev(Yd.data_ptr(), n, d, kmax, r, W, wd.data_ptr(), fd.data_ptr(), recv.data_ptr() if nrecv else 0, nrecv,
+                                        allflags.data_ptr(), out.data_ptr(), ws[r].data_ptr(), wsb, 0)
+            torch.cuda.synchronize(); t_finish.append((time.perf_counter() - t0) * 1e3)
+            total += out.cpu().numpy()
+        sent = [int(c.sum()) for c in cnt]
+        exch = [max(16.0 * sent[r], 16.0 * recv_n[r]) / (XGMI_LINK_GBS * 1e9) * 1e3 + COLLECTIVE_LATENCY_MS for r in range(W)]
+        rank_ms = [t_sweep[r] + t_export[r] + t_finish[r] + exch[r] for r in range(W)]
+        res = dict(world=W, dotp=total, rank_ms=[round(v, 3) for v in rank_ms], sweep_ms=[round(v, 3) for v in t_sweep], sweep_kernel_ms=[round(v, 3) for v in kern],
+                   export_ms=[round(v, 3) for v in t_export], finish_ms=[round(v, 3) for v in t_finish], exchange_ms_priced=[round(v, 3) for v in exch],
+                   candidates_sent=sent, candidates_received=recv_n, flagged_blocks=int(allflags.sum().item()), predicted_step_ms=round(max(rank_ms), 3), kernel=kernel)
+        if best is None or res["predicted_step_ms"] < best["predicted_step_ms"]:
+            best = res
+    del ws
+    torch.cuda.empty_cache()
+    return best
+
+
+def main():
+    import torch
+    from mcevidence_amd import _capi
+    import bench
+    reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 3
+    worlds = [int(v) for v in (sys.argv[sys.argv.index("--worlds") + 1] if "--worlds" in sys.argv else "2,4,8").split(",")]
+    name = "C3"
+    cfg = bench.prep_config(name)
+    X, kmax = cfg["X"], cfg["kmax"]
+    n, d = X.shape
+    dev = torch.device("cuda")
+    # the single-GPU call: reference sums and the time the efficiencies are against
+    Xd = torch.from_numpy(X).to(dev); w = torch.from_numpy(cfg["weight"]).to(dev); fs = torch.from_numpy(cfg["fs"]).to(dev)
+    wsb = _capi.knn_workspace_bytes(n, n, d, kmax - 1) + _capi.dotp_workspace_bytes(n, kmax)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev); out = torch.zeros(kmax, dtype=torch.float64, device=dev)
+    t1 = 1e30
+    for _ in range(reps + 1):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        _capi.knn_dotp_dev(Xd.data_ptr(), n, Xd.data_ptr(), n, d, kmax, 1, 0, w.data_ptr(), fs.data_ptr(), out.data_ptr(), 0, ws.data_ptr(), wsb, 0)
+        torch.cuda.synchronize(); t1 = min(t1, (time.perf_counter() - t0) * 1e3)
+    whole = out.cpu().numpy()
+    # the exchange-free partition / query shards the library takes today, same box, for the comparison
+    today = {}
+    for W in worlds:
+        per = []
+        for r in range(W):
+            b = 1e30
+            for _ in range(reps):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                _capi.knn_dotp_part_dev(Xd.data_ptr(), n, d, kmax, r, W, w.data_ptr(), fs.data_ptr(), out.data_ptr(), ws.data_ptr(), wsb, 0)
+                torch.cuda.synchronize(); b = min(b, (time.perf_counter() - t0) * 1e3)
+            per.append(round(b, 3))
+        today[str(W)] = dict(rank_ms=per, predicted_step_ms=max(per), efficiency=round(t1 / max(per) / W, 3))
+    del ws
+    torch.cuda.empty_cache()
+    res = dict(config=name, n=n, d=d, kmax=kmax, label="PREDICTED from one GPU: every rank's share timed serially; exchange priced, not run", one_gpu_ms=round(t1, 3),
+               xgmi_link_GBs_assumed=XGMI_LINK_GBS, todays_partition=today, pairs_once={})
+    for W in worlds:
+        r = emulate(X, cfg["weight"], cfg["fs"], kmax, W, reps)
+        dotp = r.pop("dotp")
+        r["max_rel_dev_of_summed_dotp_vs_1gpu"] = float(np.max(np.abs(dotp[1:] - whole[1:]) / whole[1:]))
+        r["efficiency"] = round(t1 / r["predicted_step_ms"] / W, 3)
+        lnE = bench.lnE_from_dotp(dotp, cfg)
+        g = bench.golden_lnE(name, cfg)
+        if g is not None:
+            r["max_abs_dlnE_vs_reference"] = float(np.max(np.abs(lnE - np.array(g["lnE"]))))
+        res["pairs_once"][str(W)] = r
+        print(json.dumps({str(W): r}), flush=True)
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    json.dump(res, open(os.path.join(REPO, "gpurun_out", "pairs_once_emulated.json"), "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
