@@ -192,8 +192,10 @@ int mce_knn_dotp_part_f64(const double *Y, int64_t nr, int32_t d, int32_t kmax, 
 /* The ALL-PAIRS-ONCE partition of the same sums (round 5; optional -- parallel.py takes it when MCE_PAIRS_ONCE=1): where one GPU
  * would run the one-pass symmetric sweep (mce_pairs_once_blocks > 0), W ranks can multiply every pair of rows once per NODE
  * instead of once per side: rank r owns the sorted 512-row blocks r, r + W, ... and runs the single-GPU units of those blocks
- * (a block against every block below it, both gates on), and ships the candidates it found for rows it does not own to their owners.  Three calls on one workspace (sized as for
+ * (a block against every block below it, both gates on), and ships the candidates it found for rows it does not own to their owners.  Four calls on one workspace (sized as for
  * mce_knn_dotp_part_f64_dev), the collectives between them are the caller's (no RCCL dependency in this library):
+ *   prepare -> *bounds_offset / *bounds_count: where in the workspace (bytes from its start) the rows' bounds lie -- doubles,
+ *              +inf for the rows of other ranks: all-reduce them with MIN (every rank bounds the rows of its own blocks only);
  *   sweep   -> d_counts[nparts]: 16-byte candidates for every rank (own entry 0); d_flags[blocks]: blocks of other ranks whose
  *              candidates did not fit here (the owner searches such a block again: all-reduce the flags with MAX);
  *   export  -> d_send: the candidates, densely, ordered by destination rank (sum of d_counts entries of 16 bytes);
@@ -203,6 +205,11 @@ int mce_knn_dotp_part_f64(const double *Y, int64_t nr, int32_t d, int32_t kmax, 
  * Adding the nparts results gives mce_knn_dotp_f64_dev's dotp up to summation order.  Replaces the same reference lines as
  * mce_knn_dotp_f64_dev (MCEvidence.py:1093-1117) for one rank's rows. */
 int32_t mce_pairs_once_blocks(int64_t nr, int32_t d, int32_t kmax);
+/* the workspace of the three calls below (0: the partition does not exist for this shape): the search's and the reduction's, plus
+ * one list set per chain of units when a rank's blocks are dealt to several chains (capi_apo.hpp: PairsOnceShape) */
+size_t mce_pairs_once_workspace_bytes(int64_t nr, int32_t d, int32_t kmax, int32_t nparts);
+int mce_pairs_once_prepare_dev(const double *dY, int64_t nr, int32_t d, int32_t kmax, int32_t part, int32_t nparts,
+                               size_t *bounds_offset, int64_t *bounds_count, void *ws, size_t ws_bytes, void *stream);
 int mce_pairs_once_sweep_dev(const double *dY, int64_t nr, int32_t d, int32_t kmax, int32_t part, int32_t nparts,
                              int64_t *d_counts, int32_t *d_flags, void *ws, size_t ws_bytes, void *stream);
 int mce_pairs_once_export_dev(int64_t nr, int32_t d, int32_t kmax, int32_t part, int32_t nparts, void *d_send, void *ws,

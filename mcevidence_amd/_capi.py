@@ -71,6 +71,9 @@ SIGNATURES = {
     "mce_knn_dotp_part_f64_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _c.c_size_t, _P]),
     "mce_knn_dotp_part_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_int32]),
     "mce_pairs_once_blocks": (_c.c_int32, [_c.c_int64, _c.c_int32, _c.c_int32]),
+    "mce_pairs_once_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32]),
+    "mce_pairs_once_prepare_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_int64), _P,
+                                              _c.c_size_t, _P]),
     "mce_pairs_once_sweep_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_size_t, _P]),
     "mce_pairs_once_export_dev": (_c.c_int, [_c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _c.c_size_t, _P]),
     "mce_pairs_once_finish_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_int64, _P, _P, _P,
@@ -107,10 +110,11 @@ def load():
     """Load the shared library (once).  Raises RuntimeError if it is not built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("MCE_LIB_PATH") or LIB_PATH          # (MCE_LIB_PATH: another build of the SAME library -- same-box A/B runs)
+        if not os.path.exists(path):
             raise RuntimeError(
                 "mcevidence_amd: %s not found -- build it with `make -C mcevidence_amd/csrc` "
-                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % path)
         # PyTorch-ROCm wheels bundle their own HIP/HSA runtime (torch/lib/libamdhip64.so, same
         # soname as /opt/rocm's).  Two HSA runtimes in one process cannot both own the GPU, so
         # when torch is installed let it load its runtime FIRST; our library then binds to the
@@ -120,8 +124,10 @@ def load():
                 import torch  # noqa: F401
             except Exception:  # torch absent: plain ROCm runtime from /opt/rocm
                 pass
-        lib = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
+            if path != LIB_PATH and not hasattr(lib, name):
+                continue                                         # (an older build in an A/B run lacks the newest entry points)
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
@@ -527,6 +533,17 @@ def pairs_once_blocks(nr, d, kmax):
     """Sorted 512-row blocks of the all-pairs-once partition for this shape (the length of its flags array); 0: the shape
     does not take the one-pass symmetric sweep and the partition does not exist (``mce_pairs_once_blocks``)."""
     return int(load().mce_pairs_once_blocks(int(nr), int(d), int(kmax)))
+
+
+def pairs_once_workspace_bytes(nr, d, kmax, nparts):
+    return int(load().mce_pairs_once_workspace_bytes(int(nr), int(d), int(kmax), int(nparts)))
+
+
+def pairs_once_prepare_dev(dY, nr, d, kmax, part, nparts, ws, ws_bytes, stream=0):
+    """-> (byte offset of the rows' bounds inside the workspace, their number): float64, to be all-reduced with MIN"""
+    off, cnt = _c.c_size_t(0), _c.c_int64(0)
+    check(load().mce_pairs_once_prepare_dev(dY, nr, d, kmax, part, nparts, _c.byref(off), _c.byref(cnt), ws, ws_bytes, stream or None))
+    return int(off.value), int(cnt.value)
 
 
 def pairs_once_sweep_dev(dY, nr, d, kmax, part, nparts, d_counts, d_flags, ws, ws_bytes, stream=0):

@@ -9,8 +9,9 @@
 // range of blocks and the rectangles against half of the other ranks: half of those rectangles then have the rows NEARER the
 // mean as queries and the farther, sparser rows on the row side, whose bounds are loose -- 6.5 M candidates shipped from rank 0
 // to rank 1 at C3 against 0.19 M the other way, and 19 ms to fold them in; profiles/r05_mid/pairs_once_contiguous.json.)
-// Three calls, the collective between them is the caller's (parallel.py: RCCL all_to_all_single):
-//   mce_pairs_once_sweep_dev   sort, pack, prepass, sweep; counts[s] = candidates for rank s, flags[b] = overflowed foreign buckets
+// Four calls, the collectives between them are the caller's (parallel.py: RCCL all_to_all_single):
+//   mce_pairs_once_prepare_dev sort, pack, prepass of the rank's OWN blocks -> their rows' bounds (all-reduce with MIN: everybody's)
+//   mce_pairs_once_sweep_dev   the sweep; counts[s] = candidates for rank s, flags[b] = overflowed foreign buckets
 //   mce_pairs_once_export_dev  the candidates, densely, ordered by destination rank (16 B each)
 //   mce_pairs_once_finish_dev  received candidates -> own buckets; repair launch; merge; volume / weight sums of the rank's own rows
 // The workspace carries the state from call to call (the plan is a pure function of the shape).  Reference: MCEvidence.py:1093-1117.
@@ -30,6 +31,102 @@ int pairs_once_plan(int64_t nr, int32_t d, int32_t kmax, Plan& p, bool quiet)
     if (p.prune || !p.sym || p.twopass || !p.vh || !p.vh->launch_panel)
         return quiet ? MCE_ERR_INVALID : fail(MCE_ERR_INVALID, "pairs-once partition: this shape does not take the one-pass symmetric sweep");
     return MCE_OK;
+}
+
+// A rank's blocks are fewer than one GPU's: with fewer CHAINS of units than the chip has workgroup slots (2 per CU) the sweep is as
+// slow as the longest block's chain of units (measured at C3, one chain per block: sweep kernel 19.9 / 11.3 / 8.9 ms at 2 / 4 / 8
+// ranks against 17.4 / 8.7 / 4.4 for perfect shares).  So a block's panels are dealt to S independent chains, each with its own
+// list set (merged at the end; the chains share the row's published bound): S such that the rank has ~3 chains per slot, the
+// panels short enough that the longest block has two units per chain.  MCE_PAIRS_ONCE_SPLIT / MCE_PAIRS_ONCE_PANEL override.
+struct PairsOnceShape {
+    int nsplit = 1, panel = 0;
+    size_t off_d = 0, off_i = 0;      // list sets [nsplit][KCAP][nq_pad] (nsplit > 1: behind the plan's workspace and the reduction's scratch)
+    size_t total = 0;
+};
+PairsOnceShape pairs_once_shape(const Plan& p, int64_t nr, int32_t kmax, int32_t nparts)
+{
+    PairsOnceShape sh;
+    const int nown = (p.nqblk + nparts - 1) / std::max(nparts, 1);
+    int S = std::min(8, std::max(1, (1536 + nown - 1) / std::max(nown, 1)));
+    if (const char* e = getenv("MCE_PAIRS_ONCE_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 8) S = v; }
+    const int def_panel = kSymPanelChunks[p.KST];
+    int panel = S > 1 ? (int)std::max<int64_t>(8, std::min<int64_t>(def_panel, p.nchunk / (2 * S))) : 0;
+    if (const char* e = getenv("MCE_PAIRS_ONCE_PANEL")) { const int v = atoi(e); if (v >= 1) panel = v; }
+    sh.nsplit = S;
+    sh.panel = panel;
+    size_t off = p.total + dotp_ws_bytes(nr, kmax);
+    if (S > 1) {
+        off = align_up(off, 256);
+        sh.off_d = off;
+        off = align_up(off + (size_t)S * p.KCAP * (size_t)p.nq_pad * sizeof(double), 256);
+        sh.off_i = off;
+        off = align_up(off + (size_t)S * p.KCAP * (size_t)p.nq_pad * sizeof(int), 256);
+    } else {
+        sh.off_d = p.off_pd;
+        sh.off_i = p.off_pi;
+    }
+    sh.total = off;
+    return sh;
+}
+// (the plan's list offsets point at the shape's list sets from here on)
+void pairs_once_apply(Plan& p, const PairsOnceShape& sh)
+{
+    p.apo = true;
+    p.apo_nsplit = sh.nsplit;
+    p.apo_panel = sh.panel;
+    p.off_pd = sh.off_d;
+    p.off_pi = sh.off_i;
+}
+
+// every list set of the rank's blocks starts empty (a chain without units -- a block with fewer panels than chains -- leaves its set untouched)
+__global__ __launch_bounds__(512) void pairs_once_init_lists_kernel(double* __restrict__ pd, int* __restrict__ pi, int64_t nq_pad, int KCAP, int S, int part, int nparts)
+{
+    const int64_t q = (int64_t)(part + nparts * (int)blockIdx.x) * 512 + threadIdx.x;
+    for (int s = 0; s < S; ++s)
+        for (int k = 0; k < KCAP; ++k) {
+            const int64_t o = ((int64_t)s * KCAP + k) * nq_pad + q;
+            pd[o] = __builtin_huge_val();
+            pi[o] = -1;
+        }
+}
+
+// list sets 1 .. S - 1 of the blocks that were searched again (their set 0 is complete): emptied
+__global__ __launch_bounds__(512) void pairs_once_clear_kernel(const int* __restrict__ bucket_flag, double* __restrict__ pd, int* __restrict__ pi, int64_t nq_pad, int KCAP,
+                                                               int S, int part, int nparts)
+{
+    const int b = part + nparts * (int)blockIdx.x;
+    if (bucket_flag[b] == 0) return;
+    const int64_t q = (int64_t)b * 512 + threadIdx.x;
+    for (int s = 1; s < S; ++s)
+        for (int k = 0; k < KCAP; ++k) {
+            const int64_t o = ((int64_t)s * KCAP + k) * nq_pad + q;
+            pd[o] = __builtin_huge_val();
+            pi[o] = -1;
+        }
+}
+
+__global__ __launch_bounds__(256) void pairs_once_fill_kernel(unsigned long long* __restrict__ p, int64_t n, unsigned long long v)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
+}
+// every row's row-side gate constant and every tile's maximum from the (all-reduced) bounds -- what the prepass writes for the rows
+// it handles (knn_f16.hpp, SYM == 1), here for all rows
+__global__ __launch_bounds__(256) void pairs_once_row_gates_kernel(unsigned long long* __restrict__ thr, unsigned* __restrict__ rrow, float* __restrict__ rtile,
+                                                                   const double* __restrict__ qinfo, const double* __restrict__ params, int64_t nq, int KST)
+{
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;         // (nq_pad rows: a whole number of workgroups)
+    float R = 0.0f;
+    if (q < nq) {
+        R = mce::sym_row_gate(__longlong_as_double((long long)thr[q]), qinfo[2 * q], params, KST);
+        rrow[q] = __float_as_uint(R);
+    } else {
+        thr[q] = 0x7FF0000000000000ull;
+        rrow[q] = 0u;
+    }
+    float m = R;
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 31) == 0) rtile[q >> 5] = m;
 }
 
 // the argument block of the symmetric sweep's launches from a plan and its workspace (after run_search has filled it)
@@ -82,6 +179,51 @@ int32_t mce_pairs_once_blocks(int64_t nr, int32_t d, int32_t kmax)
     return p.nqblk;
 }
 
+size_t mce_pairs_once_workspace_bytes(int64_t nr, int32_t d, int32_t kmax, int32_t nparts)
+{
+    Plan p;
+    if (nparts < 2 || pairs_once_plan(nr, d, kmax, p, true) != MCE_OK) return 0;
+    return pairs_once_shape(p, nr, kmax, nparts).total;
+}
+
+int mce_pairs_once_prepare_dev(const double* dY, int64_t nr, int32_t d, int32_t kmax, int32_t part, int32_t nparts, size_t* bounds_offset,
+                               int64_t* bounds_count, void* ws, size_t ws_bytes, void* stream)
+{
+    if (!dY || !ws || !bounds_offset || !bounds_count) return fail(MCE_ERR_INVALID, "null pointer argument");
+    if (nparts < 2 || part < 0 || part >= nparts) return fail(MCE_ERR_INVALID, "part %d of %d (the pairs-once partition needs two ranks or more)", part, nparts);
+    Plan p;
+    int rc = pairs_once_plan(nr, d, kmax, p, false);
+    if (rc != MCE_OK) return rc;
+    if (nparts > p.nqblk) return fail(MCE_ERR_INVALID, "pairs-once partition: %d ranks for %d blocks", nparts, p.nqblk);
+    const PairsOnceShape sh = pairs_once_shape(p, nr, kmax, nparts);
+    if (ws_bytes < sh.total) return fail(MCE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, sh.total);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* wsc = static_cast<char*>(ws);
+    p.part = part;
+    p.nparts = nparts;
+    pairs_once_apply(p, sh);
+    p.apo_phase = 1;
+    // every row's bound starts at +inf, every slot empty; the prepass below fills in the rows of this rank's blocks
+    const unsigned long long inf_bits = 0x7FF0000000000000ull;
+    hipLaunchKernelGGL(pairs_once_fill_kernel, dim3(1024), dim3(256), 0, st, reinterpret_cast<unsigned long long*>(wsc + p.off_sym + p.sl.thr), p.nq_pad, inf_bits);
+    MCE_HIP(hipGetLastError());
+    hipLaunchKernelGGL(pairs_once_fill_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<unsigned long long*>(wsc + p.off_sym + p.sl.slots),
+                       p.nq_pad * (int64_t)p.KCAP, inf_bits);
+    MCE_HIP(hipGetLastError());
+    if (sh.nsplit > 1) {
+        static_assert(mce::f16_qpb(4) == 512, "one workgroup per block of list columns");
+        hipLaunchKernelGGL(pairs_once_init_lists_kernel, dim3((unsigned)mce::apo_rank_count(p.nqblk, part, nparts)), dim3(512), 0, st,
+                           reinterpret_cast<double*>(wsc + sh.off_d), reinterpret_cast<int*>(wsc + sh.off_i), p.nq_pad, p.KCAP, sh.nsplit, (int)part, (int)nparts);
+        MCE_HIP(hipGetLastError());
+    }
+    SameSetHint hint(true);
+    rc = run_search(p, dY, nr, dY, nr, d, kmax - 1, MCE_SELF_EXCLUDE, 0, wsc, st);
+    if (rc != MCE_OK) return rc;
+    *bounds_offset = p.off_sym + p.sl.thr;
+    *bounds_count = p.nq_pad;
+    return MCE_OK;
+}
+
 int mce_pairs_once_sweep_dev(const double* dY, int64_t nr, int32_t d, int32_t kmax, int32_t part, int32_t nparts, int64_t* d_counts,
                              int32_t* d_flags, void* ws, size_t ws_bytes, void* stream)
 {
@@ -91,19 +233,23 @@ int mce_pairs_once_sweep_dev(const double* dY, int64_t nr, int32_t d, int32_t km
     int rc = pairs_once_plan(nr, d, kmax, p, false);
     if (rc != MCE_OK) return rc;
     if (nparts > p.nqblk) return fail(MCE_ERR_INVALID, "pairs-once partition: %d ranks for %d blocks", nparts, p.nqblk);
-    const size_t need = p.total + dotp_ws_bytes(nr, kmax);
-    if (ws_bytes < need) return fail(MCE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
+    const PairsOnceShape sh = pairs_once_shape(p, nr, kmax, nparts);
+    if (ws_bytes < sh.total) return fail(MCE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, sh.total);
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* wsc = static_cast<char*>(ws);
     p.part = part;
     p.nparts = nparts;
-    p.apo = true;
+    pairs_once_apply(p, sh);
+    p.apo_phase = 2;
+    mce::KnnF16Args a;
+    pairs_once_args(p, wsc, nr, d, kmax - 1, a);
+    // the bounds are everybody's now (MIN over the ranks): the row-side gate constants follow from them
+    hipLaunchKernelGGL(pairs_once_row_gates_kernel, dim3((unsigned)(p.nq_pad / 256)), dim3(256), 0, st, a.sym.thr, a.sym.rrow, a.sym.rtile, a.qinfo, a.params, nr, p.KST);
+    MCE_HIP(hipGetLastError());
     SameSetHint hint(true);
     rc = run_search(p, dY, nr, dY, nr, d, kmax - 1, MCE_SELF_EXCLUDE, 0, wsc, st);
     if (rc != MCE_OK) return rc;
     if (!p.sym_active) return fail(MCE_ERR_INVALID, "pairs-once partition: the sweep did not run");
-    mce::KnnF16Args a;
-    pairs_once_args(p, wsc, nr, d, kmax - 1, a);
     int* offs = reinterpret_cast<int*>(wsc + p.off_sym + p.sl.keys_a);     // [nqblk + 1] offsets + 1 error word (the sort's keys: n_pad words, free by now)
     static_assert(sizeof(long long) == sizeof(int64_t), "counts");
     hipLaunchKernelGGL(mce::apo_offsets_kernel, dim3(1), dim3(mce::kApoScanThreads), 0, st, a.sym.bucket_cnt, a.sym.bucket_flag, a.sym.cap, p.nqblk, (int)part,
@@ -118,14 +264,14 @@ int mce_pairs_once_export_dev(int64_t nr, int32_t d, int32_t kmax, int32_t part,
     Plan p;
     int rc = pairs_once_plan(nr, d, kmax, p, false);
     if (rc != MCE_OK) return rc;
-    if (ws_bytes < p.total + dotp_ws_bytes(nr, kmax)) return fail(MCE_ERR_WORKSPACE, "workspace too small");
+    if (nparts < 2 || nparts > p.nqblk) return fail(MCE_ERR_INVALID, "part %d of %d", part, nparts);
+    if (ws_bytes < pairs_once_shape(p, nr, kmax, nparts).total) return fail(MCE_ERR_WORKSPACE, "workspace too small");
     if (!d_send) return MCE_OK;           // (nothing to ship)
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* wsc = static_cast<char*>(ws);
     mce::KnnF16Args a;
     pairs_once_args(p, wsc, nr, d, kmax - 1, a);
     const int* offs = reinterpret_cast<const int*>(wsc + p.off_sym + p.sl.keys_a);
-    if (nparts < 2 || nparts > p.nqblk) return fail(MCE_ERR_INVALID, "part %d of %d", part, nparts);
     hipLaunchKernelGGL(mce::apo_export_kernel, dim3((unsigned)p.nqblk), dim3(256), 0, st, a.sym.bucket, offs, a.sym.cap, p.nqblk, (int)nparts,
                        static_cast<mce::SymEntry*>(d_send));
     MCE_HIP(hipGetLastError());
@@ -141,13 +287,15 @@ int mce_pairs_once_finish_dev(const double* dY, int64_t nr, int32_t d, int32_t k
     Plan p;
     int rc = pairs_once_plan(nr, d, kmax, p, false);
     if (rc != MCE_OK) return rc;
-    if (ws_bytes < p.total + dotp_ws_bytes(nr, kmax)) return fail(MCE_ERR_WORKSPACE, "workspace too small");
+    if (nparts > p.nqblk) return fail(MCE_ERR_INVALID, "pairs-once partition: %d ranks for %d blocks", nparts, p.nqblk);
+    const PairsOnceShape sh = pairs_once_shape(p, nr, kmax, nparts);
+    if (ws_bytes < sh.total) return fail(MCE_ERR_WORKSPACE, "workspace too small");
+    pairs_once_apply(p, sh);
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* wsc = static_cast<char*>(ws);
     const int K = kmax - 1;
     mce::KnnF16Args a;
     pairs_once_args(p, wsc, nr, d, K, a);
-    if (nparts > p.nqblk) return fail(MCE_ERR_INVALID, "pairs-once partition: %d ranks for %d blocks", nparts, p.nqblk);
     const int nown = mce::apo_rank_count(p.nqblk, part, nparts);          // this rank's blocks: part, part + nparts, ...
     int* err = reinterpret_cast<int*>(wsc + p.off_sym + p.sl.keys_a) + p.nqblk + 1;
     MCE_HIP(mce::zero_async(err, sizeof(int), st));
@@ -164,11 +312,15 @@ int mce_pairs_once_finish_dev(const double* dY, int64_t nr, int32_t d, int32_t k
     MCE_HIP(hipGetLastError());
     a.seed_cfg = 0;
     MCE_HIP(p.vh->launch_sym_repair(a, st));         // own blocks whose bucket overflowed here or elsewhere, or whose units gave up waiting
-    MCE_HIP(launch_sym_merge(p.KCAP, a.part_d, a.part_i, p.nq_pad, a.sym, part, p.nqblk, st, nparts));
+    if (sh.nsplit > 1 && nown > 0) {
+        hipLaunchKernelGGL(pairs_once_clear_kernel, dim3((unsigned)nown), dim3(512), 0, st, a.sym.bucket_flag, a.part_d, a.part_i, p.nq_pad, p.KCAP, sh.nsplit, (int)part, (int)nparts);
+        MCE_HIP(hipGetLastError());
+    }
+    MCE_HIP(launch_sym_merge(p.KCAP, a.part_d, a.part_i, p.nq_pad, a.sym, part, p.nqblk, st, nparts));      // (into list set 0)
     // the reduction enumerates every nparts-th block of list columns through a block table (reduce_kernels.hpp: border): the identity
     hipLaunchKernelGGL(mce::apo_iota_kernel, dim3((unsigned)((p.nqblk + 255) / 256)), dim3(256), 0, st, a.sym.done, p.nqblk);
     MCE_HIP(hipGetLastError());
-    p.part = part; p.nparts = nparts; p.apo = true; p.sym_qb_lo = 0; p.sym_qb_hi = p.nqblk; p.sym_active = true; p.L = 1;
+    p.part = part; p.nparts = nparts; p.sym_qb_lo = 0; p.sym_qb_hi = p.nqblk; p.sym_active = true; p.L = sh.nsplit;
     double* partial = reinterpret_cast<double*>(wsc + p.total);
     rc = launch_merge(p, false, true, dY, dY, nr, d, K, MCE_SELF_EXCLUDE, 0, nullptr, nullptr, 1, (int)kmax, d_w, d_fs, partial, wsc, st);
     if (rc != MCE_OK) return rc;

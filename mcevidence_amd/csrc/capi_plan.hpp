@@ -60,6 +60,9 @@ struct Plan {
                                               // contiguous range of sorted blocks [sym_qb_lo, sym_qb_hi) (one rank's share)
     int sym_qb_lo = 0, sym_qb_hi = 0;         // set by run_search when the symmetric sweep ran
     bool apo = false;                         // symmetric sweep as one rank's share of the all-pairs-once partition (capi_apo.hpp): run_search stops after the sweep
+    int apo_phase = 0;                        // ... 1: up to the prepass of the rank's own blocks; 2: the sweep (capi_search.hpp)
+    int apo_nsplit = 1;                       // ... with this many independent chains (list sets) per block, and
+    int apo_panel = 0;                        // ... panels of this many chunks (0: the default length)
     int64_t pl_nr = 0;                        // reference rows the plan was made for
     mce::PruneLayout pl;
     size_t off_prune = 0;

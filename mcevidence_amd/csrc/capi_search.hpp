@@ -27,6 +27,9 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
                int32_t self_mode, int64_t self_offset, char* ws, hipStream_t st)
 {
     p.sym_active = false;
+    // the all-pairs-once partition runs in two calls with a collective between them (capi_apo.hpp): 1 = statistics, sort, packing and
+    // the prepass of the rank's own blocks, then return (the bounds are all-reduced); 2 = the sweep on what phase 1 left in the workspace
+    const int phase = p.apo ? p.apo_phase : 0;
     double* pd = reinterpret_cast<double*>(ws + p.off_pd);
     int* pi = reinterpret_cast<int*>(ws + p.off_pi);
     if (p.generic) {
@@ -41,10 +44,12 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
     double* msum = reinterpret_cast<double*>(ws + p.off_msum);
     double* box_y = center + mce::kMaxDimPad;
     double* box_x = center + 2 * mce::kMaxDimPad;
-    hipLaunchKernelGGL(mce::col_stats_partial_kernel, dim3(mce::kMeanBlocks), dim3(mce::kMeanThreads), 0, st, dY, nr, (int)d, msum);
-    MCE_HIP(hipGetLastError());
-    hipLaunchKernelGGL(mce::col_stats_final_kernel, dim3(1), dim3(64), 0, st, msum, nr, (int)d, center, box_y);
-    MCE_HIP(hipGetLastError());
+    if (phase != 2) {
+        hipLaunchKernelGGL(mce::col_stats_partial_kernel, dim3(mce::kMeanBlocks), dim3(mce::kMeanThreads), 0, st, dY, nr, (int)d, msum);
+        MCE_HIP(hipGetLastError());
+        hipLaunchKernelGGL(mce::col_stats_final_kernel, dim3(1), dim3(64), 0, st, msum, nr, (int)d, center, box_y);
+        MCE_HIP(hipGetLastError());
+    }
     const bool prof = g_prof_on && g_ev_used < 1024;
     // bracket of the whole search: closed by the caller-visible end of run_search (SearchBracket's destructor)
     struct SearchBracket {
@@ -87,7 +92,7 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
         _Float16* xh = reinterpret_cast<_Float16*>(ws + p.off_xh);
         double* qinfo = reinterpret_cast<double*>(ws + p.off_qinfo);
         double* params = reinterpret_cast<double*>(ws + p.off_params);
-        MCE_HIP(mce::zero_async(params, mce::HP_COUNT * sizeof(double), st));
+        if (phase != 2) MCE_HIP(mce::zero_async(params, mce::HP_COUNT * sizeof(double), st));
         // queries that are literally rows of the reference buffer are inside its bounding box already
         bool separate_queries = !(dX >= dY && dX + (size_t)nq * d <= dY + (size_t)nr * d);
         const double* sX = dX;     // the rows the search reads: the caller's, or their k-d ordered copies
@@ -96,7 +101,7 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
         const bool use_sym = p.sym && dX == dY && nq == nr && self_offset == 0 && g_split_depth == 0;
         if (use_sym) {
             // rows by distance from the mean: a 32-row tile then holds rows of nearly equal K-th neighbour distance
-            MCE_HIP(mce::sym_prepare(dY, nr, (int)d, center, p.nq_pad, ws + p.off_sym, p.sl, st));
+            if (phase != 2) MCE_HIP(mce::sym_prepare(dY, nr, (int)d, center, p.nq_pad, ws + p.off_sym, p.sl, st));
             sX = sY = reinterpret_cast<const double*>(ws + p.off_sym + p.sl.Ys);
             separate_queries = false;
         }
@@ -114,9 +119,11 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             hipLaunchKernelGGL(mce::f16_box_about_kernel, dim3(1), dim3(64), 0, st, msum, (int)d, center, box_x);
             MCE_HIP(hipGetLastError());
         }
-        hipLaunchKernelGGL(mce::f16_scale_kernel, dim3(1), dim3(64), 0, st, box_y, separate_queries ? box_x : (const double*)nullptr, params);
-        MCE_HIP(hipGetLastError());
-        {
+        if (phase != 2) {
+            hipLaunchKernelGGL(mce::f16_scale_kernel, dim3(1), dim3(64), 0, st, box_y, separate_queries ? box_x : (const double*)nullptr, params);
+            MCE_HIP(hipGetLastError());
+        }
+        if (phase != 2) {
             const int64_t rows_per_block = 4 * (64 / (2 * p.KST));          // 4 waves x R rows
             const int64_t pack_blocks = std::min<int64_t>((p.nrow_pad + rows_per_block - 1) / rows_per_block, 2048);   // grid-stride
             hipLaunchKernelGGL(mce::f16_pack_refs_kernel, dim3((unsigned)pack_blocks), dim3(256), 0, st,
@@ -256,7 +263,16 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             // the all-pairs-once partition (capi_apo.hpp; sym_types.hpp): the single-GPU units of the blocks part, part + nparts, ...;
             // this call ends with the sweep -- repair and merge follow the exchange of the row-side candidates
             const bool apo = p.apo && p.nparts > 1 && !p.twopass && panel_kernel;
-            if (apo) { geom.blk_first = p.part; geom.blk_stride = p.nparts; }
+            if (apo) {
+                geom.blk_first = p.part; geom.blk_stride = p.nparts;
+                if (p.apo_panel > 0) { a.sym.panel = p.apo_panel; geom.tpp = a.sym.panel * p.CT; }
+                geom.nsplit = std::max(1, p.apo_nsplit);
+                if (geom.nsplit > 1) {
+                    // one hand-over counter per chain: nqblk * nsplit words in the sort's second key array (n_pad words, free by now)
+                    a.sym.done = reinterpret_cast<int*>(sw + p.sl.keys_b);
+                    MCE_HIP(mce::zero_async(a.sym.done, (size_t)p.nqblk * geom.nsplit * sizeof(int), st));
+                }
+            }
             // 16 < K <= 32 (round 5): TWO symmetric passes over 16-entry lists, as the exhaustive sweep does it (knn_f16.hpp, LOWER) --
             // the first finds every row's 16 nearest (lists A), the second the next K - 16 beyond them (lists B: knn_panel.hpp,
             // LOWER); the merge takes the K best of A and B.  The second pass needs bounds on the K-th distance: a prepass
@@ -283,9 +299,14 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
                 a.part_i = pip;
                 a.qblk0 = qb_lo;
                 a.nqblk_run = qb_hi - qb_lo;
-                if (qb_hi > qb_lo) MCE_HIP((lower ? p.vh->launch_sym_pre32 : p.vh->launch_sym_pre)(a, st));
+                if (apo) {      // only the rank's own blocks: the bounds of everybody's rows are all-reduced after this call (capi_apo.hpp)
+                    a.qblk0 = p.part; a.qblk_stride = p.nparts; a.nqblk_run = mce::apo_rank_count(p.nqblk, p.part, p.nparts);
+                }
+                if (a.nqblk_run > 0 && phase != 2) MCE_HIP((lower ? p.vh->launch_sym_pre32 : p.vh->launch_sym_pre)(a, st));
                 a.qblk0 = 0;
+                a.qblk_stride = 1;
                 a.nqblk_run = 0;
+                if (phase == 1) return MCE_OK;
                 if (pass == 0) seed_used = a.seed_cfg;
                 a.seed_cfg = 0;
                 a.ksel = Kp;
@@ -302,6 +323,17 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
                     pa.debug = tun.panel_debug;
                     pa.geom = geom;
                     pa.lo_d = a.lo_d; pa.lo_i = a.lo_i;
+                    if (apo) {
+                        // strided blocks, several chains per block: the units as a table (in the sort's value array: n_pad words, free by now)
+                        const int nun = mce::panel_unit_count(geom);
+                        if ((size_t)nun * sizeof(mce::PanelUnit) > (size_t)p.nq_pad * sizeof(int)) return fail(MCE_ERR_INVALID, "pairs-once partition: %d units", nun);
+                        mce::PanelUnit* tab = reinterpret_cast<mce::PanelUnit*>(sw + p.sl.vals_a);
+                        if (nun > 0) {
+                            hipLaunchKernelGGL(mce::panel_unit_table_kernel, dim3((unsigned)((nun + 255) / 256)), dim3(256), 0, st, geom, nun, tab);
+                            MCE_HIP(hipGetLastError());
+                        }
+                        pa.units = tab;
+                    }
                     MCE_HIP((lower ? p.vh->launch_panel_lower : p.vh->launch_panel)(pa, st));
                 } else {
                     MCE_HIP(p.vh->launch_sym(a, st));

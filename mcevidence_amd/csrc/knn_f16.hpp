@@ -321,8 +321,9 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
     // (sym_unit_count): the units running at the same time stream the same few MB of packed rows through L2
     int sym_a = 0, sym_p = 0;
     if constexpr (SYM == 2) sym_unit_decode((int)blockIdx.x, nqblk, kHWaves * kHQT, sym.panel * f16_chunk_tiles(KST), sym_p, sym_a);
-    // (SYM == 1, the prepass: the blocks qblk0, qblk0 + 1, ... of the launch -- one rank's share of a multi-GPU partition)
-    const int qblk = PRUNE ? pr_gw / kHWaves : (SYM == 2 ? sym_a : (SYM == 1 ? qblk0 + (int)blockIdx.x : (int)(blockIdx.x % nqblk)));
+    // (SYM == 1, the prepass: the blocks qblk0, qblk0 + 1, ... of the launch -- one rank's share of a multi-GPU partition; with a
+    //  stride: qblk0, qblk0 + stride, ... -- its share of the all-pairs-once partition)
+    const int qblk = PRUNE ? pr_gw / kHWaves : (SYM == 2 ? sym_a : (SYM == 1 ? qblk0 + (int)blockIdx.x * (qblk_stride > 1 ? qblk_stride : 1) : (int)(blockIdx.x % nqblk)));
     const int split = PRUNE ? 0 : (SYM >= 2 ? 0 : (int)(blockIdx.x / nqblk));
 
     if constexpr (SYM >= 2) {

@@ -44,6 +44,7 @@ struct PanelArgs {
                                  // second unit give up waiting at once
     SymParams sym;               // .done, .panel always; the row-side state only with geom.sym_on
     PanelGeom geom;
+    const PanelUnit* units = nullptr;   // non-null: the launch's units come from this table (sym_types.hpp) instead of the geometry -- the all-pairs-once partition
     const double* lo_d = nullptr;   // LOWER (second pass of a search for 16 < K <= 32 neighbours): the FIRST pass's lists, [KCAP][nq_pad] in the
     const int* lo_i = nullptr;      // same column order -- every row's own 16 nearest; this pass keeps only what lies beyond a row's 16th
 };
@@ -154,16 +155,40 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
     int sym_p, qblk, t_lo, t_hi, useq, sym_on, qb_lo;
     {
         const ArgsPtr a = MCE_ARGS();
-        PanelGeom g;
-        g.qb_lo = a->geom.qb_lo; g.qb_hi = a->geom.qb_hi; g.tpb = a->geom.tpb; g.tpp = a->geom.tpp;
-        g.ct = a->geom.ct; g.ntiles = a->geom.ntiles; g.sym_on = a->geom.sym_on;
-        g.blk_first = a->geom.blk_first; g.blk_stride = a->geom.blk_stride;       // (one rank's blocks of the all-pairs-once partition)
-        panel_unit_decode((int)blockIdx.x, g, sym_p, qblk);
-        panel_unit_tiles(sym_p, qblk, g, t_lo, t_hi);
-        useq = panel_unit_seq(sym_p, qblk, g);
-        sym_on = g.sym_on;
-        qb_lo = g.qb_lo;
+        if (a->units) {
+            // (a table made by panel_unit_table_kernel: strided blocks, several chains per block -- arithmetic this kernel is spared;
+            //  with it inlined here the headline sweep ran 0.45 ms slower of 34.3 although the tile loop's code was the same)
+            const auto u = (const __attribute__((address_space(1))) PanelUnit*)a->units + blockIdx.x;
+            qblk = __builtin_amdgcn_readfirstlane(u->qblk);
+            t_lo = __builtin_amdgcn_readfirstlane(u->t_lo);
+            t_hi = __builtin_amdgcn_readfirstlane(u->t_hi);
+            useq = __builtin_amdgcn_readfirstlane(u->useq);
+            sym_p = 0;
+            sym_on = a->geom.sym_on;
+            qb_lo = a->geom.qb_lo;
+        } else {
+            PanelGeom g;
+            g.qb_lo = a->geom.qb_lo; g.qb_hi = a->geom.qb_hi; g.tpb = a->geom.tpb; g.tpp = a->geom.tpp;
+            g.ct = a->geom.ct; g.ntiles = a->geom.ntiles; g.sym_on = a->geom.sym_on;
+            panel_unit_decode((int)blockIdx.x, g, sym_p, qblk);
+            panel_unit_tiles(sym_p, qblk, g, t_lo, t_hi);
+            useq = panel_unit_seq(sym_p, qblk, g);
+            sym_on = g.sym_on;
+            qb_lo = g.qb_lo;
+        }
     }
+    // the hand-over counter the unit waits on and bumps, and its list set: the block's, and set 0, unless the table says otherwise (read
+    // where needed, here and at the very end, not carried through the tile loop)
+    auto chain_of = [&](int& chain, int64_t& list_off) __attribute__((always_inline)) {
+        const ArgsPtr a = MCE_ARGS();
+        chain = qblk;
+        list_off = 0;
+        if (a->units) {
+            const auto u = (const __attribute__((address_space(1))) PanelUnit*)a->units + blockIdx.x;
+            chain = __builtin_amdgcn_readfirstlane(u->chain);
+            list_off = (int64_t)__builtin_amdgcn_readfirstlane(u->list_set) * KCAP * a->nq_pad;
+        }
+    };
     const int64_t qwave0 = (int64_t)qblk * QPB + wave * QPW;     // first query of this wave
 
     whead[lane] = -1;
@@ -187,13 +212,16 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
     {
         const ArgsPtr a = MCE_ARGS();
         if (useq > 0) {
+            int chain;
+            int64_t list_off;
+            chain_of(chain, list_off);
             int spins = 0;
             // (debug 16, tests: in every block's second unit the ODD waves give up at once -- the waves of a workgroup wait
             //  independently, so a give-up can be any subset of them)
             const int limit = ((a->debug & 16) && useq == 1 && (wave & 1)) ? -1 : a->spin_limit;
             bool ok = true;
             const auto done = gptr(a->sym.done);
-            while (spins > limit || __hip_atomic_load(done + qblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < useq) {
+            while (spins > limit || __hip_atomic_load(done + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < useq) {
                 if (++spins > limit) { ok = false; break; }
                 __builtin_amdgcn_s_sleep(32);
             }
@@ -207,8 +235,8 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
             if (ok) {
                 const int64_t q = qwave0 + lane;
                 const int64_t np = a->nq_pad;
-                const auto pd = gptr(a->part_d);
-                const auto pi = gptr(a->part_i);
+                const auto pd = gptr(a->part_d) + list_off;
+                const auto pi = gptr(a->part_i) + list_off;
 #pragma unroll
                 for (int k = 0; k < KCAP; ++k) {
                     own_d[k] = pd[(int64_t)k * np + q];
@@ -840,8 +868,11 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
         const ArgsPtr a = MCE_ARGS();
         const int64_t q = qwave0 + lane;
         const int64_t np = a->nq_pad;
-        const auto pd = gptr_w(a->part_d);
-        const auto pi = gptr_w(a->part_i);
+        int chain;
+        int64_t list_off;
+        chain_of(chain, list_off);
+        const auto pd = gptr_w(a->part_d) + list_off;
+        const auto pi = gptr_w(a->part_i) + list_off;
 #pragma unroll
         for (int k = 0; k < KCAP; ++k) {
             pd[(int64_t)k * np + q] = own_d[k];
@@ -849,7 +880,7 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(gptr_w(a->sym.done) + qblk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_add(gptr_w(a->sym.done) + chain, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #undef MCE_ARGS
 }

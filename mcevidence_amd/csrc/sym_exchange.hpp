@@ -100,6 +100,24 @@ __global__ __launch_bounds__(256) void apo_flags_kernel(const int* __restrict__ 
     if (b < nqblk && flags_all[b] != 0) bucket_flag[b] = 1;
 }
 
+// the units of a launch with strided blocks and / or several chains per block, as a table (knn_panel.hpp reads it)
+__global__ __launch_bounds__(256) void panel_unit_table_kernel(PanelGeom g, int nunits, PanelUnit* __restrict__ out)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= nunits) return;
+    int p, a, lo, hi;
+    panel_unit_decode(u, g, p, a);
+    panel_unit_tiles(p, a, g, lo, hi);
+    const int S = g.nsplit > 1 ? g.nsplit : 1;
+    PanelUnit t;
+    t.qblk = a; t.t_lo = lo; t.t_hi = hi;
+    t.useq = S > 1 ? p / S : panel_unit_seq(p, a, g);
+    t.chain = S > 1 ? a * S + p % S : a;
+    t.list_set = S > 1 ? p % S : 0;
+    t.pad0 = t.pad1 = 0;
+    out[u] = t;
+}
+
 // list column block -> block: identity (the reduction enumerates every nparts-th block through this table: reduce_kernels.hpp, border)
 __global__ __launch_bounds__(256) void apo_iota_kernel(int* __restrict__ out, int n)
 {

@@ -73,6 +73,9 @@ MCE_HD inline void sym_unit_tiles(int p, int a, int tpb, int tpp, int ntiles, in
 // hand its lists on in that order (panel_unit_seq = how many came before).
 // tests/native/sym_units_check.cpp checks the functions against each other.
 // ---------------------------------------------------------------------------
+// one unit of a launch whose units come from a table (PanelArgs.units): query block, tiles [t_lo, t_hi), how many units of its
+// chain come before it, the chain's hand-over counter, its list set
+struct PanelUnit { int qblk, t_lo, t_hi, useq, chain, list_set, pad0, pad1; };
 struct PanelGeom {
     int qb_lo = 0, qb_hi = 0;      // query blocks of the launch
     int tpb = 16;                  // tiles per query block
@@ -82,6 +85,10 @@ struct PanelGeom {
     int sym_on = 0;
     int blk_first = 0, blk_stride = 0;   // blk_stride = W > 1: only the blocks blk_first, blk_first + W, ... of [qb_lo, qb_hi) have units (one rank's share of
                                    // the all-pairs-once partition, below); needs qb_lo = 0 and sym_on = 1
+    int nsplit = 1;                // S > 1 (same launches): a block's units form S independent CHAINS -- the panels p = s, s + S, ... hand on list set s
+                                   // ([S][KCAP][nq_pad], merged afterwards) -- because a rank with fewer blocks than the chip has workgroup slots is
+                                   // as slow as its longest block's chain.  (blk_stride and nsplit are read by panel_unit_table_kernel -- sym_exchange.hpp --
+                                   // and the host; the sweep kernel takes such a launch's units from the table.)
 };
 MCE_HD inline int panel_r1(const PanelGeom& g) { return g.sym_on ? (g.tpb * g.qb_hi < g.ntiles ? g.tpb * g.qb_hi : g.ntiles) : g.ntiles; }
 MCE_HD inline int panel_r2(const PanelGeom& g) { return g.sym_on ? g.tpb * g.qb_hi : g.ntiles; }

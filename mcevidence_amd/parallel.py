@@ -201,7 +201,7 @@ def _exchange_rows(send, in_splits, out_splits, group):
 class _HipPairsOnce:
     """The three library calls of the all-pairs-once partition on this rank's GPU (device tensors through torch)."""
 
-    def __init__(self, Y, weight, fs, kmax):
+    def __init__(self, Y, weight, fs, kmax, world):
         import torch
         from . import _capi
         self.capi, self.torch = _capi, torch
@@ -211,16 +211,21 @@ class _HipPairsOnce:
         self.Y = torch.from_numpy(Y).to(self.dev)
         self.w = torch.from_numpy(np.ascontiguousarray(weight, dtype=np.float64)).to(self.dev)
         self.fs = torch.from_numpy(np.ascontiguousarray(fs, dtype=np.float64)).to(self.dev)
-        self.wsb = _capi.knn_workspace_bytes(self.n, self.n, self.d, self.kmax - 1) + _capi.dotp_workspace_bytes(self.n, self.kmax)
-        self.ws = torch.empty(self.wsb, dtype=torch.uint8, device=self.dev)
+        self.wsb = _capi.pairs_once_workspace_bytes(self.n, self.d, self.kmax, world)
+        self.ws = torch.empty(max(self.wsb, 1), dtype=torch.uint8, device=self.dev)
         self.st = torch.cuda.current_stream().cuda_stream
 
     def blocks(self):
         return self.capi.pairs_once_blocks(self.n, self.d, self.kmax)
 
+    def prepare(self, rank, world):
+        """-> the rows' bounds (float64 tensor, a view INTO the workspace): +inf outside this rank's blocks"""
+        self.rank, self.world = rank, world
+        off, cnt = self.capi.pairs_once_prepare_dev(self.Y.data_ptr(), self.n, self.d, self.kmax, rank, world, self.ws.data_ptr(), self.wsb, self.st)
+        return self.ws[off:off + 8 * cnt].view(self.torch.float64)
+
     def sweep(self, rank, world, nblk):
         torch = self.torch
-        self.rank, self.world = rank, world
         counts = torch.zeros(world, dtype=torch.int64, device=self.dev)
         flags = torch.zeros(nblk, dtype=torch.int32, device=self.dev)
         self.capi.pairs_once_sweep_dev(self.Y.data_ptr(), self.n, self.d, self.kmax, rank, world, counts.data_ptr(), flags.data_ptr(),
@@ -258,11 +263,19 @@ def pairs_once_knn_dotp(Y, weight, fs, kmax, group=None, stats=None, impl=None):
     rank = dist.get_rank(group)
     Y = np.ascontiguousarray(Y, dtype=np.float64)
     if impl is None:
-        impl = _HipPairsOnce(Y, weight, fs, kmax)
+        impl = _HipPairsOnce(Y, weight, fs, kmax, world)
     nblk = impl.blocks()
     if nblk < world or world < 2:
         raise ValueError("pairs-once partition: not applicable to %d x %d, kmax %d on %d ranks" % (Y.shape[0], Y.shape[1], kmax, world))
     nccl = dist.get_backend(group) == "nccl"
+    # every rank bounds the K-th distances of its own blocks' rows; MIN over the ranks gives everybody all of them
+    bounds = impl.prepare(rank, world)
+    if nccl:
+        dist.all_reduce(bounds, op=dist.ReduceOp.MIN, group=group)
+    else:
+        host = bounds.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.MIN, group=group)
+        bounds.copy_(host)
     counts, flags = impl.sweep(rank, world, nblk)
     cdev = counts.device if nccl else torch.device("cpu")
     # split sizes: every rank's counts to everybody (W x W integers); overflow flags: MAX over the ranks

@@ -321,8 +321,21 @@ class _HostPairsOnce:
         """(query block a, tile block b) this rank multiplies; a == b: the block against itself"""
         return [(a, b) for a in range(self.rank, self.nblk, self.world) for b in range(a + 1)]
 
-    def sweep(self, rank, world, nblk):
+    def prepare(self, rank, world):
+        """a bound on every own row's K-th squared distance (here simply the K-th distance within the row's own block), +inf elsewhere"""
         self.rank, self.world = rank, world
+        n, B, K = self.Y.shape[0], self.B, self.kmax - 1
+        Ys = self.Y[self.order]
+        self.bounds = torch.full((self.nblk * B,), float("inf"), dtype=torch.float64)
+        for b in range(rank, self.nblk, world):
+            rows = np.arange(b * B, min((b + 1) * B, n))
+            d2 = ((Ys[rows][:, None, :] - Ys[rows][None, :, :]) ** 2).sum(-1)
+            if len(rows) > K:
+                self.bounds[b * B:b * B + len(rows)] = torch.from_numpy(np.sort(d2, axis=1)[:, K])
+        return self.bounds
+
+    def sweep(self, rank, world, nblk):
+        assert bool(torch.isfinite(self.bounds[:(self.Y.shape[0] // self.B) * self.B]).all())          # after the MIN: everybody's rows (whole blocks)
         n, B = self.Y.shape[0], self.B
         Ys = self.Y[self.order]
         self.mine = {}                     # sorted row -> list of (d2, caller row of the neighbour)

@@ -583,16 +583,20 @@ def test_pairs_once_partition_refuses_what_it_cannot_do(sym):
     assert capi.pairs_once_blocks(30000, 20, 19) == 0          # K = 18 > 16: two passes -- not partitioned this way
     n, d, kmax = 30000, 20, 6
     Y = torch.from_numpy(_data(n, d, 3)).cuda()
-    wsb = capi.knn_workspace_bytes(n, n, d, kmax - 1) + capi.dotp_workspace_bytes(n, kmax)
+    wsb = capi.pairs_once_workspace_bytes(n, d, kmax, 2)
+    assert wsb >= capi.knn_workspace_bytes(n, n, d, kmax - 1) + capi.dotp_workspace_bytes(n, kmax) and capi.pairs_once_workspace_bytes(n, d, 19, 2) == 0
     ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
     cnt = torch.zeros(4, dtype=torch.int64, device="cuda"); fl = torch.zeros(capi.pairs_once_blocks(n, d, kmax), dtype=torch.int32, device="cuda")
     with pytest.raises(ValueError):
-        capi.pairs_once_sweep_dev(Y.data_ptr(), n, d, kmax, 0, 1, cnt.data_ptr(), fl.data_ptr(), ws.data_ptr(), wsb, 0)         # one rank: nothing to exchange
+        capi.pairs_once_prepare_dev(Y.data_ptr(), n, d, kmax, 0, 1, ws.data_ptr(), wsb, 0)         # one rank: nothing to exchange
     with pytest.raises(ValueError):
         capi.pairs_once_sweep_dev(Y.data_ptr(), n, d, kmax, 2, 2, cnt.data_ptr(), fl.data_ptr(), ws.data_ptr(), wsb, 0)
     with pytest.raises(ValueError):
-        capi.pairs_once_sweep_dev(Y.data_ptr(), n, d, kmax, 0, 2, cnt.data_ptr(), fl.data_ptr(), ws.data_ptr(), wsb - 4096, 0)
+        capi.pairs_once_prepare_dev(Y.data_ptr(), n, d, kmax, 0, 2, ws.data_ptr(), wsb - 4096, 0)
     # an entry for a row the rank does not own poisons the result instead of being dropped silently
+    off, nb = capi.pairs_once_prepare_dev(Y.data_ptr(), n, d, kmax, 0, 2, ws.data_ptr(), wsb, 0)
+    bounds = ws[off:off + 8 * nb].view(torch.float64)
+    assert nb == 512 * capi.pairs_once_blocks(n, d, kmax) and bool(torch.isfinite(bounds[:512]).all()) and bool(torch.isinf(bounds[512:1024]).all())
     capi.pairs_once_sweep_dev(Y.data_ptr(), n, d, kmax, 0, 2, cnt.data_ptr(), fl.data_ptr(), ws.data_ptr(), wsb, 0)
     w = torch.ones(n, dtype=torch.float64, device="cuda"); fs = torch.zeros(n, dtype=torch.float64, device="cuda")
     out = torch.zeros(kmax, dtype=torch.float64, device="cuda")

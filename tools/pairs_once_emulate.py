@@ -19,7 +19,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 XGMI_LINK_GBS = 50.0       # one direction of one link, conservatively (MI355X_MICROARCH.md: ~153 GB/s per link pair peak; RCCL all_to_all sees less)
-COLLECTIVE_LATENCY_MS = 0.06      # all_gather of the counts + all_reduce of the flags + all_to_all launch, ~20 us each
+COLLECTIVE_LATENCY_MS = 0.08      # all_reduce of the bounds, all_gather of the counts, all_reduce of the flags, all_to_all: ~20 us each
 
 
 def emulate(Y, weight, fs, kmax, W, reps=1):
@@ -35,13 +35,23 @@ def emulate(Y, weight, fs, kmax, W, reps=1):
     Yd = torch.from_numpy(Y).to(dev)
     wd = torch.from_numpy(np.ascontiguousarray(weight, dtype=np.float64)).to(dev)
     fd = torch.from_numpy(np.ascontiguousarray(fs, dtype=np.float64)).to(dev)
-    wsb = _capi.knn_workspace_bytes(n, n, d, kmax - 1) + _capi.dotp_workspace_bytes(n, kmax)
+    wsb = _capi.pairs_once_workspace_bytes(n, d, kmax, W)
     ws = [torch.empty(wsb, dtype=torch.uint8, device=dev) for _ in range(W)]
     best = None
     for _ in range(reps):
         counts = [torch.zeros(W, dtype=torch.int64, device=dev) for _ in range(W)]
         flags = [torch.zeros(nblk, dtype=torch.int32, device=dev) for _ in range(W)]
-        t_sweep, t_export, t_finish, kern = [], [], [], []
+        t_prep, t_sweep, t_export, t_finish, kern = [], [], [], [], []
+        views = []
+        for r in range(W):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            off, nb = _capi.pairs_once_prepare_dev(Yd.data_ptr(), n, d, kmax, r, W, ws[r].data_ptr(), wsb, 0)
+            torch.cuda.synchronize(); t_prep.append((time.perf_counter() - t0) * 1e3)
+            views.append(ws[r][off:off + 8 * nb].view(torch.float64))
+        allb = torch.stack(views).min(dim=0).values          # the all-reduce(MIN) of the bounds
+        for v in views:
+            v.copy_(allb)
+        bounds_bytes = 8 * int(allb.numel())
         for r in range(W):
             _capi.set_profiling(True)
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -76,9 +86,12 @@ def emulate(Y, weight, fs, kmax, W, reps=1):
             torch.cuda.synchronize(); t_finish.append((time.perf_counter() - t0) * 1e3)
             total += out.cpu().numpy()
         sent = [int(c.sum()) for c in cnt]
-        exch = [max(16.0 * sent[r], 16.0 * recv_n[r]) / (XGMI_LINK_GBS * 1e9) * 1e3 + COLLECTIVE_LATENCY_MS for r in range(W)]
-        rank_ms = [t_sweep[r] + t_export[r] + t_finish[r] + exch[r] for r in range(W)]
-        res = dict(world=W, dotp=total, rank_ms=[round(v, 3) for v in rank_ms], sweep_ms=[round(v, 3) for v in t_sweep], sweep_kernel_ms=[round(v, 3) for v in kern],
+        # priced: the candidates over one link; the bounds' all-reduce as a ring (2 (W - 1) / W of the array over one link); four collective launches
+        exch = [max(16.0 * sent[r], 16.0 * recv_n[r]) / (XGMI_LINK_GBS * 1e9) * 1e3 + 2.0 * (W - 1) / W * bounds_bytes / (XGMI_LINK_GBS * 1e9) * 1e3
+                + COLLECTIVE_LATENCY_MS for r in range(W)]
+        rank_ms = [t_prep[r] + t_sweep[r] + t_export[r] + t_finish[r] + exch[r] for r in range(W)]
+        res = dict(world=W, dotp=total, rank_ms=[round(v, 3) for v in rank_ms], prepare_ms=[round(v, 3) for v in t_prep], sweep_ms=[round(v, 3) for v in t_sweep],
+                   sweep_kernel_ms=[round(v, 3) for v in kern], bounds_bytes=bounds_bytes,
                    export_ms=[round(v, 3) for v in t_export], finish_ms=[round(v, 3) for v in t_finish], exchange_ms_priced=[round(v, 3) for v in exch],
                    candidates_sent=sent, candidates_received=recv_n, flagged_blocks=int(allflags.sum().item()), predicted_step_ms=round(max(rank_ms), 3), kernel=kernel)
         if best is None or res["predicted_step_ms"] < best["predicted_step_ms"]:
