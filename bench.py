@@ -589,6 +589,34 @@ def main():
         dist.all_gather(allr, mine)
         e2e_ranks = [dict(rank=i, seconds=round(float(t[0]), 4), max_abs_dlnE_vs_resident_path=float(t[1])) for i, t in enumerate(allr)]
 
+    # MCE_BENCH_PAIRS_ONCE=1 (two ranks or more; opt-in, off in the driver's runs): the same workload through the all-pairs-once
+    # partition -- every rank's sweep, the exchange of the candidates and the all-reduces inside the timed region, data resident
+    pairs_once = None
+    if dist_on and world >= 2 and os.environ.get("MCE_BENCH_PAIRS_ONCE") == "1" and a.mode == 0:
+        from mcevidence_amd import parallel
+        impl = parallel._HipPairsOnce(Xh, weight, fsh, kmax, world)
+        if impl.blocks() >= world:
+            progress("pairs-once partition: %d steps + %d warm-up" % (a.steps, a.warmup))
+            st = {}
+            for _ in range(max(a.warmup, 1)):
+                dp1 = parallel.pairs_once_knn_dotp(Xh, weight, fsh, kmax, stats=st, impl=impl)
+            ctx.barrier()
+            t3 = time.perf_counter()
+            for _ in range(a.steps):
+                dp1 = parallel.pairs_once_knn_dotp(Xh, weight, fsh, kmax, stats=st, impl=impl)
+            ctx.barrier()
+            mine = torch.tensor([time.perf_counter() - t3, float(st["sent"]), float(st["received"])], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            ms1 = max(float(t[0]) for t in allr) / a.steps * 1e3
+            lnE1 = lnE_from_dotp(dp1, c3)
+            pairs_once = dict(ms_per_step=round(ms1, 3), queries_per_s=round(n / (ms1 * 1e-3), 1), kernel=_capi.last_kernel(),
+                              candidates_sent=[int(t[1]) for t in allr], candidates_received=[int(t[2]) for t in allr],
+                              max_abs_dlnE_vs_default_partition=float(np.max(np.abs(lnE1 - lnE))),
+                              collectives="all_reduce(MIN) of the rows' bounds, all_gather of the counts, all_reduce(MAX) of the flags, all_to_all of the candidates, all_reduce(SUM)")
+        del impl
+        torch.cuda.empty_cache()
+
     orc = None
     if rank == 0:
         from oracle import oracle_np as orc                 # checker / CPU baseline only; never inside a timed region
@@ -690,6 +718,8 @@ def main():
                    per_rank=head.get("per_rank"),
                    max_abs_dlnE_vs_reference=dlnE, lnE=[round(float(x), 10) for x in lnE],
                    roofline=roof, cpu_baseline=cpu, evidence_call_from_host=e2e, configs=extras, fp64_mode=fp64_mode)
+        if pairs_once is not None:
+            out["pairs_once"] = pairs_once
         print(json.dumps(out), flush=True)
     if dist_on:
         progress("done")

@@ -156,7 +156,7 @@ def test_bench_gpus_2_under_the_launcher():
     port = s.getsockname()[1]
     s.close()
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(MCE_BENCH_BACKEND="gloo", MCE_BENCH_ONE_DEVICE="1")
+    env.update(MCE_BENCH_BACKEND="gloo", MCE_BENCH_ONE_DEVICE="1", MCE_BENCH_PAIRS_ONCE="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--cpu-sample", "0", "--no-extras"], capture_output=True, text=True, env=env, timeout=900, cwd=REPO)
@@ -167,3 +167,7 @@ def test_bench_gpus_2_under_the_launcher():
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["steps"] == 2 and line["warmup"] == 1
     assert line["config"]["N"] == 1_000_000 and line["config"]["D"] == 27 and line["max_abs_dlnE_vs_reference"] < LNE_TOL
     assert "symmetric" in line["roofline"]["kernel"] and len(line["per_rank"]) == 2
+    # MCE_BENCH_PAIRS_ONCE=1: the same workload through the all-pairs-once partition, collectives and all, in the same line
+    po = line["pairs_once"]
+    assert "pairs-once" in po["kernel"] and po["max_abs_dlnE_vs_default_partition"] < LNE_TOL and po["ms_per_step"] > 0
+    assert sum(po["candidates_sent"]) == sum(po["candidates_received"]) > 0

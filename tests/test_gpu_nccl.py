@@ -87,6 +87,24 @@ try:
     out["failed_rank_raises"] = False
 except MemoryError:
     out["failed_rank_raises"] = True
+# 5. the collectives of the all-pairs-once partition (parallel.pairs_once_knn_dotp) as it issues them, over RCCL on device
+#    tensors: MIN over a float64 view into a uint8 workspace, all_gather of int64 counts, MAX over int32 flags, and the
+#    all_to_all_single of 16-byte candidates with split sizes (one rank: everything comes back)
+dev = torch.device("cuda", 0)
+wsbuf = torch.zeros(4096 + 8 * 1000, dtype=torch.uint8, device=dev)
+bounds = wsbuf[4096:4096 + 8 * 1000].view(torch.float64)
+bounds.copy_(torch.arange(1000, dtype=torch.float64, device=dev))
+dist.all_reduce(bounds, op=dist.ReduceOp.MIN)
+counts = torch.tensor([777], dtype=torch.int64, device=dev)
+table = [torch.zeros(1, dtype=torch.int64, device=dev)]
+dist.all_gather(table, counts)
+flags = torch.tensor([0, 1, 0, 1], dtype=torch.int32, device=dev)
+dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+send = torch.arange(2 * 777, dtype=torch.float64, device=dev).reshape(777, 2)
+recv = parallel._exchange_rows(send, [777], [int(table[0][0])], None)
+empty = parallel._exchange_rows(send[:0], [0], [0], None)
+out["pairs_once_collectives"] = bool(torch.equal(bounds, torch.arange(1000, dtype=torch.float64, device=dev)) and int(table[0][0]) == 777
+                                     and flags.tolist() == [0, 1, 0, 1] and torch.equal(recv, send) and recv.is_cuda and empty.shape[0] == 0)
 dist.barrier()
 dist.destroy_process_group()
 print("RESULT " + json.dumps(out), flush=True)
@@ -109,6 +127,7 @@ def test_nccl_group_of_one_rank_drives_every_multi_rank_path():
         assert c["identical"], (name, c)
     assert "symmetric" in out["sharded_knn_dotp"]["auto_sym"]["kernel"] and "pruned" in out["sharded_knn_dotp"]["auto_walk"]["kernel"]
     assert out["class_auto_identical"] and out["class_cross_identical"] and out["evidence_many_identical"]
+    assert out["pairs_once_collectives"]
 
 
 def _bench_line(args, env_extra, timeout=900):

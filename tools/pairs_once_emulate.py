@@ -71,7 +71,7 @@ def emulate(Y, weight, fs, kmax, W, reps=1):
         # the exchange: rank r receives, from every rank s, the slice of s's send buffer meant for r
         allflags = torch.stack(flags).max(dim=0).values.contiguous()
         total = np.zeros(kmax)
-        recv_n = []
+        recv_n, t_finish_gpu, t_finish_host = [], [], []
         for r in range(W):
             pieces = []
             for s in range(W):
@@ -80,10 +80,15 @@ def emulate(Y, weight, fs, kmax, W, reps=1):
             recv = torch.cat(pieces).contiguous() if pieces else torch.empty((0, 2), dtype=torch.float64, device=dev)
             out = torch.zeros(kmax, dtype=torch.float64, device=dev)
             nrecv = int(recv.shape[0]); recv_n.append(nrecv)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize(); t0 = time.perf_counter()
+            e0.record()
             _capi.pairs_once_finish_dev(Yd.data_ptr(), n, d, kmax, r, W, wd.data_ptr(), fd.data_ptr(), recv.data_ptr() if nrecv else 0, nrecv,
                                         allflags.data_ptr(), out.data_ptr(), ws[r].data_ptr(), wsb, 0)
+            e1.record()
+            t_call = (time.perf_counter() - t0) * 1e3
             torch.cuda.synchronize(); t_finish.append((time.perf_counter() - t0) * 1e3)
+            t_finish_gpu.append(e0.elapsed_time(e1)); t_finish_host.append(t_call)
             total += out.cpu().numpy()
         sent = [int(c.sum()) for c in cnt]
         # priced: the candidates over one link; the bounds' all-reduce as a ring (2 (W - 1) / W of the array over one link); four collective launches
@@ -92,7 +97,8 @@ def emulate(Y, weight, fs, kmax, W, reps=1):
         rank_ms = [t_prep[r] + t_sweep[r] + t_export[r] + t_finish[r] + exch[r] for r in range(W)]
         res = dict(world=W, dotp=total, rank_ms=[round(v, 3) for v in rank_ms], prepare_ms=[round(v, 3) for v in t_prep], sweep_ms=[round(v, 3) for v in t_sweep],
                    sweep_kernel_ms=[round(v, 3) for v in kern], bounds_bytes=bounds_bytes,
-                   export_ms=[round(v, 3) for v in t_export], finish_ms=[round(v, 3) for v in t_finish], exchange_ms_priced=[round(v, 3) for v in exch],
+                   export_ms=[round(v, 3) for v in t_export], finish_ms=[round(v, 3) for v in t_finish], finish_gpu_ms=[round(v, 3) for v in t_finish_gpu],
+                   finish_host_call_ms=[round(v, 3) for v in t_finish_host], exchange_ms_priced=[round(v, 3) for v in exch],
                    candidates_sent=sent, candidates_received=recv_n, flagged_blocks=int(allflags.sum().item()), predicted_step_ms=round(max(rank_ms), 3), kernel=kernel)
         if best is None or res["predicted_step_ms"] < best["predicted_step_ms"]:
             best = res
