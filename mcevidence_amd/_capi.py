@@ -110,7 +110,7 @@ def load():
     """Load the shared library (once).  Raises RuntimeError if it is not built."""
     global _lib
     if _lib is None:
-        path = os.environ.get("MCE_LIB_PATH") or LIB_PATH          # (MCE_LIB_PATH: another build of the SAME library -- same-box A/B runs)
+        path = LIB_PATH
         if not os.path.exists(path):
             raise RuntimeError(
                 "mcevidence_amd: %s not found -- build it with `make -C mcevidence_amd/csrc` "
@@ -126,7 +126,7 @@ def load():
                 pass
         lib = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
-            if path != LIB_PATH and not hasattr(lib, name):
+            if os.environ.get("MCE_LIB") and not hasattr(lib, name):
                 continue                                         # (an older build in an A/B run lacks the newest entry points)
             fn = getattr(lib, name)
             fn.restype = res

@@ -1,9 +1,9 @@
 #!/bin/bash
-# GPU box: same-box A/B of two builds of the library (MCE_LIB_PATH) on the headline config: C3 step and sweep-kernel time
+# GPU box: same-box A/B of two builds of the library (MCE_LIB) on the headline config: C3 step and sweep-kernel time
 cd "$(dirname "$0")/.."
 for round in 1 2 3; do
   for lib in "${1:-_ab/libold.so}" mcevidence_amd/libmcevidence_hip.so; do
-    MCE_LIB_PATH=$PWD/$lib python - "$lib" <<'PY'
+    MCE_LIB=$PWD/$lib python - "$lib" <<'PY'
 import sys, json, time
 import numpy as np, torch
 import bench
