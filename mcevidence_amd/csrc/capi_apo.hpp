@@ -78,33 +78,6 @@ void pairs_once_apply(Plan& p, const PairsOnceShape& sh)
     p.off_pi = sh.off_i;
 }
 
-// every list set of the rank's blocks starts empty (a chain without units -- a block with fewer panels than chains -- leaves its set untouched)
-__global__ __launch_bounds__(512) void pairs_once_init_lists_kernel(double* __restrict__ pd, int* __restrict__ pi, int64_t nq_pad, int KCAP, int S, int part, int nparts)
-{
-    const int64_t q = (int64_t)(part + nparts * (int)blockIdx.x) * 512 + threadIdx.x;
-    for (int s = 0; s < S; ++s)
-        for (int k = 0; k < KCAP; ++k) {
-            const int64_t o = ((int64_t)s * KCAP + k) * nq_pad + q;
-            pd[o] = __builtin_huge_val();
-            pi[o] = -1;
-        }
-}
-
-// list sets 1 .. S - 1 of the blocks that were searched again (their set 0 is complete): emptied
-__global__ __launch_bounds__(512) void pairs_once_clear_kernel(const int* __restrict__ bucket_flag, double* __restrict__ pd, int* __restrict__ pi, int64_t nq_pad, int KCAP,
-                                                               int S, int part, int nparts)
-{
-    const int b = part + nparts * (int)blockIdx.x;
-    if (bucket_flag[b] == 0) return;
-    const int64_t q = (int64_t)b * 512 + threadIdx.x;
-    for (int s = 1; s < S; ++s)
-        for (int k = 0; k < KCAP; ++k) {
-            const int64_t o = ((int64_t)s * KCAP + k) * nq_pad + q;
-            pd[o] = __builtin_huge_val();
-            pi[o] = -1;
-        }
-}
-
 __global__ __launch_bounds__(256) void pairs_once_fill_kernel(unsigned long long* __restrict__ p, int64_t n, unsigned long long v)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
@@ -212,7 +185,7 @@ int mce_pairs_once_prepare_dev(const double* dY, int64_t nr, int32_t d, int32_t 
     MCE_HIP(hipGetLastError());
     if (sh.nsplit > 1) {
         static_assert(mce::f16_qpb(4) == 512, "one workgroup per block of list columns");
-        hipLaunchKernelGGL(pairs_once_init_lists_kernel, dim3((unsigned)mce::apo_rank_count(p.nqblk, part, nparts)), dim3(512), 0, st,
+        hipLaunchKernelGGL(mce::sym_chain_init_kernel, dim3((unsigned)mce::apo_rank_count(p.nqblk, part, nparts)), dim3(512), 0, st,
                            reinterpret_cast<double*>(wsc + sh.off_d), reinterpret_cast<int*>(wsc + sh.off_i), p.nq_pad, p.KCAP, sh.nsplit, (int)part, (int)nparts);
         MCE_HIP(hipGetLastError());
     }
@@ -313,7 +286,7 @@ int mce_pairs_once_finish_dev(const double* dY, int64_t nr, int32_t d, int32_t k
     a.seed_cfg = 0;
     MCE_HIP(p.vh->launch_sym_repair(a, st));         // own blocks whose bucket overflowed here or elsewhere, or whose units gave up waiting
     if (sh.nsplit > 1 && nown > 0) {
-        hipLaunchKernelGGL(pairs_once_clear_kernel, dim3((unsigned)nown), dim3(512), 0, st, a.sym.bucket_flag, a.part_d, a.part_i, p.nq_pad, p.KCAP, sh.nsplit, (int)part, (int)nparts);
+        hipLaunchKernelGGL(mce::sym_chain_clear_kernel, dim3((unsigned)nown), dim3(512), 0, st, a.sym.bucket_flag, a.part_d, a.part_i, p.nq_pad, p.KCAP, sh.nsplit, (int)part, (int)nparts);
         MCE_HIP(hipGetLastError());
     }
     MCE_HIP(launch_sym_merge(p.KCAP, a.part_d, a.part_i, p.nq_pad, a.sym, part, p.nqblk, st, nparts));      // (into list set 0)

@@ -64,7 +64,7 @@ std::atomic<int> g_prune_mode{0};
 struct Tuning {
     bool sym_kernel_f16 = false, tail_split = true, prune_prof = false, wide = true;
     int spin_limit = 1 << 21, sym_bucket = 0, sym_panel = 0, sym_seed_rows = 0, sym_seed_share = 2, sym_seed_mode = -1;
-    int f16_seed_rows = -1, f16_seed_share = -1, f16_seed_tg = -1, rsplit = 0, panel_debug = 0;
+    int f16_seed_rows = -1, f16_seed_share = -1, f16_seed_tg = -1, rsplit = 0, panel_debug = 0, sym_chains = 0;
     size_t feed_wave_bytes = 0;
 };
 Tuning read_tuning()
@@ -76,6 +76,7 @@ Tuning read_tuning()
     t.spin_limit = num("MCE_SYM_SPIN_LIMIT", 1 << 21);
     t.sym_bucket = num("MCE_SYM_BUCKET", 0);
     t.sym_panel = num("MCE_SYM_PANEL", 0);
+    t.sym_chains = num("MCE_SYM_CHAINS", 0);
     t.sym_seed_rows = num("MCE_SYM_SEED_ROWS", 0);
     t.sym_seed_share = num("MCE_SYM_SEED_SHARE", 2);
     t.sym_seed_mode = num("MCE_SYM_SEED_MODE", -1);
@@ -130,6 +131,11 @@ int eff_verify() { return t_opt.verify > 0 ? t_opt.verify : 0; }       // rows r
 // d <= 6 from 300 k rows: the pruned walk takes over before that).  The more of a search is MFMA work, the more halving the
 // products pays.
 constexpr int kSymAutoMinBlocks[5] = {0, 768, 257, 193, 193};
+// Chains per block (round 5; PanelGeom.nsplit).  A block's units hand its register lists on one after the other; a launch whose
+// blocks are few and long is as slow as its longest block's chain.  Its panels can be dealt to S chains with their own list sets,
+// merged at the end: what a rank of the all-pairs-once partition does (capi_apo.hpp); on one GPU only when MCE_SYM_CHAINS = S asks
+// (capi_plan.hpp has the measurement).
+constexpr int kSymMaxChains = 8;
 // prepass rows by k-steps: 0 spread over the sorted rows, 1 the rows nearest the mean, 2 half and half.  Fused call, ms,
 // spread / nearest / half: 1M x 3 42.6 / 152.6 / 45.2; 1M x 6 36.1 / 50.1 / 37.1; 1M x 10 34.4 / 36.8 / 34.8; 1M x 15
 // 33.8 / 33.4 / 33.2; 1M x 20 50.2 / 45.9 / 46.8; 1M x 27 48.8 / 44.4 / 45.5 (tools/sym_seedmode.py)

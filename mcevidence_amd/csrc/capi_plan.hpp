@@ -72,6 +72,8 @@ struct Plan {
     bool sym_active = false;                  // set by run_search: the lists are in sorted-row order, one split
     mce::SymLayout sl;
     size_t off_sym = 0;
+    int sym_nsplit = 1;                       // symmetric sweep on one GPU: chains (list sets) per block, and
+    int sym_panel = 0;                        // ... chunks per panel when that shortens them (0: the default length)
 };
 
 const mce::KnnVariant* variant_for(int KS, int kcap_idx)
@@ -272,7 +274,20 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
         // the *_dev ones at call time) or said by the caller of a workspace query (mce_options.same_set); unknown: reserve
         if (g_same_set_hint == 0 || (g_same_set_hint < 0 && t_opt.same_set == 0)) p.sym = false;
     }
-    const int l_alloc = p.L;
+    p.sym_nsplit = 1;
+    p.sym_panel = 0;
+    if (p.sym && !p.twopass) {
+        const Tuning tun = read_tuning();
+        // (on ONE GPU chains do not pay: measured at d = 27, K = 9, S = 1 / 2 / 3 / 6: 200 k rows 3.09 / 3.27 / 3.35 / 3.55 ms, 400 k 8.33 /
+        //  8.59 / 8.83 / 9.37 -- every chain fills a list of its own, and a block's chain is short already; only below ~130 k rows
+        //  did they win, 2.20 -> 2.05 ms.  Off unless MCE_SYM_CHAINS asks; a rank of the all-pairs-once partition, whose blocks are
+        //  few and long, takes them: capi_apo.hpp)
+        int S = 1;
+        if (tun.sym_chains >= 1) S = std::min(tun.sym_chains, kSymMaxChains);
+        p.sym_nsplit = S;
+        if (S > 1) p.sym_panel = (int)std::max<int64_t>(8, std::min<int64_t>(kSymPanelChunks[p.KST], p.nchunk / (2 * S)));
+    }
+    const int l_alloc = std::max(p.L, p.sym_nsplit);
     p.off_pd = off;
     off = align_up(off + (size_t)l_alloc * p.KCAP * (size_t)p.nq_pad * sizeof(double), 256);
     p.off_pi = off;

@@ -263,16 +263,25 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             // the all-pairs-once partition (capi_apo.hpp; sym_types.hpp): the single-GPU units of the blocks part, part + nparts, ...;
             // this call ends with the sweep -- repair and merge follow the exchange of the row-side candidates
             const bool apo = p.apo && p.nparts > 1 && !p.twopass && panel_kernel;
-            if (apo) {
-                geom.blk_first = p.part; geom.blk_stride = p.nparts;
-                if (p.apo_panel > 0) { a.sym.panel = p.apo_panel; geom.tpp = a.sym.panel * p.CT; }
-                geom.nsplit = std::max(1, p.apo_nsplit);
+            // chains of units per block (PanelGeom.nsplit): the partition's own choice, or -- one GPU, one pass -- the plan's for sets with
+            // MCE_SYM_CHAINS (capi_plan.hpp)
+            const bool chains1 = !apo && p.nparts == 1 && panel_kernel && !p.twopass && p.sym_nsplit > 1;
+            if (apo) { geom.blk_first = p.part; geom.blk_stride = p.nparts; }
+            if (apo || chains1) {
+                const int pn = apo ? p.apo_panel : p.sym_panel;
+                if (pn > 0 && (apo || tun.sym_panel <= 0)) { a.sym.panel = pn; geom.tpp = a.sym.panel * p.CT; }      // (MCE_SYM_PANEL, if set, stands)
+                geom.nsplit = std::max(1, apo ? p.apo_nsplit : p.sym_nsplit);
                 if (geom.nsplit > 1) {
                     // one hand-over counter per chain: nqblk * nsplit words in the sort's second key array (n_pad words, free by now)
                     a.sym.done = reinterpret_cast<int*>(sw + p.sl.keys_b);
                     MCE_HIP(mce::zero_async(a.sym.done, (size_t)p.nqblk * geom.nsplit * sizeof(int), st));
+                    if (!apo) {
+                        hipLaunchKernelGGL(mce::sym_chain_init_kernel, dim3((unsigned)p.nqblk), dim3(512), 0, st, pd, pi, p.nq_pad, p.KCAP, geom.nsplit, 0, 1);
+                        MCE_HIP(hipGetLastError());
+                    }
                 }
             }
+            const bool unit_table = apo || geom.nsplit > 1;
             // 16 < K <= 32 (round 5): TWO symmetric passes over 16-entry lists, as the exhaustive sweep does it (knn_f16.hpp, LOWER) --
             // the first finds every row's 16 nearest (lists A), the second the next K - 16 beyond them (lists B: knn_panel.hpp,
             // LOWER); the merge takes the K best of A and B.  The second pass needs bounds on the K-th distance: a prepass
@@ -323,10 +332,10 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
                     pa.debug = tun.panel_debug;
                     pa.geom = geom;
                     pa.lo_d = a.lo_d; pa.lo_i = a.lo_i;
-                    if (apo) {
+                    if (unit_table) {
                         // strided blocks, several chains per block: the units as a table (in the sort's value array: n_pad words, free by now)
                         const int nun = mce::panel_unit_count(geom);
-                        if ((size_t)nun * sizeof(mce::PanelUnit) > (size_t)p.nq_pad * sizeof(int)) return fail(MCE_ERR_INVALID, "pairs-once partition: %d units", nun);
+                        if ((size_t)nun * sizeof(mce::PanelUnit) > (size_t)p.nq_pad * sizeof(int)) return fail(MCE_ERR_INVALID, "symmetric sweep: %d units do not fit the table", nun);
                         mce::PanelUnit* tab = reinterpret_cast<mce::PanelUnit*>(sw + p.sl.vals_a);
                         if (nun > 0) {
                             hipLaunchKernelGGL(mce::panel_unit_table_kernel, dim3((unsigned)((nun + 255) / 256)), dim3(256), 0, st, geom, nun, tab);
@@ -342,10 +351,14 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
                 if (rc != MCE_OK) return rc;
                 if (apo) break;             // (repair and merge: pairs_once_finish, after the exchange)
                 MCE_HIP((lower ? p.vh->launch_sym_repair_lower : p.vh->launch_sym_repair)(a, st));      // blocks whose bucket overflowed (normally none: every workgroup exits at once)
+                if (geom.nsplit > 1) {       // (a repaired block's set 0 is complete: its other sets are emptied)
+                    hipLaunchKernelGGL(mce::sym_chain_clear_kernel, dim3((unsigned)p.nqblk), dim3(512), 0, st, a.sym.bucket_flag, pdp, pip, p.nq_pad, p.KCAP, geom.nsplit, 0, 1);
+                    MCE_HIP(hipGetLastError());
+                }
                 MCE_HIP(launch_sym_merge(p.KCAP, pdp, pip, p.nq_pad, a.sym, qb_lo, qb_hi, st));
             }
             p.sym_active = true;
-            p.L = npass;
+            p.L = geom.nsplit > 1 ? geom.nsplit : npass;
             int sym_units = mce::sym_unit_count(p.nqblk, mce::kHWaves * mce::kHQT, a.sym.panel * p.CT, (int)((nr + 31) / 32) + (int)(((nr + 31) / 32) & 1));
             if (panel_kernel) {
                 const mce::PanelGeom& g = geom;
@@ -370,7 +383,7 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             }
             g_last_flops_all = g_last_flops_main + (double)(seed_used & 0xffff) * p.CT * (double)(qb_hi - qb_lo) * 16.0 * 1024.0 * 32.0 * p.KST;
             snprintf(g_last_kernel, sizeof(g_last_kernel), "%s symmetric%s%s%s grid=%d block=%d lds=%zu qt=%d ct=%d panel=%d seed=%dx%d/%d bucket=%d", p.vh->name, panel_kernel ? " panel-kernel" : "",
-                     p.twopass ? " two passes" : "", geom.blk_stride > 1 ? " pairs-once" : "", sym_units,
+                     p.twopass ? " two passes" : "", geom.blk_stride > 1 ? " pairs-once" : (geom.nsplit > 1 ? " chains" : ""), sym_units,
                      mce::kHThreads, panel_kernel ? p.vh->lds_bytes_panel : p.vh->lds_bytes_sym, p.QT, p.CT, a.sym.panel, seed_used & 0xffff, (seed_used >> 16) & 0xfff, (seed_used >> 28) & 3, p.sl.cap);
             return MCE_OK;
         }

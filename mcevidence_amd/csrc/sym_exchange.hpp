@@ -133,6 +133,33 @@ __global__ __launch_bounds__(256) void panel_unit_table_kernel(PanelGeom g, int 
     out[u] = t;
 }
 
+// chains (PanelGeom.nsplit): every list set of the blocks part, part + nparts, ... starts empty -- a chain without units (a block
+// with fewer panels than chains) leaves its set untouched
+__global__ __launch_bounds__(512) void sym_chain_init_kernel(double* __restrict__ pd, int* __restrict__ pi, int64_t nq_pad, int KCAP, int S, int part, int nparts)
+{
+    const int64_t q = (int64_t)(part + nparts * (int)blockIdx.x) * 512 + threadIdx.x;
+    for (int s = 0; s < S; ++s)
+        for (int k = 0; k < KCAP; ++k) {
+            const int64_t o = ((int64_t)s * KCAP + k) * nq_pad + q;
+            pd[o] = __builtin_huge_val();
+            pi[o] = -1;
+        }
+}
+// ... and the sets 1 .. S - 1 of the blocks that were searched again (their set 0 is complete) are emptied
+__global__ __launch_bounds__(512) void sym_chain_clear_kernel(const int* __restrict__ bucket_flag, double* __restrict__ pd, int* __restrict__ pi, int64_t nq_pad, int KCAP,
+                                                              int S, int part, int nparts)
+{
+    const int b = part + nparts * (int)blockIdx.x;
+    if (bucket_flag[b] == 0) return;
+    const int64_t q = (int64_t)b * 512 + threadIdx.x;
+    for (int s = 1; s < S; ++s)
+        for (int k = 0; k < KCAP; ++k) {
+            const int64_t o = ((int64_t)s * KCAP + k) * nq_pad + q;
+            pd[o] = __builtin_huge_val();
+            pi[o] = -1;
+        }
+}
+
 // list column block -> block: identity (the reduction enumerates every nparts-th block through this table: reduce_kernels.hpp, border)
 __global__ __launch_bounds__(256) void apo_iota_kernel(int* __restrict__ out, int n)
 {

@@ -667,6 +667,29 @@ def test_pairs_once_partition_over_gloo_ranks(sym, world):
     assert sent == recv > 0
 
 
+@pytest.mark.parametrize("chains", [2, 5])
+def test_chains_of_units_per_block_are_bit_identical(sym, monkeypatch, chains):
+    """MCE_SYM_CHAINS = S: a block's panels dealt to S independent chains of units with their own list sets, merged afterwards (what
+    a rank of the all-pairs-once partition does; off by default on one GPU).  Same distances, same rows, same sums -- also with
+    blocks that have fewer panels than chains, with give-ups (repaired blocks: the other sets are emptied) and all self modes."""
+    capi = sym
+    monkeypatch.setenv("MCE_SYM_CHAINS", str(chains))
+    for n, d, K in ((70001, 27, 10), (20000, 6, 4), (150000, 15, 12)):
+        Y = _data(n, d, n + chains)
+        for sm in (capi.SELF_EXCLUDE, capi.SELF_INCLUDE):
+            (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(Y, Y, K, self_mode=sm))
+            assert "chains" in capi.last_kernel(), capi.last_kernel()
+            assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+    w = np.ones(n); fs = np.zeros(n)
+    (a,), (b,) = _both(capi, lambda: (capi.knn_dotp(Y, None, w, fs, K + 1, 1),))
+    assert np.allclose(a[1:], b[1:], rtol=1e-12, atol=0)          # (the same terms, summed in the sorted rows' order)
+    monkeypatch.setenv("MCE_SYM_PANEL", "3")
+    monkeypatch.setenv("MCE_SYM_SPIN_LIMIT", "0")
+    Y = _data(60000, 20, 7)
+    (d0, i0), (d1, i1) = _both(capi, lambda: capi.knn(Y, Y, 6, self_mode=capi.SELF_EXCLUDE))
+    assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+
+
 def test_unit_that_gives_up_waiting_is_repaired(sym, monkeypatch):
     """The wait of a unit for its block's previous unit is bounded (knn_panel.hpp).  With the bound at 0 every wait that
     is not already satisfied gives up at once: the unit starts from empty lists, flags its block, and the repair launch
