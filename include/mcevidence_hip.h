@@ -127,6 +127,13 @@ int mce_evidence_feed_part_f64(const double *S1, int64_t n1, int64_t ld1, const 
                                int32_t d, int32_t cov_mode, int32_t kmax, const double *w, const double *fs,
                                int32_t part, int32_t nparts, double *dotp_part, double *jacobian, double *eigenvalues,
                                uint64_t *checksum, int32_t device);
+/* The feeders alone (auto evidence): upload, covariance of the n1 rows, Jacobi eigen-system, whitening -- and the whitened rows,
+ * the weights and the likelihood terms left in DEVICE buffers of the caller's ([n1, d], [n1], [n1] doubles on `device`) instead of
+ * being searched.  For hosts that run the search in several calls with collectives in between (the all-pairs-once partition:
+ * parallel.py).  jacobian / eigenvalues / checksum as mce_evidence_feed_part_f64.  Reference: MCEvidence.py:1034-1060. */
+int mce_evidence_feed_whiten_f64(const double *S1, int64_t n1, int64_t ld1, int32_t d, int32_t kmax, const double *w,
+                                 const double *fs, double *d_X_out, double *d_w_out, double *d_fs_out, double *jacobian,
+                                 double *eigenvalues, uint64_t *checksum, int32_t device);
 
 /* Many independent evidence problems in one call: the reference's Planck driver
  * runs MCEvidence(...).evidence() once per (data set, model, chain) -- ~600-2400 chains of 6k-100k

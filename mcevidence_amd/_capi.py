@@ -68,6 +68,8 @@ SIGNATURES = {
                                          _P, _P, _P, _P, _P, _c.c_int32]),
     "mce_evidence_feed_part_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32,
                                               _P, _P, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _c.c_int32]),
+    "mce_evidence_feed_whiten_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _P, _c.POINTER(_c.c_double), _P,
+                                                _c.POINTER(_c.c_uint64), _c.c_int32]),
     "mce_knn_dotp_part_f64_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _c.c_size_t, _P]),
     "mce_knn_dotp_part_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_int32]),
     "mce_pairs_once_blocks": (_c.c_int32, [_c.c_int64, _c.c_int32, _c.c_int32]),
@@ -434,6 +436,25 @@ def evidence_feed_part(S1, S2, d, cov_mode, kmax, w, fs, part, nparts, device=0,
                                          w.ctypes.data, fs.ctypes.data, int(part), int(nparts), out.ctypes.data, ctypes.byref(jac),
                                          ev.ctypes.data, ctypes.byref(csum) if want_checksum else None, int(device)))
     return out, float(jac.value), ev, (int(csum.value) if want_checksum else None)
+
+
+def evidence_feed_whiten(S1, d, kmax, w, fs, d_X_out, d_w_out, d_fs_out, device=0, want_checksum=True):
+    """The feeders alone (``mce_evidence_feed_whiten_f64``, auto evidence): upload, covariance, eigen-system, whitening; the
+    whitened rows, weights and likelihood terms are left in the caller's DEVICE buffers (pointers; [n, d], [n], [n] doubles).
+    Returns (jacobian, eigenvalues[d], checksum)."""
+    lib = load()
+    S1 = _rows_f64(S1, "samples", d, check=False)
+    w = _f64(w, "weight")
+    fs = _f64_fs(fs)
+    if w.shape != (S1.shape[0],) or fs.shape != w.shape:
+        raise ValueError("weight and fs must have one entry per row")
+    jac = ctypes.c_double(0.0)
+    ev = np.zeros(int(d))
+    csum = ctypes.c_uint64(0)
+    check(lib.mce_evidence_feed_whiten_f64(S1.ctypes.data, S1.shape[0], S1.strides[0] // 8, int(d), int(kmax), w.ctypes.data, fs.ctypes.data,
+                                           d_X_out, d_w_out, d_fs_out, ctypes.byref(jac), ev.ctypes.data,
+                                           ctypes.byref(csum) if want_checksum else None, int(device)))
+    return float(jac.value), ev, (int(csum.value) if want_checksum else None)
 
 
 def _devices_arg(devices):

@@ -148,6 +148,9 @@ struct FeedJob {
     double* hbase = nullptr;  // this job's slice of the pinned host arena: cov[2] | evec[2] | scale[2] | dotp
     double jac = 0.0;
     int part = 0, nparts = 1;         // one rank's share of the problem (mce_evidence_feed_part_f64); 1: all of it
+    double* out_X = nullptr;          // mce_evidence_feed_whiten_f64: no search -- the whitened rows, the weights and the likelihood terms are left in
+    double* out_w = nullptr;          // these DEVICE buffers of the caller's (auto evidence; the all-pairs-once partition searches them in several calls
+    double* out_f = nullptr;          // with collectives in between: parallel.py)
     bool want_sum = false;            // fingerprint of the uploaded rows / weights / likelihoods (device-side)
     unsigned long long checksum = 0;
     int64_t q_lo = 0, q_hi = 0;       // cross evidence of a part: its rows of s1
@@ -201,7 +204,7 @@ int feed_plan(FeedJob& j)
     SameSetHint hint(q.S2 == nullptr);          // auto evidence: one set; cross evidence: never the symmetric sweep
     int rc = make_plan(q.n1, j.nr, q.d, j.K, j.k0 == 1 ? MCE_SELF_EXCLUDE : MCE_SELF_NONE, j.plan);
     if (rc != MCE_OK) return rc;
-    j.wsb = j.plan.total + dotp_ws_bytes(q.n1, q.kmax);
+    j.wsb = j.out_X ? 0 : j.plan.total + dotp_ws_bytes(q.n1, q.kmax);
     j.q_lo = 0;
     j.q_hi = q.n1;
     if (j.nparts > 1 && q.S2) {
@@ -224,7 +227,7 @@ int feed_plan(FeedJob& j)
     j.o_small = off; off = align_up(off + (size_t)(3 * 64 + 2 * d * d + d + 1) * sizeof(double), 256);     // mean3 | cov | evec | scale | checksum
     j.o_part = off;  off = align_up(off + (size_t)std::max<int64_t>((int64_t)mce::kCovBlocks * npair, (int64_t)mce::kMeanBlocks * mce::kStatStride) * sizeof(double), 256);
     j.o_ws = off;    off = align_up(off + j.wsb, 256);
-    j.nverify = (j.nparts == 1 && d <= mce::kVerifyMaxDim && j.K <= mce::kVerifyMaxK) ? (int)std::min<int64_t>(eff_verify(), q.n1) : 0;
+    j.nverify = (j.nparts == 1 && !j.out_X && d <= mce::kVerifyMaxDim && j.K <= mce::kVerifyMaxK) ? (int)std::min<int64_t>(eff_verify(), q.n1) : 0;
     if (j.nverify > 0) {
         j.o_vd = off; off = align_up(off + (size_t)q.n1 * j.K * sizeof(double), 256);
         j.o_vw = off; off = align_up(off + mce_verify_workspace_bytes(j.nverify, j.K), 256);
@@ -343,7 +346,12 @@ int feed_stage_c(FeedJob& j, hipStream_t st)
     }
     if (rc != MCE_OK) return rc;
     SameSetHint hint(q.S2 == nullptr);          // as in feed_plan: the workspace was sized with it
-    if (j.nparts > 1 && !q.S2)                  // one rank's share of an auto-evidence search: the library's partition
+    if (j.out_X) {                              // whitening only: hand the rows over, no search (the sums stay zero)
+        MCE_HIP(hipMemcpyAsync(j.out_X, j.dS1(), (size_t)q.n1 * q.d * sizeof(double), hipMemcpyDeviceToDevice, st));
+        MCE_HIP(hipMemcpyAsync(j.out_w, j.dW(), (size_t)q.n1 * sizeof(double), hipMemcpyDeviceToDevice, st));
+        MCE_HIP(hipMemcpyAsync(j.out_f, j.dF(), (size_t)q.n1 * sizeof(double), hipMemcpyDeviceToDevice, st));
+        rc = (mce::zero_async(j.dO(), (size_t)q.kmax * sizeof(double), st) == hipSuccess) ? MCE_OK : fail(MCE_ERR_HIP, "clearing the sums failed");
+    } else if (j.nparts > 1 && !q.S2)           // one rank's share of an auto-evidence search: the library's partition
         rc = mce_knn_dotp_part_f64_dev(j.dS1(), q.n1, q.d, q.kmax, j.part, j.nparts, j.dW(), j.dF(), j.dO(), j.ws(), j.wsb, st);
     else if (j.nparts > 1 && j.q_hi <= j.q_lo)
         rc = (mce::zero_async(j.dO(), (size_t)q.kmax * sizeof(double), st) == hipSuccess) ? MCE_OK : fail(MCE_ERR_HIP, "clearing the sums failed");
@@ -598,6 +606,33 @@ int mce_evidence_feed_part_f64(const double* S1, int64_t n1, int64_t ld1, const 
     job.q = &q;
     job.part = part;
     job.nparts = nparts;
+    job.want_sum = checksum != nullptr;
+    int rc = feed_plan(job);
+    if (rc != MCE_OK) return rc;
+    std::vector<FeedJob*> jobs{&job};
+    rc = feed_run_on_device(device, jobs);
+    if (rc != MCE_OK) return rc;
+    if (job.rc != MCE_OK) return fail(job.rc, "%s", job.err.c_str());
+    *jacobian = q.jacobian;
+    if (checksum) *checksum = job.checksum;
+    return MCE_OK;
+}
+
+int mce_evidence_feed_whiten_f64(const double* S1, int64_t n1, int64_t ld1, int32_t d, int32_t kmax, const double* w, const double* fs,
+                                 double* d_X_out, double* d_w_out, double* d_fs_out, double* jacobian, double* eigenvalues,
+                                 uint64_t* checksum, int32_t device)
+{
+    if (!jacobian || !d_X_out || !d_w_out || !d_fs_out) return fail(MCE_ERR_INVALID, "null pointer argument");
+    mce_feed_problem q;
+    std::memset(&q, 0, sizeof(q));
+    double sums[MCE_MAX_K + 2];
+    q.S1 = S1; q.n1 = n1; q.ld1 = ld1;
+    q.d = d; q.cov_mode = 0; q.kmax = kmax;
+    q.w = w; q.fs = fs; q.dotp = sums; q.eigenvalues = eigenvalues;
+    if (kmax < 2 || kmax > MCE_MAX_K + 1) return fail(MCE_ERR_K_RANGE, "kmax=%d", kmax);
+    FeedJob job;
+    job.q = &q;
+    job.out_X = d_X_out; job.out_w = d_w_out; job.out_f = d_fs_out;
     job.want_sum = checksum != nullptr;
     int rc = feed_plan(job);
     if (rc != MCE_OK) return rc;

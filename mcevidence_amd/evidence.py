@@ -71,6 +71,11 @@ class HipBackend(object):
                 return None
             group = parallel.current_group()
             dev = self.devices[0] if self.devices else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+            if S2 is None and parallel.pairs_once_enabled() and dev == torch.cuda.current_device():
+                # MCE_PAIRS_ONCE=1: every pair of rows multiplied once per node; None: not for this shape
+                got = parallel.pairs_once_feed(S1, ndim, kmax, weight, fs, group, verify=self.verify)
+                if got is not None:
+                    return got
             part, jac, csum, failed = np.zeros(kmax), float("nan"), None, None
             try:
                 part, jac, _, csum = _capi.evidence_feed_part(S1, S2, ndim, cov_mode, kmax, weight, fs, dist.get_rank(group),

@@ -201,16 +201,19 @@ def _exchange_rows(send, in_splits, out_splits, group):
 class _HipPairsOnce:
     """The three library calls of the all-pairs-once partition on this rank's GPU (device tensors through torch)."""
 
-    def __init__(self, Y, weight, fs, kmax, world):
+    def __init__(self, Y, weight, fs, kmax, world, device_tensors=None):
         import torch
         from . import _capi
         self.capi, self.torch = _capi, torch
-        self.n, self.d = Y.shape
         self.kmax = int(kmax)
         self.dev = torch.device("cuda", torch.cuda.current_device())
-        self.Y = torch.from_numpy(Y).to(self.dev)
-        self.w = torch.from_numpy(np.ascontiguousarray(weight, dtype=np.float64)).to(self.dev)
-        self.fs = torch.from_numpy(np.ascontiguousarray(fs, dtype=np.float64)).to(self.dev)
+        if device_tensors is not None:          # rows, weights and likelihood terms are on the device already (the class's feed route)
+            self.Y, self.w, self.fs = device_tensors
+        else:
+            self.Y = torch.from_numpy(Y).to(self.dev)
+            self.w = torch.from_numpy(np.ascontiguousarray(weight, dtype=np.float64)).to(self.dev)
+            self.fs = torch.from_numpy(np.ascontiguousarray(fs, dtype=np.float64)).to(self.dev)
+        self.n, self.d = int(self.Y.shape[0]), int(self.Y.shape[1])
         self.wsb = _capi.pairs_once_workspace_bytes(self.n, self.d, self.kmax, world)
         self.ws = torch.empty(max(self.wsb, 1), dtype=torch.uint8, device=self.dev)
         self.st = torch.cuda.current_stream().cuda_stream
@@ -248,34 +251,88 @@ class _HipPairsOnce:
         return out.cpu().numpy()
 
 
-def pairs_once_knn_dotp(Y, weight, fs, kmax, group=None, stats=None, impl=None):
+def pairs_once_feed(S1, ndim, kmax, weight, fs, group=None, verify=True):
+    """``MCEvidence.evidence()`` under a process group through the all-pairs-once partition (``MCE_PAIRS_ONCE=1``, auto evidence
+    of a set that takes it): every rank uploads the chain once and whitens it on its device (``mce_evidence_feed_whiten_f64``:
+    the rows stay there), then ``pairs_once_knn_dotp`` on the device tensors.  Returns (dotp, J), or None when the partition
+    does not apply to this shape (the caller falls back to the part feed).  The same on every rank."""
+    import torch
+    import torch.distributed as dist
+    from . import _capi
+    group = _GROUP if group is None else group
+    world = dist.get_world_size(group)
+    n = int(np.asarray(S1).shape[0])
+    if world < 2 or _capi.pairs_once_blocks(n, ndim, kmax) < world:
+        return None
+    dev = torch.device("cuda", torch.cuda.current_device())
+    failed, impl, jac, csum = None, None, float("nan"), None
+    try:
+        Xd = torch.empty((n, ndim), dtype=torch.float64, device=dev)
+        wd = torch.empty(n, dtype=torch.float64, device=dev)
+        fd = torch.empty(n, dtype=torch.float64, device=dev)
+        jac, _, csum = _capi.evidence_feed_whiten(S1, ndim, kmax, weight, fs, Xd.data_ptr(), wd.data_ptr(), fd.data_ptr(), device=dev.index,
+                                                  want_checksum=verify)
+        impl = _HipPairsOnce(None, None, None, kmax, world, device_tensors=(Xd, wd, fd))
+    except Exception as exc:              # still take part in the collectives (pairs_once_knn_dotp signals the failure in the first one)
+        failed = exc
+    dotp = pairs_once_knn_dotp(None, None, None, kmax, group, impl=impl, checksum=csum, failed=failed, shape=(n, ndim))
+    return dotp, jac
+
+
+def pairs_once_knn_dotp(Y, weight, fs, kmax, group=None, stats=None, impl=None, checksum=None, failed=None, shape=None):
     """Auto evidence over the ranks with every pair of rows multiplied ONCE PER NODE (``include/mcevidence_hip.h``:
     ``mce_pairs_once_*``): this rank runs the single-GPU units of every W-th sorted block (a block against
     all blocks below it, both gates on), the candidates found for other ranks' rows travel to their owners in ONE all_to_all (16 bytes
-    each; its split sizes in an all_gather of W counts, the overflow flags in an all_reduce(MAX)), every rank folds what it
-    receives into its own lists and sums its own rows' terms; the usual all-reduce(sum) of ``kmax`` doubles ends the call.
+    each; its split sizes in an all_gather of W counts, the overflow flags in an all_reduce(MAX)); before the sweep the rows'
+    prepass bounds -- each rank computes those of its own blocks -- are all-reduced with MIN (8 bytes per row); every rank folds what it
+    receives into its own lists and sums its own rows' terms; the usual all-reduce(sum) of ``kmax`` doubles ends the call
+    (``feed_part_reduce``: the ranks' input fingerprints ``checksum`` ride in it).
     Returns the full ``dotp``.  ``stats``: a dict that receives the counts (entries sent / received, bytes).
-    ``impl``: the per-rank compute (default: the HIP library; the CPU tests pass a host restatement)."""
+    ``impl``: the per-rank compute (default: the HIP library; the CPU tests pass a host restatement).
+    ``failed``: an exception this rank's preparation ended with -- it still joins the FIRST collective, with bounds of -inf, so
+    that every rank raises there instead of waiting for it (the same when ``impl.prepare`` itself fails)."""
     import torch
     import torch.distributed as dist
     group = _GROUP if group is None else group
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    Y = np.ascontiguousarray(Y, dtype=np.float64)
-    if impl is None:
-        impl = _HipPairsOnce(Y, weight, fs, kmax, world)
-    nblk = impl.blocks()
-    if nblk < world or world < 2:
-        raise ValueError("pairs-once partition: not applicable to %d x %d, kmax %d on %d ranks" % (Y.shape[0], Y.shape[1], kmax, world))
     nccl = dist.get_backend(group) == "nccl"
-    # every rank bounds the K-th distances of its own blocks' rows; MIN over the ranks gives everybody all of them
-    bounds = impl.prepare(rank, world)
+    if impl is None and failed is None:
+        Y = np.ascontiguousarray(Y, dtype=np.float64)
+        shape = Y.shape
+        try:
+            impl = _HipPairsOnce(Y, weight, fs, kmax, world)
+        except Exception as exc:
+            failed = exc
+    bounds = None
+    if failed is None:
+        try:
+            nblk = impl.blocks()
+            if nblk < world or world < 2:
+                raise ValueError("pairs-once partition: not applicable on %d ranks (%d blocks)" % (world, nblk))
+            # every rank bounds the K-th distances of its own blocks' rows; MIN over the ranks gives everybody all of them
+            bounds = impl.prepare(rank, world)
+        except Exception as exc:
+            failed = exc
+    if failed is not None:
+        from . import _capi
+        nblk = _capi.pairs_once_blocks(int(shape[0]), int(shape[1]), kmax) if shape is not None else 0
+        dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+        bounds = torch.full((max(nblk, 1) * 512,), float("-inf"), dtype=torch.float64, device=dev)
     if nccl:
         dist.all_reduce(bounds, op=dist.ReduceOp.MIN, group=group)
+        lowest = float(bounds[0].item())
     else:
         host = bounds.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.MIN, group=group)
-        bounds.copy_(host)
+        lowest = float(host[0].item())
+        if failed is None:
+            bounds.copy_(host)
+    if failed is not None:
+        raise failed
+    if lowest == float("-inf"):
+        raise RuntimeError("mcevidence_amd: pairs-once partition: another rank of this process group failed before the sweep "
+                           "(the failing rank raises its own error)")
     counts, flags = impl.sweep(rank, world, nblk)
     cdev = counts.device if nccl else torch.device("cpu")
     # split sizes: every rank's counts to everybody (W x W integers); overflow flags: MAX over the ranks
@@ -293,16 +350,9 @@ def pairs_once_knn_dotp(Y, weight, fs, kmax, group=None, stats=None, impl=None):
     part = impl.finish(recv, fl)
     if stats is not None:
         stats.update(sent=int(sum(in_splits)), received=int(recv.shape[0]), bytes_sent=16 * int(sum(in_splits)), blocks=nblk, flagged=int(fl.sum().item()))
-    failed = None if np.all(np.isfinite(part)) else 1.0
-    vec = np.zeros(int(kmax) + 1)
-    if failed is None:
-        vec[:int(kmax)] = part
-    else:
-        vec[int(kmax)] = 1.0
-    vec = _reduce_partial(vec, group)
-    if vec[int(kmax)] != 0.0:
-        raise RuntimeError("mcevidence_amd: pairs-once partition: the ranks disagree about who owns which rows (%d of %d)" % (int(vec[int(kmax)]), world))
-    return vec[:int(kmax)]
+    bad = None if np.all(np.isfinite(part)) else RuntimeError("mcevidence_amd: pairs-once partition: candidates arrived for rows this rank does not own "
+                                                              "(the ranks disagree about the partition)")
+    return feed_part_reduce(part, checksum, group, failed=bad)
 
 
 def sharded_knn_dotp(X, Y, weight, fs, kmax, k0, want_dist=False, group=None, local_fn=None, verify=True, part_fn=None):

@@ -1325,13 +1325,15 @@ def test_feed_parts_add_up_to_the_single_rank_feed(n, d, kmax, cross):
         _capi.evidence_feed_part(S1, S2, d, 0, kmax, w, fs, 2, 2)
 
 
-def _class_rank(rank, world, port, q, cross, poison):
+def _class_rank(rank, world, port, q, cross, poison, pairs_once=False):
     import os
     import sys
     import time
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if pairs_once:
+        os.environ["MCE_PAIRS_ONCE"] = "1"
     torch.cuda.set_device(0)                                 # one GPU on the test box: both ranks share it
     dist.init_process_group("gloo", rank=rank, world_size=world)
     logging.disable(logging.CRITICAL)
@@ -1342,7 +1344,11 @@ def _class_rank(rank, world, port, q, cross, poison):
         chain, (r1, r2) = config_chain("C4", n=120000)
     else:
         chain, r1 = gaussian_chain(seed=3, n=300000, d=27, cov="corr"), None
-    if poison and rank == 1:
+    if poison == "fail" and rank == 1:
+        # this rank's preparation fails (here: the whitening call is handed nonsense): it must still join the first collective
+        real = _capi.evidence_feed_whiten
+        _capi.evidence_feed_whiten = lambda *a, **k: (_ for _ in ()).throw(MemoryError("boom on rank 1"))
+    elif poison and rank == 1:
         chain = chain.copy()
         chain[1000, 5] = np.nextafter(chain[1000, 5], 1e9)
     m = pkg.MCEvidence([chain], kmax=4 if cross else 10, verbose=0)
@@ -1353,11 +1359,49 @@ def _class_rank(rank, world, port, q, cross, poison):
         t0 = time.perf_counter()
         lnE = m.evidence()
         out = ("ok", lnE, time.perf_counter() - t0, _capi.last_kernel())
-    except RuntimeError as e:
+    except (RuntimeError, MemoryError) as e:
         out = ("raised", str(e), 0.0, "")
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("poison", [False, True, "fail"])
+def test_class_under_two_ranks_through_the_pairs_once_partition(poison):
+    """MCE_PAIRS_ONCE=1: MCEvidence(...).evidence() under a 2-rank gloo group (both ranks on the box's one GPU) whitens on the
+    device (mce_evidence_feed_whiten_f64: the rows stay there) and searches through the all-pairs-once partition -- bounds
+    all-reduced, candidates exchanged, sums and input fingerprints in the last all-reduce.  ln E equals the single process's to
+    1e-12; a rank with one different bit makes both raise; a rank whose preparation fails raises its own error and the other
+    one a RuntimeError, in the FIRST collective."""
+    import socket
+    import torch.multiprocessing as mp
+    import mcevidence_amd as pkg
+    from mcevidence_amd.synth import gaussian_chain
+    if not poison:
+        one = pkg.MCEvidence([gaussian_chain(seed=3, n=300000, d=27, cov="corr")], kmax=10, verbose=0).evidence()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_class_rank, args=(r, 2, port, q, False, poison, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    if poison == "fail":
+        assert got[0][0] == got[1][0] == "raised" and "boom on rank 1" in got[1][1] and "another rank" in got[0][1], got
+        return
+    if poison:
+        assert got[0][0] == got[1][0] == "raised" and "different samples" in got[0][1]
+        return
+    assert got[0][0] == got[1][0] == "ok"
+    assert np.array_equal(got[0][1], got[1][1])
+    assert np.max(np.abs(got[0][1] - one)) < 1e-12, (got[0][1], one)
+    assert "pairs-once" in got[0][3] and "pairs-once" in got[1][3]
 
 
 @pytest.mark.parametrize("cross,poison", [(False, False), (True, False), (False, True)])
