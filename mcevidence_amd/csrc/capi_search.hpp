@@ -236,7 +236,10 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
             // prepass: every row's bound before any block runs (the seed phase as its own launch)
             // about 32 k rows (one k-step: 64 k), at most half of the chunks (tools/_tmp-style scans, fused call, share 8 -> 2:
             // 49 k x 27 1.51 -> 1.32 ms, 98 k 2.18 -> 2.03, 131 k 2.58 -> 2.47, from 197 k rows the same; 393 k x 15 7.04 -> 6.88)
-            const int seed_rows = tun.sym_seed_rows > 0 ? tun.sym_seed_rows : (p.KST == 1 ? 65536 : 32768);
+            // (a rank of the all-pairs-once partition prepasses its own blocks only and every rank's sweep gains from tighter bounds on
+            //  everybody's rows: twice the sample from four ranks on -- C3, sample 32 k / 64 k / 128 k rows: step 13.15 / 13.00 / 13.60 ms at
+            //  four ranks, 7.76 / 7.50 / 7.59 at eight, candidates shipped 5.9 M / 3.6 M / 2.4 M)
+            const int seed_rows = tun.sym_seed_rows > 0 ? tun.sym_seed_rows : (p.KST == 1 ? 65536 : 32768) * (p.apo && p.nparts >= 4 ? 2 : 1);
             const int seed_share = tun.sym_seed_share;
             auto sym_seed_for = [&](int kk) {
                 int cfg = mce::f16_seed_cfg(p.nchunk, p.CT, kk + a.self_exclude, seed_rows, seed_share, MCE_H_SEED_TG);

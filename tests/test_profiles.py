@@ -127,7 +127,7 @@ def test_pairs_once_emulation_is_labelled_adds_up_and_beats_the_default_partitio
         eff[W] = r["one_gpu_ms"] / v["predicted_step_ms"] / W
         assert abs(eff[W] - v["efficiency"]) < 2e-3
         assert v["predicted_step_ms"] < r["todays_partition"][w]["predicted_step_ms"]
-    assert eff[2] > 0.85 and 0.72 < eff[4] < 0.80 and 0.60 < eff[8] < 0.70              # the verdict's 0.80: met at two ranks only
+    assert eff[2] > 0.85 and 0.75 < eff[4] < 0.82 and 0.62 < eff[8] < 0.72              # the verdict's 0.80: met at two ranks, all but met at four
     first = json.load(open(os.path.join(REPO, "profiles", "r05_mid", "pairs_once_contiguous.json")))
     assert first["pairs_once"]["2"]["predicted_step_ms"] > first["one_gpu_ms"]          # the version with contiguous ranges: worse than one GPU
     assert first["pairs_once"]["2"]["candidates_sent"][0] > 30 * first["pairs_once"]["2"]["candidates_sent"][1]

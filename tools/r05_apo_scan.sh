@@ -1,8 +1,8 @@
 #!/bin/bash
 # GPU box: the all-pairs-once partition at C3, chains per block (MCE_PAIRS_ONCE_SPLIT) x panel length scan -> stdout
 cd "$(dirname "$0")/.."
-for cfg in "2 0 0" "2 1 0" "4 0 0" "4 2 0" "8 0 0" "8 4 0"; do
-  set -- $cfg
+for cfg in ${APO_CFGS:-2,0,0 4,0,0 8,0,0}; do
+  IFS=, read -r a1 a2 a3 <<< "$cfg"; set -- $a1 $a2 $a3
   if [ "$2" != "0" ]; then export MCE_PAIRS_ONCE_SPLIT=$2; else unset MCE_PAIRS_ONCE_SPLIT; fi
   if [ "$3" != "0" ]; then export MCE_PAIRS_ONCE_PANEL=$3; else unset MCE_PAIRS_ONCE_PANEL; fi
   python - "$1" <<'PY'
