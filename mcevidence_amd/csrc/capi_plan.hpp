@@ -79,12 +79,12 @@ struct Plan {
 const mce::KnnVariant* variant_for(int KS, int kcap_idx)
 {
     switch (kcap_idx) {
-        case 0: return &mce::g_knn_kcap4[KS - 1];
-        case 1: return &mce::g_knn_kcap8[KS - 1];
-        case 2: return &mce::g_knn_kcap12[KS - 1];
-        case 3: return &mce::g_knn_kcap16[KS - 1];
-        case 4: return &mce::g_knn_kcap24[KS - 1];
-        default: return &mce::g_knn_kcap32[KS - 1];
+        case 0: return &mce::g_knn_kcap4[mce::mfma_variant_index(KS)];
+        case 1: return &mce::g_knn_kcap8[mce::mfma_variant_index(KS)];
+        case 2: return &mce::g_knn_kcap12[mce::mfma_variant_index(KS)];
+        case 3: return &mce::g_knn_kcap16[mce::mfma_variant_index(KS)];
+        case 4: return &mce::g_knn_kcap24[mce::mfma_variant_index(KS)];
+        default: return &mce::g_knn_kcap32[mce::mfma_variant_index(KS)];
     }
 }
 
@@ -119,7 +119,10 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
         return fail(MCE_ERR_K_RANGE, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", K, (long long)usable);
     if (nr >= (int64_t)1 << 31) return fail(MCE_ERR_INVALID, "nr=%lld exceeds 2^31-1 reference rows", (long long)nr);
 
-    if (d > MCE_MAX_DIM || K > MCE_MAX_K) {
+    // 64 <= d <= 127 (round 5): the fp64 MFMA sweep at KS = 20..32, one query tile per wave -- the vector-FMA kernel below was
+    // 66x the time of d = 63 at 100 k rows (knn_generic.hpp); it keeps d > 127 and K > 32
+    const bool wide_f64 = d > MCE_MAX_DIM && d <= mce::kWideMaxDim && K <= MCE_MAX_K;
+    if ((d > MCE_MAX_DIM && !wide_f64) || K > MCE_MAX_K) {
         // outside the MFMA kernels' register budgets: plain exact kernel, lists [1][K][nq_pad]
         p.generic = true;
         p.v = nullptr;
@@ -140,11 +143,11 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
         p.total = off + 256;
         return MCE_OK;
     }
-    p.KS = (d + 1 + 3) / 4;
+    p.KS = mce::mfma_ks_for(d);
     int ki = 0;
     while (ki < mce::kNumKcap - 1 && mce::kKcapList[ki] < K) ++ki;
     p.KCAP = mce::kKcapList[ki];
-    const bool f16 = (eff_search_mode() != 1) && mce::f16_supported(d, K);
+    const bool f16 = !wide_f64 && (eff_search_mode() != 1) && mce::f16_supported(d, K);
     int qpb, rows_per_tile;
     if (f16) {
         if (K > 16) {                          // 16 nearest per reference split first, then the next K - 16 beyond them

@@ -44,7 +44,13 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
     double* msum = reinterpret_cast<double*>(ws + p.off_msum);
     double* box_y = center + mce::kMaxDimPad;
     double* box_x = center + 2 * mce::kMaxDimPad;
-    if (phase != 2) {
+    if (d > MCE_MAX_DIM) {      // (the fp64 sweep's wide form, 64 <= d <= 127: means only, 128 of the 192 doubles at `center`)
+        static_assert(3 * mce::kMaxDimPad >= 128 && mce::kStatStride >= 128, "wide column means");
+        hipLaunchKernelGGL(mce::col_mean_wide_partial_kernel, dim3(mce::kMeanBlocks), dim3(256), 0, st, dY, nr, (int)d, msum);
+        MCE_HIP(hipGetLastError());
+        hipLaunchKernelGGL(mce::col_mean_wide_final_kernel, dim3(1), dim3(128), 0, st, msum, nr, (int)d, center);
+        MCE_HIP(hipGetLastError());
+    } else if (phase != 2) {
         hipLaunchKernelGGL(mce::col_stats_partial_kernel, dim3(mce::kMeanBlocks), dim3(mce::kMeanThreads), 0, st, dY, nr, (int)d, msum);
         MCE_HIP(hipGetLastError());
         hipLaunchKernelGGL(mce::col_stats_final_kernel, dim3(1), dim3(64), 0, st, msum, nr, (int)d, center, box_y);

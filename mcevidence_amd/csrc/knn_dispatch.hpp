@@ -109,11 +109,14 @@ extern const KnnF16Variant g_knn_f16_kcap8[kMaxKST];
 extern const KnnF16Variant g_knn_f16_kcap12[kMaxKST];
 extern const KnnF16Variant g_knn_f16_kcap16[kMaxKST];
 
-constexpr int kMaxKS = 16;
+constexpr int kMaxKS = 20;         // table entries: KS = 1..16 (index KS - 1), then KS = 20, 24, 28, 32 (index 11 + KS / 4)
+constexpr int kWideMaxDim = 127;   // d up to which the fp64 sweep serves what the fp16 filter does not (d > MCE_MAX_DIM: KS = 4 ceil((d + 1) / 16))
+__host__ __device__ constexpr int mfma_ks_for(int d) { return d <= 63 ? (d + 1 + 3) / 4 : ((d + 1 + 15) / 16) * 4; }
+__host__ __device__ constexpr int mfma_variant_index(int KS) { return KS <= 16 ? KS - 1 : 11 + KS / 4; }
 constexpr int kNumKcap = 6;
 constexpr int kKcapList[kNumKcap] = {4, 8, 12, 16, 24, 32};
 
-// defined in knn_inst.hip (one per KCAP): variants for KS = 1..16 (index KS-1)
+// defined in knn_inst.hip (one per KCAP): variants for KS = 1..16, 20, 24, 28, 32 (mfma_variant_index)
 extern const KnnVariant g_knn_kcap4[kMaxKS];
 extern const KnnVariant g_knn_kcap8[kMaxKS];
 extern const KnnVariant g_knn_kcap12[kMaxKS];

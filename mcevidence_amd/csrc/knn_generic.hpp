@@ -1,5 +1,5 @@
 // knn_generic.hpp -- plain exact brute-force k-nearest-neighbour kernel for shapes outside the
-// MFMA kernels' register budgets (d > 63 or K > 32): one thread per query, direct fp64
+// MFMA kernels' register budgets (d > 127 or K > 32; 64 <= d <= 127: knn_mfma.hpp): one thread per query, direct fp64
 // differences, reference rows staged through LDS, sorted top-K list per query in global
 // memory.  Same contract and output format as the MFMA kernels (reference
 // MCEvidence.py:1093-1104).  These shapes are rare for MCMC chains; the kernel is there so that

@@ -1,4 +1,4 @@
-// knn_inst.hip -- instantiates knn_mfma_kernel<KS, MCE_KCAP> for KS = 1..16 and knn_f16_kernel<KST, MCE_KCAP, ..> for KST = 1..4.
+// knn_inst.hip -- instantiates knn_mfma_kernel<KS, MCE_KCAP> for KS = 1..16, 20, 24, 28, 32 and knn_f16_kernel<KST, MCE_KCAP, ..> for KST = 1..4.
 // Compile with -DMCE_KCAP=<4|8|12|16|24|32>.
 #include "knn_mfma.hpp"
 #include "knn_f16.hpp"
@@ -124,7 +124,7 @@ extern template hipError_t launch_panel_variant<4, MCE_KCAP, true>(const PanelAr
 #define MCE_STR2(x) #x
 #define MCE_STR(x) MCE_STR2(x)
 #define MCE_VARIANT(KS)                                                                                  \
-    {&launch_variant<KS, MCE_KCAP>, KS, MCE_KCAP, kQT, chunk_tiles(KS, MCE_KCAP), lds_bytes(KS, MCE_KCAP),  \
+    {&launch_variant<KS, MCE_KCAP>, KS, MCE_KCAP, mfma_qt(KS), chunk_tiles(KS, MCE_KCAP), lds_bytes(KS, MCE_KCAP),  \
      "knn_mfma_kernel<KS=" #KS ",KCAP=" MCE_STR(MCE_KCAP) ">"}
 
 #define MCE_CAT2(a, b) a##b
@@ -137,6 +137,7 @@ extern const KnnVariant MCE_CAT(g_knn_kcap, MCE_KCAP)[kMaxKS] = {
     MCE_VARIANT(1),  MCE_VARIANT(2),  MCE_VARIANT(3),  MCE_VARIANT(4),  MCE_VARIANT(5),  MCE_VARIANT(6),
     MCE_VARIANT(7),  MCE_VARIANT(8),  MCE_VARIANT(9),  MCE_VARIANT(10), MCE_VARIANT(11), MCE_VARIANT(12),
     MCE_VARIANT(13), MCE_VARIANT(14), MCE_VARIANT(15), MCE_VARIANT(16),
+    MCE_VARIANT(20), MCE_VARIANT(24), MCE_VARIANT(28), MCE_VARIANT(32),        // 64 <= d <= 127: KS rounded up to a multiple of four
 };
 #endif
 #if MCE_INST_F16
@@ -207,6 +208,7 @@ template __global__ void knn_panel_kernel<4, MCE_KCAP, true>(PanelArgs);
 #define MCE_INST(KS) template __global__ void knn_mfma_kernel<KS, MCE_KCAP>(const double*, int64_t, int, const double*, const double*, int64_t, int, int64_t, int, int, int64_t, int, double*, int*);
 MCE_INST(1) MCE_INST(2) MCE_INST(3) MCE_INST(4) MCE_INST(5) MCE_INST(6) MCE_INST(7) MCE_INST(8)
 MCE_INST(9) MCE_INST(10) MCE_INST(11) MCE_INST(12) MCE_INST(13) MCE_INST(14) MCE_INST(15) MCE_INST(16)
+MCE_INST(20) MCE_INST(24) MCE_INST(28) MCE_INST(32)
 #endif
 #endif
 

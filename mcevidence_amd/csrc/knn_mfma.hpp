@@ -12,7 +12,7 @@
 //    (pack_refs_kernel) so a fragment is 64 consecutive doubles: staging
 //    global->LDS is a straight 16-byte-per-lane DMA (global_load_lds) and the
 //    LDS->register read is a conflict-free ds_read_b64 at base + lane*8.
-//  * One workgroup = 8 waves x 2 query tiles = 256 queries; the query fragments
+//  * One workgroup = 8 waves x 2 query tiles = 256 queries (KS > 16, i.e. 64 <= d <= 127: one tile, 128); the query fragments
 //    live in registers for the whole kernel; all 8 waves share the LDS-staged
 //    reference chunk (double buffered, one barrier per chunk).
 //  * C/D layout of the f64 MFMA: lane l holds column (l&15) = ONE query and rows
@@ -38,27 +38,27 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int kWaves = 8;               // waves per workgroup (2 per SIMD)
 constexpr int kThreads = kWaves * 64;   // 512
 
-constexpr int kQT = 2;                  // 16-query tiles per wave
-constexpr int kQPB = kWaves * kQT * 16; // 256 queries per workgroup
-__host__ __device__ constexpr int pick_qt(int, int) { return kQT; }
-__host__ __device__ constexpr int queries_per_block(int) { return kQPB; }
+// 16-query tiles per wave: two; one for KS > 16 (64 <= d <= 127, round 5: the query fragments alone are 4 KS registers per tile)
+__host__ __device__ constexpr int mfma_qt(int KS) { return KS > 16 ? 1 : 2; }
+__host__ __device__ constexpr int queries_per_block(int qt) { return kWaves * qt * 16; }      // 256 (128)
 
 #ifndef MCE_ABLATE
 #define MCE_ABLATE 0          // tools/knn_bench.hip only: 1 = gate never passes, 2 = no gate
 #endif
 // A-fragments (512 B each) per LDS staging buffer: 32 KB, or 16 KB when the per-query
 // lists are long (KCAP > 16) so that staging + lists fit the 160 KB LDS.
-__host__ __device__ constexpr int chunk_fragments(int KCAP) { return KCAP > 16 ? 32 : 64; }
+// (KS > 16: a tile is 17..32 fragments, and the workgroup holds half the lists: 64 KB buffers, 32 KB with long lists)
+__host__ __device__ constexpr int chunk_fragments(int KS, int KCAP) { return KS > 16 ? (KCAP > 16 ? 64 : 128) : (KCAP > 16 ? 32 : 64); }
 // reference tiles (16 rows) per chunk: always even (the tile loop is unrolled by two)
 __host__ __device__ constexpr int chunk_tiles(int KS, int KCAP)
 {
-    return ((chunk_fragments(KCAP) / KS) / 2) * 2 < 2 ? 2 : ((chunk_fragments(KCAP) / KS) / 2) * 2;
+    return ((chunk_fragments(KS, KCAP) / KS) / 2) * 2 < 2 ? 2 : ((chunk_fragments(KS, KCAP) / KS) / 2) * 2;
 }
 __host__ __device__ constexpr int chunk_vpt(int KS, int KCAP) { return (chunk_tiles(KS, KCAP) * KS * 32 + kThreads - 1) / kThreads; }
 // dynamic LDS: two staging buffers + per-query lists (fp64 keys, int32 rows) + read slack
 __host__ __device__ constexpr size_t lds_bytes(int KS, int KCAP)
 {
-    return (size_t)2 * chunk_vpt(KS, KCAP) * kThreads * 16 + (size_t)kQPB * KCAP * 12 + 1024;
+    return (size_t)2 * chunk_vpt(KS, KCAP) * kThreads * 16 + (size_t)queries_per_block(mfma_qt(KS)) * KCAP * 12 + 1024;
 }
 
 // ---------------------------------------------------------------------------
@@ -73,6 +73,8 @@ __global__ __launch_bounds__(kThreads, 2) void knn_mfma_kernel(
     int self_exclude, int64_t self_offset, int ksel,
     double* __restrict__ part_d, int* __restrict__ part_i)
 {
+    constexpr int kQT = mfma_qt(KS);
+    constexpr int kQPB = queries_per_block(kQT);
     constexpr int CT = chunk_tiles(KS, KCAP);
     static_assert(CT % 2 == 0, "tile loop is unrolled by two");
     constexpr int CHUNK_DOUBLES = CT * KS * 64;

@@ -99,6 +99,36 @@ __global__ __launch_bounds__(64) void col_stats_final_kernel(const double* __res
     if (box) box[col] = (col < D && hi >= lo) ? fmax(fabs(hi - c), fabs(lo - c)) : 0.0;
 }
 
+// 64 <= D <= 128 (the fp64 sweep's wide form, round 5): column means only -- thread t sums column t % 128 over every second row of
+// its block's range; partial[b][c] in the same [kMeanBlocks][kStatStride] scratch (kStatStride = 192 >= 128).  Deterministic.
+__global__ __launch_bounds__(256) void col_mean_wide_partial_kernel(const double* __restrict__ Y, int64_t nr, int D, double* __restrict__ partial)
+{
+    __shared__ double s_sum[256];
+    const int c = threadIdx.x & 127, rl = threadIdx.x >> 7;
+    const int64_t per = (nr + kMeanBlocks - 1) / kMeanBlocks;
+    const int64_t r0 = (int64_t)blockIdx.x * per;
+    const int64_t r1 = (r0 + per < nr) ? r0 + per : nr;
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c < D) {
+        int64_t r = r0 + rl;
+        for (; r + 6 < r1; r += 8) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s4[u] += Y[(r + 2 * u) * (int64_t)D + c];
+        }
+        for (; r < r1; r += 2) s4[0] += Y[r * (int64_t)D + c];
+    }
+    s_sum[threadIdx.x] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    __syncthreads();
+    if (threadIdx.x < 128) partial[(int64_t)blockIdx.x * kStatStride + c] = s_sum[c] + s_sum[128 + c];
+}
+__global__ __launch_bounds__(128) void col_mean_wide_final_kernel(const double* __restrict__ partial, int64_t nr, int D, double* __restrict__ center /*[128]*/)
+{
+    const int c = threadIdx.x;
+    double s = 0.0;
+    for (int b = 0; b < kMeanBlocks; ++b) s += partial[(int64_t)b * kStatStride + c];
+    center[c] = (c < D) ? s / (double)nr : 0.0;
+}
+
 // ---------------------------------------------------------------------------
 // pack_refs: Y[nr, D] row-major -> Yf[tile][ks][lane], lane l <-> (row tile*16+(l&15), dim 4ks+(l>>4))
 //   with yc = y - center:  dims 0..D-1 : -2*yc ; dim D : |yc|^2 ; beyond : 0 ;

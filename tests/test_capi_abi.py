@@ -59,7 +59,8 @@ def test_argument_validation_without_gpu():
         _capi.knn_dotp(X, None, np.ones(4), np.zeros(5), kmax=2, k0=1)
     assert _capi.knn_workspace_bytes(1000, 1000, 6, 4) > 0
     assert _capi.dotp_workspace_bytes(1000, 4) >= 4 * 4 * 8
-    assert _capi.knn_workspace_bytes(10, 10, 100, 4) > 0         # d > 63: generic exact kernel
+    assert _capi.knn_workspace_bytes(10, 10, 100, 4) > 0         # 64 <= d <= 127: the fp64 sweep's wide form
+    assert _capi.knn_workspace_bytes(10, 10, 300, 4) > 0         # d > 127: generic exact kernel
     with pytest.raises(ValueError):
         _capi.knn_workspace_bytes(10, 10, 2000, 4)
 

@@ -321,14 +321,16 @@ def test_knn_adversarial_inputs_stay_exact(capi, kind, d):
     assert np.all(np.diff(dist, axis=1) >= 0)
 
 
-@pytest.mark.parametrize("d,K", [(64, 5), (100, 12), (10, 40), (200, 33)])
-def test_generic_kernel_beyond_mfma_limits(capi, d, K):
-    """d > 63 or K > 32: plain exact kernel -- no shape the reference accepts is refused."""
+@pytest.mark.parametrize("d,K,kernel", [(64, 5, "knn_mfma_kernel<KS=20"), (79, 3, "knn_mfma_kernel<KS=20"), (80, 20, "knn_mfma_kernel<KS=24"), (100, 12, "knn_mfma_kernel<KS=28"),
+                                        (127, 32, "knn_mfma_kernel<KS=32"), (128, 6, "generic"), (10, 40, "generic"), (200, 33, "generic"), (100, 33, "generic")])
+def test_beyond_the_filter_kernels_limits(capi, d, K, kernel):
+    """64 <= d <= 127 (K <= 32): the fp64 MFMA sweep at KS = 20..32, one query tile per wave (round 5: the vector-FMA kernel took
+    66x the time of d = 63).  d > 127 or K > 32: the plain exact kernel -- no shape the reference accepts is refused."""
     rng = np.random.default_rng(d * 7 + K)
     Y = rng.standard_normal((1500, d))
     X = rng.standard_normal((333, d))
     dist, idx = capi.knn(X, Y, K)
-    assert "generic" in capi.last_kernel()
+    assert kernel in capi.last_kernel(), capi.last_kernel()
     od, oi = orc.knn_brute(X, Y, K) if K <= 64 else (None, None)
     assert _rel(dist, od) < 1e-13 and np.array_equal(idx, oi)
     d1, i1 = capi.knn(Y, Y, K, self_mode=capi.SELF_INCLUDE)
