@@ -331,6 +331,10 @@ def test_beyond_the_filter_kernels_limits(capi, d, K, kernel):
     X = rng.standard_normal((333, d))
     dist, idx = capi.knn(X, Y, K)
     assert kernel in capi.last_kernel(), capi.last_kernel()
+    if d <= 128 and K <= 32:          # the run-time certificate covers these shapes too: an independent exact scan agrees
+        assert capi.verify_knn(X, Y, dist, nsample=200) == 0
+        bad = dist.copy(); bad[7, K - 1] *= 0.99
+        assert capi.verify_knn(X, Y, bad, nsample=len(X)) == 1
     od, oi = orc.knn_brute(X, Y, K) if K <= 64 else (None, None)
     assert _rel(dist, od) < 1e-13 and np.array_equal(idx, oi)
     d1, i1 = capi.knn(Y, Y, K, self_mode=capi.SELF_INCLUDE)
