@@ -49,7 +49,7 @@ extern "C" {
 #define MCE_ERR_VERIFY (-7)    /* the re-check of sampled rows disagrees with the search (mce_options.verify) -> RuntimeError */
 
 #define MCE_MAX_K 32    /* neighbours per query handled by the MFMA kernels (fp16 filter: 17..32 in two sweeps) */
-#define MCE_MAX_DIM 63  /* dimensions handled by the fp16 filter and the feeders (64..127: fp64 sweep)  */
+#define MCE_MAX_DIM 63  /* dimensions handled by the fp16 filter (64..127: fp64 sweep; feeders: d <= 127) */
 #define MCE_GENERIC_MAX_K 1024   /* beyond the MFMA limits a plain exact kernel takes over, up to */
 #define MCE_GENERIC_MAX_DIM 1024 /* these sizes; larger -> MCE_ERR_K_RANGE / MCE_ERR_DIM_RANGE    */
 

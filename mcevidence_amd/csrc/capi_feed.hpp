@@ -64,13 +64,22 @@ void jacobi_eig(std::vector<double>& A, int d, std::vector<double>& lam, std::ve
 // covariance (two-pass, unweighted, n-1) of the device matrix S[n, d] -> device cov[d*d]; enqueue only
 int launch_covariance(const double* dS, int64_t n, int d, double* scratch_partial, double* d_mean3, double* d_cov, hipStream_t st)
 {
-    hipLaunchKernelGGL(mce::col_stats_partial_kernel, dim3(mce::kMeanBlocks), dim3(mce::kMeanThreads), 0, st, dS, n, d, scratch_partial);
-    MCE_HIP(hipGetLastError());
-    hipLaunchKernelGGL(mce::col_stats_final_kernel, dim3(1), dim3(64), 0, st, scratch_partial, n, d, d_mean3, (double*)nullptr);
-    MCE_HIP(hipGetLastError());
-    hipLaunchKernelGGL(mce::cov_partial_kernel, dim3(mce::kCovBlocks), dim3(mce::kCovThreads), (size_t)mce::kCovTileRows * d * sizeof(double), st,
-                       dS, n, d, d_mean3, scratch_partial);
-    MCE_HIP(hipGetLastError());
+    if (d > 63) {           // (the wide feeders, 64 <= d <= kFeedMaxDim: the means take 128 of the 192 doubles at d_mean3)
+        hipLaunchKernelGGL(mce::col_mean_wide_partial_kernel, dim3(mce::kMeanBlocks), dim3(256), 0, st, dS, n, d, scratch_partial);
+        MCE_HIP(hipGetLastError());
+        hipLaunchKernelGGL(mce::col_mean_wide_final_kernel, dim3(1), dim3(128), 0, st, scratch_partial, n, d, d_mean3);
+        MCE_HIP(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(mce::col_stats_partial_kernel, dim3(mce::kMeanBlocks), dim3(mce::kMeanThreads), 0, st, dS, n, d, scratch_partial);
+        MCE_HIP(hipGetLastError());
+        hipLaunchKernelGGL(mce::col_stats_final_kernel, dim3(1), dim3(64), 0, st, scratch_partial, n, d, d_mean3, (double*)nullptr);
+        MCE_HIP(hipGetLastError());
+    }
+    for (int p0 = 0; p0 < d * (d + 1) / 2; p0 += mce::kCovPairsPerLaunch) {
+        hipLaunchKernelGGL(mce::cov_partial_kernel, dim3(mce::kCovBlocks), dim3(mce::kCovThreads), (size_t)mce::kCovTileRows * d * sizeof(double), st,
+                           dS, n, d, d_mean3, scratch_partial, p0);
+        MCE_HIP(hipGetLastError());
+    }
     hipLaunchKernelGGL(mce::cov_final_kernel, dim3(1), dim3(mce::kCovThreads), 0, st, scratch_partial, n, d, d_cov);
     MCE_HIP(hipGetLastError());
     return MCE_OK;
@@ -118,6 +127,8 @@ int fused_on_device(int device, const double* X, int64_t q_lo, int64_t q_hi, con
     return MCE_OK;
 }
 
+constexpr int kFeedMaxDim = 127;      // device feeders: d <= 63 on the narrow kernels, 64..127 on the wide ones (round 5; the search: knn_mfma.hpp's wide form)
+static_assert(kFeedMaxDim <= mce::kWideMaxDim && mce::whiten_wide_lds_bytes(kFeedMaxDim) <= 160 * 1024, "wide feeders");
 // ---- evidence feed: covariance -> eigen-system -> whitening -> search -> reduction ---------------
 // One problem is four stages; only B runs on the host:
 //   A  upload the raw rows, enqueue the covariance kernels, copy cov back (async, pinned)
@@ -195,7 +206,7 @@ int feed_plan(FeedJob& j)
     if (q.n1 < 2 || q.d < 1 || q.ld1 < q.d || (q.S2 && (q.n2 < 1 || q.ld2 < q.d)) || (q.cov_mode != 0 && q.cov_mode != 1))
         return fail(MCE_ERR_INVALID, "invalid sizes n1=%lld ld1=%lld n2=%lld ld2=%lld d=%d cov_mode=%d", (long long)q.n1, (long long)q.ld1,
                     (long long)q.n2, (long long)q.ld2, q.d, q.cov_mode);
-    if (q.d > 63) return fail(MCE_ERR_DIM_RANGE, "device feeders support d <= 63 (got %d)", q.d);
+    if (q.d > kFeedMaxDim) return fail(MCE_ERR_DIM_RANGE, "device feeders support d <= %d (got %d)", kFeedMaxDim, q.d);
     j.k0 = q.S2 ? 0 : 1;
     j.K = q.kmax - j.k0;
     if (q.kmax <= j.k0) return fail(MCE_ERR_INVALID, "kmax=%d must exceed k0=%d", q.kmax, j.k0);
@@ -318,8 +329,12 @@ int feed_whiten(FeedJob& j, int sidx, double* rows, int64_t n, hipStream_t st)
     const int d = j.d();
     MCE_HIP(hipMemcpyAsync(j.d_evec(), j.h_evec(sidx), (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, st));
     MCE_HIP(hipMemcpyAsync(j.d_scale(), j.h_scale(sidx), (size_t)d * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(mce::whiten_kernel, dim3((unsigned)((n + mce::kWhitenRows - 1) / mce::kWhitenRows)), dim3(mce::kWhitenRows),
-                       mce::whiten_lds_bytes(d), st, rows, n, d, j.d_evec(), j.d_scale(), rows);
+    if (d > 63)
+        hipLaunchKernelGGL(mce::whiten_wide_kernel, dim3((unsigned)((n + mce::kWhitenRows - 1) / mce::kWhitenRows)), dim3(mce::kWhitenRows),
+                           mce::whiten_wide_lds_bytes(d), st, rows, n, d, j.d_evec(), j.d_scale(), rows);
+    else
+        hipLaunchKernelGGL(mce::whiten_kernel, dim3((unsigned)((n + mce::kWhitenRows - 1) / mce::kWhitenRows)), dim3(mce::kWhitenRows),
+                           mce::whiten_lds_bytes(d), st, rows, n, d, j.d_evec(), j.d_scale(), rows);
     MCE_HIP(hipGetLastError());
     return MCE_OK;
 }
@@ -333,6 +348,8 @@ int feed_stage_c(FeedJob& j, hipStream_t st)
         MCE_HIP(hipGetDevice(&dev));
         if (dev < kMaxDevices && !attr_set[dev].load()) {
             MCE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mce::whiten_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mce::whiten_lds_bytes(63)));
+            MCE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mce::whiten_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)mce::whiten_wide_lds_bytes(kFeedMaxDim)));
             attr_set[dev].store(true);
         }
     }

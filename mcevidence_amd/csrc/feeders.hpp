@@ -17,20 +17,24 @@ constexpr int kCovTileRows = 32;
 
 // partial[b][p] = sum over the block's rows of (s_i - m_i)(s_j - m_j), p = packed index of (i <= j).
 // Rows are staged through LDS (centred on the way); thread t owns pairs t, t+256, ...
+// A launch covers the pairs [p0, p0 + kCovPairsPerLaunch): d <= 63 has at most 2016 of them, one launch; the wide feeders
+// (64 <= d <= 127, round 5) take up to four.
+constexpr int kCovPairsPerLaunch = 8 * kCovThreads;
 __global__ __launch_bounds__(kCovThreads) void cov_partial_kernel(const double* __restrict__ S, int64_t n, int d,
                                                                   const double* __restrict__ mean,
-                                                                  double* __restrict__ partial /*[kCovBlocks][npair]*/)
+                                                                  double* __restrict__ partial /*[kCovBlocks][npair]*/, int p0)
 {
     extern __shared__ double tile[];                 // kCovTileRows * d
-    const int npair = d * (d + 1) / 2;
+    const int npair_all = d * (d + 1) / 2;
+    const int npair = p0 + kCovPairsPerLaunch < npair_all ? p0 + kCovPairsPerLaunch : npair_all;      // end of this launch's pairs
     const int64_t per = (n + kCovBlocks - 1) / kCovBlocks;
     const int64_t r0 = (int64_t)blockIdx.x * per;
     const int64_t r1 = (r0 + per < n) ? r0 + per : n;
-    // this thread's pairs (at most 8: d <= 63 -> npair <= 2016)
+    // this thread's pairs (at most 8)
     int pi_[8], pj_[8];
     double acc[8];
     int np = 0;
-    for (int p = threadIdx.x; p < npair && np < 8; p += kCovThreads) {
+    for (int p = p0 + threadIdx.x; p < npair && np < 8; p += kCovThreads) {
         int i = 0, base = 0;                         // packed upper triangle, row-major: (i, j>=i)
         while (base + (d - i) <= p) { base += d - i; ++i; }
         pi_[np] = i;
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(kCovThreads) void cov_partial_kernel(const double* 
         }
     }
     int u = 0;
-    for (int p = threadIdx.x; p < npair && u < 8; p += kCovThreads, ++u) partial[(int64_t)blockIdx.x * npair + p] = acc[u];
+    for (int p = p0 + threadIdx.x; p < npair && u < 8; p += kCovThreads, ++u) partial[(int64_t)blockIdx.x * npair_all + p] = acc[u];
 }
 
 // cov[i][j] = cov[j][i] = sum_b partial[b][p] / (n - 1)   (fixed order: deterministic)
@@ -112,6 +116,40 @@ __global__ __launch_bounds__(kWhitenRows) void whiten_kernel(const double* S, in
     }
 }
 
+
+// the same for 64 <= d <= 127 (round 5): the eigenvectors (up to 126 KB) stay in global memory -- every thread of the workgroup
+// reads the same element, a uniform load -- and the rows go through LDS as above (2 x 64 x 127 doubles = 127 KB).  The sums add
+// their terms in the same order: the results are what the narrow kernel's would be.
+__host__ __device__ constexpr size_t whiten_wide_lds_bytes(int d) { return ((size_t)2 * kWhitenRows * (d | 1)) * sizeof(double); }
+__global__ __launch_bounds__(kWhitenRows) void whiten_wide_kernel(const double* S, int64_t n, int d, const double* __restrict__ evec,
+                                                                  const double* __restrict__ scale, double* out)
+{
+    extern __shared__ double sh[];                   // rows in 64*(d|1) | rows out 64*(d|1)
+    const int ld = d | 1;
+    double* rin = sh;
+    double* rout = rin + kWhitenRows * ld;
+    const int64_t row0 = (int64_t)blockIdx.x * kWhitenRows;
+    const int64_t e0 = row0 * d, e1 = ((row0 + kWhitenRows < n) ? row0 + kWhitenRows : n) * (int64_t)d;
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += kWhitenRows) {
+        const int r = (int)((e - e0) / d), c = (int)((e - e0) - (int64_t)r * d);
+        rin[r * ld + c] = S[e];
+    }
+    __syncthreads();
+    {
+        const double* s = rin + threadIdx.x * ld;      // (rows beyond n: whatever the buffer holds; never written out)
+        double* o = rout + threadIdx.x * ld;
+        for (int c = 0; c < d; ++c) {
+            double a = 0.0;
+            for (int k = 0; k < d; ++k) a = fma(s[k], evec[k * d + c], a);
+            o[c] = a * scale[c];
+        }
+    }
+    __syncthreads();
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += kWhitenRows) {
+        const int r = (int)((e - e0) / d), c = (int)((e - e0) - (int64_t)r * d);
+        out[e] = rout[r * ld + c];
+    }
+}
 
 // 64-bit fingerprint of a device buffer of 8-byte words: sum over i of mix64(word_i + (salt + i) * golden) -- the sum of
 // per-word hashes is order-independent (integer adds), position-sensitive (i enters the hash), and costs one pass at HBM

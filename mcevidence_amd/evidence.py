@@ -58,7 +58,7 @@ class HipBackend(object):
         """feeders on the device too (get_covariance + diagonalise_chain + the hot path, one upload);
         returns (dotp, J) or None when this route does not apply (multi-process / multi-device runs)."""
         from . import parallel
-        if ndim > 63:
+        if ndim > 127:            # (device feeders: d <= 127 -- the fp16 filter up to 63, the fp64 sweep's wide form beyond)
             return None
         from . import _capi
         if parallel.is_distributed():
@@ -94,7 +94,7 @@ class HipBackend(object):
         the problems are farmed over the ranks instead (parallel.farm_evidence_feed).  Returns a list
         of (dotp, J) or None when this route does not apply."""
         from . import parallel
-        if any(p[2] > 63 for p in problems):
+        if any(p[2] > 127 for p in problems):
             return None
         if parallel.is_distributed():
             return parallel.farm_evidence_feed(problems)

@@ -499,6 +499,43 @@ def test_device_feeder_route_matches_reference_and_host_route(name):
     assert np.max(np.abs(dev - host)) < 1e-10
 
 
+@pytest.mark.parametrize("d,split", [(64, False), (90, False), (127, False), (80, True)])
+def test_device_feeders_beyond_63_dimensions(d, split):
+    """64 <= d <= 127 (round 5): covariance (pairs in batches of 2048), the Jacobi eigen-system and the wide whitening kernel on the
+    device, the search on the fp64 sweep's wide form -- the class no longer leaves the device-feeder route at d = 64.  Same ln E as
+    the host-feeder route (np.cov + np.linalg.eig + whitening on the host) of the same class; d = 128 is refused by the feeders and
+    served by the host route."""
+    import mcevidence_amd as pkg
+    from mcevidence_amd import _capi
+    from mcevidence_amd.synth import gaussian_chain
+    chain = gaussian_chain(seed=d, n=24000, d=d, weights="int", cov="corr")
+    calls = {}
+
+    class Spy(pkg.HipBackend):
+        def evidence_feed(self, *a, **k):
+            out = super().evidence_feed(*a, **k)
+            calls["feed"] = calls.get("feed", 0) + (out is not None)
+            return out
+
+    def run(backend):
+        m = pkg.MCEvidence([chain], kmax=4, verbose=0, backend=backend)
+        if split:
+            m.set_split(np.arange(0, 12000), np.arange(12000, 24000))
+        return m.evidence(covtype="all")
+
+    dev = run(Spy())
+    assert calls.get("feed", 0) == 1 and "knn_mfma_kernel<KS=" in _capi.last_kernel()
+    host = run(type("H", (), {"name": "hip", "knn_dotp": pkg.HipBackend().knn_dotp})())
+    assert np.all(np.isfinite(dev)) and np.max(np.abs(dev - host)) < 1e-9, (dev, host)
+    if d == 127:
+        wide = gaussian_chain(seed=1, n=3000, d=128, cov="corr")
+        with pytest.raises(ValueError):
+            _capi.evidence_feed(wide[:, 2:], None, 128, 0, 3, np.ones(3000), np.zeros(3000))
+        calls.clear()
+        lnE = pkg.MCEvidence([wide], kmax=3, verbose=0, backend=Spy()).evidence()
+        assert calls.get("feed", 0) == 0 and np.all(np.isfinite(lnE)) and "generic" in _capi.last_kernel()
+
+
 def _feed_problems(rng, count):
     """mixed bag of small evidence problems: auto/cross, both covariance modes, ragged sizes, padded rows"""
     probs = []
