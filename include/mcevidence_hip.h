@@ -228,6 +228,8 @@ int mce_pairs_once_finish_dev(const double *dY, int64_t nr, int32_t d, int32_t k
 /* Name of the dominant kernel last launched by this thread and its launch
  * geometry (for bench.py / profiles): "knn_mfma_f64<KS=7,KCAP=12>" etc. */
 const char *mce_last_kernel(void);
+/* rows that the run-time certificate (mce_options.verify) of the most recent host-pointer search re-checked; 0: none ran */
+int32_t mce_last_verify_rows(void);
 /* SHA-256 (hex) of the kernel sources this library was built from (every .hpp and .hip file of csrc/ in name order; csrc/Makefile).
  * A committed rocprofv3 profile carries the same digest (profiles/<round>/meta.json): bench.py only quotes counters of a
  * profile that was taken from THESE sources. */
@@ -260,8 +262,10 @@ typedef struct mce_options {
     int32_t verify;        /* > 0: after the search, re-check this many query rows (spread over the set) by an independent exact
                               fp64 scan of ALL reference rows (mce_verify_knn_f64_dev below) and fail with MCE_ERR_VERIFY if a row
                               disagrees; honoured by the host-pointer entry points (mce_knn_f64[_opt], mce_knn_dotp_f64[_opt],
-                              mce_evidence_feed[_batch]_f64 -- not by a rank's share, *_part_*); 0 / -1: off (the default).
-                              ~2 ms per 1024 rows at 1 M x 27 */
+                              mce_evidence_feed[_batch]_f64 -- not by a rank's share, *_part_*) at d <= 128, K <= 32 (other shapes
+                              run on exact fp64 kernels and are skipped silently).  0: off.  -1 (the default, round 6): a search
+                              that went through the fp16 FILTER is re-checked on 256 rows (MCE_VERIFY=n in the environment: n
+                              rows; MCE_VERIFY=0: off), one on the fp64 kernels is not.  ~0.5 ms per 256 rows at 1 M x 27 */
     int32_t reserved[2];   /* 0 */
 } mce_options;
 int mce_options_push(const mce_options* opt);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "mce_device_count": (_c.c_int, []),
     "mce_last_error": (_c.c_char_p, []),
     "mce_last_kernel": (_c.c_char_p, []),
+    "mce_last_verify_rows": (_c.c_int32, []),
     "mce_source_hash": (_c.c_char_p, []),
     "mce_release_device_memory": (None, []),
     "mce_set_search_mode": (_c.c_int, [_c.c_int]),
@@ -302,6 +303,11 @@ def knn(X, Y, K, self_mode=SELF_NONE, self_offset=0, return_index=True, device=0
         check(lib.mce_knn_f64_opt(X.ctypes.data, nq, Y.ctypes.data, nr, d, K, int(self_mode), int(self_offset),
                                   dist.ctypes.data, idx.ctypes.data if idx is not None else None, int(device), _c.addressof(options)))
     return dist, idx
+
+
+def last_verify_rows():
+    """rows the run-time certificate of the most recent host-pointer search re-checked (0: it did not run)"""
+    return int(load().mce_last_verify_rows())
 
 
 def verify_knn(X, Y, dist, self_mode=SELF_NONE, self_offset=0, nsample=1024, seed=0, device=0):

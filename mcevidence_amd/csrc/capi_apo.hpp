@@ -47,11 +47,15 @@ PairsOnceShape pairs_once_shape(const Plan& p, int64_t nr, int32_t kmax, int32_t
 {
     PairsOnceShape sh;
     const int nown = (p.nqblk + nparts - 1) / std::max(nparts, 1);
+    // (the two overrides are read ONCE per process: the five entry points below derive the workspace layout from them again and
+    //  again, and an environment that changes between the calls on one workspace would misplace the list sets -- ADVICE round 5)
+    static const int env_split = [] { const char* e = getenv("MCE_PAIRS_ONCE_SPLIT"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 8) ? v : 0; }();
+    static const int env_panel = [] { const char* e = getenv("MCE_PAIRS_ONCE_PANEL"); const int v = e ? atoi(e) : 0; return v >= 1 ? v : 0; }();
     int S = std::min(8, std::max(1, (1536 + nown - 1) / std::max(nown, 1)));
-    if (const char* e = getenv("MCE_PAIRS_ONCE_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 8) S = v; }
+    if (env_split) S = env_split;
     const int def_panel = kSymPanelChunks[p.KST];
     int panel = S > 1 ? (int)std::max<int64_t>(8, std::min<int64_t>(def_panel, p.nchunk / (2 * S))) : 0;
-    if (const char* e = getenv("MCE_PAIRS_ONCE_PANEL")) { const int v = atoi(e); if (v >= 1) panel = v; }
+    if (env_panel) panel = env_panel;
     sh.nsplit = S;
     sh.panel = panel;
     size_t off = p.total + dotp_ws_bytes(nr, kmax);
@@ -67,6 +71,34 @@ PairsOnceShape pairs_once_shape(const Plan& p, int64_t nr, int32_t kmax, int32_t
     }
     sh.total = off;
     return sh;
+}
+// The four calls of one rank's share work on ONE workspace in a fixed order (prepare, sweep, export, finish) with the same
+// arguments; this table -- keyed by the workspace pointer, host memory, no device round trip -- records where a workspace
+// stands, and a call that arrives out of order or with other arguments is refused (MCE_ERR_INVALID) instead of reading
+// lists and buckets that are not there.
+struct ApoCall { int64_t nr; int d, kmax, part, nparts, nsplit, panel, phase; };
+std::mutex g_apo_mutex;
+std::unordered_map<const void*, ApoCall> g_apo_calls;
+// phase_from <= recorded phase <= phase_to required (0: no record needed -- prepare); afterwards the record's phase is phase_set (-1: erased)
+int apo_step(const void* ws, int64_t nr, int d, int kmax, int part, int nparts, const PairsOnceShape& sh, int phase_from, int phase_to, int phase_set,
+             const char* what)
+{
+    std::lock_guard<std::mutex> lk(g_apo_mutex);
+    auto it = g_apo_calls.find(ws);
+    if (phase_from > 0) {
+        if (it == g_apo_calls.end())
+            return fail(MCE_ERR_INVALID, "pairs-once partition: %s on a workspace that mce_pairs_once_prepare_dev has not prepared", what);
+        const ApoCall& c = it->second;
+        if (c.nr != nr || c.d != d || c.kmax != kmax || c.part != part || c.nparts != nparts || c.nsplit != sh.nsplit || c.panel != sh.panel)
+            return fail(MCE_ERR_INVALID, "pairs-once partition: %s with other arguments than the workspace was prepared with (prepared: nr=%lld d=%d kmax=%d part %d "
+                        "of %d, %d chains, panel %d)", what, (long long)c.nr, c.d, c.kmax, c.part, c.nparts, c.nsplit, c.panel);
+        if (c.phase < phase_from || c.phase > phase_to)
+            return fail(MCE_ERR_INVALID, "pairs-once partition: %s out of order (the calls are prepare, sweep, export, finish; this workspace stands after step %d)",
+                        what, c.phase);
+    }
+    if (phase_set < 0) { if (it != g_apo_calls.end()) g_apo_calls.erase(it); }
+    else g_apo_calls[ws] = ApoCall{nr, d, kmax, part, nparts, sh.nsplit, sh.panel, phase_set};
+    return MCE_OK;
 }
 // (the plan's list offsets point at the shape's list sets from here on)
 void pairs_once_apply(Plan& p, const PairsOnceShape& sh)
@@ -172,6 +204,8 @@ int mce_pairs_once_prepare_dev(const double* dY, int64_t nr, int32_t d, int32_t 
     if (ws_bytes < sh.total) return fail(MCE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, sh.total);
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* wsc = static_cast<char*>(ws);
+    rc = apo_step(ws, nr, d, kmax, part, nparts, sh, 0, 0, 1, "prepare");
+    if (rc != MCE_OK) return rc;
     p.part = part;
     p.nparts = nparts;
     pairs_once_apply(p, sh);
@@ -210,6 +244,8 @@ int mce_pairs_once_sweep_dev(const double* dY, int64_t nr, int32_t d, int32_t km
     if (ws_bytes < sh.total) return fail(MCE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, sh.total);
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* wsc = static_cast<char*>(ws);
+    rc = apo_step(ws, nr, d, kmax, part, nparts, sh, 1, 1, 2, "sweep");
+    if (rc != MCE_OK) return rc;
     p.part = part;
     p.nparts = nparts;
     pairs_once_apply(p, sh);
@@ -238,7 +274,10 @@ int mce_pairs_once_export_dev(int64_t nr, int32_t d, int32_t kmax, int32_t part,
     int rc = pairs_once_plan(nr, d, kmax, p, false);
     if (rc != MCE_OK) return rc;
     if (nparts < 2 || nparts > p.nqblk) return fail(MCE_ERR_INVALID, "part %d of %d", part, nparts);
-    if (ws_bytes < pairs_once_shape(p, nr, kmax, nparts).total) return fail(MCE_ERR_WORKSPACE, "workspace too small");
+    const PairsOnceShape sh = pairs_once_shape(p, nr, kmax, nparts);
+    if (ws_bytes < sh.total) return fail(MCE_ERR_WORKSPACE, "workspace too small");
+    rc = apo_step(ws, nr, d, kmax, part, nparts, sh, 2, 3, 3, "export");
+    if (rc != MCE_OK) return rc;
     if (!d_send) return MCE_OK;           // (nothing to ship)
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* wsc = static_cast<char*>(ws);
@@ -263,6 +302,8 @@ int mce_pairs_once_finish_dev(const double* dY, int64_t nr, int32_t d, int32_t k
     if (nparts > p.nqblk) return fail(MCE_ERR_INVALID, "pairs-once partition: %d ranks for %d blocks", nparts, p.nqblk);
     const PairsOnceShape sh = pairs_once_shape(p, nr, kmax, nparts);
     if (ws_bytes < sh.total) return fail(MCE_ERR_WORKSPACE, "workspace too small");
+    rc = apo_step(ws, nr, d, kmax, part, nparts, sh, 2, 3, -1, "finish");      // (export may be skipped by a rank with nothing to ship)
+    if (rc != MCE_OK) return rc;
     pairs_once_apply(p, sh);
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* wsc = static_cast<char*>(ws);

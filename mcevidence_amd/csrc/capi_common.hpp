@@ -119,7 +119,23 @@ thread_local std::vector<CallOptions> t_opt_stack;
 int eff_search_mode() { return t_opt.search >= 0 ? t_opt.search : g_mode.load(); }
 int eff_prune_mode() { return t_opt.prune >= 0 ? t_opt.prune : g_prune_mode.load(); }
 int eff_sym_mode() { return t_opt.sym >= 0 ? t_opt.sym : sym_mode(); }
-int eff_verify() { return t_opt.verify > 0 ? t_opt.verify : 0; }       // rows re-checked after a host-pointer search (mce_options.verify)
+// Rows re-checked after a host-pointer search (mce_options.verify; verify_kernels.hpp).  An explicit value (>= 0; 0 = off) wins.
+// Unset (-1): searches that took the fp16 FILTER -- whose exactness rests on a measured rounding model of the matrix core, not
+// on fp64 arithmetic throughout -- are certified on kVerifyDefaultRows rows by default (round 6; MCE_VERIFY=n in the
+// environment changes the number, MCE_VERIFY=0 turns the default off); the fp64 sweep and the generic kernel are not.
+constexpr int kVerifyDefaultRows = 256;
+int default_verify_rows()
+{
+    static const int v = [] {
+        const char* e = getenv("MCE_VERIFY");
+        if (!e || !*e) return kVerifyDefaultRows;
+        const long n = strtol(e, nullptr, 10);
+        return (int)std::max<long>(0, std::min<long>(n, 1 << 20));
+    }();
+    return v;
+}
+std::atomic<int> g_last_verify_rows{0};     // mce_last_verify_rows(): rows the certificate of the most recent host-pointer search checked
+int eff_verify(bool filter_path) { return t_opt.verify >= 0 ? t_opt.verify : (filter_path ? default_verify_rows() : 0); }
 // query blocks (512 rows each) from which the automatic mode takes it, by 16-wide k-steps of the filter.  Measured with the
 // panel kernel (tools/sym_crossover.py -> profiles/r03_panel/crossover.json; fused search + reduction, exhaustive -> symmetric,
 // ms).  Up to ~256 blocks -- one round of workgroups -- the seeded exhaustive sweep with its reference splits is faster

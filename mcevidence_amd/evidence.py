@@ -40,19 +40,21 @@ class HipBackend(object):
 
     name = "hip"
 
-    def __init__(self, devices=None, verify=True, recheck_rows=0):
+    def __init__(self, devices=None, verify=True, recheck_rows=None):
         self.devices = devices
         self.verify = verify        # multi-rank runs: compare a fingerprint of the inputs across the ranks on every call
         # run-time certificate of the search (mce_options.verify): after every single-process search this many query rows,
         # spread over the set, are re-checked by an exact fp64 scan of all reference rows that shares nothing with the
-        # search kernels; a disagreement raises RuntimeError.  0 = off (the default); ~2 ms per 1024 rows at 1 M x 27.
-        self.recheck_rows = int(recheck_rows)
+        # search kernels; a disagreement raises RuntimeError.  None (the default): the library's choice -- 256 rows behind
+        # the fp16 filter (MCE_VERIFY=n / MCE_VERIFY=0 in the environment), nothing behind the fp64 kernels; 0 = off;
+        # ~0.5 ms per 256 rows at 1 M x 27.
+        self.recheck_rows = None if recheck_rows is None else int(recheck_rows)
 
     def _scoped(self):
         """the per-call options of this backend's library calls (thread-scoped: mce_options_push / _pop)"""
         import contextlib
         from . import _capi
-        return _capi.options(verify=self.recheck_rows) if self.recheck_rows > 0 else contextlib.nullcontext()
+        return _capi.options(verify=self.recheck_rows) if self.recheck_rows is not None else contextlib.nullcontext()
 
     def evidence_feed(self, S1, S2, ndim, cov_mode, kmax, weight, fs):
         """feeders on the device too (get_covariance + diagonalise_chain + the hot path, one upload);
@@ -71,8 +73,10 @@ class HipBackend(object):
                 return None
             group = parallel.current_group()
             dev = self.devices[0] if self.devices else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
-            if S2 is None and parallel.pairs_once_enabled() and dev == torch.cuda.current_device():
-                # MCE_PAIRS_ONCE=1: every pair of rows multiplied once per node; None: not for this shape
+            if S2 is None and dist.get_world_size(group) >= 2 and parallel.pairs_once_route(
+                    np.asarray(S1).shape[0], ndim, kmax, group, local_ok=(parallel.pairs_once_enabled() and dev == torch.cuda.current_device())):
+                # MCE_PAIRS_ONCE=1 on EVERY rank (agreed in one tiny all-reduce -- the two routes' collectives differ, a choice per
+                # rank would pair them wrongly): every pair of rows multiplied once per node
                 got = parallel.pairs_once_feed(S1, ndim, kmax, weight, fs, group, verify=self.verify)
                 if got is not None:
                     return got

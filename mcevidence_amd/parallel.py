@@ -186,6 +186,38 @@ def pairs_once_enabled():
     return os.environ.get("MCE_PAIRS_ONCE") == "1"
 
 
+def agree_all(flag, group=None):
+    """True iff ``flag`` holds on EVERY rank of the group: one all-reduce(MIN) of a single integer.  Used where the ranks choose
+    between code paths with DIFFERENT collectives (the all-pairs-once partition against the part feed): a choice made per rank
+    -- an environment variable set on some ranks only, a device that differs -- would otherwise pair mismatched collectives
+    and hang.  Every rank of the group must call it at the same point, whatever its own ``flag``."""
+    import torch
+    import torch.distributed as dist
+    group = _GROUP if group is None else group
+    backend = dist.get_backend(group)
+    device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t[0].item()))
+
+
+def pairs_once_route(n, d, kmax, group=None, local_ok=True):
+    """Do ALL ranks take the all-pairs-once partition for an auto-evidence search of this shape?  (``MCE_PAIRS_ONCE=1`` on this
+    rank, the partition applicable to the shape on this many ranks, ``local_ok``; agreed with ``agree_all``, so a rank that
+    differs sends everybody down the default route instead of into mismatched collectives.)"""
+    import torch.distributed as dist
+    from . import _capi
+    group = _GROUP if group is None else group
+    world = dist.get_world_size(group)
+    mine = bool(local_ok) and pairs_once_enabled() and world >= 2
+    if mine:
+        try:
+            mine = _capi.pairs_once_blocks(int(n), int(d), int(kmax)) >= world
+        except Exception:
+            mine = False
+    return agree_all(mine, group)
+
+
 def _exchange_rows(send, in_splits, out_splits, group):
     """all_to_all of rows of a [n, 2] float64 tensor (16-byte candidates), ``in_splits[s]`` rows to rank s, ``out_splits[s]``
     from it.  RCCL moves device tensors; any other backend goes through the host."""
@@ -333,25 +365,51 @@ def pairs_once_knn_dotp(Y, weight, fs, kmax, group=None, stats=None, impl=None, 
     if lowest == float("-inf"):
         raise RuntimeError("mcevidence_amd: pairs-once partition: another rank of this process group failed before the sweep "
                            "(the failing rank raises its own error)")
-    counts, flags = impl.sweep(rank, world, nblk)
-    cdev = counts.device if nccl else torch.device("cpu")
-    # split sizes: every rank's counts to everybody (W x W integers); overflow flags: MAX over the ranks
-    mine = counts.to(cdev)
-    table = [torch.zeros(world, dtype=torch.int64, device=cdev) for _ in range(world)]
+    # From here on a rank that fails must not leave the others in a collective: sweep and export run BEFORE the next one and
+    # their failure travels in it -- a slot behind the W counts of the all_gather, so every rank sees every rank's flag and
+    # all raise together (the failing ranks their own exception); a failure in finish rides in the last all-reduce
+    # (feed_part_reduce: failed=).
+    cdev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+    mine = torch.zeros(world + 1, dtype=torch.int64, device=cdev)
+    fl = torch.zeros(max(nblk, 1), dtype=torch.int32, device=cdev)
+    send, in_splits = None, [0] * world
+    try:
+        counts, flags = impl.sweep(rank, world, nblk)
+        mine[:world] = counts.to(cdev)
+        fl = flags.to(cdev)
+        in_splits = [int(v) for v in mine[:world].tolist()]
+        if in_splits[rank] != 0:
+            raise RuntimeError("pairs-once partition: a rank has candidates addressed to itself")
+        send = impl.export(sum(in_splits))
+    except Exception as exc:
+        failed = exc
+        mine.zero_()
+        mine[world] = 1
+        fl = torch.zeros(max(nblk, 1), dtype=torch.int32, device=cdev)
+        in_splits = [0] * world
+    # split sizes: every rank's counts (+ its failure flag) to everybody
+    table = [torch.zeros(world + 1, dtype=torch.int64, device=cdev) for _ in range(world)]
     dist.all_gather(table, mine, group=group)
-    fl = flags.to(cdev)
+    nfailed = sum(int(t[world]) for t in table)
+    if failed is not None:
+        raise failed
+    if nfailed:
+        raise RuntimeError("mcevidence_amd: pairs-once partition: the sweep of %d of the %d ranks of this process group failed "
+                           "(the failing ranks raise their own error)" % (nfailed, world))
+    # overflow flags: MAX over the ranks
     dist.all_reduce(fl, op=dist.ReduceOp.MAX, group=group)
-    in_splits = [int(v) for v in mine.tolist()]
     out_splits = [int(table[s][rank]) for s in range(world)]
-    if in_splits[rank] != 0:
-        raise RuntimeError("pairs-once partition: a rank has candidates addressed to itself")
-    send = impl.export(sum(in_splits))
     recv = _exchange_rows(send, in_splits, out_splits, group)
-    part = impl.finish(recv, fl)
+    part, bad = np.zeros(int(kmax)), None
+    try:
+        part = impl.finish(recv, fl)
+        if not np.all(np.isfinite(part)):
+            bad = RuntimeError("mcevidence_amd: pairs-once partition: candidates arrived for rows this rank does not own "
+                               "(the ranks disagree about the partition)")
+    except Exception as exc:
+        bad = exc
     if stats is not None:
         stats.update(sent=int(sum(in_splits)), received=int(recv.shape[0]), bytes_sent=16 * int(sum(in_splits)), blocks=nblk, flagged=int(fl.sum().item()))
-    bad = None if np.all(np.isfinite(part)) else RuntimeError("mcevidence_amd: pairs-once partition: candidates arrived for rows this rank does not own "
-                                                              "(the ranks disagree about the partition)")
     return feed_part_reduce(part, checksum, group, failed=bad)
 
 
@@ -380,7 +438,7 @@ def sharded_knn_dotp(X, Y, weight, fs, kmax, k0, want_dist=False, group=None, lo
         if part_fn is None:
             from . import _capi
             dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
-            if pairs_once_enabled() and world >= 2 and _capi.pairs_once_blocks(X.shape[0], X.shape[1], kmax) >= world:
+            if world >= 2 and pairs_once_route(X.shape[0], X.shape[1], kmax, group):      # (agreed by all ranks: one tiny all-reduce)
                 return pairs_once_knn_dotp(X, weight, fs, kmax, group), None
             part = _capi.knn_dotp_part(X, weight, fs, kmax, rank, world, device=dev)
         else:

@@ -428,6 +428,113 @@ def test_pairs_once_partition_collectives_over_gloo(world):
     assert sum(s for s, _ in traffic) == sum(r for _, r in traffic) > 0
 
 
+class _FailingPairsOnce(_HostPairsOnce):
+    """one of the three calls after the bounds raises on this rank (a HIP error, an out-of-memory send buffer, ...)"""
+    def __init__(self, *a, stage=None):
+        super().__init__(*a)
+        self.stage = stage
+
+    def sweep(self, rank, world, nblk):
+        if self.stage == "sweep":
+            raise MemoryError("pairs-once sweep: out of device memory (test)")
+        counts, flags = super().sweep(rank, world, nblk)
+        if self.stage == "self":
+            counts[rank] = 3            # candidates addressed to itself: the rank-local check must not strand the others either
+        return counts, flags
+
+    def export(self, total):
+        if self.stage == "export":
+            raise MemoryError("pairs-once export: send buffer (test)")
+        return super().export(total)
+
+    def finish(self, recv, flags):
+        if self.stage == "finish":
+            raise MemoryError("pairs-once finish (test)")
+        return super().finish(recv, flags)
+
+
+def _pairs_once_failing_worker(rank, world, port, q, stage):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    from mcevidence_amd import parallel
+    rng = np.random.default_rng(11)
+    n, d, kmax = 400, 4, 3
+    Y = rng.standard_normal((n, d))
+    w = np.ones(n)
+    fs = -rng.random(n)
+    impl = _FailingPairsOnce(Y, w, fs, kmax, stage=stage if rank == 1 else None)
+    try:
+        parallel.pairs_once_knn_dotp(Y, w, fs, kmax, impl=impl)
+        out = ("ok", "")
+    except (RuntimeError, MemoryError) as e:
+        out = ("raised", type(e).__name__ + ": " + str(e))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stage", ["sweep", "self", "export", "finish"])
+def test_pairs_once_rank_failing_after_the_bounds_strands_nobody(stage):
+    """only the FIRST collective of pairs_once_knn_dotp was protected.  A rank whose sweep, export or finish raises
+    (or whose counts fail the rank-local check) still joins the collectives that follow -- the failure flag rides behind the
+    counts in the all_gather, or in the last all-reduce -- so every rank raises instead of sitting in a collective until its
+    timeout: the failing rank its own exception, the others a RuntimeError that says a rank failed."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pairs_once_failing_worker, args=(r, 3, port, q, stage)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(got[r][0] == "raised" for r in range(3)), got
+    own = "RuntimeError: pairs-once partition: a rank has candidates" if stage == "self" else "MemoryError"
+    assert got[1][1].startswith(own), got
+    for r in (0, 2):
+        assert "1 of the 3 ranks" in got[r][1], got
+
+
+def _route_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if rank == 1:
+        os.environ["MCE_PAIRS_ONCE"] = "1"          # set on ONE rank only
+    else:
+        os.environ.pop("MCE_PAIRS_ONCE", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mcevidence_amd import parallel, _capi
+    _capi.pairs_once_blocks = lambda n, d, kmax: 100           # (no library call on the CPU box)
+    a = parallel.pairs_once_route(100000, 27, 10)
+    os.environ["MCE_PAIRS_ONCE"] = "1"
+    b = parallel.pairs_once_route(100000, 27, 10)
+    c = parallel.pairs_once_route(100000, 27, 10, local_ok=(rank != 0))
+    q.put((rank, (a, b, c)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pairs_once_route_is_agreed_by_all_ranks():
+    """The choice between the all-pairs-once partition and the part feed is made ONCE for the group (all-reduce MIN of every
+    rank's own answer): the variable set on one rank only, or a rank whose device differs, sends everybody down the default
+    route -- never into mismatched collectives."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_route_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == (False, True, False)
+
+
 def test_replica_fingerprint_sees_every_row():
     from mcevidence_amd.parallel import replica_fingerprint
     rng = np.random.default_rng(3)

@@ -605,6 +605,18 @@ def test_pairs_once_partition_refuses_what_it_cannot_do(sym):
     capi.pairs_once_finish_dev(Y.data_ptr(), n, d, kmax, 0, 2, w.data_ptr(), fs.data_ptr(), bad.data_ptr(), 1, fl.data_ptr(), out.data_ptr(), ws.data_ptr(), wsb, 0)
     torch.cuda.synchronize()
     assert torch.isnan(out).all()
+    # the four calls come in order, on one workspace, with the arguments it was prepared with: anything else is refused
+    with pytest.raises(ValueError, match="out of order|not prepared"):       # finish has closed the workspace
+        capi.pairs_once_sweep_dev(Y.data_ptr(), n, d, kmax, 0, 2, cnt.data_ptr(), fl.data_ptr(), ws.data_ptr(), wsb, 0)
+    capi.pairs_once_prepare_dev(Y.data_ptr(), n, d, kmax, 0, 2, ws.data_ptr(), wsb, 0)
+    with pytest.raises(ValueError, match="out of order"):                    # no sweep yet
+        capi.pairs_once_finish_dev(Y.data_ptr(), n, d, kmax, 0, 2, w.data_ptr(), fs.data_ptr(), 0, 0, fl.data_ptr(), out.data_ptr(), ws.data_ptr(), wsb, 0)
+    with pytest.raises(ValueError, match="other arguments"):                 # prepared as part 0, swept as part 1
+        capi.pairs_once_sweep_dev(Y.data_ptr(), n, d, kmax, 1, 2, cnt.data_ptr(), fl.data_ptr(), ws.data_ptr(), wsb, 0)
+    capi.pairs_once_sweep_dev(Y.data_ptr(), n, d, kmax, 0, 2, cnt.data_ptr(), fl.data_ptr(), ws.data_ptr(), wsb, 0)
+    with pytest.raises(ValueError, match="out of order"):                    # swept twice
+        capi.pairs_once_sweep_dev(Y.data_ptr(), n, d, kmax, 0, 2, cnt.data_ptr(), fl.data_ptr(), ws.data_ptr(), wsb, 0)
+    torch.cuda.synchronize()
 
 
 def _pairs_once_rank(rank, world, port, q, n, d, kmax):

@@ -118,3 +118,33 @@ def test_class_with_recheck_rows_gives_the_same_lnE(capi):
     be = pkg.HipBackend(recheck_rows=256)
     b = pkg.evidence_many([pkg.MCEvidence([c], kmax=3, verbose=0, backend=be) for c in chains])
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_certificate_runs_by_default_behind_the_filter_and_not_behind_the_fp64_kernels(capi):
+    """Round 6 (parity footnote b): a production call carries the check.  With no option set a host-pointer
+    search that went through the fp16 filter is re-checked on 256 rows (mce_last_verify_rows says so); the fp64 sweep and the
+    generic kernel -- fp64 arithmetic throughout -- are not; verify=0 turns it off, a number replaces the default; shapes the
+    re-check does not handle (K > 32: the generic kernel) are searched without it and do NOT become an error."""
+    import mcevidence_amd as pkg
+    from mcevidence_amd.synth import gaussian_chain
+    Y = _data(30000, 12, 3)
+    capi.knn(Y, Y, 5, self_mode=capi.SELF_EXCLUDE)
+    assert capi.last_verify_rows() == 256 and "f16" in capi.last_kernel()
+    capi.knn(Y, Y, 5, self_mode=capi.SELF_EXCLUDE, options=capi.Options(verify=0))
+    assert capi.last_verify_rows() == 0
+    capi.knn(Y, Y, 5, self_mode=capi.SELF_EXCLUDE, options=capi.Options(verify=1000))
+    assert capi.last_verify_rows() == 1000
+    capi.knn(Y, Y, 5, self_mode=capi.SELF_EXCLUDE, options=capi.Options(search_mode=capi.MODE_F64))
+    assert capi.last_verify_rows() == 0 and "mfma" in capi.last_kernel()
+    # K = 40: the generic kernel; with an explicit row count the call still succeeds, unchecked
+    d40, _ = capi.knn(Y[:4000], Y, 40, options=capi.Options(verify=500))
+    assert capi.last_verify_rows() == 0 and d40.shape == (4000, 40) and "generic" in capi.last_kernel()
+    # the fused entry points and the class
+    w, fs = np.ones(len(Y)), np.zeros(len(Y))
+    capi.knn_dotp(Y, Y, w, fs, 5, 1)
+    assert capi.last_verify_rows() == 256
+    chain = gaussian_chain(seed=4, n=40000, d=8, weights="int", cov="corr")
+    a = pkg.MCEvidence([chain], kmax=5, verbose=0).evidence()
+    assert capi.last_verify_rows() == 256
+    b = pkg.MCEvidence([chain], kmax=5, verbose=0, backend=pkg.HipBackend(recheck_rows=0)).evidence()
+    assert capi.last_verify_rows() == 0 and np.array_equal(a, b)
