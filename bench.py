@@ -214,7 +214,7 @@ def progress(msg):
         sys.stderr.flush()
 
 
-def self_launch(argv, gpus, timeout_s=None):
+def self_launch(argv, gpus, timeout_s=None, grace_s=15.0, reap_s=30.0):
     """Start the N ranks as children -- one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment,
     exactly what a launcher would hand them -- and wait.  Runs before torch is imported: this process never touches the GPU,
     and nothing is exec'ed from a process that has.  (Not through `python -m torch.distributed.run`: its argument parser
@@ -224,7 +224,8 @@ def self_launch(argv, gpus, timeout_s=None):
     Watchdog: the ranks' stdout and stderr come through pipes and are relayed line by line; every rank reports its phases on
     stderr (`progress`).  A rank that has been SILENT for `timeout_s` seconds (MCE_BENCH_RANK_TIMEOUT, default 900: a hung
     collective, a wedged device) is terminated -- as a child, by PID; nothing is re-exec'ed -- together with the others, the
-    tail of its stderr is printed, and the parent exits with 124."""
+    tail of its stderr is printed, and the parent exits with 124.  Ranks that do not leave on SIGTERM within `grace_s` are
+    killed (SIGKILL, by PID); one that cannot be reaped `reap_s` after that is abandoned -- the parent never waits forever."""
     import collections
     import threading
     timeout_s = RANK_TIMEOUT_S if timeout_s is None else timeout_s
@@ -260,6 +261,17 @@ def self_launch(argv, gpus, timeout_s=None):
                 threads.append(t)
     rc = 0
     live = list(range(gpus))
+    stop_at = None                      # when the survivors were told to stop (SIGTERM); GRACE_S later they are killed (SIGKILL)
+    GRACE_S, REAP_S = grace_s, reap_s
+
+    def stop_all():
+        nonlocal stop_at
+        if stop_at is None:
+            stop_at = time.monotonic()
+            for q in live:
+                if procs[q].poll() is None:
+                    procs[q].terminate()
+
     while live:
         for r in list(live):
             code = procs[r].poll()
@@ -269,14 +281,25 @@ def self_launch(argv, gpus, timeout_s=None):
                     sys.stderr.write("bench.py: rank %d silent for %.0f s -- stopping all ranks.  Its last stderr lines:\n%s\n"
                                      % (r, timeout_s, "".join(tails[r]) or "(none)"))
                     sys.stderr.flush()
-                    for q in live:
-                        procs[q].terminate()
+                    stop_all()
                 continue
             live.remove(r)
             if code != 0 and rc == 0:
                 rc = code
-                for q in live:           # a rank failed: the others would wait for it in the next collective
-                    procs[q].terminate()
+                stop_all()               # a rank failed: the others would wait for it in the next collective
+        if live and stop_at is not None:
+            # a rank wedged in a driver call, or one that handles SIGTERM, does not leave by itself: SIGKILL after the grace
+            # period -- children only, by PID -- and a bounded wait for the reaping; a child that cannot be reaped even then
+            # (uninterruptible sleep in the driver) is abandoned, and the parent still exits non-zero
+            waited = time.monotonic() - stop_at
+            if waited > GRACE_S:
+                for q in live:
+                    if procs[q].poll() is None:
+                        procs[q].kill()
+            if waited > GRACE_S + REAP_S:
+                sys.stderr.write("bench.py: rank(s) %s could not be reaped %.0f s after SIGKILL -- giving up on them\n" % (live, REAP_S))
+                rc = rc or 124
+                break
         if live:
             time.sleep(0.05)
     for t in threads:
@@ -589,31 +612,51 @@ def main():
         dist.all_gather(allr, mine)
         e2e_ranks = [dict(rank=i, seconds=round(float(t[0]), 4), max_abs_dlnE_vs_resident_path=float(t[1])) for i, t in enumerate(allr)]
 
-    # MCE_BENCH_PAIRS_ONCE=1 (two ranks or more; opt-in, off in the driver's runs): the same workload through the all-pairs-once
-    # partition -- every rank's sweep, the exchange of the candidates and the all-reduces inside the timed region, data resident
+    # Two ranks or more: the same workload through the ALL-PAIRS-ONCE partition as well, by default (round 6; MCE_BENCH_PAIRS_ONCE=0
+    # skips it) -- every rank's sweep, the exchange of the candidates and the all-reduces inside the timed region, data resident --
+    # so that the first run on a multi-GPU node times both partitions.  `value` stays the default partition's.  The section is
+    # guarded: whatever fails in it (on any rank: the partition's collectives carry failure flags, so the ranks fail TOGETHER
+    # and nobody is left in a collective) becomes {"error": ...} in the line, never a lost headline.
     pairs_once = None
-    if dist_on and world >= 2 and os.environ.get("MCE_BENCH_PAIRS_ONCE") == "1" and a.mode == 0:
+    if dist_on and world >= 2 and os.environ.get("MCE_BENCH_PAIRS_ONCE", "1") != "0" and a.mode == 0:
         from mcevidence_amd import parallel
-        impl = parallel._HipPairsOnce(Xh, weight, fsh, kmax, world)
-        if impl.blocks() >= world:
-            progress("pairs-once partition: %d steps + %d warm-up" % (a.steps, a.warmup))
-            st = {}
-            for _ in range(max(a.warmup, 1)):
-                dp1 = parallel.pairs_once_knn_dotp(Xh, weight, fsh, kmax, stats=st, impl=impl)
-            ctx.barrier()
-            t3 = time.perf_counter()
-            for _ in range(a.steps):
-                dp1 = parallel.pairs_once_knn_dotp(Xh, weight, fsh, kmax, stats=st, impl=impl)
-            ctx.barrier()
-            mine = torch.tensor([time.perf_counter() - t3, float(st["sent"]), float(st["received"])], dtype=torch.float64, device=dev)
-            allr = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(allr, mine)
-            ms1 = max(float(t[0]) for t in allr) / a.steps * 1e3
-            lnE1 = lnE_from_dotp(dp1, c3)
-            pairs_once = dict(ms_per_step=round(ms1, 3), queries_per_s=round(n / (ms1 * 1e-3), 1), kernel=_capi.last_kernel(),
-                              candidates_sent=[int(t[1]) for t in allr], candidates_received=[int(t[2]) for t in allr],
-                              max_abs_dlnE_vs_default_partition=float(np.max(np.abs(lnE1 - lnE))),
-                              collectives="all_reduce(MIN) of the rows' bounds, all_gather of the counts, all_reduce(MAX) of the flags, all_to_all of the candidates, all_reduce(SUM)")
+        impl = None
+        try:
+            try:
+                impl = parallel._HipPairsOnce(Xh, weight, fsh, kmax, world)
+                applicable = impl.blocks() >= world
+            except Exception as exc:         # (this rank cannot even set up: the others must not start the collectives without it)
+                applicable, impl = False, None
+                progress("pairs-once partition: setup failed on this rank: %s" % exc)
+            if parallel.agree_all(applicable):
+                progress("pairs-once partition: %d steps + %d warm-up" % (a.steps, a.warmup))
+                st = {}
+                for _ in range(max(a.warmup, 1)):
+                    dp1 = parallel.pairs_once_knn_dotp(Xh, weight, fsh, kmax, stats=st, impl=impl)
+                ctx.barrier()
+                t3 = time.perf_counter()
+                for _ in range(a.steps):
+                    dp1 = parallel.pairs_once_knn_dotp(Xh, weight, fsh, kmax, stats=st, impl=impl)
+                mine_s = time.perf_counter() - t3
+                ctx.barrier()
+                mine = torch.tensor([time.perf_counter() - t3, float(st["sent"]), float(st["received"]), mine_s, float(torch.cuda.current_device())],
+                                    dtype=torch.float64, device=dev)
+                allr = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allr, mine)
+                ms1 = max(float(t[0]) for t in allr) / a.steps * 1e3
+                lnE1 = lnE_from_dotp(dp1, c3)
+                pairs_once = dict(ms_per_step=round(ms1, 3), queries_per_s=round(n / (ms1 * 1e-3), 1), kernel=_capi.last_kernel(),
+                                  per_rank=[dict(rank=i, device=int(t[4]), ms_per_step=round(float(t[3]) / a.steps * 1e3, 3), candidates_sent=int(t[1]),
+                                                 candidates_received=int(t[2])) for i, t in enumerate(allr)],
+                                  candidates_sent=[int(t[1]) for t in allr], candidates_received=[int(t[2]) for t in allr],
+                                  max_abs_dlnE_vs_default_partition=float(np.max(np.abs(lnE1 - lnE))),
+                                  vs_default_partition=round(ms_step / ms1, 3),
+                                  collectives="all_reduce(MIN) of the rows' bounds, all_gather of the counts, all_reduce(MAX) of the flags, all_to_all of the candidates, all_reduce(SUM)")
+            else:
+                pairs_once = dict(skipped="the partition does not apply to this shape on %d ranks (or a rank could not set it up)" % world)
+        except Exception as exc:
+            pairs_once = dict(error="%s: %s" % (type(exc).__name__, exc))
+            progress("pairs-once partition failed: %s" % exc)
         del impl
         torch.cuda.empty_cache()
 

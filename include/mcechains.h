@@ -40,6 +40,12 @@ void mce_chain_close(void *handle);
 /* Parses one numeric token (no surrounding whitespace) exactly as the reader does; for tests. */
 int mce_chain_parse_token(const char *token, int64_t len, double *value);
 
+/* 64-bit fingerprint of the dense array rows[n][d] (row stride ld doubles) on the host's cores: sum over the words i = r d + c
+ * of mix64(word_i + (salt + i) * 0x9E3779B97F4A7C15) -- bit for bit what libmcevidence_hip's device-side checksum computes over an
+ * uploaded copy.  Multi-rank evidence() with one upload of the chain per node (mcevidence_amd/parallel.py) compares the
+ * ranks' host fingerprints with it.  nthreads <= 0: one thread per 2 MB, at most the hardware concurrency (capped at 32). */
+uint64_t mce_chain_fingerprint_f64(const double *rows, int64_t n, int64_t d, int64_t ld, uint64_t salt, int32_t nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -127,6 +127,14 @@ int mce_evidence_feed_part_f64(const double *S1, int64_t n1, int64_t ld1, const 
                                int32_t d, int32_t cov_mode, int32_t kmax, const double *w, const double *fs,
                                int32_t part, int32_t nparts, double *dotp_part, double *jacobian, double *eigenvalues,
                                uint64_t *checksum, int32_t device);
+/* The same with the inputs ON THE DEVICE already (round 6; SURVEY.md 5: "one H2D + broadcast over xGMI instead of 8 PCIe
+ * copies"): dS1 / dS2 / d_w / d_fs are device pointers on `device` (rows ld1 / ld2 doubles apart), produced on a stream the
+ * caller has synchronised -- parallel.py uploads 1/W of the chain per rank and all_gathers it over RCCL.  Everything else
+ * (host outputs included) as mce_evidence_feed_part_f64; the inputs are copied, not modified. */
+int mce_evidence_feed_part_dev_f64(const double *dS1, int64_t n1, int64_t ld1, const double *dS2, int64_t n2, int64_t ld2,
+                                   int32_t d, int32_t cov_mode, int32_t kmax, const double *d_w, const double *d_fs,
+                                   int32_t part, int32_t nparts, double *dotp_part, double *jacobian, double *eigenvalues,
+                                   uint64_t *checksum, int32_t device);
 /* The feeders alone (auto evidence): upload, covariance of the n1 rows, Jacobi eigen-system, whitening -- and the whitened rows,
  * the weights and the likelihood terms left in DEVICE buffers of the caller's ([n1, d], [n1], [n1] doubles on `device`) instead of
  * being searched.  For hosts that run the search in several calls with collectives in between (the all-pairs-once partition:
@@ -134,6 +142,10 @@ int mce_evidence_feed_part_f64(const double *S1, int64_t n1, int64_t ld1, const 
 int mce_evidence_feed_whiten_f64(const double *S1, int64_t n1, int64_t ld1, int32_t d, int32_t kmax, const double *w,
                                  const double *fs, double *d_X_out, double *d_w_out, double *d_fs_out, double *jacobian,
                                  double *eigenvalues, uint64_t *checksum, int32_t device);
+/* ... with the inputs on the device already (as mce_evidence_feed_part_dev_f64) */
+int mce_evidence_feed_whiten_dev_f64(const double *dS1, int64_t n1, int64_t ld1, int32_t d, int32_t kmax, const double *d_w,
+                                     const double *d_fs, double *d_X_out, double *d_w_out, double *d_fs_out, double *jacobian,
+                                     double *eigenvalues, uint64_t *checksum, int32_t device);
 
 /* Many independent evidence problems in one call: the reference's Planck driver
  * runs MCEvidence(...).evidence() once per (data set, model, chain) -- ~600-2400 chains of 6k-100k

@@ -71,6 +71,10 @@ SIGNATURES = {
                                               _P, _P, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _c.c_int32]),
     "mce_evidence_feed_whiten_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _P, _c.POINTER(_c.c_double), _P,
                                                 _c.POINTER(_c.c_uint64), _c.c_int32]),
+    "mce_evidence_feed_part_dev_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32,
+                                                  _P, _P, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _c.c_int32]),
+    "mce_evidence_feed_whiten_dev_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _P, _c.POINTER(_c.c_double), _P,
+                                                    _c.POINTER(_c.c_uint64), _c.c_int32]),
     "mce_knn_dotp_part_f64_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _c.c_size_t, _P]),
     "mce_knn_dotp_part_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_int32]),
     "mce_pairs_once_blocks": (_c.c_int32, [_c.c_int64, _c.c_int32, _c.c_int32]),
@@ -442,6 +446,31 @@ def evidence_feed_part(S1, S2, d, cov_mode, kmax, w, fs, part, nparts, device=0,
                                          w.ctypes.data, fs.ctypes.data, int(part), int(nparts), out.ctypes.data, ctypes.byref(jac),
                                          ev.ctypes.data, ctypes.byref(csum) if want_checksum else None, int(device)))
     return out, float(jac.value), ev, (int(csum.value) if want_checksum else None)
+
+
+def evidence_feed_part_dev(dS1, n1, ld1, dS2, n2, ld2, d, cov_mode, kmax, d_w, d_fs, part, nparts, device=0, want_checksum=True):
+    """``evidence_feed_part`` with the inputs on the device already (``mce_evidence_feed_part_dev_f64``): device POINTERS (rows
+    ``ld`` doubles apart; ``dS2`` = 0 for auto evidence), produced on a stream the caller has synchronised.  Same returns."""
+    lib = load()
+    out = np.zeros(int(kmax))
+    jac = ctypes.c_double(0.0)
+    ev = np.zeros(int(d))
+    csum = ctypes.c_uint64(0)
+    check(lib.mce_evidence_feed_part_dev_f64(dS1, int(n1), int(ld1), dS2 or None, int(n2) if dS2 else 0, int(ld2) if dS2 else 0, int(d), int(cov_mode), int(kmax),
+                                             d_w, d_fs, int(part), int(nparts), out.ctypes.data, ctypes.byref(jac), ev.ctypes.data,
+                                             ctypes.byref(csum) if want_checksum else None, int(device)))
+    return out, float(jac.value), ev, (int(csum.value) if want_checksum else None)
+
+
+def evidence_feed_whiten_dev(dS1, n1, ld1, d, kmax, d_w, d_fs, d_X_out, d_w_out, d_fs_out, device=0, want_checksum=True):
+    """``evidence_feed_whiten`` with the inputs on the device already (``mce_evidence_feed_whiten_dev_f64``)."""
+    lib = load()
+    jac = ctypes.c_double(0.0)
+    ev = np.zeros(int(d))
+    csum = ctypes.c_uint64(0)
+    check(lib.mce_evidence_feed_whiten_dev_f64(dS1, int(n1), int(ld1), int(d), int(kmax), d_w, d_fs, d_X_out, d_w_out, d_fs_out, ctypes.byref(jac),
+                                               ev.ctypes.data, ctypes.byref(csum) if want_checksum else None, int(device)))
+    return float(jac.value), ev, (int(csum.value) if want_checksum else None)
 
 
 def evidence_feed_whiten(S1, d, kmax, w, fs, d_X_out, d_w_out, d_fs_out, device=0, want_checksum=True):

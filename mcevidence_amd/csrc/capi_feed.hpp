@@ -163,6 +163,8 @@ struct FeedJob {
     double* out_X = nullptr;          // mce_evidence_feed_whiten_f64: no search -- the whitened rows, the weights and the likelihood terms are left in
     double* out_w = nullptr;          // these DEVICE buffers of the caller's (auto evidence; the all-pairs-once partition searches them in several calls
     double* out_f = nullptr;          // with collectives in between: parallel.py)
+    bool src_device = false;          // S1 / S2 / w / fs are DEVICE pointers (mce_evidence_feed_part_dev_f64: the node uploaded the chain once and
+                                      // gathered it over xGMI): stage A copies device to device on the job's stream
     bool want_sum = false;            // fingerprint of the uploaded rows / weights / likelihoods (device-side)
     unsigned long long checksum = 0;
     int64_t q_lo = 0, q_hi = 0;       // cross evidence of a part: its rows of s1
@@ -263,7 +265,13 @@ int feed_stage_a(FeedJob& j, hipStream_t st)
     // hipStreamNonBlocking streams do not synchronise with the legacy default stream).  MCE_FEED_UPLOAD=async: the
     // copies themselves on the job's stream.
     static const bool async_upload = [] { const char* e = getenv("MCE_FEED_UPLOAD"); return e && !strcmp(e, "async"); }();
-    if (async_upload || st == nullptr) {
+    if (j.src_device) {
+        // the rows are on this device already (the caller has synchronised the stream that produced them)
+        MCE_HIP(hipMemcpy2DAsync(j.dS1(), row, q.S1, (size_t)q.ld1 * sizeof(double), row, (size_t)q.n1, hipMemcpyDeviceToDevice, st));
+        if (q.S2) MCE_HIP(hipMemcpy2DAsync(j.dS2(), row, q.S2, (size_t)q.ld2 * sizeof(double), row, (size_t)q.n2, hipMemcpyDeviceToDevice, st));
+        MCE_HIP(hipMemcpyAsync(j.dW(), q.w, (size_t)q.n1 * sizeof(double), hipMemcpyDeviceToDevice, st));
+        MCE_HIP(hipMemcpyAsync(j.dF(), q.fs, (size_t)q.n1 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    } else if (async_upload || st == nullptr) {
         MCE_HIP(hipMemcpy2DAsync(j.dS1(), row, q.S1, (size_t)q.ld1 * sizeof(double), row, (size_t)q.n1, hipMemcpyHostToDevice, st));
         if (q.S2) MCE_HIP(hipMemcpy2DAsync(j.dS2(), row, q.S2, (size_t)q.ld2 * sizeof(double), row, (size_t)q.n2, hipMemcpyHostToDevice, st));
         MCE_HIP(hipMemcpyAsync(j.dW(), q.w, (size_t)q.n1 * sizeof(double), hipMemcpyHostToDevice, st));
@@ -608,10 +616,10 @@ int mce_evidence_feed_f64(const double* S1, int64_t n1, int64_t ld1, const doubl
 }
 
 
-int mce_evidence_feed_part_f64(const double* S1, int64_t n1, int64_t ld1, const double* S2, int64_t n2, int64_t ld2,
-                               int32_t d, int32_t cov_mode, int32_t kmax, const double* w, const double* fs,
-                               int32_t part, int32_t nparts, double* dotp_part, double* jacobian, double* eigenvalues,
-                               uint64_t* checksum, int32_t device)
+static int feed_part_impl(bool src_device, const double* S1, int64_t n1, int64_t ld1, const double* S2, int64_t n2, int64_t ld2,
+                          int32_t d, int32_t cov_mode, int32_t kmax, const double* w, const double* fs,
+                          int32_t part, int32_t nparts, double* dotp_part, double* jacobian, double* eigenvalues,
+                          uint64_t* checksum, int32_t device)
 {
     if (!jacobian) return fail(MCE_ERR_INVALID, "null pointer argument");
     if (nparts < 1 || part < 0 || part >= nparts) return fail(MCE_ERR_INVALID, "part %d of %d", part, nparts);
@@ -625,6 +633,51 @@ int mce_evidence_feed_part_f64(const double* S1, int64_t n1, int64_t ld1, const 
     job.q = &q;
     job.part = part;
     job.nparts = nparts;
+    job.src_device = src_device;
+    job.want_sum = checksum != nullptr;
+    int rc = feed_plan(job);
+    if (rc != MCE_OK) return rc;
+    std::vector<FeedJob*> jobs{&job};
+    rc = feed_run_on_device(device, jobs);
+    if (rc != MCE_OK) return rc;
+    if (job.rc != MCE_OK) return fail(job.rc, "%s", job.err.c_str());
+    *jacobian = q.jacobian;
+    if (checksum) *checksum = job.checksum;
+    return MCE_OK;
+}
+
+int mce_evidence_feed_part_f64(const double* S1, int64_t n1, int64_t ld1, const double* S2, int64_t n2, int64_t ld2,
+                               int32_t d, int32_t cov_mode, int32_t kmax, const double* w, const double* fs,
+                               int32_t part, int32_t nparts, double* dotp_part, double* jacobian, double* eigenvalues,
+                               uint64_t* checksum, int32_t device)
+{
+    return feed_part_impl(false, S1, n1, ld1, S2, n2, ld2, d, cov_mode, kmax, w, fs, part, nparts, dotp_part, jacobian, eigenvalues, checksum, device);
+}
+
+int mce_evidence_feed_part_dev_f64(const double* dS1, int64_t n1, int64_t ld1, const double* dS2, int64_t n2, int64_t ld2,
+                                   int32_t d, int32_t cov_mode, int32_t kmax, const double* d_w, const double* d_fs,
+                                   int32_t part, int32_t nparts, double* dotp_part, double* jacobian, double* eigenvalues,
+                                   uint64_t* checksum, int32_t device)
+{
+    return feed_part_impl(true, dS1, n1, ld1, dS2, n2, ld2, d, cov_mode, kmax, d_w, d_fs, part, nparts, dotp_part, jacobian, eigenvalues, checksum, device);
+}
+
+static int feed_whiten_impl(bool src_device, const double* S1, int64_t n1, int64_t ld1, int32_t d, int32_t kmax, const double* w, const double* fs,
+                            double* d_X_out, double* d_w_out, double* d_fs_out, double* jacobian, double* eigenvalues,
+                            uint64_t* checksum, int32_t device)
+{
+    if (!jacobian || !d_X_out || !d_w_out || !d_fs_out) return fail(MCE_ERR_INVALID, "null pointer argument");
+    mce_feed_problem q;
+    std::memset(&q, 0, sizeof(q));
+    double sums[MCE_MAX_K + 2];
+    q.S1 = S1; q.n1 = n1; q.ld1 = ld1;
+    q.d = d; q.cov_mode = 0; q.kmax = kmax;
+    q.w = w; q.fs = fs; q.dotp = sums; q.eigenvalues = eigenvalues;
+    if (kmax < 2 || kmax > MCE_MAX_K + 1) return fail(MCE_ERR_K_RANGE, "kmax=%d", kmax);
+    FeedJob job;
+    job.q = &q;
+    job.out_X = d_X_out; job.out_w = d_w_out; job.out_f = d_fs_out;
+    job.src_device = src_device;
     job.want_sum = checksum != nullptr;
     int rc = feed_plan(job);
     if (rc != MCE_OK) return rc;
@@ -641,27 +694,14 @@ int mce_evidence_feed_whiten_f64(const double* S1, int64_t n1, int64_t ld1, int3
                                  double* d_X_out, double* d_w_out, double* d_fs_out, double* jacobian, double* eigenvalues,
                                  uint64_t* checksum, int32_t device)
 {
-    if (!jacobian || !d_X_out || !d_w_out || !d_fs_out) return fail(MCE_ERR_INVALID, "null pointer argument");
-    mce_feed_problem q;
-    std::memset(&q, 0, sizeof(q));
-    double sums[MCE_MAX_K + 2];
-    q.S1 = S1; q.n1 = n1; q.ld1 = ld1;
-    q.d = d; q.cov_mode = 0; q.kmax = kmax;
-    q.w = w; q.fs = fs; q.dotp = sums; q.eigenvalues = eigenvalues;
-    if (kmax < 2 || kmax > MCE_MAX_K + 1) return fail(MCE_ERR_K_RANGE, "kmax=%d", kmax);
-    FeedJob job;
-    job.q = &q;
-    job.out_X = d_X_out; job.out_w = d_w_out; job.out_f = d_fs_out;
-    job.want_sum = checksum != nullptr;
-    int rc = feed_plan(job);
-    if (rc != MCE_OK) return rc;
-    std::vector<FeedJob*> jobs{&job};
-    rc = feed_run_on_device(device, jobs);
-    if (rc != MCE_OK) return rc;
-    if (job.rc != MCE_OK) return fail(job.rc, "%s", job.err.c_str());
-    *jacobian = q.jacobian;
-    if (checksum) *checksum = job.checksum;
-    return MCE_OK;
+    return feed_whiten_impl(false, S1, n1, ld1, d, kmax, w, fs, d_X_out, d_w_out, d_fs_out, jacobian, eigenvalues, checksum, device);
+}
+
+int mce_evidence_feed_whiten_dev_f64(const double* dS1, int64_t n1, int64_t ld1, int32_t d, int32_t kmax, const double* d_w, const double* d_fs,
+                                     double* d_X_out, double* d_w_out, double* d_fs_out, double* jacobian, double* eigenvalues,
+                                     uint64_t* checksum, int32_t device)
+{
+    return feed_whiten_impl(true, dS1, n1, ld1, d, kmax, d_w, d_fs, d_X_out, d_w_out, d_fs_out, jacobian, eigenvalues, checksum, device);
 }
 
 int mce_knn_dotp_f64(const double* X, int64_t nq, const double* Y, int64_t nr, int32_t d, int32_t kmax,

@@ -369,4 +369,43 @@ int mce_chain_read(void* handle, double* out)
 
 void mce_chain_close(void* handle) { delete static_cast<Chain*>(handle); }
 
+// 64-bit fingerprint of the logical dense array rows[n][d] (row stride ld doubles): the sum over its words i = r d + c of
+// mix64(word_i + (salt + i) * golden) -- the function feeders.hpp's checksum_kernel computes on the device, here on the host's
+// cores (order-independent integer adds, so threads take row ranges).  Multi-rank evidence() with ONE upload of the chain
+// per node compares the ranks' host fingerprints instead of uploading every rank's copy to hash it on the device.
+uint64_t mce_chain_fingerprint_f64(const double* rows, int64_t n, int64_t d, int64_t ld, uint64_t salt, int32_t nthreads)
+{
+    if (!rows || n <= 0 || d <= 0 || ld < d) return 0;
+    auto mix64 = [](uint64_t z) {
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    int nt = nthreads > 0 ? nthreads : (int)std::min<int64_t>(std::max<unsigned>(1u, std::thread::hardware_concurrency()), (n * d + (1 << 18) - 1) >> 18);
+    nt = std::max(1, std::min(nt, 32));
+    std::vector<uint64_t> part((size_t)nt, 0);
+    auto work = [&](int t) {
+        const int64_t r0 = n * t / nt, r1 = n * (t + 1) / nt;
+        uint64_t h = 0;
+        for (int64_t r = r0; r < r1; ++r) {
+            const double* row = rows + r * ld;
+            for (int64_t c = 0; c < d; ++c) {
+                uint64_t w;
+                std::memcpy(&w, row + c, sizeof(w));
+                h += mix64(w + (salt + (uint64_t)(r * d + c)) * 0x9E3779B97F4A7C15ull);
+            }
+        }
+        part[(size_t)t] = h;
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    uint64_t h = 0;
+    for (uint64_t v : part) h += v;
+    return h;
+}
+
 }  // extern "C"

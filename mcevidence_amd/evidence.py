@@ -81,9 +81,27 @@ class HipBackend(object):
                 if got is not None:
                     return got
             part, jac, csum, failed = np.zeros(kmax), float("nan"), None, None
+            # ONE upload of the chain per node (round 6): every rank uploads 1/W of the rows, an all_gather over RCCL hands
+            # everybody the whole set; the ranks' inputs are compared through fingerprints of their HOST copies, computed on a
+            # thread beside the GPU work (the gathered set is identical everywhere by construction).  Collective calls:
+            # every rank takes the same branch (the backend and the environment decide; a rank that cannot allocate sends
+            # everybody back to the per-rank upload).
+            gathered, hostsum = None, None
+            if (dist.get_world_size(group) >= 2 or parallel._forced()) and parallel.node_upload_enabled(group) and dev == torch.cuda.current_device():
+                hostsum = parallel._HostFingerprint(S1, S2, ndim, weight, fs) if self.verify else None
+                gathered = parallel.gather_chain_on_device(S1, S2, ndim, weight, fs, group)
             try:
-                part, jac, _, csum = _capi.evidence_feed_part(S1, S2, ndim, cov_mode, kmax, weight, fs, dist.get_rank(group),
-                                                              dist.get_world_size(group), device=dev, want_checksum=self.verify)
+                if gathered is not None:
+                    Sg, wg, fg = gathered
+                    n1 = int(np.asarray(S1).shape[0])
+                    n2 = 0 if S2 is None else int(np.asarray(S2).shape[0])
+                    part, jac, _, _ = _capi.evidence_feed_part_dev(Sg.data_ptr(), n1, ndim, Sg[n1:].data_ptr() if n2 else 0, n2, ndim, ndim, cov_mode, kmax,
+                                                                   wg.data_ptr(), fg.data_ptr(), dist.get_rank(group), dist.get_world_size(group),
+                                                                   device=dev, want_checksum=False)
+                    csum = hostsum.value() if hostsum is not None else None
+                else:
+                    part, jac, _, csum = _capi.evidence_feed_part(S1, S2, ndim, cov_mode, kmax, weight, fs, dist.get_rank(group),
+                                                                  dist.get_world_size(group), device=dev, want_checksum=self.verify)
             except Exception as exc:        # still join the collective (with a failure flag): the other ranks must not hang in it
                 failed = exc
             return parallel.feed_part_reduce(part, csum, group, failed=failed), jac

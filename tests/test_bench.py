@@ -68,6 +68,41 @@ def test_self_launch_watchdog_stops_a_silent_rank(monkeypatch, capsys):
     assert "silent for" in err and "init_process_group(nccl)" in err
 
 
+def test_self_launch_watchdog_kills_what_sigterm_does_not_stop(monkeypatch, capsys):
+    """a rank wedged in a driver call (or one that handles SIGTERM) ignores terminate(); after the grace period it
+    is killed by PID, and a rank that cannot even be reaped does not keep the parent: 124 after a bounded wait."""
+    import io
+    import bench
+
+    def make(reapable):
+        started = []
+
+        class Wedged(object):
+            def __init__(self, cmd, env=None, **kw):
+                self.rank, self.terminated, self.killed = int(env["RANK"]), False, False
+                self.stdout, self.stderr = io.StringIO(""), io.StringIO("")
+                started.append(self)
+
+            def poll(self):
+                if self.rank == 0:
+                    return -15 if self.terminated else None          # rank 0 leaves on SIGTERM
+                return -9 if (self.killed and reapable) else None       # rank 1 only on SIGKILL -- or never
+
+            def terminate(self):
+                self.terminated = True
+
+            def kill(self):
+                self.killed = True
+        return Wedged, started
+
+    for reapable in (True, False):
+        cls, started = make(reapable)
+        monkeypatch.setattr(bench.subprocess, "Popen", cls)
+        assert bench.self_launch(["--gpus", "2"], 2, timeout_s=0.2, grace_s=0.3, reap_s=0.3) == 124
+        assert started[1].terminated and started[1].killed and not started[0].killed
+    assert "could not be reaped" in capsys.readouterr().err
+
+
 def test_parent_of_a_self_launch_never_imports_torch():
     """`python bench.py --gpus 2` without a launcher: the parent only spawns (nothing that could initialise the GPU is even
     imported); here the ranks are replaced by a stub."""
@@ -133,6 +168,8 @@ def test_bench_gpus_2_from_a_plain_shell():
     one = _bench_line(["--gpus", "1"] + common, {})
     assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and two["backend"] == "gloo" and one["n_gpus"] == 1
     assert [r["rank"] for r in two["per_rank"]] == [0, 1] and all(r["device"] == 0 for r in two["per_rank"])
+    # both partitions in the line by default; at 150 k rows (293 blocks on 2 ranks) the all-pairs-once partition applies
+    assert "error" not in two["pairs_once"] and two["pairs_once"]["max_abs_dlnE_vs_default_partition"] < LNE_TOL, two["pairs_once"]
     assert two["steps"] == 2 and two["warmup"] == 1 and two["scaling"] == "strong"
     e2e = two["evidence_call_from_host"]                  # the class under the process group: part feed + one all-reduce
     assert len(e2e["per_rank"]) == 2 and e2e["max_abs_dlnE_vs_resident_path"] < LNE_TOL
@@ -156,7 +193,9 @@ def test_bench_gpus_2_under_the_launcher():
     port = s.getsockname()[1]
     s.close()
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(MCE_BENCH_BACKEND="gloo", MCE_BENCH_ONE_DEVICE="1", MCE_BENCH_PAIRS_ONCE="1")
+    env.pop("MCE_BENCH_PAIRS_ONCE", None)                  # (round 6: the second partition is timed by DEFAULT under two ranks or more)
+    env.pop("MCE_PAIRS_ONCE", None)
+    env.update(MCE_BENCH_BACKEND="gloo", MCE_BENCH_ONE_DEVICE="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--cpu-sample", "0", "--no-extras"], capture_output=True, text=True, env=env, timeout=900, cwd=REPO)
@@ -167,7 +206,12 @@ def test_bench_gpus_2_under_the_launcher():
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["steps"] == 2 and line["warmup"] == 1
     assert line["config"]["N"] == 1_000_000 and line["config"]["D"] == 27 and line["max_abs_dlnE_vs_reference"] < LNE_TOL
     assert "symmetric" in line["roofline"]["kernel"] and len(line["per_rank"]) == 2
-    # MCE_BENCH_PAIRS_ONCE=1: the same workload through the all-pairs-once partition, collectives and all, in the same line
+    # the same workload through the all-pairs-once partition, collectives and all, in the same line -- WITHOUT any opt-in in the
+    # environment: both partitions with their per-rank figures, equal ln E
     po = line["pairs_once"]
+    assert "error" not in po and "skipped" not in po, po
     assert "pairs-once" in po["kernel"] and po["max_abs_dlnE_vs_default_partition"] < LNE_TOL and po["ms_per_step"] > 0
     assert sum(po["candidates_sent"]) == sum(po["candidates_received"]) > 0
+    assert [r["rank"] for r in po["per_rank"]] == [0, 1] and all(r["ms_per_step"] > 0 for r in po["per_rank"])
+    e2e = line["evidence_call_from_host"]
+    assert len(e2e["per_rank"]) == 2 and e2e["max_abs_dlnE_vs_resident_path"] < LNE_TOL

@@ -11,14 +11,17 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <map>
+#include <vector>
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-enum { C_FMA32 = 0, C_MIN3, C_CMP, C_CMPBR, C_PKFMA, C_FMA64, C_ADD64, C_INT, C_CNDMASK, C_MOV, C_CVT, C_READLANE, C_MAXMIN, C_NCLS };
+enum { C_FMA32 = 0, C_MIN3, C_CMP, C_CMPBR, C_PKFMA, C_FMA64, C_ADD64, C_INT, C_CNDMASK, C_MOV, C_CVT, C_READLANE, C_MAXMIN, C_SELECT, C_NCLS };
 static const char* kNames[C_NCLS] = {"v_fma_f32", "v_min3_f32", "v_cmp_lt_f32", "v_cmp_lt_f32+s_cbranch_vccnz", "v_pk_fma_f32", "v_fma_f64", "v_add_f64",
                                      "v_add_u32/v_lshlrev/v_and", "v_cndmask_b32", "v_mov_b32", "v_cvt_f32_f64/v_cvt_f64_f32", "v_readlane_b32",
-                                     "v_max_f32/v_min_f32"};
+                                     "v_max_f32/v_min_f32", "v_cmp_lt_f32+v_cndmask_b32"};
 
 // 32 independent instructions of class CLS on the registers r[0..7] (f32) / d[0..7] (f64)
 template <int CLS>
@@ -68,6 +71,11 @@ __device__ __forceinline__ void block32(float (&r)[8], double (&d)[8], v2f (&p)[
         REP4(asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
                           "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc"
                           : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "v"(k0) : "vcc");)
+    } else if constexpr (CLS == C_SELECT) {
+        // the select idiom: a compare and the conditional move that reads its mask (16 pairs = 32 instructions)
+        REP4(asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                          "v_cmp_lt_f32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %8, vcc\n v_cmp_lt_f32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %8, vcc"
+                          : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "v"(k0) : "vcc");)
     } else if constexpr (CLS == C_MOV) {
         REP4(asm volatile("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8"
                           : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "v"(k0));)
@@ -103,6 +111,7 @@ __global__ __launch_bounds__(512) void k(float* out, long long* clk, int iters, 
     const int wave = threadIdx.x >> 6;
     const bool mfma_wave = ROLE == 1 && wave < 4;
     __syncthreads();
+    const long long w0 = wall_clock64();
     const long long c0 = clock64();
     if (mfma_wave) {
         for (int it = 0; it < iters; ++it) {
@@ -119,12 +128,19 @@ __global__ __launch_bounds__(512) void k(float* out, long long* clk, int iters, 
         }
     }
     const long long c1 = clock64();
+    const long long w1 = wall_clock64();
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     float s = (float)sacc;
     for (int i = 0; i < 8; ++i) s += r[i] + (float)d[i] + p[i][0] + p[i][1];
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 16; ++j) s += acc[i][j];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-    if ((threadIdx.x & 63) == 0) clk[(size_t)blockIdx.x * 8 + wave] = c1 - c0;
+    if ((threadIdx.x & 63) == 0) {
+        long long* o = clk + ((size_t)blockIdx.x * 8 + wave) * 4;
+        o[0] = c1 - c0; o[1] = w0; o[2] = w1; o[3] = (long long)(((unsigned long long)(xcc & 0xf) << 32) | hwid);
+    }
 }
 
 static float* g_out; static long long* g_clk; static v8h* g_ab;
@@ -145,17 +161,42 @@ void run(int waves_per_simd, int iters)
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    long long hc[8];
-    hipMemcpy(hc, g_clk, sizeof(hc), hipMemcpyDeviceToHost);
+    const int wpb = threads / 64;
+    std::vector<long long> hc((size_t)blocks * 8 * 4);
+    hipMemcpy(hc.data(), g_clk, hc.size() * sizeof(long long), hipMemcpyDeviceToHost);
     const double n_valu = 32.0 * iters;                          // class instructions per class wave
-    const int wv = ROLE == 1 ? 7 : 0;                            // a class wave of block 0
-    const double ticks = (double)hc[wv];
-    const double mhz = ticks / (ms * 1e3);                       // s_memtime ticks are shader cycles (MI355X_MICROARCH.md)
+    // per wave: shader cycles (s_memtime), start / end on the constant 100 MHz clock (s_memrealtime), and WHERE it ran (HW_ID: SIMD
+    // [5:4], CU [11:8], SH [12], SE [15:13]; XCC_ID).  From these: the waves that shared a SIMD, how far their lifetimes overlapped,
+    // the shader clock each wave saw -- so that "waves per SIMD" and "cycles" below are measured, not assumed from the launch.
+    std::map<long long, std::vector<int>> by_simd;
+    long long wmin = 0x7fffffffffffffffll, wmax = 0;
+    double sum_ticks = 0, sum_wall = 0, sum_clock = 0;
+    int nclass = 0;
+    for (int b = 0; b < blocks; ++b)
+        for (int w = 0; w < wpb; ++w) {
+            const long long* o = &hc[((size_t)b * 8 + w) * 4];
+            const long long id = ((o[3] >> 32) << 16) | (o[3] & 0xfff0 & ~0xc0ll);      // xcc | se, sh, cu, simd (pipe and wave-slot bits dropped)
+            by_simd[id].push_back(b * 8 + w);
+            wmin = std::min(wmin, o[1]); wmax = std::max(wmax, o[2]);
+            if (ROLE == 1 && w < 4) continue;
+            sum_ticks += (double)o[0]; sum_wall += (double)(o[2] - o[1]);
+            sum_clock += (double)o[0] / ((double)(o[2] - o[1]) * 10.0);                  // cycles per ns x 1000 = MHz / 1000 ... (100 MHz ticks = 10 ns)
+            nclass += 1;
+        }
+    size_t maxw = 0, minw = 1u << 30;
+    for (auto& kv : by_simd) { maxw = std::max(maxw, kv.second.size()); minw = std::min(minw, kv.second.size()); }
+    const double ticks = sum_ticks / nclass;                      // mean shader cycles of a class wave
+    const double span_ns = (double)(wmax - wmin) * 10.0, life_ns = sum_wall / nclass * 10.0;
+    const double mhz = sum_clock / nclass * 1000.0;
     const int class_waves_per_simd = ROLE == 1 ? 1 : waves_per_simd;
+    const double simds = (double)by_simd.size();
+    const double inst_total = n_valu * nclass;
     printf("{\"class\": \"%s\", \"role\": \"%s\", \"waves_per_simd\": %d, \"mfma_per_32\": %d, \"ms\": %.3f, \"clock_mhz\": %.0f, "
-           "\"cycles_per_inst_per_wave\": %.3f, \"simd_cycles_per_inst\": %.3f",
+           "\"cycles_per_inst_per_wave\": %.3f, \"simd_cycles_per_inst\": %.3f, \"simds_used\": %d, \"waves_on_a_simd_min_max\": [%d, %d], "
+           "\"wave_lifetime_over_kernel_span\": %.3f, \"ns_per_inst_per_simd\": %.4f, \"cycles_at_2p4GHz_per_inst_per_simd\": %.3f",
            kNames[CLS], ROLE == 0 ? "alone" : (ROLE == 1 ? "beside an MFMA wave on the same SIMD" : "MFMAs interleaved in the same wave"),
-           ROLE == 1 ? 2 : waves_per_simd, ROLE == 2 ? NMF : 0, ms, mhz, ticks / n_valu, ticks / n_valu / class_waves_per_simd);
+           ROLE == 1 ? 2 : waves_per_simd, ROLE == 2 ? NMF : 0, ms, mhz, ticks / n_valu, ticks / n_valu / class_waves_per_simd, (int)by_simd.size(), (int)minw, (int)maxw,
+           life_ns / span_ns, span_ns * simds / inst_total, span_ns * simds / inst_total * 2.4);
     if (ROLE == 1) printf(", \"mfma_wave_cycles_per_mfma\": %.2f", (double)hc[0] / (4.0 * iters));
     if (ROLE == 2) printf(", \"cycles_per_group\": %.2f, \"mfma_floor_cycles_per_group\": %d", ticks / iters, 32 * NMF);
     printf("}\n");
@@ -175,7 +216,7 @@ int main(int argc, char** argv)
     g_cus = pr.multiProcessorCount;
     fprintf(stderr, "device: %s CUs=%d clockRate=%d MHz\n", pr.gcnArchName, pr.multiProcessorCount, pr.clockRate / 1000);
     hipMalloc(&g_out, sizeof(float) * (size_t)g_cus * 4 * 512);
-    hipMalloc(&g_clk, sizeof(long long) * 8 * (size_t)g_cus * 4);
+    hipMalloc(&g_clk, sizeof(long long) * 8 * 4 * (size_t)g_cus * 4);
     hipMalloc(&g_ab, sizeof(v8h) * 128);
     _Float16 h[128 * 8];
     srand(1);
@@ -188,6 +229,7 @@ int main(int argc, char** argv)
     run_class<C_CMP>(iters);
     run_class<C_CMPBR>(iters);
     run_class<C_CNDMASK>(iters);
+    run_class<C_SELECT>(iters);
     run_class<C_MOV>(iters);
     run_class<C_INT>(iters);
     run_class<C_PKFMA>(iters);
