@@ -38,6 +38,7 @@ bool prune_heavy_enabled()
 }
 static_assert(mce::kPruneWavesPerBlock == mce::kHWaves, "prune.hip orders kHWaves waves per query block");
 
+constexpr int kRefineMargin = 2;
 struct Plan {
     const mce::KnnVariant* v = nullptr;
     const mce::KnnF16Variant* vh = nullptr;   // non-null: fp16-filter path
@@ -53,6 +54,8 @@ struct Plan {
     int L = 4;
     size_t off_yf = 0, off_pd = 0, off_pi = 0, off_center = 0, off_msum = 0, total = 0;
     double cost = 0.0;                        // the split model's estimate for this plan (cycles per SIMD; exhaustive kernels)
+    int ksel = 0;                             // fp64 sweep: entries kept per list -- K + kRefineMargin (capped at MCE_MAX_K): the lists are chosen on
+                                              // GEMM-form keys, the final K among them on EXACT distances (reduce_kernels.hpp, REFINE); 0: K
     bool twopass = false;                     // fp16 filter, 16 < K <= 32: two sweeps of 16-entry lists (knn_f16.hpp, LOWER)
     bool wide_ok = false;                     // the exhaustive sweep may run four query tiles per wave (knn_f16.hpp, QTT = 4): nqblk is even
     bool prune = false;                       // fp16 filter walking k-d ordered chunk lists (prune.hpp)
@@ -165,6 +168,15 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
         qpb = mce::f16_qpb(p.KCAP);
         rows_per_tile = 32;
     } else {
+        // The fp64 sweep SELECTS on GEMM-form keys (|x|^2 + |y|^2 - 2 x.y: good to ~1e-16 |x|^2 absolute) and the merge refines
+        // the selected pairs to exact direct-difference distances.  A near-tie at the K-th place could therefore hand the
+        // merge the (K + 1)-th neighbour instead of the K-th (parity footnote a).  The lists carry
+        // kRefineMargin more entries than asked for, so the final K are chosen on exact distances among K + 2 candidates
+        // (a wrong row would need three rows within the keys' rounding of each other at the K-th place).
+        p.ksel = std::min<int>(K + kRefineMargin, MCE_MAX_K);
+        ki = 0;
+        while (ki < mce::kNumKcap - 1 && mce::kKcapList[ki] < p.ksel) ++ki;
+        p.KCAP = mce::kKcapList[ki];
         p.v = variant_for(p.KS, ki);
         p.vh = nullptr;
         p.QT = p.v->qt;

@@ -447,7 +447,7 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
     a.nqblk = p.nqblk;
     a.self_exclude = (self_mode == MCE_SELF_EXCLUDE) ? 1 : 0;
     a.self_offset = self_offset;
-    a.ksel = K;
+    a.ksel = p.ksel > K ? p.ksel : K;          // (K + kRefineMargin: the merge picks the K on exact distances)
     a.part_d = pd;
     a.part_i = pi;
     int rc = prof_begin();
@@ -497,7 +497,7 @@ int launch_merge(const Plan& p, bool write_dist, bool fuse, const double* dX, co
     if (p.sym_active) qperm = reinterpret_cast<const int*>(ws + p.off_sym + p.sl.perm);     // list column = sorted position
 #define MCE_MERGE(W, F, R)                                                                                          \
     hipLaunchKernelGGL((mce::merge_lists_kernel<W, F, R>), dim3(blocks), dim3(mce::kRedThreads), 0, st, pd, pi, p.L,  \
-                       p.KCAP, nq, p.nq_pad, dX, dY, (int)d, K, self_mode, self_offset, d_dist, d_idx, K, k0, kmax, \
+                       p.KCAP, nq, p.nq_pad, dX, dY, (int)d, K, (refine && p.ksel > K) ? p.ksel : K, self_mode, self_offset, d_dist, d_idx, K, k0, kmax, \
                        d_w, d_fs, lnc, partial, qperm, p.part, p.nparts, qpb, border, nunits, col0, col1)
     if (write_dist && !fuse) { if (refine) MCE_MERGE(true, false, true); else MCE_MERGE(true, false, false); }
     else if (write_dist && fuse) { if (refine) MCE_MERGE(true, true, true); else MCE_MERGE(true, true, false); }

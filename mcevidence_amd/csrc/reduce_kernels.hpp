@@ -51,7 +51,8 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 // the K selected pairs get their exact direct-difference distance sum_i (x_i - y_i)^2 from
 // the original rows and are re-sorted -- so reported distances equal an exact search's
 // (duplicates give exactly 0, like the reference's KD-tree path) and only the choice
-// between candidates that tie to the last bits can differ.  (REFINE=false when the lists
+// between candidates that tie to the last bits could differ -- which is why Kc = K + 2 candidates are selected and refined and
+// the K nearest BY EXACT DISTANCE reported (round 6: the rows then equal an exact search's too).  (REFINE=false when the lists
 // already hold exact distances: the fp16-filter path.)  Optionally feeds the evidence
 // reduction directly.
 //   part_d/part_i : [L][KCAP][nq_pad]
@@ -61,7 +62,7 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 template <bool WRITE_DIST, bool FUSE_DOTP, bool REFINE>
 __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
     const double* __restrict__ part_d, const int* __restrict__ part_i, int L, int KCAP,
-    int64_t nq, int64_t nq_pad, const double* __restrict__ X, const double* __restrict__ Y, int D, int K,
+    int64_t nq, int64_t nq_pad, const double* __restrict__ X, const double* __restrict__ Y, int D, int K, int Kc,
     int self_mode, int64_t self_offset,
     double* __restrict__ dist, int64_t* __restrict__ idx, int ld_out,
     int k0, int kmax, const double* __restrict__ w, const double* __restrict__ fs, double lnc,
@@ -128,7 +129,8 @@ __global__ __launch_bounds__(kRedThreads) void merge_lists_kernel(
         // it made it into a list (K or more exact duplicates with lower row numbers push it out of one) -- so the result
         // does not depend on how many lists the plan happened to use
         if (selfj >= 0) { sel_d[0] = -1.0; sel_i[0] = selfj; nsel = 1; }     // (-1: sentinel, sorts first, reported as 0)
-        for (int k = nsel; k < K; ++k) {
+        // (REFINE: Kc >= K candidates are selected on the keys and refined; the K nearest by EXACT distance are reported)
+        for (int k = nsel; k < (REFINE ? Kc : K); ++k) {
             double bv = INF;
             int bi = 0x7fffffff, bl = -1;
             for (int l = 0; l < L; ++l) {
