@@ -133,20 +133,68 @@ def profile_counters(kernel_desc, library_hash=None, tag=""):
             out["wait_frac"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 3)
         if c.get("SQ_INSTS_VALU"):
             out["valu_insts"] = c["SQ_INSTS_VALU"]
+        out["counters"] = c
         return out
     return {}
 
 
-VALU_ISSUE_PEAK = N_SIMD * PEAK_CLOCK_HZ / 4.0        # one wave64 vector instruction per 4 cycles and SIMD (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1 quad-cycle)
+def valu_issue_table():
+    """Measured issue cost of a wave64 vector instruction by class (tools/valu_issue_clock.hip -> profiles/<round>/valu_issue_clock.json,
+    round 6): SIMD cycles per instruction at the nominal 2.4 GHz with the SIMD saturated (best of 1 - 4 waves issuing independent
+    instructions of the class).  MI355X_MICROARCH.md's "a wave64 fp32 op issues over 2 cycles" is not reached by any class: v_mov 2.6,
+    v_fma_f32 2.8, integer 3.6, compares / min / max / selects / fp64 / conversions 4.2 - 4.5."""
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*", "valu_issue_clock.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+            return {k: v["simd_cycles_per_inst_saturated"] for k, v in t["classes"].items() if v.get("simd_cycles_per_inst_saturated")}, os.path.relpath(f, REPO)
+        except (ValueError, KeyError, OSError):
+            continue
+    return {}, None
 
 
-def config_roofline(kdesc, stats, nq, nr, d, lib_hash, tag="", prune_stats=None):
+# which measured class prices which SQ_INSTS_VALU_* counter; what no class counter counts (compares, selects, min / max, moves, lane
+# reads, logic: SQ_INSTS_VALU - MFMA - the classes) is priced as the compare + select pair -- the CHEAPEST of those, so the peak is not
+# understated
+VALU_CLASS_OF = {"ADD_F32": "v_fma_f32", "MUL_F32": "v_fma_f32", "FMA_F32": "v_fma_f32", "ADD_F64": "v_add_f64", "MUL_F64": "v_fma_f64", "FMA_F64": "v_fma_f64",
+                 "INT32": "v_add_u32/v_lshlrev/v_and", "INT64": "v_add_u32/v_lshlrev/v_and", "CVT": "v_cvt_f32_f64/v_cvt_f64_f32",
+                 "TRANS_F32": "v_cvt_f32_f64/v_cvt_f64_f32", "TRANS_F64": "v_cvt_f32_f64/v_cvt_f64_f32"}
+VALU_OTHER_CLASS = "v_cmp_lt_f32+v_cndmask_b32"
+
+
+def valu_issue_floor(counters):
+    """Issue time floor of a kernel from its per-launch instruction mix: sum over classes of count x measured SIMD cycles per instruction,
+    spread over the 1024 SIMDs at 2.4 GHz.  -> (seconds, by_class) or (None, None) when the mix or the table is missing."""
+    table, src = valu_issue_table()
+    total = counters.get("SQ_INSTS_VALU")
+    if not table or not total or "SQ_INSTS_VALU_FMA_F32" not in counters:
+        return None, None
+    by, classified, cycles = {}, 0.0, 0.0
+    for cname, cls in VALU_CLASS_OF.items():
+        n = counters.get("SQ_INSTS_VALU_" + cname, 0.0)
+        if n <= 0 or cls not in table:
+            continue
+        by[cname] = dict(insts=n, cycles_per_inst=table[cls], priced_as=cls)
+        classified += n
+        cycles += n * table[cls]
+    other = max(total - counters.get("SQ_INSTS_MFMA", 0.0) - classified, 0.0)
+    by["other (compare, select, min / max, move, lane read, logic)"] = dict(insts=other, cycles_per_inst=table.get(VALU_OTHER_CLASS), priced_as=VALU_OTHER_CLASS)
+    cycles += other * table.get(VALU_OTHER_CLASS, 4.2)
+    for v in by.values():
+        v["share_of_issue_cycles"] = round(v["insts"] * v["cycles_per_inst"] / cycles, 4)
+    return cycles / N_SIMD / PEAK_CLOCK_HZ, dict(classes=by, table=src, issue_cycles_total=cycles,
+                                                 salu_insts=counters.get("SQ_INSTS_SALU"), lds_insts=counters.get("SQ_INSTS_LDS"), branch_insts=counters.get("SQ_INSTS_BRANCH"))
+
+
+def config_roofline(kdesc, stats, nq, nr, d, lib_hash, tag="", prune_stats=None, profiled_shape=True):
     """`roofline` object of one timed config: what bounds its dominant kernel, what the kernel achieved against that bound over
     its HIP-event duration, and the same from the committed rocprofv3 passes of that config when they are of this build.
     Sweeps (fp16 filter, fp64): matrix-core bound -- executed MFMA flops (mce_last_search_stats) / duration against the dense
     peak.  Pruned walk: its binding resource is vector-instruction ISSUE (a tree walk: box tests, reach tests, list upkeep --
-    ~180 k VALU against ~1 k MFMA per wave): achieved = SQ_INSTS_VALU per launch (committed counters, source-hash guarded) /
-    duration against 1024 SIMDs x 2.4 GHz / 4 cycles per instruction; the MFMA figure rides along as `mfma_frac`."""
+    ~180 k VALU against ~1 k MFMA per wave).  Round 6: the peak is no longer "one instruction per 4 cycles whatever it is" but the
+    launch's own instruction MIX (SQ_INSTS_VALU_* class counters of the committed pass of this config, source-hash guarded) priced
+    with the issue cost MEASURED per class (tools/valu_issue_clock.hip): frac = issue-time floor of the mix / kernel duration.
+    `profiled_shape`: the run has the shape the committed counters were taken at (counters of the full-size pass
+    divided by a scaled-down run's time mean nothing) -- otherwise the counter-derived fields are None."""
     kms = stats["kernel_ms"]
     if kms <= 0:
         return None
@@ -159,16 +207,20 @@ def config_roofline(kdesc, stats, nq, nr, d, lib_hash, tag="", prune_stats=None)
         executed = prune_stats[1] * math.ceil(nq / 32.0) * math.ceil(nr / 32.0) * 32768.0 * kst      # tile fraction x tile pairs x flop per tile
     tf = executed / (kms * 1e-3) / 1e12 if executed > 0 else None
     prof = profile_counters(kdesc, lib_hash, tag) if tag else {}
-    stale = bool(prof.get("stale", True))
+    stale = bool(prof.get("stale", True)) or not profiled_shape
     live = (lambda k: None if stale else prof.get(k))
     if "pruned" in kdesc:
         vi = live("valu_insts")
+        floor_s, mix = valu_issue_floor(prof.get("counters", {})) if not stale else (None, None)
         ach = vi / (kms * 1e-3) / 1e9 if vi else None
-        roof = dict(bound="valu_issue", achieved=(round(ach, 1) if ach else None), peak=round(VALU_ISSUE_PEAK / 1e9, 1), unit="Ginst/s",
-                    frac=(round(ach * 1e9 / VALU_ISSUE_PEAK, 4) if ach else None), traffic=None,
-                    what="k-d pruned walk: bound by vector-instruction issue (box / reach tests, list upkeep), not by the matrix cores; "
-                         "achieved = SQ_INSTS_VALU per launch (committed rocprofv3 pass of this config) / kernel_ms; peak = 1024 SIMDs x 2.4 GHz / 4 cycles",
-                    valu_insts_per_launch=vi, mfma_tflops=(round(tf, 1) if tf else None), mfma_frac=(round(tf / peak, 4) if tf else None))
+        peak_g = vi / floor_s / 1e9 if (vi and floor_s) else None
+        roof = dict(bound="valu_issue", achieved=(round(ach, 1) if ach else None), peak=(round(peak_g, 1) if peak_g else None), unit="Ginst/s",
+                    frac=(round(floor_s / (kms * 1e-3), 4) if floor_s else None), traffic=None,
+                    what="k-d pruned walk: bound by vector-instruction issue (box / reach tests, list upkeep), not by the matrix cores; achieved = "
+                         "SQ_INSTS_VALU per launch (committed rocprofv3 pass of this config) / kernel_ms; peak = the same instructions at the issue cost "
+                         "measured per class (issue_cycles_by_class: SQ_INSTS_VALU_* mix x tools/valu_issue_clock.hip, 1024 SIMDs at 2.4 GHz)",
+                    valu_insts_per_launch=vi, issue_cycles_by_class=mix, issue_floor_ms=(round(floor_s * 1e3, 3) if floor_s else None),
+                    mfma_tflops=(round(tf, 1) if tf else None), mfma_frac=(round(tf / peak, 4) if tf else None))
     else:
         roof = dict(bound="mfma", achieved=(round(tf, 2) if tf else None), peak=peak, unit="TFLOP/s", frac=(round(tf / peak, 4) if tf else None),
                     traffic=None, executed_flops_per_launch=executed)
@@ -335,7 +387,7 @@ def prep_config(name, scale=1.0):
     logLmax = float(np.amax(logL))
     return dict(name=name, X=X, Y=Y, weight=np.ascontiguousarray(c1[:, 0]), fs=np.ascontiguousarray(logL - logLmax),
                 kmax=CONFIGS[name]["kmax"], k0=1 if Y is None else 0, S=len(X), SumW=float(np.sum(c1[:, 0])), J=J, logLmax=logLmax,
-                chain=chain if r1 is not None else None, split=(r1, r2))
+                chain=chain if r1 is not None else None, split=(r1, r2), full_size=(scale == 1.0))
 
 
 def lnE_from_dotp(dotp, cfg, lnPV=0.0):
@@ -464,7 +516,7 @@ def time_config(ctx, cfg, steps, warmup, mode=0, nsample=0, orc=None):
         except Exception:
             pass
     if cfg["name"] != "C3":          # (the headline's own, fuller object is built in main())
-        res["roofline"] = config_roofline(kdesc, stats, nq, nr, d, _capi.source_hash(), "_" + cfg["name"], pstats)
+        res["roofline"] = config_roofline(kdesc, stats, nq, nr, d, _capi.source_hash(), "_" + cfg["name"], pstats, profiled_shape=cfg.get("full_size", True))
     _capi.set_search_mode(0)
     del Xd, Yd, ws, w, fs
     torch.cuda.empty_cache()

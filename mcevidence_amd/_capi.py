@@ -625,8 +625,8 @@ def debug_mfma_tile(yprime, xprime, device=0):
     sequence computes it; ``yprime``, ``xprime``: float16 arrays [32, 16 * kst]."""
     y = np.ascontiguousarray(yprime, dtype=np.float16)
     x = np.ascontiguousarray(xprime, dtype=np.float16)
-    if y.shape != x.shape or y.shape[0] != 32 or y.shape[1] % 16 or not 1 <= y.shape[1] // 16 <= 4:
-        raise ValueError("yprime and xprime must be float16 [32, 16*kst], kst = 1..4")
+    if y.shape != x.shape or y.shape[0] != 32 or y.shape[1] % 16 or not 1 <= y.shape[1] // 16 <= 8:
+        raise ValueError("yprime and xprime must be float16 [32, 16*kst], kst = 1..8")
     out = np.empty((32, 32), dtype=np.float32)
     check(load().mce_debug_mfma_tile_f16(y.ctypes.data, x.ctypes.data, y.shape[1] // 16, out.ctypes.data, int(device)))
     return out
@@ -636,8 +636,8 @@ def debug_mfma_tiles(yprime, xprime, device=0):
     """``debug_mfma_tile`` for a batch: float16 arrays [ntiles, 32, 16 * kst] -> float32 [ntiles, 32, 32] (row, query)."""
     y = np.ascontiguousarray(yprime, dtype=np.float16)
     x = np.ascontiguousarray(xprime, dtype=np.float16)
-    if y.ndim != 3 or y.shape != x.shape or y.shape[1] != 32 or y.shape[2] % 16 or not 1 <= y.shape[2] // 16 <= 4:
-        raise ValueError("yprime and xprime must be float16 [ntiles, 32, 16*kst], kst = 1..4")
+    if y.ndim != 3 or y.shape != x.shape or y.shape[1] != 32 or y.shape[2] % 16 or not 1 <= y.shape[2] // 16 <= 8:
+        raise ValueError("yprime and xprime must be float16 [ntiles, 32, 16*kst], kst = 1..8")
     out = np.empty((y.shape[0], 32, 32), dtype=np.float32)
     check(load().mce_debug_mfma_tiles_f16(y.ctypes.data, x.ctypes.data, y.shape[2] // 16, y.shape[0], out.ctypes.data, int(device)))
     return out

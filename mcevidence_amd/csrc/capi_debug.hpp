@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64) void mfma_tile_probe_kernel(const _Float16* __r
 extern "C" int mce_debug_mfma_tiles_f16(const uint16_t* yprime, const uint16_t* xprime, int32_t kst, int32_t ntiles, float* out, int32_t device)
 {
     if (!yprime || !xprime || !out) return fail(MCE_ERR_INVALID, "null pointer argument");
-    if (kst < 1 || kst > 4) return fail(MCE_ERR_INVALID, "kst must be 1..4");
+    if (kst < 1 || kst > 8) return fail(MCE_ERR_INVALID, "kst must be 1..8");
     if (ntiles < 1 || ntiles > (1 << 20)) return fail(MCE_ERR_INVALID, "ntiles must be 1..2^20");
     int rc = select_device(device);
     if (rc != MCE_OK) return rc;
@@ -52,7 +52,11 @@ extern "C" int mce_debug_mfma_tiles_f16(const uint16_t* yprime, const uint16_t* 
             case 1: hipLaunchKernelGGL(mce::mfma_tile_probe_kernel<1>, g, dim3(64), 0, nullptr, y, x, o); break;
             case 2: hipLaunchKernelGGL(mce::mfma_tile_probe_kernel<2>, g, dim3(64), 0, nullptr, y, x, o); break;
             case 3: hipLaunchKernelGGL(mce::mfma_tile_probe_kernel<3>, g, dim3(64), 0, nullptr, y, x, o); break;
-            default: hipLaunchKernelGGL(mce::mfma_tile_probe_kernel<4>, g, dim3(64), 0, nullptr, y, x, o); break;
+            case 4: hipLaunchKernelGGL(mce::mfma_tile_probe_kernel<4>, g, dim3(64), 0, nullptr, y, x, o); break;
+            case 5: hipLaunchKernelGGL(mce::mfma_tile_probe_kernel<5>, g, dim3(64), 0, nullptr, y, x, o); break;      // (5, 6, 8: knn_deep.hpp)
+            case 6: hipLaunchKernelGGL(mce::mfma_tile_probe_kernel<6>, g, dim3(64), 0, nullptr, y, x, o); break;
+            case 7: hipLaunchKernelGGL(mce::mfma_tile_probe_kernel<7>, g, dim3(64), 0, nullptr, y, x, o); break;
+            default: hipLaunchKernelGGL(mce::mfma_tile_probe_kernel<8>, g, dim3(64), 0, nullptr, y, x, o); break;
         }
         e = hipGetLastError();
     }

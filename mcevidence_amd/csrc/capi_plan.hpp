@@ -42,6 +42,8 @@ constexpr int kRefineMargin = 2;
 struct Plan {
     const mce::KnnVariant* v = nullptr;
     const mce::KnnF16Variant* vh = nullptr;   // non-null: fp16-filter path
+    const mce::KnnDeepVariant* vd = nullptr;  // non-null: the DEEP fp16 filter (knn_deep.hpp: 64 <= d <= 127, K <= 16); vh and v are null then
+    bool filter() const { return vh != nullptr || vd != nullptr; }      // exact lists behind an fp16 filter (no refine in the merge; certified by default)
     bool generic = false;                     // plain exact kernel (d > 63 or K > 32)
     int KST = 0;
     size_t off_yh = 0, off_xh = 0, off_qinfo = 0, off_params = 0;
@@ -151,8 +153,24 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     while (ki < mce::kNumKcap - 1 && mce::kKcapList[ki] < K) ++ki;
     p.KCAP = mce::kKcapList[ki];
     const bool f16 = !wide_f64 && (eff_search_mode() != 1) && mce::f16_supported(d, K);
+    // 64 <= d <= 127 (round 6): the fp16 filter with 5, 6 or 8 k-steps (knn_deep.hpp) for K <= 16; search mode 1, or longer lists,
+    // keep the fp64 sweep's wide form.  (MCE_DEEP=0: comparisons.)
+    static const bool deep_on = [] { const char* e = getenv("MCE_DEEP"); return !(e && e[0] == '0'); }();
+    const bool deep = wide_f64 && (eff_search_mode() != 1) && mce::deep_supported(d, K) && deep_on;
+    const bool filt = f16 || deep;          // fp16 operands in the workspace, 32-row tiles, 512-query blocks
+    p.vd = nullptr;
     int qpb, rows_per_tile;
-    if (f16) {
+    if (deep) {
+        p.KST = mce::deep_ksteps(d);
+        const mce::KnnDeepVariant* tab = ki == 0 ? mce::g_knn_deep_kcap4 : ki == 1 ? mce::g_knn_deep_kcap8 : ki == 2 ? mce::g_knn_deep_kcap12 : mce::g_knn_deep_kcap16;
+        p.vd = &tab[p.KST == 5 ? 0 : (p.KST == 6 ? 1 : 2)];
+        p.v = nullptr;
+        p.vh = nullptr;
+        p.QT = mce::kHQT;
+        p.CT = p.vd->ct;
+        qpb = mce::f16_qpb(p.KCAP);
+        rows_per_tile = 32;
+    } else if (f16) {
         if (K > 16) {                          // 16 nearest per reference split first, then the next K - 16 beyond them
             p.twopass = true;
             ki = 3;
@@ -228,12 +246,14 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     double best_c = 1e300;
     const int rmax = (int)std::min<int64_t>(p.twopass ? mce::kMaxLists / 2 : mce::kMaxLists, p.nchunk);
     const int rmin = f16 ? (int)((nr + ((int64_t)1 << mce::kHRelBits) - 1) >> mce::kHRelBits) : 1;   // queue entries hold 26-bit row offsets
+    if (deep && p.nrow_pad > ((int64_t)1 << mce::kHRelBits))      // (the deep kernel's queue entries hold ABSOLUTE 26-bit rows)
+        return fail(MCE_ERR_INVALID, "reference set too large for the fp16-filter path at d = %d (nr=%lld): use search mode 1", d, (long long)nr);
     if (rmin > rmax) return fail(MCE_ERR_INVALID, "reference set too large for the fp16-filter path (nr=%lld)", (long long)nr);
     for (int r = std::max(1, rmin); r <= rmax; ++r) {
         const double n_r = (double)nr / r;
         const double lnf = 1.0 + std::log(std::max(1.0, n_r / K));
-        const double block = f16 ? 64.0 * p.QT * p.KST * (n_r / 32.0) + 300.0 * 32.0 * p.QT * K * lnf
-                                 : 256.0 * p.KS * (n_r / 16.0) + 1000.0 * 32.0 * K * lnf;
+        const double block = filt ? 64.0 * p.QT * p.KST * (n_r / 32.0) + 300.0 * 32.0 * p.QT * K * lnf
+                                  : 256.0 * p.KS * (n_r / 16.0) + 1000.0 * 32.0 * K * lnf;
         const double rounds = std::ceil((double)p.nqblk * r / kAssumedCUs);
         const double c = rounds * block;
         if (c < best_c * 0.98) { best_c = c; best_r = r; }   // need >2% gain to take a bigger split
@@ -248,6 +268,12 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
         for (int r = std::min(rmax, kAssumedCUs / p.nqblk); r >= std::max(1, rmin); --r)
             if (sweep_seed_cfg(p.nchunk / r, p.CT, kneed)) { best_r = r; break; }
     }
+    if (deep && p.nqblk <= kAssumedCUs) {
+        // at most one round of workgroups: as above -- the largest split count that fits the round and leaves every split four
+        // seed groups' worth of tiles per neighbour (knn_deep.hpp: its seed phase needs K + 1 groups)
+        for (int r = std::min(rmax, kAssumedCUs / p.nqblk); r >= 1; --r)
+            if ((p.nchunk / r) * p.CT >= 4 * (K + 1)) { best_r = r; break; }
+    }
     if (const int r = read_tuning().rsplit) {          // tuning
         if (r >= std::max(1, rmin) && r <= rmax) best_r = r;
     }
@@ -256,7 +282,7 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     {   // the model's cost of the split count actually taken (the overrides above may have left its minimum)
         const double n_r = (double)nr / best_r;
         const double lnf = 1.0 + std::log(std::max(1.0, n_r / K));
-        const double block = f16 ? 64.0 * p.QT * p.KST * (n_r / 32.0) + 300.0 * 32.0 * p.QT * K * lnf : 256.0 * p.KS * (n_r / 16.0) + 1000.0 * 32.0 * K * lnf;
+        const double block = filt ? 64.0 * p.QT * p.KST * (n_r / 32.0) + 300.0 * 32.0 * p.QT * K * lnf : 256.0 * p.KS * (n_r / 16.0) + 1000.0 * 32.0 * K * lnf;
         best_c = std::ceil((double)p.nqblk * best_r / kAssumedCUs) * block;
     }
     p.cost = best_c;
@@ -268,7 +294,7 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
 
     size_t off = 0;
     p.off_yf = off;
-    if (f16) {
+    if (filt) {
         p.off_yh = off;
         off = align_up(off + (size_t)p.nrow_pad * (size_t)(16 * p.KST) * 2, 256);
         p.off_xh = off;

@@ -92,6 +92,57 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
         return MCE_OK;
     };
     const int threads = 256;
+    if (p.vd) {
+        // ---- the deep fp16 filter (64 <= d <= 127; knn_deep.hpp) + exact fp64 refine -------------------------------------------
+        _Float16* yh = reinterpret_cast<_Float16*>(ws + p.off_yh);
+        _Float16* xh = reinterpret_cast<_Float16*>(ws + p.off_xh);
+        double* qinfo = reinterpret_cast<double*>(ws + p.off_qinfo);
+        double* params = reinterpret_cast<double*>(ws + p.off_params);
+        MCE_HIP(mce::zero_async(params, mce::HP_COUNT * sizeof(double), st));
+        const bool separate_queries = !(dX >= dY && dX + (size_t)nq * d <= dY + (size_t)nr * d);
+        // radius about the references' mean (the wide column means above), over both sets; power-of-two scale; packing
+        hipLaunchKernelGGL(mce::f16_radius_rows_kernel, dim3((unsigned)std::min<int64_t>((nr + 255) / 256, 2048)), dim3(256), 0, st, dY, nr, (int)d, center, params);
+        MCE_HIP(hipGetLastError());
+        if (separate_queries && nq > 0) {
+            hipLaunchKernelGGL(mce::f16_radius_rows_kernel, dim3((unsigned)std::min<int64_t>((nq + 255) / 256, 2048)), dim3(256), 0, st, dX, nq, (int)d, center, params);
+            MCE_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(mce::f16_scale_from_radius_kernel, dim3(1), dim3(1), 0, st, params);
+        MCE_HIP(hipGetLastError());
+        const int64_t rows_per_block = 4 * (64 / (2 * p.KST));          // 4 waves x R rows
+        const int64_t pack_blocks = std::min<int64_t>((p.nrow_pad + rows_per_block - 1) / rows_per_block, 2048);   // grid-stride
+        hipLaunchKernelGGL(mce::f16_pack_refs_kernel, dim3((unsigned)pack_blocks), dim3(256), 0, st, dY, nr, (int)d, p.KST, p.nrow_pad, center, params, yh);
+        MCE_HIP(hipGetLastError());
+        hipLaunchKernelGGL(mce::f16_pack_queries_kernel, dim3((unsigned)((p.nq_pad + rows_per_block - 1) / rows_per_block)), dim3(256), 0, st,
+                           dX, nq, p.nq_pad, (int)d, p.KST, center, params, xh, qinfo);
+        MCE_HIP(hipGetLastError());
+        mce::DeepArgs a;
+        a.Yh = yh; a.Xh = xh; a.qinfo = qinfo; a.params = params; a.X = dX; a.Y = dY; a.part_d = pd; a.part_i = pi;
+        a.nq = nq; a.nr = nr; a.nq_pad = p.nq_pad; a.self_offset = self_offset; a.nchunk_total = p.nchunk;
+        a.D = d; a.ksel = K; a.self_exclude = (self_mode == MCE_SELF_EXCLUDE) ? 1 : 0; a.nqblk = p.nqblk; a.rsplit = p.rsplit;
+        a.debug = read_tuning().panel_debug;
+        // seed phase: K (+ 1) groups of tg tiles from the start of every split -- about 24 k rows, at most a quarter of the smallest
+        // split (a half if a quarter does not hold one tile per group); MCE_F16_SEED_ROWS=0: none (tests)
+        {
+            const int64_t tiles_split = (p.nchunk / p.rsplit) * p.CT;
+            const int G = K + a.self_exclude;
+            const Tuning tun = read_tuning();
+            const int64_t want = (tun.f16_seed_rows >= 0 ? tun.f16_seed_rows : MCE_H_SEED_ROWS) / 32;
+            int64_t tg = std::min<int64_t>(want, tiles_split / 4) / G;
+            if (tg < 1) tg = std::min<int64_t>(want, tiles_split / 2) / G;
+            a.seed_tg = (int)std::max<int64_t>(tg, 0);
+        }
+        int rc = prof_begin();
+        if (rc != MCE_OK) return rc;
+        MCE_HIP(p.vd->launch(a, st));
+        rc = prof_end();
+        if (rc != MCE_OK) return rc;
+        const double seed_rows = (double)a.seed_tg * (K + a.self_exclude) * 32.0 * p.rsplit;
+        g_last_flops_main = g_last_flops_all = (double)p.nq_pad * ((double)p.nrow_pad + seed_rows) * 2.0 * 16.0 * p.KST;
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d seed=%dx%d", p.vd->name, p.nqblk * p.rsplit, mce::kHThreads,
+                 p.vd->lds_bytes, p.QT, p.CT, p.rsplit, K + a.self_exclude, a.seed_tg);
+        return MCE_OK;
+    }
     if (p.vh) {
         // ---- fp16 filter + exact fp64 refine ------------------------------------
         _Float16* yh = reinterpret_cast<_Float16*>(ws + p.off_yh);
@@ -471,7 +522,7 @@ int launch_merge(const Plan& p, bool write_dist, bool fuse, const double* dX, co
     // enumerate those columns compactly
     // (a part of a pruned walk takes every nparts-th WAVE of the dispatch order: its list columns come in runs of 64)
     const bool wave_parts = p.prune && p.nparts > 1 && !p.sym_active;
-    const int qpb = wave_parts ? kPruneWaveQueries : (p.vh ? mce::f16_qpb(p.KCAP) : 1);
+    const int qpb = wave_parts ? kPruneWaveQueries : (p.filter() ? mce::f16_qpb(p.KCAP) : 1);
     const int nunits = wave_parts ? p.nqblk * mce::kHWaves : p.nqblk;
     int64_t ncol = nq;
     int64_t col0 = 0, col1 = INT64_MAX;
@@ -489,7 +540,7 @@ int launch_merge(const Plan& p, bool write_dist, bool fuse, const double* dX, co
     const unsigned blocks = (unsigned)std::max<int64_t>((ncol + mce::kRedThreads - 1) / mce::kRedThreads, 1);
     const double* pd = reinterpret_cast<const double*>(ws + p.off_pd);
     const int* pi = reinterpret_cast<const int*>(ws + p.off_pi);
-    const bool refine = p.vh == nullptr && !p.generic;   // fp64 sweep keys are GEMM-form: refine; the others are exact
+    const bool refine = !p.filter() && !p.generic;   // fp64 sweep keys are GEMM-form: refine; the others are exact
     const double lnc = fuse ? ln_unit_ball(d) : 0.0;
     // pruned search: list column q is the q-th query in k-d order; its caller row is qperm[q]
     const int* qperm = nullptr;

@@ -36,6 +36,31 @@ __global__ __launch_bounds__(64) void f16_scale_kernel(const double* __restrict_
     }
 }
 
+// d > 63 (the deep filter, knn_deep.hpp): the column statistics above hold 64 columns; here the radius is taken from the rows
+// themselves -- the largest |row - centre| of a set, one thread per row, one atomic per wave -- and the scale from it
+// (launch f16_radius_rows_kernel once per set, then f16_scale_from_radius_kernel)
+__global__ __launch_bounds__(256) void f16_radius_rows_kernel(const double* __restrict__ Y, int64_t n, int D, const double* __restrict__ center,
+                                                              double* __restrict__ params)
+{
+    double r2 = 0.0;
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += (int64_t)gridDim.x * 256) {
+        double s2 = 0.0;
+        for (int k = 0; k < D; ++k) { const double t = Y[row * (int64_t)D + k] - center[k]; s2 = fma(t, t, s2); }
+        r2 = fmax(r2, s2);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) r2 = fmax(r2, __shfl_xor(r2, o, 64));
+    // (NaN / inf rows: the maximum is then not a number the scale can use -- f16_scale_from_radius_kernel keeps s = 1, as f16_scale_kernel does)
+    if ((threadIdx.x & 63) == 0 && r2 > 0.0) atomic_max_pos(params + HP_RMAX, sqrt(r2) * (1.0 + 1e-12));
+}
+__global__ void f16_scale_from_radius_kernel(double* __restrict__ params)
+{
+    const double r = params[HP_RMAX];
+    double s = 1.0;
+    if (r > 0.0 && r < __builtin_huge_val()) s = exp2(floor(log2(kHTargetRadius / r)));
+    params[HP_SCALE] = s;
+}
+
 // box of a second point set about an EXISTING centre (cross evidence: queries != references)
 __global__ __launch_bounds__(64) void f16_box_about_kernel(const double* __restrict__ partial, int D,
                                                            const double* __restrict__ center, double* __restrict__ box)

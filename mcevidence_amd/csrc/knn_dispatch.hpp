@@ -103,6 +103,21 @@ struct KnnF16Variant {
     knn_f16_launch_fn launch_sym_repair_lower;
     knn_f16_launch_fn launch_sym_pre32;
 };
+// ---- deep fp16-filter variants (knn_deep.hpp): 64 <= d <= 127, KST = 5, 6 or 8 sixteen-wide k-steps, K <= 16 ----
+struct DeepArgs;                   // knn_deep.hpp
+typedef hipError_t (*knn_deep_launch_fn)(const DeepArgs&, hipStream_t);
+struct KnnDeepVariant {
+    knn_deep_launch_fn launch;
+    int kst, kcap, ct;
+    size_t lds_bytes;
+    const char* name;
+};
+constexpr int kNumDeepKST = 3;     // index 0, 1, 2 <-> KST = 5, 6, 8
+extern const KnnDeepVariant g_knn_deep_kcap4[kNumDeepKST];
+extern const KnnDeepVariant g_knn_deep_kcap8[kNumDeepKST];
+extern const KnnDeepVariant g_knn_deep_kcap12[kNumDeepKST];
+extern const KnnDeepVariant g_knn_deep_kcap16[kNumDeepKST];
+
 constexpr int kMaxKST = 4;
 extern const KnnF16Variant g_knn_f16_kcap4[kMaxKST];
 extern const KnnF16Variant g_knn_f16_kcap8[kMaxKST];

@@ -3,6 +3,7 @@
 #include "knn_mfma.hpp"
 #include "knn_f16.hpp"
 #include "knn_panel.hpp"
+#include "knn_deep.hpp"
 #include "knn_dispatch.hpp"
 
 #ifndef MCE_KCAP
@@ -16,6 +17,7 @@
 #define MCE_INST_F16 (MCE_KCAP <= 16 && (MCE_INST_PART == 0 || MCE_INST_PART == 1))
 #define MCE_INST_F64 (MCE_INST_PART == 0 || MCE_INST_PART == 2)
 #define MCE_INST_PANEL (MCE_KCAP <= 16 && (MCE_INST_PART == 0 || MCE_INST_PART == 3))
+#define MCE_INST_DEEP (MCE_KCAP <= 16 && (MCE_INST_PART == 0 || MCE_INST_PART == 4))     // knn_deep.hpp: 64 <= d <= 127 on the fp16 filter
 
 namespace mce {
 
@@ -121,6 +123,26 @@ extern template hipError_t launch_panel_variant<4, MCE_KCAP, true>(const PanelAr
 #endif
 #endif
 
+#if MCE_INST_DEEP
+template <int KST, int KCAP>
+hipError_t launch_deep_variant(const DeepArgs& a, hipStream_t st)
+{
+    constexpr size_t LDS = deep_lds_bytes(KST);
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    static bool attr_set[kMaxDevices] = {};
+    auto kern = knn_deep_kernel<KST, KCAP>;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= kMaxDevices || !attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (e != hipSuccess) return e;
+        if (dev < kMaxDevices) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.nqblk * a.rsplit)), dim3(kHThreads), LDS, st, a);
+    return hipGetLastError();
+}
+#endif
+
 #define MCE_STR2(x) #x
 #define MCE_STR(x) MCE_STR2(x)
 #define MCE_VARIANT(KS)                                                                                  \
@@ -170,8 +192,17 @@ extern const KnnF16Variant MCE_CAT(g_knn_f16_kcap, MCE_KCAP)[kMaxKST] = {
     MCE_F16_VARIANT(4, nullptr),
 };
 #endif
+#if MCE_INST_DEEP
+#define MCE_DEEP_VARIANT(KST) {&launch_deep_variant<KST, MCE_KCAP>, KST, MCE_KCAP, deep_chunk_tiles(KST), deep_lds_bytes(KST), "knn_deep_kernel<KST=" #KST ",KCAP=" MCE_STR(MCE_KCAP) ">"}
+extern const KnnDeepVariant MCE_CAT(g_knn_deep_kcap, MCE_KCAP)[kNumDeepKST] = {MCE_DEEP_VARIANT(5), MCE_DEEP_VARIANT(6), MCE_DEEP_VARIANT(8)};
+#endif
 #else
 // device pass: force the kernel instantiations
+#if MCE_INST_DEEP
+template __global__ void knn_deep_kernel<5, MCE_KCAP>(DeepArgs);
+template __global__ void knn_deep_kernel<6, MCE_KCAP>(DeepArgs);
+template __global__ void knn_deep_kernel<8, MCE_KCAP>(DeepArgs);
+#endif
 #if MCE_INST_F16
 #define MCE_F16_INST(KST, PR, LW, SY) template __global__ void knn_f16_kernel<KST, MCE_KCAP, PR, LW, SY>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*, int, int, const int*, const double*, const int*, int, SymParams, float*);
 MCE_F16_INST(1, false, false, 0) MCE_F16_INST(2, false, false, 0) MCE_F16_INST(3, false, false, 0) MCE_F16_INST(4, false, false, 0) MCE_F16_INST(1, true, false, 0)

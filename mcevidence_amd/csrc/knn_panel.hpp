@@ -756,7 +756,13 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
         // slots re-armed right after the read let a late thread 0 wipe the vote of a wave already one chunk ahead.)
         const int vs = k % 3;
         if (qcount >= MCE_PANEL_TRIGGER && lane == 0) wvote[vs] = 1;
+#if MCE_PANEL_STATS
+        const long long t_b0 = clock64();
+#endif
         dma_barrier();
+#if MCE_PANEL_STATS
+        st_tB += clock64() - t_b0;
+#endif
         if (tid == 0) wvote[vs == 0 ? 2 : vs - 1] = 0;             // the slot of chunk k - 1: all its readers are behind this barrier
         rt_cur = rt_next;
         if (k + 1 < ntot) {
@@ -860,7 +866,7 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
         o[0] = (double)st_drains; o[1] = (double)st_enq; o[2] = (double)st_redo; o[3] = (double)st_events;
         o[4] = (double)st_tE; o[5] = (double)st_tD; o[6] = (double)(clock64() - t_kernel0); o[7] = (double)st_tPro;
         double* o2 = const_cast<double*>(a->params) + 16 + ((int64_t)gridDim.x * kHWaves) * 8 + ((int64_t)blockIdx.x * kHWaves + wave) * 8;
-        o2[0] = (double)st_tA; o2[1] = (double)st_tR; o2[2] = (double)(st_tD - st_tA - st_tR); o2[3] = 0; o2[4] = 0; o2[5] = 0; o2[6] = 0; o2[7] = 0;
+        o2[0] = (double)st_tA; o2[1] = (double)st_tR; o2[2] = (double)(st_tD - st_tA - st_tR); o2[3] = (double)st_tB; o2[4] = 0; o2[5] = 0; o2[6] = 0; o2[7] = 0;
     }
 #endif
     // ---- write the lists (lane l owns wave-local query l: coalesced) and hand them to the block's next unit ------------

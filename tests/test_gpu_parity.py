@@ -29,7 +29,7 @@ def _rel(a, b):
 
 
 # --------------------------------------------------------------------------- kNN
-@pytest.mark.parametrize("d", [1, 2, 3, 6, 7, 8, 13, 14, 15, 16, 27, 30, 31, 33, 47, 48, 62, 63])
+@pytest.mark.parametrize("d", [1, 2, 3, 6, 7, 8, 13, 14, 15, 16, 27, 30, 31, 33, 47, 48, 62, 63, 64, 79, 80, 95, 96, 100, 111, 112, 127])
 def test_knn_matches_oracle_over_dims(capi, d):
     rng = np.random.default_rng(100 + d)
     n = 3001
@@ -320,15 +320,18 @@ def test_knn_adversarial_inputs_stay_exact(capi, kind, d):
     assert np.all(np.diff(dist, axis=1) >= 0)
 
 
-@pytest.mark.parametrize("d,K,kernel", [(64, 5, "knn_mfma_kernel<KS=20"), (79, 3, "knn_mfma_kernel<KS=20"), (80, 20, "knn_mfma_kernel<KS=24"), (100, 12, "knn_mfma_kernel<KS=28"),
-                                        (127, 32, "knn_mfma_kernel<KS=32"), (128, 6, "generic"), (10, 40, "generic"), (200, 33, "generic"), (100, 33, "generic")])
+@pytest.mark.parametrize("d,K,kernel", [(64, 5, "knn_deep_kernel<KST=5"), (79, 3, "knn_deep_kernel<KST=5"), (80, 20, "knn_mfma_kernel<KS=24"), (100, 12, "knn_deep_kernel<KST=8"),
+                                        (90, 16, "knn_deep_kernel<KST=6"), (127, 32, "knn_mfma_kernel<KS=32"), (128, 6, "generic"), (10, 40, "generic"), (200, 33, "generic"), (100, 33, "generic")])
 def test_beyond_the_filter_kernels_limits(capi, d, K, kernel):
-    """64 <= d <= 127 (K <= 32): the fp64 MFMA sweep at KS = 20..32, one query tile per wave (round 5: the vector-FMA kernel took
-    66x the time of d = 63).  d > 127 or K > 32: the plain exact kernel -- no shape the reference accepts is refused."""
+    """64 <= d <= 127: the DEEP fp16 filter (round 6: 5, 6 or 8 k-steps, K <= 16) or -- longer lists, search mode 1 -- the fp64 MFMA
+    sweep at KS = 20..32, one query tile per wave (round 5: the vector-FMA kernel took 66x the time of d = 63).  d > 127 or K > 32:
+    the plain exact kernel -- no shape the reference accepts is refused."""
     rng = np.random.default_rng(d * 7 + K)
     Y = rng.standard_normal((1500, d))
     X = rng.standard_normal((333, d))
     dist, idx = capi.knn(X, Y, K)
+    if "deep" in kernel and capi.get_search_mode() == capi.MODE_F64:
+        kernel = "knn_mfma_kernel<KS=%d" % (4 * ((d + 1 + 15) // 16))
     assert kernel in capi.last_kernel(), capi.last_kernel()
     if d <= 128 and K <= 32:          # the run-time certificate covers these shapes too: an independent exact scan agrees
         assert capi.verify_knn(X, Y, dist, nsample=200) == 0
@@ -1187,7 +1190,7 @@ def test_two_threads_with_different_modes_on_one_device():
 
 
 # --------------------------------------------------------------------------- the matrix-core error model, measured
-@pytest.mark.parametrize("kst", [1, 2, 3, 4])
+@pytest.mark.parametrize("kst", [1, 2, 3, 4, 5, 6, 8])       # (5, 6, 8: the deep filter, 64 <= d <= 127 -- knn_deep.hpp)
 def test_mfma_error_model(kst):
     """The filter's bound (knn_f16.hpp) assumes: products of two fp16 values are exact, and the fp32 accumulation of the
     16 KST terms of A = |y^|^2 - 2 x^.y^ errs by at most eps_q = 32 KST 2^-24 (|x^| + max |y^|)^2.  Measured here on the
@@ -1231,7 +1234,7 @@ def test_mfma_error_model(kst):
     assert worst < 0.5, worst             # headroom: the model is not tight
 
 
-@pytest.mark.parametrize("kst", [1, 2, 3, 4])
+@pytest.mark.parametrize("kst", [1, 2, 3, 4, 5, 6, 8])
 def test_mfma_error_model_over_thousands_of_tiles(kst):
     """The same model as a DISTRIBUTION: 3 000+ tiles per k-step count (12 000+ in all) through the kernels' MFMA sequence
     in one launch (mce_debug_mfma_tiles_f16) -- near-coincident rows, antipodal rows, random rows, fp16 subnormals next to
@@ -1515,3 +1518,89 @@ def test_class_under_two_ranks_equals_the_single_rank_lnE(cross, poison, node_up
     assert max(got[0][2], got[1][2]) < (6.0 if node_upload else 4.0) * t_one + 0.05, (got[0][2], got[1][2], t_one)      # (gloo gathers through the host)
     if not cross:
         assert "symmetric" in got[0][3]          # 300 k x 27 over two ranks: the symmetric partition
+
+
+# --------------------------------------------------------------------------- the deep fp16 filter (64 <= d <= 127; knn_deep.hpp)
+def _deep_data(n, d, seed, corr=True):
+    rng = np.random.default_rng(seed)
+    Y = rng.standard_normal((n, d))
+    if corr:
+        Y = Y @ (np.eye(d) + 0.2 * rng.standard_normal((d, d)) / np.sqrt(d)) + 3.0 * rng.standard_normal((1, d))
+    return Y
+
+
+@pytest.mark.parametrize("d,K", [(64, 9), (72, 1), (80, 4), (100, 12), (127, 16)])
+@pytest.mark.parametrize("variant", ["default", "redo", "noseed", "split3"])
+def test_deep_filter_is_exact(variant, d, K, monkeypatch):
+    """The fp16 filter at five to eight k-steps: distances AND rows of the exact CPU search, for every self mode, separate query
+    sets and ragged sizes -- with the seed phase on and off, every candidate forced through the redo list (queue-overflow path),
+    and three reference splits (several lists per query, merged)."""
+    from mcevidence_amd import _capi
+    _capi.require_device()
+    if variant == "redo":
+        monkeypatch.setenv("MCE_PANEL_DEBUG", "8")
+    elif variant == "noseed":
+        monkeypatch.setenv("MCE_F16_SEED_ROWS", "0")
+    elif variant == "split3":
+        monkeypatch.setenv("MCE_RSPLIT", "3")
+    n = 5000 if variant == "default" else 2600
+    Y = _deep_data(n + 37, d, 11 * d + K)
+    X = _deep_data(700 + 13, d, 5 * d + K)
+    dist, idx = _capi.knn(X, Y, K)
+    assert "knn_deep_kernel" in _capi.last_kernel(), _capi.last_kernel()
+    od, oi = orc.knn_brute(X, Y, K)
+    assert _rel(dist, od) < 1e-13 and np.array_equal(idx, oi)
+    d2, i2 = _capi.knn(Y, Y, K, self_mode=_capi.SELF_EXCLUDE)
+    od, oi = orc.knn_brute(Y, Y, K, self_mode=2)
+    assert _rel(d2, od) < 1e-13 and np.array_equal(i2, oi)
+    if K > 1:
+        d1, i1 = _capi.knn(Y, Y, K, self_mode=_capi.SELF_INCLUDE)
+        assert np.all(d1[:, 0] == 0) and np.array_equal(d1[:, 1:], d2[:, :K - 1]) and np.array_equal(i1[:, 1:], i2[:, :K - 1])
+    lo = 1000                                              # a query shard of the set: self_offset = its first row
+    d3, i3 = _capi.knn(Y[lo:lo + 600], Y, K, self_mode=_capi.SELF_EXCLUDE, self_offset=lo)
+    assert np.array_equal(d3, d2[lo:lo + 600]) and np.array_equal(i3, i2[lo:lo + 600])
+    assert _capi.verify_knn(Y, Y, d2, self_mode=_capi.SELF_EXCLUDE, nsample=len(Y)) == 0
+
+
+@pytest.mark.parametrize("kind", sorted(ADVERSARIAL))
+def test_deep_filter_adversarial_inputs_stay_exact(kind):
+    """the adversarial families of test_knn_adversarial_inputs_stay_exact at d = 100 through the deep filter: whatever the data
+    look like, it never drops a true neighbour"""
+    import zlib
+    from mcevidence_amd import _capi
+    _capi.require_device()
+    d, n, K = 100, 3000, 6
+    rng = np.random.default_rng(zlib.crc32(("deep-%s" % kind).encode()))
+    Y = np.ascontiguousarray(ADVERSARIAL[kind](rng, n, d), dtype=np.float64)
+    dist, idx = _capi.knn(Y, Y, K, self_mode=_capi.SELF_EXCLUDE)
+    assert "knn_deep_kernel" in _capi.last_kernel(), _capi.last_kernel()
+    od, oi = orc.knn_brute(Y, Y, K, self_mode=2)
+    exact = np.sqrt(((Y[:, None, :] - Y[idx]) ** 2).sum(-1))
+    assert np.allclose(dist, exact, rtol=1e-13, atol=0)
+    assert np.array_equal(dist, od) or _rel(dist, od) < 1e-13
+    if kind not in ("all_identical", "few_distinct"):
+        assert np.mean(np.sort(idx, axis=1) == np.sort(oi, axis=1)) > 0.999          # identical sets except exact distance ties
+    assert _capi.verify_knn(Y, Y, dist, self_mode=_capi.SELF_EXCLUDE, nsample=n) == 0
+
+
+def test_deep_filter_behind_the_class_and_the_fused_sums():
+    """MCEvidence(...).evidence() at ndim = 80 (a chain taken with its derived columns): device feeders + the deep filter, ln E
+    equal to the oracle's; the fused sums equal the literal sum of the returned distances; search mode 1 (fp64 sweep) agrees."""
+    import mcevidence_amd as pkg
+    from mcevidence_amd import _capi
+    from mcevidence_amd.synth import gaussian_chain
+    _capi.require_device()
+    chain = gaussian_chain(seed=8, n=9000, d=80, weights="int", cov="corr")
+    lnE = pkg.MCEvidence([chain], kmax=5, verbose=0).evidence()
+    assert "knn_deep_kernel<KST=6" in _capi.last_kernel(), _capi.last_kernel()
+    ref = orc.evidence_from_chain(chain, kmax=5, knn="brute")
+    assert np.max(np.abs(lnE - ref["lnE"])) < LNE_TOL
+    with _capi.options(search_mode=_capi.MODE_F64):
+        lnE64 = pkg.MCEvidence([chain], kmax=5, verbose=0).evidence()
+        assert "knn_mfma_kernel" in _capi.last_kernel()
+    assert np.max(np.abs(lnE - lnE64)) < 1e-11
+    X = ref["X"]
+    w, fs = chain[:, 0], -chain[:, 1] - np.max(-chain[:, 1])
+    dp, dd = _capi.knn_dotp(X, None, w, fs, 5, 1, return_dist=True)
+    full = np.zeros((len(X), 5)); full[:, 1:] = dd
+    assert np.allclose(dp[1:], orc.dotp_logdomain(full, w, fs, 80, 1, 5)[1:], rtol=1e-11)

@@ -147,6 +147,7 @@ int main(int argc, char** argv)
         printf("   drain phases (cycles per drain): A (exact distances) %.0f  R (row side) %.0f  B + publish + gates %.0f\n", m[8] / (m[0] > 0 ? m[0] : 1), m[9] / (m[0] > 0 ? m[0] : 1), m[10] / (m[0] > 0 ? m[0] : 1));
         printf("per wave and unit (mean): drains %.1f  enq %.0f  redo tiles %.2f  event (tile, query tile)s %.0f | cycles: events %.3g (%.1f %%)  drains %.3g (%.1f %%)  prologue %.3g (%.1f %%)  kernel %.3g\n",
                m[0], m[1], m[2], m[3], m[4], 100 * m[4] / m[6], m[5], 100 * m[5] / m[6], m[7], 100 * m[7] / m[6], m[6]);
+        printf("   waiting at the chunk barrier (incl. the DMA's landing): %.3g cycles per wave and unit (%.1f %%)\n", m[11], 100 * m[11] / m[6]);
         printf("   per event %.0f cycles, per drain %.0f cycles, per queued pair %.1f drain cycles; enq per query (whole search) %.1f\n", m[4] / (m[3] > 0 ? m[3] : 1), m[5] / (m[0] > 0 ? m[0] : 1), m[5] / (m[1] > 0 ? m[1] : 1), m[1] * nw / 64.0 / n * 64.0 / 64.0);
     }
 #endif

@@ -91,7 +91,7 @@ def main():
     out = dict(what="|v_mfma_f32_32x32x16_f16 chain - exact| / eps_q, eps_q = 32 KST 2^-24 (|x^| + max|y^|)^2 (knn_f16.hpp)", tiles_per_kind_and_kst=per, kst={})
     edges = [0, 1e-4, 1e-3, 1e-2, 0.03, 0.1, 0.2, 0.3, 0.4, 0.5, 0.75, 1.0, np.inf]
     total = 0
-    for kst in (1, 2, 3, 4):
+    for kst in (1, 2, 3, 4, 5, 6, 8):
         rec = {}
         for kind in KINDS:
             yp, xp = make_tiles(kind, kst, per if kind != "max_magnitude" else min(per, 200), rng)

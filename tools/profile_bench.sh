@@ -9,6 +9,8 @@ out=$R/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY"
+SQC1="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT"
+SQC2="SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_SMEM"
 need() { f=$(find $1 -name "$2" | head -1); [ -n "$f" ] || { echo "profile_bench.sh: $1 holds no $2 -- log:"; tail -5 $3; exit 1; }; echo $f; }
 pass() {    # pass <dir> <log> <rocprofv3 options...> -- <program...>
   d=$1; log=$2; shift 2; rm -rf $d
@@ -53,11 +55,20 @@ for c in C2 C4 C5; do
   pass /tmp/kc_${tag}_$c $out/run_configs_$c.log --kernel-trace --stats --output-format csv -d /tmp/kc_${tag}_$c -o kt -- python3 $R/tools/run_configs.py $c
   cp $(need /tmp/kc_${tag}_$c "*kernel_stats.csv" $out/run_configs_$c.log) $out/kernel_stats_$c.csv || exit 1
   pass /tmp/pc_${tag}_$c $out/run_configs_${c}_sq.log --pmc $SQ --kernel-trace --output-format csv -d /tmp/pc_${tag}_$c -o ps -- python3 $R/tools/run_configs.py $c
-  summarise $out/pmc_summary_$c.csv S:/tmp/pc_${tag}_$c || exit 1
+  if [ $c = C5 ]; then
+    # the pruned walk is priced by its instruction MIX (bench.py: valu_issue_floor): the class counters, in two more passes
+    pass /tmp/pd_${tag}_$c $out/run_configs_${c}_sq2.log --pmc $SQC1 --kernel-trace --output-format csv -d /tmp/pd_${tag}_$c -o ps -- python3 $R/tools/run_configs.py $c
+    pass /tmp/pe_${tag}_$c $out/run_configs_${c}_sq3.log --pmc $SQC2 --kernel-trace --output-format csv -d /tmp/pe_${tag}_$c -o ps -- python3 $R/tools/run_configs.py $c
+    summarise $out/pmc_summary_$c.csv S:/tmp/pc_${tag}_$c C1:/tmp/pd_${tag}_$c C2:/tmp/pe_${tag}_$c || exit 1
+  else
+    summarise $out/pmc_summary_$c.csv S:/tmp/pc_${tag}_$c || exit 1
+  fi
 done
 pass /tmp/kf_$tag $out/bench_fp64_under_kernel_trace.log --kernel-trace --stats --output-format csv -d /tmp/kf_$tag -o kt -- $B --mode 1 --steps 2 --warmup 1
 cp $(need /tmp/kf_$tag "*kernel_stats.csv" $out/bench_fp64_under_kernel_trace.log) $out/kernel_stats_fp64.csv || exit 1
 grep '^{"metric"' $out/bench_fp64_under_kernel_trace.log | tail -1 > $out/bench_fp64.json
+pass /tmp/pq_$tag $out/bench_fp64_under_sq.log --pmc $SQ --kernel-trace --output-format csv -d /tmp/pq_$tag -o ps -- $B --mode 1 --steps 1 --warmup 0
+summarise $out/pmc_summary_fp64.csv S:/tmp/pq_$tag || exit 1
 # what the profile was taken from: bench.py quotes its counters only for a library built from the same kernel sources
 python3 - $out $tag <<'PY'
 import json, sys, os, time

@@ -11,6 +11,7 @@ tools/profile_bench.sh $tag > gpurun_out/refresh_$tag.log 2>&1 || { echo "profil
 out=$R/gpurun_out/prof_$tag
 mkdir -p profiles/$tag
 cp $out/bench.json $out/bench_fp64.json $out/kernel_stats*.csv $out/pmc_summary*.csv $out/meta.json profiles/$tag/ || exit 1
+# (the issue-cost table of tools/valu_issue_clock.hip is box-independent: profiles/r06_valu/valu_issue_clock.json, committed)
 python bench.py > $out/bench_all_configs.json 2> $out/bench_all_configs.err || { echo "bench.py failed"; tail -5 $out/bench_all_configs.err; exit 1; }
 python - "$out/bench_all_configs.json" <<'PY'
 import json, sys
