@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_deep_kernel(DeepArgs a)
             if (q < a.nq) {
                 const double ex = qinfo[2 * q], xn = qinfo[2 * q + 1];
                 const double r = sqrt(xn) + p_ym;
-                const double eps = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 1e-9) + p_rho + 1e-30;
+                const double eps = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 0x1p-9) + p_rho + 1e-30;
                 gq_a[qt] = (ex + p_ey) * (1.0 + 1e-9) + slack;
                 gq_c[qt] = eps - xn;
                 gq_xn[qt] = xn;

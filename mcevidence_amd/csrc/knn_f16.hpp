@@ -407,7 +407,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
             if (q < nq) {
                 const double xn = qinfo[2 * q + 1];
                 const double r = sqrt(xn) + params[HP_YHATMAX];
-                const double eps = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 1e-9) + params[HP_RHO] + 1e-30;
+                const double eps = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 0x1p-9) + params[HP_RHO] + 1e-30;
                 cR[qt] = __double2float_ru(eps - xn);
             }
         }
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
         // + 2*sqrt(16 KST)*2^-14: even if the matrix unit flushed fp16 subnormal inputs (it does not
         // on gfx950) the bound would hold
         const double ga = (ex + params[HP_EY]) * (1.0 + 1e-9) + 2.0 * sqrt(16.0 * KST) * 0x1p-14;
-        const double eps = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 1e-9) + params[HP_RHO] + 1e-30;
+        const double eps = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 0x1p-9) + params[HP_RHO] + 1e-30;
         const double rr = sqrt(thr * s2) * (1.0 + 1e-12) + ga;
         const double g = rr * rr * (1.0 + 1e-12) - xn + eps;
         return __double2float_ru(g);
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                         const double ex = qinfo[2 * q], xn = qinfo[2 * q + 1];
                         const double r = sqrt(xn) + params[HP_YHATMAX];
                         const double ga = (ex + params[HP_EY]) * (1.0 + 1e-9) + 2.0 * sqrt(16.0 * KST) * 0x1p-14;
-                        const double eps = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 1e-9) + params[HP_RHO] + 1e-30;
+                        const double eps = (32.0 * KST) * 0x1p-24 * r * r * (1.0 + 0x1p-9) + params[HP_RHO] + 1e-30;
                         const double h2 = fmax((double)a_up + xn + eps, 0.0);
                         const double dd = sqrt(h2) * (1.0 + 1e-12) + ga;
                         seed_thr[nl] = dd * dd * (1.0 + 1e-12) / s2 * (1.0 + 1e-12);

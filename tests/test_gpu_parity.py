@@ -1521,6 +1521,16 @@ def test_class_under_two_ranks_equals_the_single_rank_lnE(cross, poison, node_up
 
 
 # --------------------------------------------------------------------------- the deep fp16 filter (64 <= d <= 127; knn_deep.hpp)
+@pytest.fixture()
+def deep_capi():
+    """the library in the DEFAULT search mode for the duration of a test, whatever the module-scoped `capi` fixture's current
+    parameter has set process-wide (per-call options: thread-scoped, they win over the process default)"""
+    from mcevidence_amd import _capi
+    _capi.require_device()
+    with _capi.options(search_mode=_capi.MODE_AUTO):
+        yield _capi
+
+
 def _deep_data(n, d, seed, corr=True):
     rng = np.random.default_rng(seed)
     Y = rng.standard_normal((n, d))
@@ -1531,12 +1541,11 @@ def _deep_data(n, d, seed, corr=True):
 
 @pytest.mark.parametrize("d,K", [(64, 9), (72, 1), (80, 4), (100, 12), (127, 16)])
 @pytest.mark.parametrize("variant", ["default", "redo", "noseed", "split3"])
-def test_deep_filter_is_exact(variant, d, K, monkeypatch):
+def test_deep_filter_is_exact(variant, d, K, monkeypatch, deep_capi):
     """The fp16 filter at five to eight k-steps: distances AND rows of the exact CPU search, for every self mode, separate query
     sets and ragged sizes -- with the seed phase on and off, every candidate forced through the redo list (queue-overflow path),
     and three reference splits (several lists per query, merged)."""
-    from mcevidence_amd import _capi
-    _capi.require_device()
+    _capi = deep_capi
     if variant == "redo":
         monkeypatch.setenv("MCE_PANEL_DEBUG", "8")
     elif variant == "noseed":
@@ -1563,12 +1572,11 @@ def test_deep_filter_is_exact(variant, d, K, monkeypatch):
 
 
 @pytest.mark.parametrize("kind", sorted(ADVERSARIAL))
-def test_deep_filter_adversarial_inputs_stay_exact(kind):
+def test_deep_filter_adversarial_inputs_stay_exact(kind, deep_capi):
     """the adversarial families of test_knn_adversarial_inputs_stay_exact at d = 100 through the deep filter: whatever the data
     look like, it never drops a true neighbour"""
     import zlib
-    from mcevidence_amd import _capi
-    _capi.require_device()
+    _capi = deep_capi
     d, n, K = 100, 3000, 6
     rng = np.random.default_rng(zlib.crc32(("deep-%s" % kind).encode()))
     Y = np.ascontiguousarray(ADVERSARIAL[kind](rng, n, d), dtype=np.float64)
@@ -1583,13 +1591,12 @@ def test_deep_filter_adversarial_inputs_stay_exact(kind):
     assert _capi.verify_knn(Y, Y, dist, self_mode=_capi.SELF_EXCLUDE, nsample=n) == 0
 
 
-def test_deep_filter_behind_the_class_and_the_fused_sums():
+def test_deep_filter_behind_the_class_and_the_fused_sums(deep_capi):
     """MCEvidence(...).evidence() at ndim = 80 (a chain taken with its derived columns): device feeders + the deep filter, ln E
     equal to the oracle's; the fused sums equal the literal sum of the returned distances; search mode 1 (fp64 sweep) agrees."""
     import mcevidence_amd as pkg
-    from mcevidence_amd import _capi
     from mcevidence_amd.synth import gaussian_chain
-    _capi.require_device()
+    _capi = deep_capi
     chain = gaussian_chain(seed=8, n=9000, d=80, weights="int", cov="corr")
     lnE = pkg.MCEvidence([chain], kmax=5, verbose=0).evidence()
     assert "knn_deep_kernel<KST=6" in _capi.last_kernel(), _capi.last_kernel()
