@@ -504,7 +504,8 @@ def test_device_feeder_route_matches_reference_and_host_route(name):
 @pytest.mark.parametrize("d,split", [(64, False), (90, False), (127, False), (80, True)])
 def test_device_feeders_beyond_63_dimensions(d, split):
     """64 <= d <= 127 (round 5): covariance (pairs in batches of 2048), the Jacobi eigen-system and the wide whitening kernel on the
-    device, the search on the fp64 sweep's wide form -- the class no longer leaves the device-feeder route at d = 64.  Same ln E as
+    device, the search on the deep fp16 filter (round 6; round 5: the fp64 sweep's wide form) -- the class no longer leaves the
+    device-feeder route at d = 64.  Same ln E as
     the host-feeder route (np.cov + np.linalg.eig + whitening on the host) of the same class; d = 128 is refused by the feeders and
     served by the host route."""
     import mcevidence_amd as pkg
@@ -526,7 +527,11 @@ def test_device_feeders_beyond_63_dimensions(d, split):
         return m.evidence(covtype="all")
 
     dev = run(Spy())
-    assert calls.get("feed", 0) == 1 and "knn_mfma_kernel<KS=" in _capi.last_kernel()
+    assert calls.get("feed", 0) == 1 and "knn_deep_kernel<KST=" in _capi.last_kernel(), _capi.last_kernel()
+    with _capi.options(search_mode=_capi.MODE_F64):          # ... and on the fp64 sweep's wide form when asked for
+        dev64 = run(Spy())
+        assert "knn_mfma_kernel<KS=" in _capi.last_kernel(), _capi.last_kernel()
+    assert np.max(np.abs(dev - dev64)) < 1e-10
     host = run(type("H", (), {"name": "hip", "knn_dotp": pkg.HipBackend().knn_dotp})())
     assert np.all(np.isfinite(dev)) and np.max(np.abs(dev - host)) < 1e-9, (dev, host)
     if d == 127:
