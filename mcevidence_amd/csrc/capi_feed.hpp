@@ -252,96 +252,6 @@ int feed_plan(FeedJob& j)
     return MCE_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Upload of a large row block from the caller's PAGEABLE array (round 6).  A blocking hipMemcpy2D from pageable memory is
-// staged by the runtime on one thread (~20 GB/s measured: 11 ms of the 51 ms evidence() call at 1 M x 27 went there).  Here
-// kUpThreads host threads pack the rows (dropping the columns beyond d: the row pitch of `samples[:, :ndim]`) into their own
-// pinned slots and queue dense asynchronous copies on their own streams, two slots deep; the consumer stream is made to
-// wait on every thread's last copy.  The pinned slots, streams and events are created once per device and kept
-// (mce_release_device_memory does not free them: 64 MB of pinned host memory per device that ever uploaded a large chain).
-// Small arrays keep the blocking path (thread start-up would cost more than it saves).  MCE_FEED_UPLOAD=plain: always the
-// blocking path.
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int kUpThreads = 4, kUpSlots = 2;
-constexpr size_t kUpSlotBytes = (size_t)8 << 20;
-constexpr size_t kUpMinBytes = (size_t)32 << 20;
-struct UploadPool {
-    std::mutex mu;                 // one large upload at a time per device
-    bool ready = false, failed = false;
-    void* slot[kUpThreads][kUpSlots] = {};
-    bool used[kUpThreads][kUpSlots] = {};      // the slot's event has been recorded: wait for it before the slot is written again
-    hipEvent_t ev[kUpThreads][kUpSlots] = {};
-    hipEvent_t done[kUpThreads] = {};
-    hipStream_t st[kUpThreads] = {};
-};
-UploadPool g_upload_pool[kMaxDevices];
-
-bool upload_pool_init(UploadPool& P)
-{
-    if (P.ready || P.failed) return P.ready;
-    for (int t = 0; t < kUpThreads && !P.failed; ++t) {
-        if (hipStreamCreateWithFlags(&P.st[t], hipStreamNonBlocking) != hipSuccess) P.failed = true;
-        if (!P.failed && hipEventCreateWithFlags(&P.done[t], hipEventDisableTiming) != hipSuccess) P.failed = true;
-        for (int b = 0; b < kUpSlots && !P.failed; ++b) {
-            if (hipHostMalloc(&P.slot[t][b], kUpSlotBytes, hipHostMallocDefault) != hipSuccess) P.failed = true;
-            if (!P.failed && hipEventCreateWithFlags(&P.ev[t][b], hipEventDisableTiming) != hipSuccess) P.failed = true;
-        }
-    }
-    (void)hipGetLastError();
-    P.ready = !P.failed;
-    return P.ready;
-}
-
-// rows [n][row_bytes] from src (pitch bytes apart) to the dense device block dst; `consumer` waits for it.  false: not taken (the
-// caller falls back to the blocking copy); errors inside are reported through rc
-bool upload_rows_threaded(void* dst, size_t row_bytes, const void* src, size_t pitch, int64_t n, hipStream_t consumer, int& rc)
-{
-    rc = MCE_OK;
-    static const bool plain = [] { const char* e = getenv("MCE_FEED_UPLOAD"); return e && !strcmp(e, "plain"); }();
-    if (plain || (size_t)n * row_bytes < kUpMinBytes || row_bytes == 0 || row_bytes > kUpSlotBytes) return false;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev >= kMaxDevices) return false;
-    UploadPool& P = g_upload_pool[dev];
-    std::lock_guard<std::mutex> lk(P.mu);
-    if (!upload_pool_init(P)) return false;
-    const int64_t rows_per_slot = (int64_t)(kUpSlotBytes / row_bytes);
-    const int64_t nchunks = (n + rows_per_slot - 1) / rows_per_slot;
-    const int T = (int)std::min<int64_t>(kUpThreads, nchunks);
-    std::atomic<int> err{0};
-    auto work = [&](int t) {
-        if (hipSetDevice(dev) != hipSuccess) { err.store(1); return; }
-        for (int64_t c = t; c < nchunks && !err.load(); c += T) {
-            const int b = (int)((c / T) % kUpSlots);
-            // the slot's previous copy -- of this upload, or of an earlier one still in flight (batched feed: the next group's uploads
-            // run while this group's searches do) -- has left it
-            if (P.used[t][b] && hipEventSynchronize(P.ev[t][b]) != hipSuccess) { err.store(1); return; }
-            P.used[t][b] = true;
-            const int64_t r0 = c * rows_per_slot, r1 = std::min(n, r0 + rows_per_slot);
-            char* out = static_cast<char*>(P.slot[t][b]);
-            const char* in = static_cast<const char*>(src) + (size_t)r0 * pitch;
-            if (pitch == row_bytes) std::memcpy(out, in, (size_t)(r1 - r0) * row_bytes);
-            else for (int64_t r = r0; r < r1; ++r, out += row_bytes, in += pitch) std::memcpy(out, in, row_bytes);
-            if (hipMemcpyAsync(static_cast<char*>(dst) + (size_t)r0 * row_bytes, P.slot[t][b], (size_t)(r1 - r0) * row_bytes, hipMemcpyHostToDevice, P.st[t]) != hipSuccess ||
-                hipEventRecord(P.ev[t][b], P.st[t]) != hipSuccess) { err.store(1); return; }
-        }
-        if (hipEventRecord(P.done[t], P.st[t]) != hipSuccess) err.store(1);
-    };
-    {
-        std::vector<std::thread> th;
-        for (int t = 1; t < T; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
-    }
-    if (err.load()) {
-        for (int t = 0; t < T; ++t) (void)hipStreamSynchronize(P.st[t]);
-        rc = fail(MCE_ERR_HIP, "upload of %lld rows failed: %s", (long long)n, hipGetErrorString(hipGetLastError()));
-        return true;
-    }
-    for (int t = 0; t < T; ++t)
-        if (hipStreamWaitEvent(consumer, P.done[t], 0) != hipSuccess) { rc = fail(MCE_ERR_HIP, "hipStreamWaitEvent failed"); return true; }
-    return true;
-}
-
 int feed_stage_a(FeedJob& j, hipStream_t st)
 {
     const mce_feed_problem& q = *j.q;
@@ -362,23 +272,13 @@ int feed_stage_a(FeedJob& j, hipStream_t st)
         MCE_HIP(hipMemcpyAsync(j.dW(), q.w, (size_t)q.n1 * sizeof(double), hipMemcpyDeviceToDevice, st));
         MCE_HIP(hipMemcpyAsync(j.dF(), q.fs, (size_t)q.n1 * sizeof(double), hipMemcpyDeviceToDevice, st));
     } else if (async_upload || st == nullptr) {
-        int urc = MCE_OK;
-        if (async_upload || !upload_rows_threaded(j.dS1(), row, q.S1, (size_t)q.ld1 * sizeof(double), q.n1, st, urc))
-            MCE_HIP(hipMemcpy2DAsync(j.dS1(), row, q.S1, (size_t)q.ld1 * sizeof(double), row, (size_t)q.n1, hipMemcpyHostToDevice, st));
-        if (urc != MCE_OK) return urc;
-        if (q.S2 && (async_upload || !upload_rows_threaded(j.dS2(), row, q.S2, (size_t)q.ld2 * sizeof(double), q.n2, st, urc)))
-            MCE_HIP(hipMemcpy2DAsync(j.dS2(), row, q.S2, (size_t)q.ld2 * sizeof(double), row, (size_t)q.n2, hipMemcpyHostToDevice, st));
-        if (urc != MCE_OK) return urc;
+        MCE_HIP(hipMemcpy2DAsync(j.dS1(), row, q.S1, (size_t)q.ld1 * sizeof(double), row, (size_t)q.n1, hipMemcpyHostToDevice, st));
+        if (q.S2) MCE_HIP(hipMemcpy2DAsync(j.dS2(), row, q.S2, (size_t)q.ld2 * sizeof(double), row, (size_t)q.n2, hipMemcpyHostToDevice, st));
         MCE_HIP(hipMemcpyAsync(j.dW(), q.w, (size_t)q.n1 * sizeof(double), hipMemcpyHostToDevice, st));
         MCE_HIP(hipMemcpyAsync(j.dF(), q.fs, (size_t)q.n1 * sizeof(double), hipMemcpyHostToDevice, st));
     } else {
-        int urc = MCE_OK;
-        if (!upload_rows_threaded(j.dS1(), row, q.S1, (size_t)q.ld1 * sizeof(double), q.n1, st, urc))
-            MCE_HIP(hipMemcpy2D(j.dS1(), row, q.S1, (size_t)q.ld1 * sizeof(double), row, (size_t)q.n1, hipMemcpyHostToDevice));
-        if (urc != MCE_OK) return urc;
-        if (q.S2 && !upload_rows_threaded(j.dS2(), row, q.S2, (size_t)q.ld2 * sizeof(double), q.n2, st, urc))
-            MCE_HIP(hipMemcpy2D(j.dS2(), row, q.S2, (size_t)q.ld2 * sizeof(double), row, (size_t)q.n2, hipMemcpyHostToDevice));
-        if (urc != MCE_OK) return urc;
+        MCE_HIP(hipMemcpy2D(j.dS1(), row, q.S1, (size_t)q.ld1 * sizeof(double), row, (size_t)q.n1, hipMemcpyHostToDevice));
+        if (q.S2) MCE_HIP(hipMemcpy2D(j.dS2(), row, q.S2, (size_t)q.ld2 * sizeof(double), row, (size_t)q.n2, hipMemcpyHostToDevice));
         MCE_HIP(hipMemcpy(j.dW(), q.w, (size_t)q.n1 * sizeof(double), hipMemcpyHostToDevice));
         MCE_HIP(hipMemcpy(j.dF(), q.fs, (size_t)q.n1 * sizeof(double), hipMemcpyHostToDevice));
         if (!j.upload_ev) MCE_HIP(hipEventCreateWithFlags(&j.upload_ev, hipEventDisableTiming));

@@ -526,8 +526,9 @@ def test_device_feeders_beyond_63_dimensions(d, split):
             m.set_split(np.arange(0, 12000), np.arange(12000, 24000))
         return m.evidence(covtype="all")
 
-    dev = run(Spy())
-    assert calls.get("feed", 0) == 1 and "knn_deep_kernel<KST=" in _capi.last_kernel(), _capi.last_kernel()
+    with _capi.options(search_mode=_capi.MODE_AUTO):          # (whatever the module's `capi` fixture has set process-wide)
+        dev = run(Spy())
+        assert calls.get("feed", 0) == 1 and "knn_deep_kernel<KST=" in _capi.last_kernel(), _capi.last_kernel()
     with _capi.options(search_mode=_capi.MODE_F64):          # ... and on the fp64 sweep's wide form when asked for
         dev64 = run(Spy())
         assert "knn_mfma_kernel<KS=" in _capi.last_kernel(), _capi.last_kernel()
