@@ -205,9 +205,6 @@ __device__ __forceinline__ float sym_row_gate(double thr, double ex, const doubl
 }
 
 __host__ __device__ constexpr int f16_prune_slice_bytes(int KST, int KCAP) { return f16_prune_batch(KCAP) * KST * 1024 + 256; }   // kBatch tiles + pending ids
-#ifndef MCE_H_PRUNE_BOOT_ORDER
-#define MCE_H_PRUNE_BOOT_ORDER 1   // 1: own tiles first, then outward; 0: ascending tile number
-#endif
 #ifndef MCE_H_PRUNE_BOOT
 #define MCE_H_PRUNE_BOOT 12
 #endif
@@ -1265,12 +1262,8 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
         // squared gap between a reference box (lower edges at p[i * stride], upper at p[(D + i) * stride]) and each query
         // tile's box.  The loads of eight dimensions are issued together (indices past d clamped, their terms zeroed:
         // fma(0, 0, acc) = acc, so the sums are those of the one-dimension-at-a-time loop, bit for bit).
-#ifndef MCE_H_PRUNE_QREACH
-#define MCE_H_PRUNE_QREACH 1
-#endif
-#define MCE_H_PRUNE_QREACH_ON (MCE_H_PRUNE_QREACH != 0)
         // (keep: the lane's box, widened, goes to LDS for query_reach below -- the tile slice, idle while tiles are collected)
-        static_assert(!MCE_H_PRUNE_QREACH_ON || kBatch * KST * 1024 >= 64 * 64, "tile slice: room for 64 boxes of 8 dimensions");
+        static_assert(kBatch * KST * 1024 >= 64 * 64, "tile slice: room for 64 boxes of 8 dimensions");
         typedef float v4f_t __attribute__((ext_vector_type(4)));
         typedef float v2f_t __attribute__((ext_vector_type(2)));
         auto box_gap = [&](const float* p, const int stride, float (&acc)[QT], auto keep) __attribute__((always_inline)) {
@@ -1438,11 +1431,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                 if (boot_k < boot_n) {
                     const int room = kBatch - pend;                 // the next `room` positions of the sequence
                     const int k = boot_k + lane;
-#if MCE_H_PRUNE_BOOT_ORDER == 1
-                    const int id = own_t + ((k & 1) ? (k + 1) / 2 : -(k / 2));
-#else
-                    const int id = own_t - kHPruneBoot + k;
-#endif
+                    const int id = own_t + ((k & 1) ? (k + 1) / 2 : -(k / 2));         // own tiles first, then outward (ascending tile number was measured and dropped, round 3)
                     const bool take = lane < room && k < boot_n && id >= boot_lo && id < boot_hi;   // (off the ends: skipped)
                     const unsigned long long tm = __ballot(take);
                     if (take) wl[pend + __builtin_amdgcn_mbcnt_hi((unsigned)(tm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)tm, 0))] = id;
@@ -1477,7 +1466,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
 #if MCE_PRUNE_PROF == 2
                         const long long tw0_ = clock64();
 #endif
-                        box_gap(bb, 1, acc, std::integral_constant<bool, MCE_H_PRUNE_QREACH != 0>());
+                        box_gap(bb, 1, acc, std::true_type());
 #if MCE_PRUNE_PROF == 2
                         asm volatile("" :: "v"(acc[0]), "v"(acc[1]));
                         w2_win += clock64() - tw0_;
@@ -1486,12 +1475,10 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) reach |= !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]);
                         cand = __ballot(in && !far && reach);
-#if MCE_H_PRUNE_QREACH
                         // (the same per-query test on the window's CHUNK boxes: about half of the chunks whose box is within reach
                         //  of a query tile's box are within reach of no single query -- their 64 tile boxes are then never fetched.
                         //  Not in the first window of a separate query set: that one is walked twice, see xb_state.)
                         if (xb_state != 0 && cand != 0) cand = query_reach(cand);
-#endif
                         e = (__ballot(in && stop) != 0) ? list_len : e + 64 * pr_step;
                         st_chunks += 1;
                         if (xb_state == 0) {                           // first window of a separate query set
@@ -1516,7 +1503,7 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
 #if MCE_PRUNE_PROF == 2
                     const long long tb0_ = clock64();
 #endif
-                    box_gap(cb, PCT, acc, std::integral_constant<bool, MCE_H_PRUNE_QREACH != 0>());
+                    box_gap(cb, PCT, acc, std::true_type());
 #if MCE_PRUNE_PROF == 2
                     asm volatile("" :: "v"(acc[0]), "v"(acc[1]));
                     w2_box += clock64() - tb0_; w2_nbox += 1;
@@ -1533,14 +1520,12 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                         const bool booted = same_order ? (tile_id >= boot_lo && tile_id < boot_hi) : (xb_win0 && ((xb_mask[cur_bsel] >> lane) & 1ull));
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) need |= __ballot(!booted && !(acc[qt] * (1.0f - 0x1p-18f) > Tq[qt]));
-#if MCE_H_PRUNE_QREACH
 #if MCE_PRUNE_PROF == 2
                         const long long tq0_ = clock64(); w2_ntile += __builtin_popcountll(need);
 #endif
                         if (need != 0) need = query_reach(need);
 #if MCE_PRUNE_PROF == 2
                         w2_qr += clock64() - tq0_;
-#endif
 #endif
                     }
                     st_tiles += __builtin_popcountll(need);
@@ -1561,10 +1546,6 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
             // global -> the wave's LDS slice by LDS-DMA (all tiles of the batch in flight together, no registers in between).
             // A DMA's landing is ordered for the ISSUING wave's ds_read by its own vmcnt wait alone (for other waves' reads a
             // workgroup barrier must follow, dma_barrier above -- these workgroups are one wave).
-#ifndef MCE_H_PRUNE_DMA
-#define MCE_H_PRUNE_DMA 1
-#endif
-#if MCE_H_PRUNE_DMA
 #pragma unroll
             for (int u = 0; u < kBatch; ++u) {
                 if (u < pend) {
@@ -1577,27 +1558,6 @@ __global__ __launch_bounds__(PRUNE ? 64 : kHThreads, PRUNE ? (LC <= MCE_H_PRUNE_
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-            {
-                v8h stg[kBatch][KST];
-#pragma unroll
-                for (int u = 0; u < kBatch; ++u) {
-                    if (u < pend) {
-                        const int id = __builtin_amdgcn_readfirstlane(wl[u]);
-                        const _Float16* src = Yh + (int64_t)id * (KST * 512) + lane * 8;
-#pragma unroll
-                        for (int ks = 0; ks < KST; ++ks) stg[u][ks] = *reinterpret_cast<const v8h*>(src + ks * 512);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < kBatch; ++u) {
-                    if (u < pend) {
-#pragma unroll
-                        for (int ks = 0; ks < KST; ++ks) *reinterpret_cast<v8h*>(wbuf + (u * KST + ks) * 1024 + lane * 16) = stg[u][ks];
-                    }
-                }
-            }
-#endif
             MCE_PT(pt_stage);
             {
                 // (no mfma/gate overlap across tiles: measured, the multiply phase is bound by the gate and
