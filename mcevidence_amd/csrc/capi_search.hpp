@@ -183,12 +183,18 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
         if (phase != 2) {
             const int64_t rows_per_block = 4 * (64 / (2 * p.KST));          // 4 waves x R rows
             const int64_t pack_blocks = std::min<int64_t>((p.nrow_pad + rows_per_block - 1) / rows_per_block, 2048);   // grid-stride
+            // queries and references are ONE buffer in the same order (auto evidence: the symmetric sweep's sorted rows, the pruned walk's
+            // k-d order over one set, or the caller's buffer itself): one packing pass writes both forms (f16_prep.hpp)
+            const bool one_pass = sX == sY && nq == nr && p.nq_pad <= p.nrow_pad;
             hipLaunchKernelGGL(mce::f16_pack_refs_kernel, dim3((unsigned)pack_blocks), dim3(256), 0, st,
-                               sY, nr, (int)d, p.KST, p.nrow_pad, center, params, yh);
+                               sY, nr, (int)d, p.KST, p.nrow_pad, center, params, yh, one_pass ? xh : (_Float16*)nullptr, one_pass ? qinfo : (double*)nullptr,
+                               one_pass ? p.nq_pad : (int64_t)0);
             MCE_HIP(hipGetLastError());
-            hipLaunchKernelGGL(mce::f16_pack_queries_kernel, dim3((unsigned)((p.nq_pad + rows_per_block - 1) / rows_per_block)), dim3(256), 0, st,
-                               sX, nq, p.nq_pad, (int)d, p.KST, center, params, xh, qinfo);
-            MCE_HIP(hipGetLastError());
+            if (!one_pass) {
+                hipLaunchKernelGGL(mce::f16_pack_queries_kernel, dim3((unsigned)((p.nq_pad + rows_per_block - 1) / rows_per_block)), dim3(256), 0, st,
+                                   sX, nq, p.nq_pad, (int)d, p.KST, center, params, xh, qinfo);
+                MCE_HIP(hipGetLastError());
+            }
         }
         mce::KnnF16Args a;
         a.Yh = yh; a.nchunk_total = p.nchunk; a.rsplit = p.rsplit; a.Xh = xh; a.qinfo = qinfo; a.params = params;

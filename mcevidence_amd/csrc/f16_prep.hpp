@@ -83,9 +83,15 @@ __global__ __launch_bounds__(64) void f16_box_about_kernel(const double* __restr
 // writes its own 16-byte fragment piece.  Lane = f*R + r with R = 64/G rows per wave, so the
 // stores of a wave are G contiguous runs (same fragment slot, consecutive rows).
 // ---------------------------------------------------------------------------
+// Xh_same / qinfo_same (round 6; null: not asked for): the queries ARE these rows (auto evidence, one buffer) -- the same pass
+// also writes their fp16 query rows x' = [x^, 1, 1, 1, 0..] and qinfo = {e_x, |x^|^2} for the rows below nq_pad_same, bit for
+// bit what f16_pack_queries_kernel would write (the same converted values, the same order of the partial sums), and that
+// kernel's launch is saved (0.095 ms of a C3 step).
 __global__ __launch_bounds__(256) void f16_pack_refs_kernel(const double* __restrict__ Y, int64_t nr, int D, int KST,
                                                             int64_t nrow_pad, const double* __restrict__ center,
-                                                            double* __restrict__ params, _Float16* __restrict__ Yh)
+                                                            double* __restrict__ params, _Float16* __restrict__ Yh,
+                                                            _Float16* __restrict__ Xh_same = nullptr, double* __restrict__ qinfo_same = nullptr,
+                                                            int64_t nq_pad_same = 0)
 {
     const int G = 2 * KST, R = 64 / G;
     const int lane = threadIdx.x & 63;
@@ -142,6 +148,24 @@ __global__ __launch_bounds__(256) void f16_pack_refs_kernel(const double* __rest
             const int i32 = (int)(row & 31);
             const int ks = f >> 1, hh = f & 1;
             *reinterpret_cast<v8h*>(Yh + (((tile * KST + ks) * 64 + i32 + 32 * hh) * 8)) = v;
+            if (Xh_same && row < nq_pad_same) {
+                v8h xq;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 8 * f + e;
+                    _Float16 x = (_Float16)0.0f;
+                    if (live) {
+                        if (k < D) x = (_Float16)th[e];                       // (th holds the converted value: the conversion back is exact)
+                        else if (k < D + npieces) x = (_Float16)1.0f;
+                    }
+                    xq[e] = x;
+                }
+                *reinterpret_cast<v8h*>(Xh_same + row * (int64_t)(16 * KST) + 8 * f) = xq;
+                if (f == 0) {
+                    qinfo_same[2 * row + 0] = sqrt(e_tot);
+                    qinfo_same[2 * row + 1] = n_tot;
+                }
+            }
         }
         if (live) {
             ey = fmax(ey, sqrt(e_tot));
