@@ -36,8 +36,11 @@
 extern "C" {
 #endif
 
-#define MCE_ABI_VERSION 2     /* 2: per-call options (mce_options, *_opt), mce_last_search_stats; mce_options.verify and mce_verify_* were
-                               * added compatibly (the field lies in what was reserved[0] = 0) */
+#define MCE_ABI_VERSION 3     /* 2: per-call options (mce_options, *_opt), mce_last_search_stats; mce_options.verify and mce_verify_* were
+                               * added compatibly (the field lies in what was reserved[0] = 0).
+                               * 3 (round 6): every signature of 2 unchanged; NEW entry points (mce_last_verify_rows,
+                               * mce_evidence_feed_part_dev_f64, mce_evidence_feed_whiten_dev_f64) and one changed DEFAULT:
+                               * mce_options.verify = -1 now means "256 rows behind the fp16 filter" (0 still means off) */
 
 #define MCE_OK 0
 #define MCE_ERR_INVALID (-1)   /* bad argument (NULL, d<1, K<1, ...)        -> ValueError  */

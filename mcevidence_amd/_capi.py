@@ -138,7 +138,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.mce_abi_version() != 2 or lib.mce_feed_problem_size() != ctypes.sizeof(FeedProblem):
+        if lib.mce_abi_version() not in (2, 3) or lib.mce_feed_problem_size() != ctypes.sizeof(FeedProblem):
             raise RuntimeError("mcevidence_amd: ABI version mismatch")
         _lib = lib
     return _lib

@@ -36,7 +36,7 @@ def test_header_constants_match_binding():
                  "MCE_ERR_WORKSPACE", "MCE_ERR_DIM_RANGE"):
         m = re.search(r"#define\s+%s\s+\(?(-?\d+)\)?" % name, txt)
         assert m and int(m.group(1)) == getattr(_capi, name), name
-    assert _capi.load().mce_abi_version() == 2
+    assert _capi.load().mce_abi_version() == 3
 
 
 def test_argument_validation_without_gpu():
