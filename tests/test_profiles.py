@@ -1,5 +1,5 @@
 """The committed measurement artefacts are consistent with each other: the roofline figures bench.py prints -- the headline's and,
-since round 5, every config's own -- follow from the committed rocprofv3 summaries (profiles/r05_final/): executed MFMA flops from
+since round 5, every config's own -- follow from the committed rocprofv3 summaries (profiles/r06_final/): executed MFMA flops from
 SQ_INSTS_MFMA, vector instructions from SQ_INSTS_VALU, the kernels' durations from the kernel traces; the profile names the kernel
 sources it was taken from; per-config traces and counter passes let every config's figure be recomputed.  CPU only (reads files)."""
 import csv
@@ -11,7 +11,8 @@ import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-PROF = os.path.join(REPO, "profiles", "r05_final")
+PROF = os.path.join(REPO, "profiles", "r06_final")
+PROF5 = os.path.join(REPO, "profiles", "r05_final")
 PROF4 = os.path.join(REPO, "profiles", "r04_final")
 
 
@@ -37,7 +38,7 @@ def test_roofline_fraction_follows_from_the_profile():
     roof = line["roofline"]
     assert meta["source_hash"] == meta["library_source_hash"]          # the library that was profiled was built from the tree that was hashed
     c = bench.profile_counters(roof["kernel"], library_hash=meta["source_hash"])
-    assert c["source"] == "profiles/r05_final/pmc_summary.csv" and c["stale"] is False
+    assert c["source"] == "profiles/r06_final/pmc_summary.csv" and c["stale"] is False
     # executed flops: one v_mfma_f32_32x32x16_f16 = 32 x 32 x 16 multiply-adds
     assert abs(c["mfma_insts"] * 32768.0 / roof["executed_flops_per_launch"] - 1.0) < 1e-3
     # duration: rocprofv3's average over the process's six searches vs the HIP-event bracket over its three timed ones
@@ -65,14 +66,33 @@ def test_every_config_carries_a_roofline_that_its_own_counter_pass_reproduces():
         ms, calls = _avg_ms("kernel_stats_%s.csv" % name, needle)
         assert calls <= 2
         assert abs(ms / cfg["kernel_ms"] - 1.0) < 0.10, (name, ms, cfg["kernel_ms"])        # different boxes of the pool: +- 4 %
-        assert roof["counters_stale"] is False and roof["counters_source"] == "profiles/r05_final/pmc_summary_%s.csv" % name
+        assert roof["counters_stale"] is False and roof["counters_source"] == "profiles/r06_final/pmc_summary_%s.csv" % name
         assert abs(roof["kernel_ms"] - cfg["kernel_ms"]) < 1e-3
         if name == "C5":
-            assert roof["bound"] == "valu_issue" and roof["unit"] == "Ginst/s" and roof["peak"] == 614.4
+            # round 6: the walk's peak is its own instruction MIX (SQ_INSTS_VALU_* of this config's committed pass) priced with the issue
+            # cost MEASURED per class (profiles/r06_valu/valu_issue_clock.json) -- recomputed here from the two committed files
+            assert roof["bound"] == "valu_issue" and roof["unit"] == "Ginst/s"
             valu = _per_dispatch("pmc_summary_C5.csv", needle, "SQ_INSTS_VALU")
             assert abs(valu / roof["valu_insts_per_launch"] - 1.0) < 1e-6
             assert abs(valu / (roof["kernel_ms"] * 1e-3) / 1e9 / roof["achieved"] - 1.0) < 1e-3
-            assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0.6 < roof["frac"] < 0.8
+            table = json.load(open(os.path.join(REPO, "profiles", "r06_valu", "valu_issue_clock.json")))["classes"]
+            cost = lambda cls: table[cls]["simd_cycles_per_inst_saturated"]
+            assert 2.5 < cost("v_mov_b32") < cost("v_fma_f32") < 3.0 and 4.0 < cost("v_cmp_lt_f32+v_cndmask_b32") < cost("v_min3_f32") < 4.6      # no class at the guide's 2
+            priced = {"ADD_F32": "v_fma_f32", "MUL_F32": "v_fma_f32", "FMA_F32": "v_fma_f32", "ADD_F64": "v_add_f64", "MUL_F64": "v_fma_f64", "FMA_F64": "v_fma_f64",
+                      "INT32": "v_add_u32/v_lshlrev/v_and", "INT64": "v_add_u32/v_lshlrev/v_and", "CVT": "v_cvt_f32_f64/v_cvt_f64_f32",
+                      "TRANS_F32": "v_cvt_f32_f64/v_cvt_f64_f32", "TRANS_F64": "v_cvt_f32_f64/v_cvt_f64_f32"}
+            cycles, classified = 0.0, 0.0
+            for cname, cls in priced.items():
+                n = _per_dispatch("pmc_summary_C5.csv", needle, "SQ_INSTS_VALU_" + cname)
+                cycles += n * cost(cls)
+                classified += n
+            other = valu - _per_dispatch("pmc_summary_C5.csv", needle, "SQ_INSTS_MFMA") - classified
+            assert 0.55 < other / valu < 0.7                                                       # compares, selects, min / max, moves: two thirds of the walk
+            cycles += other * cost("v_cmp_lt_f32+v_cndmask_b32")
+            floor_ms = cycles / 1024 / 2.4e9 * 1e3
+            assert abs(floor_ms / roof["issue_floor_ms"] - 1.0) < 1e-3 and abs(floor_ms / roof["kernel_ms"] / roof["frac"] - 1.0) < 1e-3
+            assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 2e-3 and 0.6 < roof["frac"] < 0.75
+            assert abs(sum(v["share_of_issue_cycles"] for v in roof["issue_cycles_by_class"]["classes"].values()) - 1.0) < 1e-3
             assert 0.02 < roof["mfma_frac"] < 0.06 and cfg["pruned_walk"]["tile_fraction"] < 0.003
         else:
             assert roof["bound"] == "mfma" and roof["peak"] == 2500.0
@@ -87,6 +107,9 @@ def test_every_config_carries_a_roofline_that_its_own_counter_pass_reproduces():
     ms64, _ = _avg_ms("kernel_stats_fp64.csv", "knn_mfma_kernel<7, 12>")
     frac64 = 1e12 * 56.0 / (ms64 * 1e-3) / 78.6e12
     assert abs(frac64 / allc["fp64_mode"]["roofline"]["frac"] - 1.0) < 0.04 and 0.7 < frac64 < 0.85
+    # round 6: a counter pass of the fp64-mode kernel too (executed flops from SQ_INSTS_VALU_MFMA_MOPS_F64 or the MFMA count x 2 x 16 x 16 x 4)
+    mf = _per_dispatch("pmc_summary_fp64.csv", "knn_mfma_kernel<7, 12>", "SQ_INSTS_MFMA")
+    assert abs(mf * 2048.0 / (1e12 * 56.0) - 1.0) < 0.02                    # v_mfma_f64_16x16x4_f64 = 2048 flop: padded rows and queries, all pairs
     # ln E of every config against the reference's own output, in the same line
     for name in ("C2", "C4", "C5"):
         assert allc["configs"][name]["max_abs_dlnE_vs_reference"] < 1e-9
@@ -136,7 +159,7 @@ def test_pairs_once_emulation_is_labelled_adds_up_and_beats_the_default_partitio
 def test_c5_preparation_in_the_kernel_trace():
     """seven sorts instead of thirteen (key kernel calls of one traced call), the bottom levels, chunk lists
     and merge at their new durations; everything outside the walk under 9 ms"""
-    rows = list(csv.DictReader(open(os.path.join(PROF, "kernel_stats_C5.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(PROF5, "kernel_stats_C5.csv"))))
     calls = max(int(r["Calls"]) for r in rows if "knn_f16_kernelILi1ELi12ELb1E" in r["Name"])        # searches in the traced process
     get = lambda needle: [r for r in rows if needle in r["Name"]]
     assert sum(int(r["Calls"]) for r in get("kd_key_kernel")) == 7 * calls
@@ -144,7 +167,7 @@ def test_c5_preparation_in_the_kernel_trace():
     assert float(get("chunk_list_kernel")[0]["AverageNs"]) < 0.9e6         # 1.33 ms
     # (this trace is of tools/run_configs.py, which also asks for the distance matrix: the merge then writes 720 MB of rows in the
     #  caller's order; the fused call bench.py times is traced in kernel_stats_C5_fused_call.csv -- tools/c5_ab.sh)
-    fused = list(csv.DictReader(open(os.path.join(PROF, "kernel_stats_C5_fused_call.csv"))))
+    fused = list(csv.DictReader(open(os.path.join(PROF5, "kernel_stats_C5_fused_call.csv"))))
     assert float([r for r in fused if "merge_lists_kernel<false, true, false>" in r["Name"]][0]["AverageNs"]) < 1.0e6        # round 4: 2.05 ms
     fcalls = max(int(r["Calls"]) for r in fused if "knn_f16_kernelILi1ELi12ELb1E" in r["Name"])
     walk = sum(float(r["TotalDurationNs"]) for r in fused if "knn_f16_kernelILi1ELi12ELb1E" in r["Name"])
