@@ -508,6 +508,34 @@ def time_config(ctx, cfg, steps, warmup, mode=0, nsample=0, orc=None):
         res["sampled_rows"] = len(rows)
         res["max_rel_dist_err_sampled_rows_vs_exact_cpu_search"] = float(np.max(np.abs(got - od) / od))
         del dd
+    if not dist_on and K <= 32 and d <= 128:
+        # what the default run-time certificate costs a host-pointer call of this shape (round 6: it is ON by default behind the fp16
+        # filter): the step once more WITH the distances written out (what the check reads) + the re-check of 256 rows by an exact fp64
+        # scan (mce_verify_knn_f64_dev), against the plain step -- resident data, after the timed region, best of 3
+        try:
+            dd = torch.zeros((nq, K), dtype=torch.float64, device=dev)
+            vws = _capi.load().mce_verify_workspace_bytes(256, K)
+            vbuf = torch.empty(max(int(vws), 1), dtype=torch.uint8, device=dev)
+            vres = torch.zeros(2, dtype=torch.int32, device=dev)
+            best = []
+            for with_check in (False, True):
+                ts = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    step(dd.data_ptr() if with_check else 0)
+                    if with_check:
+                        _capi.check(_capi.load().mce_verify_knn_f64_dev(Xd.data_ptr(), nq, Yd.data_ptr(), nr, d, K, 2 if auto else 0, 0, dd.data_ptr(), K, 256,
+                                                                         12345, vres.data_ptr(), vbuf.data_ptr(), int(vws), st))
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t1) * 1e3)
+                best.append(min(ts))
+            failed_rows = int(vres.cpu()[1])
+            res["certificate"] = dict(rows=256, overhead_ms=round(best[1] - best[0], 3), step_without_ms=round(best[0], 3), rows_failed=failed_rows,
+                                      note="default of the host-pointer entry points behind the fp16 filter (mce_options.verify = -1); MCE_VERIFY=0 turns it off")
+            del dd, vbuf, vres
+        except Exception as exc:          # (never lose the line over a diagnostic)
+            res["certificate"] = dict(error="%s: %s" % (type(exc).__name__, exc))
     pstats = None
     if "pruned" in kdesc:            # (device counters in the workspace: read before it is freed)
         try:
@@ -812,7 +840,7 @@ def main():
                    ranks_seen=(dist.get_world_size() if dist_on else 1), backend=(dist.get_backend() if dist_on else None),
                    per_rank=head.get("per_rank"),
                    max_abs_dlnE_vs_reference=dlnE, lnE=[round(float(x), 10) for x in lnE],
-                   roofline=roof, cpu_baseline=cpu, evidence_call_from_host=e2e, configs=extras, fp64_mode=fp64_mode)
+                   roofline=roof, cpu_baseline=cpu, evidence_call_from_host=e2e, certificate=head.get("certificate"), configs=extras, fp64_mode=fp64_mode)
         if pairs_once is not None:
             out["pairs_once"] = pairs_once
         print(json.dumps(out), flush=True)
