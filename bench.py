@@ -450,8 +450,22 @@ def time_config(ctx, cfg, steps, warmup, mode=0, nsample=0, orc=None):
     out = torch.zeros(kmax, dtype=torch.float64, device=dev)
     st = torch.cuda.current_stream().cuda_stream
 
+    # a pruned search over several ranks (C5): the k-d preparation is DISTRIBUTED (round 6) -- this rank's part of the sorts, one all-reduce
+    # of the permutation, the search on the shared order; agreed once, outside the timed region (MCE_BENCH_DIST_PREP=0: every rank repeats
+    # the whole preparation, as before)
+    dist_prep = False
+    if dist_on and auto and world >= 2 and os.environ.get("MCE_BENCH_DIST_PREP", "1") != "0":
+        from mcevidence_amd import parallel
+        dist_prep = parallel.agree_all(_capi.prune_part_applies(nr, d, kmax, world))
+
     def step(dist_out=0):
-        if dist_on and auto:
+        if dist_on and auto and dist_prep:
+            off, cnt = _capi.prune_part_prepare_dev(Xd.data_ptr(), nr, d, kmax, rank, world, ws.data_ptr(), wsb, st)
+            if cnt <= 0:
+                raise RuntimeError("bench.py: the distributed k-d preparation was agreed on but does not apply on rank %d" % rank)
+            parallel.allreduce_permutation(ws, off, cnt)
+            _capi.knn_dotp_part_prepared_dev(Xd.data_ptr(), nr, d, kmax, rank, world, w.data_ptr(), fs.data_ptr(), out.data_ptr(), ws.data_ptr(), wsb, st)
+        elif dist_on and auto:
             _capi.knn_dotp_part_dev(Xd.data_ptr(), nr, d, kmax, rank, world, w.data_ptr(), fs.data_ptr(), out.data_ptr(), ws.data_ptr(), wsb, st)
         else:
             _capi.knn_dotp_dev(Xd.data_ptr(), nq, Yd.data_ptr(), nr, d, kmax, k0, 0, w.data_ptr(), fs.data_ptr(), out.data_ptr(),
@@ -486,8 +500,11 @@ def time_config(ctx, cfg, steps, warmup, mode=0, nsample=0, orc=None):
                search_ms=round(stats["search_ms"], 3), queries_per_s=round(S / (ms * 1e-3), 1), kernel=kdesc, ranks=world)
     if per_rank:
         res["per_rank"] = per_rank
-        res["partition"] = ("library partition of the auto-evidence search (mce_knn_dotp_part_f64_dev), one all-reduce" if auto
+        res["partition"] = (("library partition of the auto-evidence search, k-d preparation distributed over the ranks (mce_prune_part_prepare_dev, all-reduce of "
+                             "the permutation, mce_knn_dotp_part_prepared_f64_dev), one all-reduce of the sums" if dist_prep else
+                             "library partition of the auto-evidence search (mce_knn_dotp_part_f64_dev), one all-reduce") if auto
                             else "contiguous query rows of s1 against the replicated s2, one all-reduce")
+        res["distributed_kd_preparation"] = bool(dist_prep)
     if stats["flops_main"] > 0 and stats["kernel_ms"] > 0:
         res["executed_tflops"] = round(stats["flops_main"] / (stats["kernel_ms"] * 1e-3) / 1e12, 1)
     lnE = lnE_from_dotp(dotp, cfg)

@@ -130,6 +130,23 @@ int mce_evidence_feed_part_f64(const double *S1, int64_t n1, int64_t ld1, const 
                                int32_t d, int32_t cov_mode, int32_t kmax, const double *w, const double *fs,
                                int32_t part, int32_t nparts, double *dotp_part, double *jacobian, double *eigenvalues,
                                uint64_t *checksum, int32_t device);
+/* Distributed k-d preparation of the pruned walk (round 6; reference: the `fit` of MCEvidence.py:1100-1101, which every rank of a
+ * multi-GPU run repeated in full).  Rank `part` of nparts = 2, 4, 8, ... calls mce_prune_part_prepare_dev on the workspace it will
+ * search with: the sorts that settle the tree's top log2(nparts) levels run over all rows, everything below them over the rank's
+ * own subtree only.  On return *perm_count int32 values at ws + *perm_offset hold the final k-d order inside the rank's range and
+ * ZEROS elsewhere: one all-reduce(SUM) of that array over the ranks (the host's: torch.distributed over RCCL) gives every rank the
+ * whole permutation -- bit for bit the single-GPU one -- and mce_knn_dotp_part_prepared_f64_dev then runs the rank's share of the
+ * search like mce_knn_dotp_part_f64_dev, minus the sorts.  *perm_count = 0: nothing to exchange (the shape does not take the
+ * pruned walk, nparts is not a power of two, the tree is too shallow) -- call mce_knn_dotp_part_f64_dev as before. */
+int mce_prune_part_prepare_dev(const double *dY, int64_t nr, int32_t d, int32_t kmax, int32_t part, int32_t nparts,
+                               size_t *perm_offset, int64_t *perm_count, void *ws, size_t ws_bytes, void *stream);
+/* 1: an auto-evidence search of this shape on nparts ranks takes the pruned walk AND its preparation can be distributed (plan only,
+ * no device work): what a host asks before it chooses the three-step route */
+int32_t mce_prune_part_applies(int64_t nr, int32_t d, int32_t kmax, int32_t nparts);
+int mce_knn_dotp_part_prepared_f64_dev(const double *dY, int64_t nr, int32_t d, int32_t kmax, int32_t part, int32_t nparts,
+                                       const double *d_w, const double *d_fs, double *d_dotp, void *ws, size_t ws_bytes,
+                                       void *stream);
+
 /* The same with the inputs ON THE DEVICE already (round 6; SURVEY.md 5: "one H2D + broadcast over xGMI instead of 8 PCIe
  * copies"): dS1 / dS2 / d_w / d_fs are device pointers on `device` (rows ld1 / ld2 doubles apart), produced on a stream the
  * caller has synchronised -- parallel.py uploads 1/W of the chain per rank and all_gathers it over RCCL.  Everything else

@@ -77,6 +77,10 @@ SIGNATURES = {
                                                     _c.POINTER(_c.c_uint64), _c.c_int32]),
     "mce_knn_dotp_part_f64_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _c.c_size_t, _P]),
     "mce_knn_dotp_part_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_int32]),
+    "mce_knn_dotp_part_prepared_f64_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _c.c_size_t, _P]),
+    "mce_prune_part_applies": (_c.c_int32, [_c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32]),
+    "mce_prune_part_prepare_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_int64), _P,
+                                              _c.c_size_t, _P]),
     "mce_pairs_once_blocks": (_c.c_int32, [_c.c_int64, _c.c_int32, _c.c_int32]),
     "mce_pairs_once_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32]),
     "mce_pairs_once_prepare_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_int64), _P,
@@ -579,6 +583,24 @@ def knn_dev(dX, nq, dY, nr, d, K, self_mode, self_offset, d_dist, d_idx, ws, ws_
 
 def dotp_dev(d_dist, nq, ld, k0, kmax, d, d_w, d_fs, d_dotp, ws, ws_bytes, stream=0):
     check(load().mce_dotp_f64_dev(d_dist, nq, ld, k0, kmax, d, d_w, d_fs, d_dotp, ws, ws_bytes, stream or None))
+
+
+def prune_part_applies(nr, d, kmax, nparts):
+    """Does an auto-evidence search of this shape on ``nparts`` ranks take the pruned walk with a preparation that can be distributed?"""
+    return bool(load().mce_prune_part_applies(int(nr), int(d), int(kmax), int(nparts)))
+
+
+def prune_part_prepare_dev(dY, nr, d, kmax, part, nparts, ws, ws_bytes, stream=0):
+    """This rank's part of the DISTRIBUTED k-d preparation of a pruned auto-evidence search (``mce_prune_part_prepare_dev``): returns
+    (byte offset into ``ws``, count) of the int32 permutation array -- final inside the rank's range, zeros elsewhere: all-reduce(SUM)
+    it over the ranks, then ``knn_dotp_part_prepared_dev`` -- or (0, 0) when there is nothing to exchange (call ``knn_dotp_part_dev``)."""
+    off, cnt = _c.c_size_t(0), _c.c_int64(0)
+    check(load().mce_prune_part_prepare_dev(dY, nr, d, kmax, part, nparts, _c.byref(off), _c.byref(cnt), ws, ws_bytes, stream or None))
+    return int(off.value), int(cnt.value)
+
+
+def knn_dotp_part_prepared_dev(dY, nr, d, kmax, part, nparts, d_w, d_fs, d_dotp, ws, ws_bytes, stream=0):
+    check(load().mce_knn_dotp_part_prepared_f64_dev(dY, nr, d, kmax, part, nparts, d_w, d_fs, d_dotp, ws, ws_bytes, stream or None))
 
 
 def knn_dotp_part_dev(dY, nr, d, kmax, part, nparts, d_w, d_fs, d_dotp, ws, ws_bytes, stream=0):

@@ -61,6 +61,8 @@ struct Plan {
     bool twopass = false;                     // fp16 filter, 16 < K <= 32: two sweeps of 16-entry lists (knn_f16.hpp, LOWER)
     bool wide_ok = false;                     // the exhaustive sweep may run four query tiles per wave (knn_f16.hpp, QTT = 4): nqblk is even
     bool prune = false;                       // fp16 filter walking k-d ordered chunk lists (prune.hpp)
+    bool kd_ready = false;                    // ... whose k-d order is in the workspace already (mce_prune_part_prepare_dev on every rank + the all-reduce
+                                              // of the permutation: mce_knn_dotp_part_prepared_f64_dev)
     int part = 0, nparts = 1;                 // pruned walk over the waves part, part + nparts, ... of the dispatch order only; symmetric sweep: the
                                               // contiguous range of sorted blocks [sym_qb_lo, sym_qb_hi) (one rank's share)
     int sym_qb_lo = 0, sym_qb_hi = 0;         // set by run_search when the symmetric sweep ran

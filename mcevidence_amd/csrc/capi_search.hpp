@@ -165,7 +165,7 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
         if (p.prune) {
             const bool same_set = (dX == dY && nq == nr);
             MCE_HIP(mce::prune_prepare(dX, nq, dY, nr, (int)d, same_set, mce::f16_qpb(p.KCAP), p.CT * 32, p.nq_pad, p.nqblk, p.nrow_pad,
-                                       p.nchunk, ws + p.off_prune, p.pl, st, po));
+                                       p.nchunk, ws + p.off_prune, p.pl, st, po, p.kd_ready && same_set));
             sX = po.Xs;
             sY = po.Ys;
             separate_queries = separate_queries && !same_set;

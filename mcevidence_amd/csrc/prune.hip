@@ -40,10 +40,11 @@ int top_tree_levels(int64_t n_units)
 template <class Key>
 __global__ __launch_bounds__(kThreads) void kd_key_kernel(const int* __restrict__ perm_in, int64_t n, int64_t n_pad, int unit_rows,
                                                           int n_units, int top_levels, int level, const float* __restrict__ Cf, int d, int dim,
-                                                          int cbits, Key* __restrict__ keys, int* __restrict__ vals)
+                                                          int cbits, Key* __restrict__ keys, int* __restrict__ vals, int64_t pos0 = 0, int64_t pos1 = -1)
 {
-    const int64_t pos = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (pos >= n_pad) return;
+    // (pos0, pos1: the positions [pos0, pos1) only -- one rank's subtree of a distributed preparation; default: all of them)
+    const int64_t pos = pos0 + (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (pos >= (pos1 < 0 ? n_pad : pos1)) return;
     const int row = perm_in ? perm_in[pos] : (pos < n ? (int)pos : -1);
     // ALIGNED tree: the top levels split whole groups of kAlign units (2048 rows) between the children, the
     // last log2(kAlign) levels halve a group bit by bit -- so every aligned run of 2, 16 or 64 units (a
@@ -96,12 +97,13 @@ constexpr int kGroupRows = kAlign * kPruneTileRows;      // 2048
 // SLOWER, 2.0 ms: the kernel is bound by the trips through LDS and the barriers, not by those loads.)
 constexpr int kBottomSlots = kGroupRows + kGroupRows / 32;          // one slot of padding per 32: eight slots a thread apart stay off one bank
 __device__ __forceinline__ int bslot(int i) { return i + (i >> 5); }
-__global__ __launch_bounds__(kThreads) void kd_bottom_kernel(int* __restrict__ perm, int64_t n, int64_t n_pad, int top_levels, const float* __restrict__ Cf, int d)
+__global__ __launch_bounds__(kThreads) void kd_bottom_kernel(int* __restrict__ perm, int64_t n, int64_t n_pad, int top_levels, const float* __restrict__ Cf, int d,
+                                                             int64_t group0 = 0)
 {
     static_assert(kGroupRows == 8 * kThreads, "eight slots per thread");
     __shared__ unsigned long long key[kBottomSlots];
     __shared__ int val[2][kGroupRows];
-    const int64_t base = (int64_t)blockIdx.x * kGroupRows;
+    const int64_t base = (group0 + (int64_t)blockIdx.x) * kGroupRows;
     const int m = (int)(n_pad - base < kGroupRows ? n_pad - base : kGroupRows);
     for (int i = threadIdx.x; i < kGroupRows; i += kThreads) val[0][i] = i < m ? perm[base + i] : -2;
     __syncthreads();
@@ -432,9 +434,34 @@ hipError_t sort_pairs(void* tmp, size_t tmp_bytes, const Key* keys_in, Key* keys
 size_t sort_tmp_bytes(int64_t n) { return std::max(sort_pairs_tmp_bytes<unsigned long long>(n, 64u), sort_pairs_tmp_bytes<unsigned>(n, 32u)); }
 
 // k-d order of P[n, d] in units of unit_rows; final permutation in `perm` ([n_pad])
-hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_rows, int n_units, int* perm, unsigned long long* keys_a,
-                   unsigned long long* keys_b, int* vals_b, float* Cf, void* tmp, size_t tmp_bytes, hipStream_t st)
+// the node `part` of the 2^lv nodes at level lv of the aligned tree, as a range of groups (kd_key_kernel's bisection)
+void kd_node_groups(int64_t n_units, int lv, int part, int64_t& glo, int64_t& ghi)
 {
+    glo = 0;
+    ghi = (n_units + kAlign - 1) / kAlign;
+    for (int l = 0; l < lv; ++l) {
+        const int bit = (part >> (lv - 1 - l)) & 1;
+        if (ghi - glo > 1) {
+            const int64_t mid = (glo + ghi) >> 1;
+            if (bit) glo = mid; else ghi = mid;
+        } else if (bit) {
+            glo = ghi;            // (a node that did not split: its second child is empty)
+        }
+    }
+}
+
+// part / nparts (round 6, a DISTRIBUTED preparation): with nparts = 2^lv > 1 ranks, rank `part` finishes only ITS subtree -- node
+// `part` of level lv.  The sorts that settle the levels above lv run over all rows on every rank (they decide which rows the
+// subtree holds); every later sort, and the bottom levels, only move rows INSIDE a node of level lv, so a rank runs them over its
+// own position range [*seg_lo, *seg_hi) alone -- the same keys, the same stable radix sort: the range comes out exactly as the
+// full sort would leave it, and the ranks' ranges put together (one all-reduce of the permutation, zeros outside the own range)
+// ARE the single-GPU order.  *seg_lo = 0, *seg_hi = n_pad: nothing was left out (one rank, or a tree too shallow to split).
+hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_rows, int n_units, int* perm, unsigned long long* keys_a,
+                   unsigned long long* keys_b, int* vals_b, float* Cf, void* tmp, size_t tmp_bytes, hipStream_t st, int part = 0, int nparts = 1,
+                   int64_t* seg_lo = nullptr, int64_t* seg_hi = nullptr)
+{
+    if (seg_lo) *seg_lo = 0;
+    if (seg_hi) *seg_hi = n_pad;
     hipLaunchKernelGGL(coords_f32_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, P, n, d, Cf);
     {
         const hipError_t e0 = hipGetLastError();
@@ -477,6 +504,21 @@ hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_ro
             for (int j = 0; j < d; ++j) { sdim[nsort] = j; level_of[nsort + 1] = level_of[nsort] + rounds; ++nsort; }
         for (int l = rounds * d; l < Lradix; ++l) { sdim[nsort] = l % d; level_of[nsort + 1] = level_of[nsort] + 1; ++nsort; }
     }
+    // distributed: which node is this rank's, and from which sort on the rows stay inside it
+    int lvW = 0;
+    while ((1 << lvW) < nparts) ++lvW;
+    const bool ranged = nparts > 1 && (1 << lvW) == nparts && bottom_in_lds && lvW <= Ltop && seg_lo && seg_hi;
+    int64_t r_lo = 0, r_hi = n_pad, g_lo = 0, g_hi = (n_pad + kGroupRows - 1) / kGroupRows;
+    int j0 = nsort;                 // first sort that runs on the own range only
+    if (ranged) {
+        kd_node_groups(n_units, lvW, part, g_lo, g_hi);
+        r_lo = std::min<int64_t>(g_lo * kGroupRows, n_pad);
+        r_hi = std::min<int64_t>(g_hi * kGroupRows, n_pad);
+        for (int j = nsort; j >= 0; --j)
+            if (level_of[j] >= lvW) j0 = j;
+        *seg_lo = r_lo;
+        *seg_hi = r_hi;
+    }
     const int idbits = nsort > 0 ? level_of[nsort - 1] : 0;        // node id bits of the last sort
     // 32-bit keys where the node id leaves at least kMinCoordBits32 coordinate bits AND no dimension is split more than four
     // times by these levels (a dimension split often needs its quantiles placed finely: d = 1, 2 keep 64 bits)
@@ -484,27 +526,35 @@ hipError_t kd_sort(const double* P, int64_t n, int64_t n_pad, int d, int unit_ro
     const bool keys32 = Lradix > 0 && cb32 >= kMinCoordBits32 && (Lradix + d - 1) / d <= 4;
     for (int j = 0; j < nsort; ++j) {
         const int level = level_of[j];
+        // (sorts from j0 on: this rank's position range only -- an empty range has nothing to do)
+        const bool own = ranged && j >= j0;
+        const int64_t p0 = own ? r_lo : 0, p1 = own ? r_hi : n_pad;
+        if (p1 <= p0) continue;
+        const unsigned kb_blocks = (unsigned)((p1 - p0 + kThreads - 1) / kThreads);
         hipError_t e;
         if (keys32) {
             unsigned* ka = reinterpret_cast<unsigned*>(keys_a);
             unsigned* kb = reinterpret_cast<unsigned*>(keys_b);
-            hipLaunchKernelGGL(kd_key_kernel<unsigned>, dim3(blocks), dim3(kThreads), 0, st, j == 0 ? (const int*)nullptr : perm, n, n_pad, unit_rows,
-                               n_units, Ltop, level, Cf, d, sdim[j], cb32, ka, vals_b);
+            hipLaunchKernelGGL(kd_key_kernel<unsigned>, dim3(kb_blocks), dim3(kThreads), 0, st, j == 0 ? (const int*)nullptr : perm, n, n_pad, unit_rows,
+                               n_units, Ltop, level, Cf, d, sdim[j], cb32, ka, vals_b, p0, p1);
             if ((e = hipGetLastError()) != hipSuccess) return e;
-            e = sort_pairs(tmp, tmp_bytes, (const unsigned*)ka, kb, (const int*)vals_b, perm, n_pad, (unsigned)(cb32 + level), st);
+            e = sort_pairs(tmp, tmp_bytes, (const unsigned*)ka + p0, kb + p0, (const int*)vals_b + p0, perm + p0, p1 - p0, (unsigned)(cb32 + level), st);
         } else {
-            hipLaunchKernelGGL(kd_key_kernel<unsigned long long>, dim3(blocks), dim3(kThreads), 0, st, j == 0 ? (const int*)nullptr : perm, n, n_pad, unit_rows,
-                               n_units, Ltop, level, Cf, d, sdim[j], kCoordBits, keys_a, vals_b);
+            hipLaunchKernelGGL(kd_key_kernel<unsigned long long>, dim3(kb_blocks), dim3(kThreads), 0, st, j == 0 ? (const int*)nullptr : perm, n, n_pad, unit_rows,
+                               n_units, Ltop, level, Cf, d, sdim[j], kCoordBits, keys_a, vals_b, p0, p1);
             if ((e = hipGetLastError()) != hipSuccess) return e;
-            e = sort_pairs(tmp, tmp_bytes, (const unsigned long long*)keys_a, keys_b, (const int*)vals_b, perm, n_pad, (unsigned)(kCoordBits + level), st);
+            e = sort_pairs(tmp, tmp_bytes, (const unsigned long long*)keys_a + p0, keys_b + p0, (const int*)vals_b + p0, perm + p0, p1 - p0, (unsigned)(kCoordBits + level), st);
         }
         if (e != hipSuccess) return e;
     }
     // ... the last kAlignLevels stay inside a group: one pass through LDS (10 M rows: 6 x 0.72 ms of sorts -> one kernel)
     if (bottom_in_lds && L > Ltop) {
-        hipLaunchKernelGGL(kd_bottom_kernel, dim3((unsigned)((n_pad + kGroupRows - 1) / kGroupRows)), dim3(kThreads), 0, st, perm, n, n_pad, Ltop, Cf, d);
-        const hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
+        const int64_t ng = ranged ? std::min<int64_t>(g_hi, (n_pad + kGroupRows - 1) / kGroupRows) - g_lo : (n_pad + kGroupRows - 1) / kGroupRows;
+        if (ng > 0) {
+            hipLaunchKernelGGL(kd_bottom_kernel, dim3((unsigned)ng), dim3(kThreads), 0, st, perm, n, n_pad, Ltop, Cf, d, ranged ? g_lo : (int64_t)0);
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
     }
     return hipSuccess;
 }
@@ -548,9 +598,24 @@ int prune_layout(int64_t nq, int64_t nq_pad, int nqblk, int64_t nr, int64_t nr_p
     return 0;
 }
 
+hipError_t prune_prepare_part(const double* dY, int64_t nr, int d, int64_t nr_pad, char* ws, const PruneLayout& L, int part, int nparts, hipStream_t st,
+                              int64_t& seg_lo, int64_t& seg_hi)
+{
+    int* perm_r = reinterpret_cast<int*>(ws + L.perm_r);
+    const int64_t ntile_r = nr_pad / kPruneTileRows;
+    hipError_t e = kd_sort(dY, nr, nr_pad, d, kPruneTileRows, (int)ntile_r, perm_r, reinterpret_cast<unsigned long long*>(ws + L.keys_a),
+                           reinterpret_cast<unsigned long long*>(ws + L.keys_b), reinterpret_cast<int*>(ws + L.vals_b), reinterpret_cast<float*>(ws + L.cf32),
+                           ws + L.tmp, L.tmp_bytes, st, part, nparts, &seg_lo, &seg_hi);
+    if (e != hipSuccess) return e;
+    // zeros outside the own range: the ranks' permutations ADD up to the whole one (padding rows are -1 inside the range that holds them)
+    if (seg_lo > 0 && (e = zero_async(perm_r, (size_t)seg_lo * sizeof(int), st)) != hipSuccess) return e;
+    if (seg_hi < nr_pad && (e = zero_async(perm_r + seg_hi, (size_t)(nr_pad - seg_hi) * sizeof(int), st)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
 hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t nr, int d, bool same_set, int qpb, int chunk_rows,
                          int64_t nq_pad, int nqblk, int64_t nr_pad, int64_t nchunk, char* ws, const PruneLayout& L, hipStream_t st,
-                         PruneOut& out)
+                         PruneOut& out, bool perm_ready)
 {
     int* perm_r = reinterpret_cast<int*>(ws + L.perm_r);
     int* perm_q = reinterpret_cast<int*>(ws + L.perm_q);
@@ -572,7 +637,8 @@ hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t
     auto blocks_for = [](int64_t n) { return dim3((unsigned)((n + kThreads - 1) / kThreads)); };
 
     // references: k-d order down to single 32-row tiles, reordered copy, tile and chunk boxes
-    hipError_t e = kd_sort(dY, nr, nr_pad, d, kPruneTileRows, (int)ntile_r, perm_r, keys_a, keys_b, vals_b, cf32, tmp, L.tmp_bytes, st);
+    // (perm_ready: the order is in perm_r already -- prune_prepare_part on every rank + the all-reduce of the permutation)
+    hipError_t e = perm_ready ? hipSuccess : kd_sort(dY, nr, nr_pad, d, kPruneTileRows, (int)ntile_r, perm_r, keys_a, keys_b, vals_b, cf32, tmp, L.tmp_bytes, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gather_rows_kernel, blocks_for(nr * d), dim3(kThreads), 0, st, dY, perm_r, nr, d, Ys);
     if ((e = hipGetLastError()) != hipSuccess) return e;

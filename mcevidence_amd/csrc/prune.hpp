@@ -75,9 +75,17 @@ struct PruneOut {
 };
 
 // same_set: the queries ARE the reference rows (same pointer, nq == nr): one ordering serves both
+// perm_ready (round 6): the k-d order of the references is in the workspace already (prune_prepare_part + the ranks' all-reduce)
 hipError_t prune_prepare(const double* dX, int64_t nq, const double* dY, int64_t nr, int d, bool same_set, int qpb,
                          int chunk_rows, int64_t nq_pad, int nqblk, int64_t nr_pad, int64_t nchunk, char* ws,
-                         const PruneLayout& L, hipStream_t st, PruneOut& out);
+                         const PruneLayout& L, hipStream_t st, PruneOut& out, bool perm_ready = false);
+// Distributed k-d preparation (round 6; reference: the `fit` of MCEvidence.py:1100-1101, which every rank of a multi-GPU run repeated
+// in full -- 4.85 ms of sorts of the 7.8 ms a rank of C5 spends preparing): rank `part` of nparts = 2, 4, 8, ... runs the sorts that
+// settle the tree's top log2(nparts) levels over all rows and everything below them over ITS subtree only; perm_r then holds the
+// final order in [seg_lo, seg_hi) and zeros elsewhere -- the ranks' arrays add up to the single-GPU permutation, bit for bit.
+// seg_lo = 0, seg_hi = nr_pad: the whole order was made here (a count that is not a power of two, a tree too shallow).
+hipError_t prune_prepare_part(const double* dY, int64_t nr, int d, int64_t nr_pad, char* ws, const PruneLayout& L, int part, int nparts,
+                              hipStream_t st, int64_t& seg_lo, int64_t& seg_hi);
 
 // ---- symmetric sweep (knn_f16.hpp, "Symmetric sweep"): rows sorted by distance from the mean + its scratch ----
 struct SymLayout {

@@ -80,6 +80,12 @@ class HipBackend(object):
                 got = parallel.pairs_once_feed(S1, ndim, kmax, weight, fs, group, verify=self.verify)
                 if got is not None:
                     return got
+            if S2 is None and dist.get_world_size(group) >= 2 and dev == (torch.cuda.current_device() if torch.cuda.is_available() else -1):
+                # a search that takes the pruned walk (C5's shape): the k-d preparation is distributed over the ranks -- whitening on
+                # the device, this rank's part of the sorts, one all-reduce of the permutation, the search (None: not this shape)
+                got = parallel.pruned_part_feed(S1, ndim, kmax, weight, fs, group, verify=self.verify)
+                if got is not None:
+                    return got
             part, jac, csum, failed = np.zeros(kmax), float("nan"), None, None
             # ONE upload of the chain per node (round 6): every rank uploads 1/W of the rows, an all_gather over RCCL hands
             # everybody the whole set; the ranks' inputs are compared through fingerprints of their HOST copies, computed on a

@@ -271,6 +271,119 @@ def symmetric_partition_rows(Y, world, rank, block=512):
     return order[lo * block: min(hi * block, n)]
 
 
+def allreduce_permutation(ws, off, cnt, group=None):
+    """The ONE extra collective of the distributed k-d preparation: all-reduce(SUM) of the int32 permutation array inside the
+    workspace tensor ``ws`` (uint8, on the device) -- every rank holds the final order in its own range and zeros elsewhere
+    (``mce_prune_part_prepare_dev``), so the sum is the whole permutation on every rank.  RCCL reduces the device view in place;
+    any other backend goes through the host."""
+    import torch
+    import torch.distributed as dist
+    group = _GROUP if group is None else group
+    view = ws[off:off + 4 * cnt].view(torch.int32)
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+    else:
+        host = view.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        view.copy_(host)
+
+
+def pruned_part_knn_dotp(Yd, wd, fd, kmax, group=None, ws=None):
+    """One rank's share of a PRUNED auto-evidence search with the k-d preparation distributed over the ranks (round 6): this rank's
+    part of the sorts (``mce_prune_part_prepare_dev``), one all-reduce of the permutation, the search on the shared order
+    (``mce_knn_dotp_part_prepared_f64_dev``).  ``Yd`` [n, d], ``wd``, ``fd``: float64 device tensors (the replicated set).  Returns the
+    partial sums as a device tensor [kmax] -- still to be all-reduced by the caller -- or None when the route does not apply on EVERY
+    rank (agreed by one all-reduce(MIN): the caller takes ``mce_knn_dotp_part_f64_dev``).  Collective."""
+    import torch
+    import torch.distributed as dist
+    from . import _capi
+    group = _GROUP if group is None else group
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n, d = int(Yd.shape[0]), int(Yd.shape[1])
+    dev = Yd.device
+    ok, off, cnt = False, 0, 0
+    st = torch.cuda.current_stream().cuda_stream
+    try:
+        if _capi.prune_part_applies(n, d, kmax, world):
+            if ws is None:
+                wsb = _capi.knn_workspace_bytes(n, n, d, kmax - 1) + _capi.dotp_workspace_bytes(n, kmax)
+                ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            off, cnt = _capi.prune_part_prepare_dev(Yd.data_ptr(), n, d, kmax, rank, world, ws.data_ptr(), int(ws.numel()), st)
+            ok = cnt > 0
+    except Exception:
+        ok = False
+    if not agree_all(ok, group):
+        return None
+    allreduce_permutation(ws, off, cnt, group)
+    out = torch.zeros(int(kmax), dtype=torch.float64, device=dev)
+    _capi.knn_dotp_part_prepared_dev(Yd.data_ptr(), n, d, kmax, rank, world, wd.data_ptr(), fd.data_ptr(), out.data_ptr(), ws.data_ptr(), int(ws.numel()), st)
+    return out
+
+
+def pruned_part_feed(S1, ndim, kmax, weight, fs, group=None, verify=True):
+    """``MCEvidence.evidence()`` under a process group for an auto-evidence search that takes the pruned walk (C5's shape), with the
+    k-d preparation DISTRIBUTED: the chain reaches every device (one upload per node when enabled), is whitened there
+    (``mce_evidence_feed_whiten[_dev]_f64``), then ``pruned_part_knn_dotp``; the usual all-reduce of the sums ends the call.  Returns
+    (dotp, J), or None when the route does not apply (decided from the shape alone, the same on every rank; the caller falls back to
+    the part feed)."""
+    import torch
+    import torch.distributed as dist
+    from . import _capi
+    group = _GROUP if group is None else group
+    world = dist.get_world_size(group)
+    n = int(np.asarray(S1).shape[0])
+    applies = False
+    try:
+        applies = world >= 2 and _capi.prune_part_applies(n, ndim, kmax, world)
+    except Exception:
+        applies = False
+    if not agree_all(applies, group):
+        return None
+    dev = torch.device("cuda", torch.cuda.current_device())
+    gathered, hostsum = None, None
+    if node_upload_enabled(group):
+        hostsum = _HostFingerprint(S1, None, ndim, weight, fs) if verify else None
+        gathered = gather_chain_on_device(S1, None, ndim, weight, fs, group)
+    failed, part, jac, csum = None, None, float("nan"), None
+    Xd = wd = fd = None
+    try:
+        Xd = torch.empty((n, ndim), dtype=torch.float64, device=dev)
+        wd = torch.empty(n, dtype=torch.float64, device=dev)
+        fd = torch.empty(n, dtype=torch.float64, device=dev)
+        if gathered is not None:
+            Sg, wg, fg = gathered
+            jac, _, _ = _capi.evidence_feed_whiten_dev(Sg.data_ptr(), n, ndim, ndim, kmax, wg.data_ptr(), fg.data_ptr(), Xd.data_ptr(), wd.data_ptr(), fd.data_ptr(),
+                                                       device=dev.index, want_checksum=False)
+            csum = hostsum.value() if hostsum is not None else None
+            del Sg, wg, fg, gathered
+        else:
+            jac, _, csum = _capi.evidence_feed_whiten(S1, ndim, kmax, weight, fs, Xd.data_ptr(), wd.data_ptr(), fd.data_ptr(), device=dev.index, want_checksum=verify)
+    except Exception as exc:
+        failed = exc
+    # (a rank whose whitening failed still takes part in the agreement inside pruned_part_knn_dotp -- with "not ok" -- so that nobody
+    #  is left in the permutation's all-reduce; everybody then falls through to the last collective, which carries the failure flag)
+    out = None
+    try:
+        if failed is None:
+            out = pruned_part_knn_dotp(Xd, wd, fd, kmax, group)
+        else:
+            agree_all(False, group)
+    except Exception as exc:
+        failed = exc
+    if failed is None and out is None:
+        # not everybody could take the distributed preparation: this rank's share with its own (full) preparation
+        try:
+            wsb = _capi.knn_workspace_bytes(n, n, ndim, kmax - 1) + _capi.dotp_workspace_bytes(n, kmax)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            out = torch.zeros(int(kmax), dtype=torch.float64, device=dev)
+            _capi.knn_dotp_part_dev(Xd.data_ptr(), n, ndim, kmax, dist.get_rank(group), world, wd.data_ptr(), fd.data_ptr(), out.data_ptr(), ws.data_ptr(), wsb,
+                                    torch.cuda.current_stream().cuda_stream)
+        except Exception as exc:
+            failed = exc
+    part = np.zeros(int(kmax)) if failed is not None else out.cpu().numpy()
+    return feed_part_reduce(part, csum, group, failed=failed), jac
+
+
 def pairs_once_enabled():
     """``MCE_PAIRS_ONCE=1``: auto evidence of a set large enough for the symmetric sweep takes the all-pairs-once partition
     (``pairs_once_knn_dotp``) instead of the exchange-free one."""

@@ -1617,3 +1617,130 @@ def test_deep_filter_behind_the_class_and_the_fused_sums(deep_capi):
     dp, dd = _capi.knn_dotp(X, None, w, fs, 5, 1, return_dist=True)
     full = np.zeros((len(X), 5)); full[:, 1:] = dd
     assert np.allclose(dp[1:], orc.dotp_logdomain(full, w, fs, 80, 1, 5)[1:], rtol=1e-11)
+
+
+# --------------------------------------------------------------------------- distributed k-d preparation of the pruned walk (round 6)
+@pytest.mark.parametrize("n,d,kmax", [(150000, 6, 10), (70001, 3, 5), (260000, 4, 4)])
+def test_distributed_kd_preparation_is_the_single_gpu_order(prune_modes, n, d, kmax):
+    """every rank of a pruned multi-GPU search repeated the whole k-d preparation.  Now rank r of W = 2, 4, 8
+    sorts only ITS subtree below the top log2 W levels (mce_prune_part_prepare_dev); the ranks' permutation arrays -- final inside the
+    own range, zeros outside -- ADD UP to the single-GPU permutation bit for bit, and every rank's share of the search on that shared
+    order (mce_knn_dotp_part_prepared_f64_dev) equals its share with the replicated preparation bit for bit; the shares add up to the
+    one-GPU sums.  The W ranks run one after the other on this box's GPU."""
+    import torch
+    capi = prune_modes
+    capi.set_prune_mode(capi.PRUNE_FORCE)
+    with capi.options(search_mode=capi.MODE_AUTO):
+        rng = np.random.default_rng(n + d)
+        Y = rng.standard_normal((n, d)) @ (np.eye(d) + 0.3 * rng.standard_normal((d, d)))
+        Yd = torch.from_numpy(Y).cuda()
+        w = torch.from_numpy(rng.integers(1, 4, n).astype(np.float64)).cuda()
+        fs = torch.from_numpy(-rng.random(n)).cuda()
+        wsb = capi.knn_workspace_bytes(n, n, d, kmax - 1) + capi.dotp_workspace_bytes(n, kmax)
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        one = torch.zeros(kmax, dtype=torch.float64, device="cuda")
+        capi.knn_dotp_dev(Yd.data_ptr(), n, Yd.data_ptr(), n, d, kmax, 1, 0, w.data_ptr(), fs.data_ptr(), one.data_ptr(), 0, ws.data_ptr(), wsb, 0)
+        torch.cuda.synchronize()
+        assert "pruned" in capi.last_kernel()
+        assert not capi.prune_part_applies(n, d, kmax, 3) and not capi.prune_part_applies(n, d, kmax, 1)        # powers of two only
+        for W in (2, 4, 8):
+            assert capi.prune_part_applies(n, d, kmax, W)
+            # the single-GPU permutation: what the plain call above left in the workspace (same plan, same offset)
+            perms, segs = [], []
+            for r in range(W):
+                off, cnt = capi.prune_part_prepare_dev(Yd.data_ptr(), n, d, kmax, r, W, ws.data_ptr(), wsb, 0)
+                torch.cuda.synchronize()
+                assert cnt > 0 and cnt % 2048 == 0
+                pr = ws[off:off + 4 * cnt].view(torch.int32).clone()
+                nz = torch.nonzero(pr).flatten()
+                segs.append((int(nz.min()), int(nz.max())))
+                perms.append(pr)
+            total = torch.stack(perms).sum(dim=0)
+            for a, b in zip(segs[:-1], segs[1:]):
+                assert a[1] < b[0]                                   # disjoint, ascending ranges: rank r holds subtree r
+            # reference order: the replicated preparation
+            ref = torch.zeros(kmax, dtype=torch.float64, device="cuda")
+            capi.knn_dotp_part_dev(Yd.data_ptr(), n, d, kmax, 0, W, w.data_ptr(), fs.data_ptr(), ref.data_ptr(), ws.data_ptr(), wsb, 0)
+            torch.cuda.synchronize()
+            single = ws[off:off + 4 * cnt].view(torch.int32).clone()
+            assert torch.equal(total, single)                        # bit for bit the single-GPU order
+            assert int((single >= 0).sum()) == n and set(single[single >= 0].cpu().numpy().tolist()) == set(range(n))
+            acc = np.zeros(kmax)
+            for r in range(W):
+                rep = torch.zeros(kmax, dtype=torch.float64, device="cuda")
+                capi.knn_dotp_part_dev(Yd.data_ptr(), n, d, kmax, r, W, w.data_ptr(), fs.data_ptr(), rep.data_ptr(), ws.data_ptr(), wsb, 0)
+                torch.cuda.synchronize()
+                ws[off:off + 4 * cnt].view(torch.int32).copy_(total)            # what the all-reduce hands every rank
+                got = torch.zeros(kmax, dtype=torch.float64, device="cuda")
+                capi.knn_dotp_part_prepared_dev(Yd.data_ptr(), n, d, kmax, r, W, w.data_ptr(), fs.data_ptr(), got.data_ptr(), ws.data_ptr(), wsb, 0)
+                torch.cuda.synchronize()
+                assert torch.equal(got, rep), (W, r)
+                acc += got.cpu().numpy()
+            assert np.allclose(acc[1:], one.cpu().numpy()[1:], rtol=1e-12, atol=0), W
+
+
+def _pruned_class_rank(rank, world, port, q, poison):
+    import os
+    import time
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MCE_NODE_UPLOAD="1")
+    torch.cuda.set_device(0)                                 # one GPU on the test box: both ranks share it
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    logging.disable(logging.CRITICAL)
+    import mcevidence_amd as pkg
+    from mcevidence_amd import _capi
+    from mcevidence_amd.synth import gaussian_chain
+    chain = gaussian_chain(seed=6, n=400000, d=6, cov="corr")
+    if poison == "fail" and rank == 1:
+        boom = lambda *a, **k: (_ for _ in ()).throw(MemoryError("boom on rank 1"))
+        _capi.evidence_feed_whiten = boom
+        _capi.evidence_feed_whiten_dev = boom
+    elif poison and rank == 1:
+        chain = chain.copy()
+        chain[1000, 5] = np.nextafter(chain[1000, 5], 1e9)
+    m = pkg.MCEvidence([chain], kmax=10, verbose=0)
+    try:
+        out = ("ok", m.evidence(), _capi.last_kernel())
+    except (RuntimeError, MemoryError) as e:
+        out = ("raised", str(e), "")
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("poison", [False, True, "fail"])
+def test_class_under_two_ranks_with_the_distributed_kd_preparation(poison):
+    """MCEvidence(...).evidence() of a chain that takes the pruned walk (400 k x 6) under a 2-rank gloo group sharing this box's GPU:
+    one upload per node, whitening on the device, each rank's half of the k-d sorts, the all-reduce of the permutation, the search,
+    the all-reduce of the sums (parallel.pruned_part_feed).  ln E equals the single process's to 1e-12; a rank with one different bit
+    makes both raise; a rank whose whitening fails raises its own error and the other one a RuntimeError -- nobody is left in the
+    permutation's all-reduce."""
+    import socket
+    import torch.multiprocessing as mp
+    import mcevidence_amd as pkg
+    from mcevidence_amd.synth import gaussian_chain
+    if not poison:
+        one = pkg.MCEvidence([gaussian_chain(seed=6, n=400000, d=6, cov="corr")], kmax=10, verbose=0).evidence()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pruned_class_rank, args=(r, 2, port, q, poison)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    if poison == "fail":
+        assert got[0][0] == got[1][0] == "raised" and "boom on rank 1" in got[1][1] and "1 of the 2 ranks" in got[0][1], got
+        return
+    if poison:
+        assert got[0][0] == got[1][0] == "raised" and "different samples" in got[0][1]
+        return
+    assert got[0][0] == got[1][0] == "ok" and np.array_equal(got[0][1], got[1][1])
+    assert np.max(np.abs(got[0][1] - one)) < 1e-12, (got[0][1], one)
+    assert "pruned" in got[0][2] and "pruned" in got[1][2]
