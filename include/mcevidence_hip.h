@@ -296,8 +296,10 @@ typedef struct mce_options {
                               disagrees; honoured by the host-pointer entry points (mce_knn_f64[_opt], mce_knn_dotp_f64[_opt],
                               mce_evidence_feed[_batch]_f64 -- not by a rank's share, *_part_*) at d <= 128, K <= 32 (other shapes
                               run on exact fp64 kernels and are skipped silently).  0: off.  -1 (the default, round 6): a search
-                              that went through the fp16 FILTER is re-checked on 256 rows (MCE_VERIFY=n in the environment: n
-                              rows; MCE_VERIFY=0: off), one on the fp64 kernels is not.  ~0.5 ms per 256 rows at 1 M x 27 */
+                              that went through the fp16 FILTER is re-checked on 256 rows -- every call from 65 536 query rows
+                              on, one call in eight of the smaller ones (there the check is launch overhead, not rows: 0.16 of
+                              0.68 ms at 7 k x 6) -- and one on the fp64 kernels is not; MCE_VERIFY=n in the environment: n rows
+                              on EVERY call; MCE_VERIFY=0: off.  ~1 ms at 1 M x 27 with the distances it needs written out */
     int32_t reserved[2];   /* 0 */
 } mce_options;
 int mce_options_push(const mce_options* opt);

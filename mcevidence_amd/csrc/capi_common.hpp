@@ -120,10 +120,17 @@ int eff_search_mode() { return t_opt.search >= 0 ? t_opt.search : g_mode.load();
 int eff_prune_mode() { return t_opt.prune >= 0 ? t_opt.prune : g_prune_mode.load(); }
 int eff_sym_mode() { return t_opt.sym >= 0 ? t_opt.sym : sym_mode(); }
 // Rows re-checked after a host-pointer search (mce_options.verify; verify_kernels.hpp).  An explicit value (>= 0; 0 = off) wins.
-// Unset (-1): searches that took the fp16 FILTER -- whose exactness rests on a measured rounding model of the matrix core, not
-// on fp64 arithmetic throughout -- are certified on kVerifyDefaultRows rows by default (round 6; MCE_VERIFY=n in the
-// environment changes the number, MCE_VERIFY=0 turns the default off); the fp64 sweep and the generic kernel are not.
+// Unset (-1): searches that took the fp16 FILTER -- whose exactness rests on a rounding model of the matrix core (derived from one
+// assumption and measured: docs/design/sweep_f16_exhaustive.md), not on fp64 arithmetic throughout -- are certified on
+// kVerifyDefaultRows rows by default (round 6; MCE_VERIFY=n in the environment changes the number, MCE_VERIFY=0 turns the default
+// off); the fp64 sweep and the generic kernel are not.  What "by default" costs was measured (bench.py: `certificate`): 0.4 - 1.1 ms
+// of a 37 ms search (C3, C4), 3.5 of 73.5 (C5: the distances of 10 M rows have to be written out for it) -- but 0.16 ms of a 0.68 ms
+// call on a Planck-sized chain, which is launches and one synchronisation, not rows.  So searches of kVerifyAlwaysFrom query rows and
+// more are certified on EVERY call, smaller ones on one call in kVerifySmallEvery (a per-thread counter: a loop over thousands of
+// small chains still samples hundreds of searches, at 3 % instead of 24 %).
 constexpr int kVerifyDefaultRows = 256;
+constexpr int64_t kVerifyAlwaysFrom = 65536;
+constexpr int kVerifySmallEvery = 8;
 int default_verify_rows()
 {
     static const int v = [] {
@@ -134,8 +141,16 @@ int default_verify_rows()
     }();
     return v;
 }
+bool verify_env_set() { static const bool s = [] { const char* e = getenv("MCE_VERIFY"); return e && *e; }(); return s; }
 std::atomic<int> g_last_verify_rows{0};     // mce_last_verify_rows(): rows the certificate of the most recent host-pointer search checked
-int eff_verify(bool filter_path) { return t_opt.verify >= 0 ? t_opt.verify : (filter_path ? default_verify_rows() : 0); }
+thread_local unsigned t_small_search_count = 0;
+int eff_verify(bool filter_path, int64_t nq)
+{
+    if (t_opt.verify >= 0) return t_opt.verify;
+    if (!filter_path) return 0;
+    if (nq < kVerifyAlwaysFrom && !verify_env_set() && (t_small_search_count++ % kVerifySmallEvery) != 0) return 0;
+    return default_verify_rows();
+}
 // query blocks (512 rows each) from which the automatic mode takes it, by 16-wide k-steps of the filter.  Measured with the
 // panel kernel (tools/sym_crossover.py -> profiles/r03_panel/crossover.json; fused search + reduction, exhaustive -> symmetric,
 // ms).  Up to ~256 blocks -- one round of workgroups -- the seeded exhaustive sweep with its reference splits is faster

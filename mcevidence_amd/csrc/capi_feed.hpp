@@ -107,7 +107,7 @@ int fused_on_device(int device, const double* X, int64_t q_lo, int64_t q_hi, con
     MCE_HIP(dW.alloc((size_t)nq * sizeof(double)));
     MCE_HIP(dF.alloc((size_t)nq * sizeof(double)));
     MCE_HIP(dO.alloc((size_t)kmax * sizeof(double)));
-    const int nverify = (d <= mce::kVerifyMaxDim && K <= mce::kVerifyMaxK) ? eff_verify(p.filter()) : 0;     // mce_options.verify (default: on behind the fp16 filter)
+    const int nverify = (d <= mce::kVerifyMaxDim && K <= mce::kVerifyMaxK) ? eff_verify(p.filter(), nq) : 0;     // mce_options.verify (default: on behind the fp16 filter)
     if (dist_out || nverify) MCE_HIP(dD.alloc((size_t)nq * K * sizeof(double)));
     MCE_HIP(ws.alloc(wsb));
     if (!inside) MCE_HIP(hipMemcpy(dX.p, Xs, (size_t)nq * d * sizeof(double), hipMemcpyHostToDevice));
@@ -241,7 +241,7 @@ int feed_plan(FeedJob& j)
     j.o_small = off; off = align_up(off + (size_t)(3 * 64 + 2 * d * d + d + 1) * sizeof(double), 256);     // mean3 | cov | evec | scale | checksum
     j.o_part = off;  off = align_up(off + (size_t)std::max<int64_t>((int64_t)mce::kCovBlocks * npair, (int64_t)mce::kMeanBlocks * mce::kStatStride) * sizeof(double), 256);
     j.o_ws = off;    off = align_up(off + j.wsb, 256);
-    j.nverify = (j.nparts == 1 && !j.out_X && d <= mce::kVerifyMaxDim && j.K <= mce::kVerifyMaxK) ? (int)std::min<int64_t>(eff_verify(j.plan.filter()), q.n1) : 0;
+    j.nverify = (j.nparts == 1 && !j.out_X && d <= mce::kVerifyMaxDim && j.K <= mce::kVerifyMaxK) ? (int)std::min<int64_t>(eff_verify(j.plan.filter(), q.n1), q.n1) : 0;
     if (j.nverify > 0) {
         j.o_vd = off; off = align_up(off + (size_t)q.n1 * j.K * sizeof(double), 256);
         j.o_vw = off; off = align_up(off + mce_verify_workspace_bytes(j.nverify, j.K), 256);

@@ -127,23 +127,36 @@ def test_certificate_runs_by_default_behind_the_filter_and_not_behind_the_fp64_k
     re-check does not handle (K > 32: the generic kernel) are searched without it and do NOT become an error."""
     import mcevidence_amd as pkg
     from mcevidence_amd.synth import gaussian_chain
-    Y = _data(30000, 12, 3)
+    Y = _data(70000, 12, 3)                                   # from 65 536 query rows on: every call
     capi.knn(Y, Y, 5, self_mode=capi.SELF_EXCLUDE)
     assert capi.last_verify_rows() == 256 and "f16" in capi.last_kernel()
+    capi.knn(Y, Y, 5, self_mode=capi.SELF_EXCLUDE)
+    assert capi.last_verify_rows() == 256
     capi.knn(Y, Y, 5, self_mode=capi.SELF_EXCLUDE, options=capi.Options(verify=0))
     assert capi.last_verify_rows() == 0
     capi.knn(Y, Y, 5, self_mode=capi.SELF_EXCLUDE, options=capi.Options(verify=1000))
     assert capi.last_verify_rows() == 1000
     capi.knn(Y, Y, 5, self_mode=capi.SELF_EXCLUDE, options=capi.Options(search_mode=capi.MODE_F64))
     assert capi.last_verify_rows() == 0 and "mfma" in capi.last_kernel()
+    # smaller searches (the check is launch overhead there): one call in eight
+    small = Y[:20000]
+    ran = []
+    for _ in range(16):
+        capi.knn(small, small, 5, self_mode=capi.SELF_EXCLUDE)
+        ran.append(capi.last_verify_rows())
+    assert sorted(set(ran)) == [0, 256] and ran.count(256) == 2
+    capi.knn(small, small, 5, self_mode=capi.SELF_EXCLUDE, options=capi.Options(verify=300))      # asked for: always
+    assert capi.last_verify_rows() == 300
+    Y = _data(30000, 12, 3)
     # K = 40: the generic kernel; with an explicit row count the call still succeeds, unchecked
     d40, _ = capi.knn(Y[:4000], Y, 40, options=capi.Options(verify=500))
     assert capi.last_verify_rows() == 0 and d40.shape == (4000, 40) and "generic" in capi.last_kernel()
     # the fused entry points and the class
-    w, fs = np.ones(len(Y)), np.zeros(len(Y))
-    capi.knn_dotp(Y, Y, w, fs, 5, 1)
+    big = _data(70000, 12, 5)
+    w, fs = np.ones(len(big)), np.zeros(len(big))
+    capi.knn_dotp(big, big, w, fs, 5, 1)
     assert capi.last_verify_rows() == 256
-    chain = gaussian_chain(seed=4, n=40000, d=8, weights="int", cov="corr")
+    chain = gaussian_chain(seed=4, n=70000, d=8, weights="int", cov="corr")
     a = pkg.MCEvidence([chain], kmax=5, verbose=0).evidence()
     assert capi.last_verify_rows() == 256
     b = pkg.MCEvidence([chain], kmax=5, verbose=0, backend=pkg.HipBackend(recheck_rows=0)).evidence()

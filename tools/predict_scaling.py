@@ -32,13 +32,38 @@ def run(name, worlds, reps):
     out = torch.zeros(kmax, dtype=torch.float64, device=dev)
     res = dict(config=name, n=S, nr=nr, d=d, kmax=kmax, k0=k0, label="PREDICTED from one GPU: every rank's share timed serially, slowest rank = step time", worlds={})
     whole = None
+    # link rate the exchange of the distributed k-d preparation is PRICED at (bytes per second and direction, as the pairs-once emulation)
+    LINK = 50e9
     for W in worlds:
         per_rank, kern, total = [], [], np.zeros(kmax)
+        # round 6: a pruned search's k-d preparation is distributed over the ranks (mce_prune_part_prepare_dev + all-reduce of the
+        # permutation + mce_knn_dotp_part_prepared_f64_dev).  Emulated: every rank's part of the sorts is run first and the arrays
+        # summed (what the all-reduce does); then, per rank and timed: its own part again, the summed permutation put in place, the
+        # search -- plus the ring all-reduce of the int32 permutation priced at 2 (W - 1) / W x bytes / LINK.
+        dist_prep = auto and W > 1 and _capi.prune_part_applies(S, d, kmax, W) and os.environ.get("MCE_BENCH_DIST_PREP", "1") != "0"
+        perm_sum, perm_off, perm_cnt, prep_ms, xchg_ms = None, 0, 0, [], 0.0
+        if dist_prep:
+            for r in range(W):
+                perm_off, perm_cnt = _capi.prune_part_prepare_dev(Xd.data_ptr(), S, d, kmax, r, W, ws.data_ptr(), wsb, 0)
+                torch.cuda.synchronize()
+                pr = ws[perm_off:perm_off + 4 * perm_cnt].view(torch.int32)
+                perm_sum = pr.clone() if perm_sum is None else perm_sum + pr
+            xchg_ms = 2.0 * (W - 1) / W * 4.0 * perm_cnt / LINK * 1e3
         for r in range(W):
             lo, hi = (0, S) if auto else ((S * r) // W, (S * (r + 1)) // W)
             best, km = 1e30, None
             for _ in range(reps):
                 _capi.set_profiling(True); torch.cuda.synchronize(); t0 = time.perf_counter()
+                if dist_prep:
+                    _capi.prune_part_prepare_dev(Xd.data_ptr(), S, d, kmax, r, W, ws.data_ptr(), wsb, 0)
+                    torch.cuda.synchronize(); tp = time.perf_counter() - t0
+                    ws[perm_off:perm_off + 4 * perm_cnt].view(torch.int32).copy_(perm_sum)          # (untimed: the collective is priced instead)
+                    torch.cuda.synchronize(); t0b = time.perf_counter()
+                    _capi.knn_dotp_part_prepared_dev(Xd.data_ptr(), S, d, kmax, r, W, w.data_ptr(), fs.data_ptr(), out.data_ptr(), ws.data_ptr(), wsb, 0)
+                    torch.cuda.synchronize(); t = tp + (time.perf_counter() - t0b) + xchg_ms * 1e-3
+                    k = _capi.last_kernel_ms(); _capi.set_profiling(False)
+                    if t < best: best, km, bp = t, k, tp
+                    continue
                 if auto:
                     _capi.knn_dotp_part_dev(Xd.data_ptr(), S, d, kmax, r, W, w.data_ptr(), fs.data_ptr(), out.data_ptr(), ws.data_ptr(), wsb, 0)
                 else:
@@ -48,10 +73,13 @@ def run(name, worlds, reps):
                 k = _capi.last_kernel_ms(); _capi.set_profiling(False)
                 if t < best: best, km = t, k
             per_rank.append(round(best * 1e3, 3)); kern.append(round(km, 3)); total += out.cpu().numpy()
+            if dist_prep: prep_ms.append(round(bp * 1e3, 3))
         if whole is None: whole = total.copy()
         step = max(per_rank)
         res["worlds"][str(W)] = dict(rank_ms=per_rank, rank_search_kernel_ms=kern, predicted_step_ms=step, predicted_queries_per_s=round(S / (step * 1e-3), 1),
-                                     speedup_vs_1=None, max_rel_dev_of_summed_dotp_vs_1gpu=float(np.max(np.abs(total[k0:] - whole[k0:]) / whole[k0:])), kernel=_capi.last_kernel())
+                                     speedup_vs_1=None, max_rel_dev_of_summed_dotp_vs_1gpu=float(np.max(np.abs(total[k0:] - whole[k0:]) / whole[k0:])), kernel=_capi.last_kernel(),
+                                     distributed_kd_preparation=bool(dist_prep), own_sorts_ms=prep_ms or None,
+                                     permutation_allreduce_ms_priced=(round(xchg_ms, 3) if dist_prep else None))
         if W == worlds[0]:
             lnE = bench.lnE_from_dotp(total, cfg)
             g = bench.golden_lnE(name, cfg)
