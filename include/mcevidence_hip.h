@@ -133,13 +133,15 @@ int mce_evidence_feed_part_f64(const double *S1, int64_t n1, int64_t ld1, const 
 /* Distributed k-d preparation of the pruned walk (round 6; reference: the `fit` of MCEvidence.py:1100-1101, which every rank of a
  * multi-GPU run repeated in full).  Rank `part` of nparts = 2, 4, 8, ... calls mce_prune_part_prepare_dev on the workspace it will
  * search with: the sorts that settle the tree's top log2(nparts) levels run over all rows, everything below them over the rank's
- * own subtree only.  On return *perm_count int32 values at ws + *perm_offset hold the final k-d order inside the rank's range and
- * ZEROS elsewhere: one all-reduce(SUM) of that array over the ranks (the host's: torch.distributed over RCCL) gives every rank the
- * whole permutation -- bit for bit the single-GPU one -- and mce_knn_dotp_part_prepared_f64_dev then runs the rank's share of the
+ * own subtree only.  On return *perm_count int32 values at ws + *perm_offset hold the final k-d order inside the rank's range
+ * [*seg_lo, *seg_hi) (positions; the ranks' ranges follow each other in rank order and tile the array) and ZEROS elsewhere: an
+ * all_gather of the ranges -- or one all-reduce(SUM) of the whole array -- over the ranks (the host's: torch.distributed over RCCL)
+ * gives every rank the whole permutation -- bit for bit the single-GPU one -- and mce_knn_dotp_part_prepared_f64_dev then runs the rank's share of the
  * search like mce_knn_dotp_part_f64_dev, minus the sorts.  *perm_count = 0: nothing to exchange (the shape does not take the
  * pruned walk, nparts is not a power of two, the tree is too shallow) -- call mce_knn_dotp_part_f64_dev as before. */
 int mce_prune_part_prepare_dev(const double *dY, int64_t nr, int32_t d, int32_t kmax, int32_t part, int32_t nparts,
-                               size_t *perm_offset, int64_t *perm_count, void *ws, size_t ws_bytes, void *stream);
+                               size_t *perm_offset, int64_t *perm_count, int64_t *seg_lo, int64_t *seg_hi, void *ws,
+                               size_t ws_bytes, void *stream);
 /* 1: an auto-evidence search of this shape on nparts ranks takes the pruned walk AND its preparation can be distributed (plan only,
  * no device work): what a host asks before it chooses the three-step route */
 int32_t mce_prune_part_applies(int64_t nr, int32_t d, int32_t kmax, int32_t nparts);

@@ -79,8 +79,8 @@ SIGNATURES = {
     "mce_knn_dotp_part_f64": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _c.c_int32]),
     "mce_knn_dotp_part_prepared_f64_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P, _P, _P, _c.c_size_t, _P]),
     "mce_prune_part_applies": (_c.c_int32, [_c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32]),
-    "mce_prune_part_prepare_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_int64), _P,
-                                              _c.c_size_t, _P]),
+    "mce_prune_part_prepare_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_int64),
+                                              _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _P, _c.c_size_t, _P]),
     "mce_pairs_once_blocks": (_c.c_int32, [_c.c_int64, _c.c_int32, _c.c_int32]),
     "mce_pairs_once_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32]),
     "mce_pairs_once_prepare_dev": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_int64), _P,
@@ -590,12 +590,15 @@ def prune_part_applies(nr, d, kmax, nparts):
     return bool(load().mce_prune_part_applies(int(nr), int(d), int(kmax), int(nparts)))
 
 
-def prune_part_prepare_dev(dY, nr, d, kmax, part, nparts, ws, ws_bytes, stream=0):
+def prune_part_prepare_dev(dY, nr, d, kmax, part, nparts, ws, ws_bytes, stream=0, want_range=False):
     """This rank's part of the DISTRIBUTED k-d preparation of a pruned auto-evidence search (``mce_prune_part_prepare_dev``): returns
-    (byte offset into ``ws``, count) of the int32 permutation array -- final inside the rank's range, zeros elsewhere: all-reduce(SUM)
-    it over the ranks, then ``knn_dotp_part_prepared_dev`` -- or (0, 0) when there is nothing to exchange (call ``knn_dotp_part_dev``)."""
-    off, cnt = _c.c_size_t(0), _c.c_int64(0)
-    check(load().mce_prune_part_prepare_dev(dY, nr, d, kmax, part, nparts, _c.byref(off), _c.byref(cnt), ws, ws_bytes, stream or None))
+    (byte offset into ``ws``, count) of the int32 permutation array -- final inside the rank's range, zeros elsewhere: gather the
+    ranges (or all-reduce(SUM) the array) over the ranks, then ``knn_dotp_part_prepared_dev`` -- or (0, 0) when there is nothing to
+    exchange (call ``knn_dotp_part_dev``).  ``want_range``: also the rank's range (lo, hi) in positions."""
+    off, cnt, lo, hi = _c.c_size_t(0), _c.c_int64(0), _c.c_int64(0), _c.c_int64(0)
+    check(load().mce_prune_part_prepare_dev(dY, nr, d, kmax, part, nparts, _c.byref(off), _c.byref(cnt), _c.byref(lo), _c.byref(hi), ws, ws_bytes, stream or None))
+    if want_range:
+        return int(off.value), int(cnt.value), int(lo.value), int(hi.value)
     return int(off.value), int(cnt.value)
 
 

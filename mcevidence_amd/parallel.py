@@ -271,21 +271,46 @@ def symmetric_partition_rows(Y, world, rank, block=512):
     return order[lo * block: min(hi * block, n)]
 
 
-def allreduce_permutation(ws, off, cnt, group=None):
-    """The ONE extra collective of the distributed k-d preparation: all-reduce(SUM) of the int32 permutation array inside the
-    workspace tensor ``ws`` (uint8, on the device) -- every rank holds the final order in its own range and zeros elsewhere
-    (``mce_prune_part_prepare_dev``), so the sum is the whole permutation on every rank.  RCCL reduces the device view in place;
-    any other backend goes through the host."""
+def allreduce_permutation(ws, off, cnt, group=None, seg=None):
+    """The ONE extra collective of the distributed k-d preparation: every rank holds the final order in its own range of the int32
+    permutation array inside the workspace tensor ``ws`` (uint8, on the device) and zeros elsewhere (``mce_prune_part_prepare_dev``).
+    With ``seg`` = this rank's range (lo, hi): the ranges follow each other in rank order and tile the array, so they are
+    all_gather'ed (a tiny all_gather of the bounds first, then equal-length chunks: half the traffic of a reduction); without:
+    all-reduce(SUM) of the whole array.  RCCL works on device tensors; any other backend goes through the host."""
     import torch
     import torch.distributed as dist
     group = _GROUP if group is None else group
+    world = dist.get_world_size(group)
     view = ws[off:off + 4 * cnt].view(torch.int32)
-    if dist.get_backend(group) == "nccl":
-        dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+    nccl = dist.get_backend(group) == "nccl"
+    if seg is None:
+        if nccl:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+        else:
+            host = view.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            view.copy_(host)
+        return
+    dev = view.device if nccl else torch.device("cpu")
+    mine = torch.tensor([int(seg[0]), int(seg[1])], dtype=torch.int64, device=dev)
+    bounds = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(bounds, mine, group=group)
+    bounds = [(int(b[0]), int(b[1])) for b in bounds]
+    if bounds[0][0] != 0 or bounds[-1][1] != cnt or any(a[1] != b[0] for a, b in zip(bounds[:-1], bounds[1:])):
+        raise RuntimeError("mcevidence_amd: the ranks' ranges of the k-d order do not tile it (%r): the ranks disagree about the partition" % (bounds,))
+    C = max(b[1] - b[0] for b in bounds)
+    chunk = torch.zeros(C, dtype=torch.int32, device=dev)
+    chunk[:seg[1] - seg[0]].copy_(view[seg[0]:seg[1]])
+    full = torch.empty(world * C, dtype=torch.int32, device=dev)
+    if nccl:
+        dist.all_gather_into_tensor(full, chunk, group=group)
     else:
-        host = view.cpu()
-        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-        view.copy_(host)
+        parts = [torch.empty(C, dtype=torch.int32) for _ in range(world)]
+        dist.all_gather(parts, chunk, group=group)
+        full = torch.cat(parts)
+    for r, (lo, hi) in enumerate(bounds):
+        if r != dist.get_rank(group) and hi > lo:
+            view[lo:hi].copy_(full[r * C:r * C + (hi - lo)])
 
 
 def pruned_part_knn_dotp(Yd, wd, fd, kmax, group=None, ws=None):
@@ -301,20 +326,20 @@ def pruned_part_knn_dotp(Yd, wd, fd, kmax, group=None, ws=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     n, d = int(Yd.shape[0]), int(Yd.shape[1])
     dev = Yd.device
-    ok, off, cnt = False, 0, 0
+    ok, off, cnt, lo, hi = False, 0, 0, 0, 0
     st = torch.cuda.current_stream().cuda_stream
     try:
         if _capi.prune_part_applies(n, d, kmax, world):
             if ws is None:
                 wsb = _capi.knn_workspace_bytes(n, n, d, kmax - 1) + _capi.dotp_workspace_bytes(n, kmax)
                 ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            off, cnt = _capi.prune_part_prepare_dev(Yd.data_ptr(), n, d, kmax, rank, world, ws.data_ptr(), int(ws.numel()), st)
+            off, cnt, lo, hi = _capi.prune_part_prepare_dev(Yd.data_ptr(), n, d, kmax, rank, world, ws.data_ptr(), int(ws.numel()), st, want_range=True)
             ok = cnt > 0
     except Exception:
         ok = False
     if not agree_all(ok, group):
         return None
-    allreduce_permutation(ws, off, cnt, group)
+    allreduce_permutation(ws, off, cnt, group, seg=(lo, hi))
     out = torch.zeros(int(kmax), dtype=torch.float64, device=dev)
     _capi.knn_dotp_part_prepared_dev(Yd.data_ptr(), n, d, kmax, rank, world, wd.data_ptr(), fd.data_ptr(), out.data_ptr(), ws.data_ptr(), int(ws.numel()), st)
     return out

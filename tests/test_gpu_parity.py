@@ -1649,16 +1649,15 @@ def test_distributed_kd_preparation_is_the_single_gpu_order(prune_modes, n, d, k
             # the single-GPU permutation: what the plain call above left in the workspace (same plan, same offset)
             perms, segs = [], []
             for r in range(W):
-                off, cnt = capi.prune_part_prepare_dev(Yd.data_ptr(), n, d, kmax, r, W, ws.data_ptr(), wsb, 0)
+                off, cnt, lo, hi = capi.prune_part_prepare_dev(Yd.data_ptr(), n, d, kmax, r, W, ws.data_ptr(), wsb, 0, want_range=True)
                 torch.cuda.synchronize()
-                assert cnt > 0 and cnt % 2048 == 0
+                assert cnt > 0 and cnt % 2048 == 0 and lo % 2048 == 0 and 0 <= lo < hi <= cnt
                 pr = ws[off:off + 4 * cnt].view(torch.int32).clone()
-                nz = torch.nonzero(pr).flatten()
-                segs.append((int(nz.min()), int(nz.max())))
+                assert int(torch.count_nonzero(pr[:lo])) == 0 and int(torch.count_nonzero(pr[hi:])) == 0        # zeros outside the own range
+                segs.append((lo, hi))
                 perms.append(pr)
             total = torch.stack(perms).sum(dim=0)
-            for a, b in zip(segs[:-1], segs[1:]):
-                assert a[1] < b[0]                                   # disjoint, ascending ranges: rank r holds subtree r
+            assert segs[0][0] == 0 and segs[-1][1] == cnt and all(a[1] == b[0] for a, b in zip(segs[:-1], segs[1:]))      # rank order, tiling the array
             # reference order: the replicated preparation
             ref = torch.zeros(kmax, dtype=torch.float64, device="cuda")
             capi.knn_dotp_part_dev(Yd.data_ptr(), n, d, kmax, 0, W, w.data_ptr(), fs.data_ptr(), ref.data_ptr(), ws.data_ptr(), wsb, 0)

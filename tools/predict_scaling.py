@@ -39,7 +39,7 @@ def run(name, worlds, reps):
         # round 6: a pruned search's k-d preparation is distributed over the ranks (mce_prune_part_prepare_dev + all-reduce of the
         # permutation + mce_knn_dotp_part_prepared_f64_dev).  Emulated: every rank's part of the sorts is run first and the arrays
         # summed (what the all-reduce does); then, per rank and timed: its own part again, the summed permutation put in place, the
-        # search -- plus the ring all-reduce of the int32 permutation priced at 2 (W - 1) / W x bytes / LINK.
+        # search -- plus the all_gather of the int32 permutation's ranges priced at (W - 1) / W x bytes / LINK.
         dist_prep = auto and W > 1 and _capi.prune_part_applies(S, d, kmax, W) and os.environ.get("MCE_BENCH_DIST_PREP", "1") != "0"
         perm_sum, perm_off, perm_cnt, prep_ms, xchg_ms = None, 0, 0, [], 0.0
         if dist_prep:
@@ -48,7 +48,7 @@ def run(name, worlds, reps):
                 torch.cuda.synchronize()
                 pr = ws[perm_off:perm_off + 4 * perm_cnt].view(torch.int32)
                 perm_sum = pr.clone() if perm_sum is None else perm_sum + pr
-            xchg_ms = 2.0 * (W - 1) / W * 4.0 * perm_cnt / LINK * 1e3
+            xchg_ms = (W - 1) / W * 4.0 * perm_cnt / LINK * 1e3             # an all_gather of the ranges: every rank receives (W - 1) / W of the array
         for r in range(W):
             lo, hi = (0, S) if auto else ((S * r) // W, (S * (r + 1)) // W)
             best, km = 1e30, None
