@@ -535,6 +535,54 @@ def test_pairs_once_route_is_agreed_by_all_ranks():
     assert got[0] == got[1] == (False, True, False)
 
 
+def _perm_worker(rank, world, port, q, mode):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mcevidence_amd import parallel
+    cnt, off = 10 * 2048, 256
+    bounds = [0, 3 * 2048, 7 * 2048, cnt] if world == 3 else [0, 5 * 2048, cnt]      # uneven ranges, in rank order
+    full = torch.arange(cnt, dtype=torch.int32).flip(0) - 1                           # the "single-GPU permutation" (with a -1 in it)
+    ws = torch.zeros(off + 4 * cnt + 64, dtype=torch.uint8)
+    view = ws[off:off + 4 * cnt].view(torch.int32)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    view[lo:hi] = full[lo:hi]
+    try:
+        if mode == "gather":
+            parallel.allreduce_permutation(ws, off, cnt, seg=(lo, hi))
+        elif mode == "reduce":
+            parallel.allreduce_permutation(ws, off, cnt)
+        else:                          # a rank that reports a range which does not tile the array: everybody raises
+            parallel.allreduce_permutation(ws, off, cnt, seg=(lo, hi - (2048 if rank == 0 else 0)))
+        out = ("ok", bool(torch.equal(view, full)) and int(ws[:off].sum()) == 0 and int(ws[off + 4 * cnt:].sum()) == 0)
+    except RuntimeError as e:
+        out = ("raised", str(e))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(3, "gather"), (2, "gather"), (3, "reduce"), (2, "gap")])
+def test_the_ranks_ranges_of_the_kd_order_are_put_together(world, mode):
+    """The one extra collective of the distributed k-d preparation (parallel.allreduce_permutation): every rank holds its own range of the
+    permutation and zeros elsewhere; all_gather of the (uneven) ranges -- bounds first, then equal-length chunks -- or the all-reduce of the
+    whole array leaves the SAME full array on every rank and touches nothing around it; ranges that do not tile the array raise everywhere."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_perm_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if mode == "gap":
+        assert all(got[r][0] == "raised" and "do not tile" in got[r][1] for r in range(world)), got
+    else:
+        assert all(got[r] == ("ok", True) for r in range(world)), got
+
+
 def test_replica_fingerprint_sees_every_row():
     from mcevidence_amd.parallel import replica_fingerprint
     rng = np.random.default_rng(3)
