@@ -463,7 +463,7 @@ def time_config(ctx, cfg, steps, warmup, mode=0, nsample=0, orc=None):
             off, cnt, lo_, hi_ = _capi.prune_part_prepare_dev(Xd.data_ptr(), nr, d, kmax, rank, world, ws.data_ptr(), wsb, st, want_range=True)
             if cnt <= 0:
                 raise RuntimeError("bench.py: the distributed k-d preparation was agreed on but does not apply on rank %d" % rank)
-            parallel.allreduce_permutation(ws, off, cnt, seg=(lo_, hi_))
+            parallel.gather_permutation(ws, off, cnt, seg=(lo_, hi_))
             _capi.knn_dotp_part_prepared_dev(Xd.data_ptr(), nr, d, kmax, rank, world, w.data_ptr(), fs.data_ptr(), out.data_ptr(), ws.data_ptr(), wsb, st)
         elif dist_on and auto:
             _capi.knn_dotp_part_dev(Xd.data_ptr(), nr, d, kmax, rank, world, w.data_ptr(), fs.data_ptr(), out.data_ptr(), ws.data_ptr(), wsb, st)

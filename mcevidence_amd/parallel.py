@@ -271,7 +271,7 @@ def symmetric_partition_rows(Y, world, rank, block=512):
     return order[lo * block: min(hi * block, n)]
 
 
-def allreduce_permutation(ws, off, cnt, group=None, seg=None):
+def gather_permutation(ws, off, cnt, group=None, seg=None):
     """The ONE extra collective of the distributed k-d preparation: every rank holds the final order in its own range of the int32
     permutation array inside the workspace tensor ``ws`` (uint8, on the device) and zeros elsewhere (``mce_prune_part_prepare_dev``).
     With ``seg`` = this rank's range (lo, hi): the ranges follow each other in rank order and tile the array, so they are
@@ -339,7 +339,7 @@ def pruned_part_knn_dotp(Yd, wd, fd, kmax, group=None, ws=None):
         ok = False
     if not agree_all(ok, group):
         return None
-    allreduce_permutation(ws, off, cnt, group, seg=(lo, hi))
+    gather_permutation(ws, off, cnt, group, seg=(lo, hi))
     out = torch.zeros(int(kmax), dtype=torch.float64, device=dev)
     _capi.knn_dotp_part_prepared_dev(Yd.data_ptr(), n, d, kmax, rank, world, wd.data_ptr(), fd.data_ptr(), out.data_ptr(), ws.data_ptr(), int(ws.numel()), st)
     return out

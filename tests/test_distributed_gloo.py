@@ -549,11 +549,11 @@ def _perm_worker(rank, world, port, q, mode):
     view[lo:hi] = full[lo:hi]
     try:
         if mode == "gather":
-            parallel.allreduce_permutation(ws, off, cnt, seg=(lo, hi))
+            parallel.gather_permutation(ws, off, cnt, seg=(lo, hi))
         elif mode == "reduce":
-            parallel.allreduce_permutation(ws, off, cnt)
+            parallel.gather_permutation(ws, off, cnt)
         else:                          # a rank that reports a range which does not tile the array: everybody raises
-            parallel.allreduce_permutation(ws, off, cnt, seg=(lo, hi - (2048 if rank == 0 else 0)))
+            parallel.gather_permutation(ws, off, cnt, seg=(lo, hi - (2048 if rank == 0 else 0)))
         out = ("ok", bool(torch.equal(view, full)) and int(ws[:off].sum()) == 0 and int(ws[off + 4 * cnt:].sum()) == 0)
     except RuntimeError as e:
         out = ("raised", str(e))
@@ -564,7 +564,7 @@ def _perm_worker(rank, world, port, q, mode):
 
 @pytest.mark.parametrize("world,mode", [(3, "gather"), (2, "gather"), (3, "reduce"), (2, "gap")])
 def test_the_ranks_ranges_of_the_kd_order_are_put_together(world, mode):
-    """The one extra collective of the distributed k-d preparation (parallel.allreduce_permutation): every rank holds its own range of the
+    """The one extra collective of the distributed k-d preparation (parallel.gather_permutation): every rank holds its own range of the
     permutation and zeros elsewhere; all_gather of the (uneven) ranges -- bounds first, then equal-length chunks -- or the all-reduce of the
     whole array leaves the SAME full array on every rank and touches nothing around it; ranges that do not tile the array raise everywhere."""
     ctx = mp.get_context("spawn")

@@ -759,8 +759,8 @@ def test_every_candidate_through_the_redo_list(sym, monkeypatch):
 # --------------------------------------------------------------------------- many searches at once (tools/stress_concurrent.py, in the suite)
 @pytest.mark.parametrize("spin_limit", [50, None])
 def test_concurrent_searches_on_many_streams_and_threads_are_bit_identical(spin_limit, monkeypatch):
-    """Twelve searches of every kind -- symmetric sweep (panel kernel), exhaustive sweep with splits and seeds, pruned walk
-    -- enqueued at once on twelve streams, first from one thread, then from four threads (modes through the thread-scoped
+    """Fourteen searches of every kind -- symmetric sweep (panel kernel), exhaustive sweep with splits and seeds, pruned walk, and
+    (round 6) the deep filter -- enqueued at once on as many streams, first from one thread, then from four threads (modes through the thread-scoped
     mce_options), several rounds in shuffled order: distances and sums bit-identical to the same searches run one at a time.
     With MCE_SYM_SPIN_LIMIT = 50 (~50 us) units of the symmetric sweep that meet a loaded chip give up waiting for their
     block's previous unit -- any subset of a unit's waves -- and the repair launch must make up for it (the hole
@@ -775,7 +775,8 @@ def test_concurrent_searches_on_many_streams_and_threads_are_bit_identical(spin_
     rng = np.random.default_rng(11)
     shapes = [(9000, 6, 2, 0), (26862, 6, 2, 0), (60000, 8, 3, 0), (40000, 27, 10, 0),          # kind 0: exhaustive (automatic splits, seeds)
               (150000, 27, 10, 2), (120000, 45, 6, 2), (200000, 20, 4, 2), (70000, 27, 10, 2),    # kind 2: symmetric sweep
-              (300000, 3, 5, 1), (400000, 6, 4, 1), (250000, 2, 3, 1), (131072, 10, 5, 0)]         # kind 1: pruned walk
+              (300000, 3, 5, 1), (400000, 6, 4, 1), (250000, 2, 3, 1), (131072, 10, 5, 0),         # kind 1: pruned walk
+              (50000, 70, 5, 0), (60000, 100, 10, 0)]                                               # (round 6) kind 0 at d >= 64: the deep filter
     modes = {0: dict(prune_mode=capi.PRUNE_OFF, sym_mode=capi.SYM_OFF), 1: dict(prune_mode=capi.PRUNE_FORCE, sym_mode=capi.SYM_OFF),
              2: dict(prune_mode=capi.PRUNE_OFF, sym_mode=capi.SYM_FORCE)}
     jobs = []
@@ -803,6 +804,7 @@ def test_concurrent_searches_on_many_streams_and_threads_are_bit_identical(spin_
         assert ("pruned" in k) == (j["kind"] == 1) and ("symmetric" in k) == (j["kind"] == 2), k
         if j["kind"] == 2:
             assert "panel-kernel" in k
+        assert ("knn_deep_kernel" in k) == (j["d"] >= 64), k
 
     def check(tag):
         bad = []
