@@ -73,29 +73,32 @@ class HipBackend(object):
                 return None
             group = parallel.current_group()
             dev = self.devices[0] if self.devices else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
-            if S2 is None and dist.get_world_size(group) >= 2 and parallel.pairs_once_route(
-                    np.asarray(S1).shape[0], ndim, kmax, group, local_ok=(parallel.pairs_once_enabled() and dev == torch.cuda.current_device())):
-                # MCE_PAIRS_ONCE=1 on EVERY rank (agreed in one tiny all-reduce -- the two routes' collectives differ, a choice per
-                # rank would pair them wrongly): every pair of rows multiplied once per node
-                got = parallel.pairs_once_feed(S1, ndim, kmax, weight, fs, group, verify=self.verify)
-                if got is not None:
-                    return got
-            if S2 is None and dist.get_world_size(group) >= 2 and dev == (torch.cuda.current_device() if torch.cuda.is_available() else -1):
+            # this rank's device is the process's current one (what the torch-side routes below work on).  The routes differ in their
+            # COLLECTIVES, so none of them is chosen by a rank for itself: each is entered by every rank and agreed inside, in one
+            # all-reduce(MIN) of the ranks' own answers (the variable set on one rank only, a rank on another device: everybody
+            # takes the fallback together -- ADVICE round 5)
+            here = torch.cuda.is_available() and dev == torch.cuda.current_device()
+            multi = dist.get_world_size(group) >= 2
+            if S2 is None and multi:
+                if parallel.pairs_once_route(np.asarray(S1).shape[0], ndim, kmax, group, local_ok=(parallel.pairs_once_enabled() and here)):
+                    # MCE_PAIRS_ONCE=1 on EVERY rank: every pair of rows multiplied once per node
+                    got = parallel.pairs_once_feed(S1, ndim, kmax, weight, fs, group, verify=self.verify)
+                    if got is not None:
+                        return got
                 # a search that takes the pruned walk (C5's shape): the k-d preparation is distributed over the ranks -- whitening on
-                # the device, this rank's part of the sorts, one all-reduce of the permutation, the search (None: not this shape)
-                got = parallel.pruned_part_feed(S1, ndim, kmax, weight, fs, group, verify=self.verify)
+                # the device, this rank's part of the sorts, one gather of the permutation, the search (None: not this shape)
+                got = parallel.pruned_part_feed(S1, ndim, kmax, weight, fs, group, verify=self.verify, local_ok=here)
                 if got is not None:
                     return got
             part, jac, csum, failed = np.zeros(kmax), float("nan"), None, None
             # ONE upload of the chain per node (round 6): every rank uploads 1/W of the rows, an all_gather over RCCL hands
             # everybody the whole set; the ranks' inputs are compared through fingerprints of their HOST copies, computed on a
-            # thread beside the GPU work (the gathered set is identical everywhere by construction).  Collective calls:
-            # every rank takes the same branch (the backend and the environment decide; a rank that cannot allocate sends
-            # everybody back to the per-rank upload).
+            # thread beside the GPU work (the gathered set is identical everywhere by construction).
             gathered, hostsum = None, None
-            if (dist.get_world_size(group) >= 2 or parallel._forced()) and parallel.node_upload_enabled(group) and dev == torch.cuda.current_device():
-                hostsum = parallel._HostFingerprint(S1, S2, ndim, weight, fs) if self.verify else None
-                gathered = parallel.gather_chain_on_device(S1, S2, ndim, weight, fs, group)
+            if multi or parallel._forced():
+                want_node = here and parallel.node_upload_enabled(group)
+                hostsum = parallel._HostFingerprint(S1, S2, ndim, weight, fs) if (self.verify and want_node) else None
+                gathered = parallel.gather_chain_on_device(S1, S2, ndim, weight, fs, group, local_ok=want_node)      # (collective whatever this rank wants)
             try:
                 if gathered is not None:
                     Sg, wg, fg = gathered

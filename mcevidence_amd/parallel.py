@@ -200,32 +200,34 @@ class _HostFingerprint:
         return v
 
 
-def gather_chain_on_device(S1, S2, ndim, weight, fs, group=None):
+def gather_chain_on_device(S1, S2, ndim, weight, fs, group=None, local_ok=True):
     """ONE upload of the chain per node ("one H2D + broadcast over xGMI instead of 8 PCIe H2D copies"; VERDICT
     round 5, missing #5): rank r uploads the rows [C r, C (r + 1)) of [s1; s2] (C = ceil(rows / W); the first ``ndim``
     columns) and its W-th of (weight, fs); two ``all_gather``s over RCCL hand every rank the whole set in ITS device memory --
     1/W of the chain through each rank's PCIe link and the host's memory system instead of all of it W times.
     Returns (rows [n1 + n2, ndim], weight [n1], fs [n1]) as device tensors, identical on every rank BY CONSTRUCTION -- which
     is why the ranks' inputs are then compared through HOST fingerprints (``_HostFingerprint``), not device ones --
-    or None when some rank could not allocate its buffers (agreed by all ranks: everybody falls back to its own upload).
-    Collective: every rank of the group calls it."""
+    or None when some rank could not allocate its buffers or does not want the route (``local_ok``: the variable set on this rank, its
+    device the current one) -- agreed by all ranks in one all-reduce(MIN), so everybody falls back to its own upload TOGETHER.
+    Collective: every rank of the group calls it, whatever its own ``local_ok``."""
     import torch
     import torch.distributed as dist
     group = _GROUP if group is None else group
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     nccl = dist.get_backend(group) == "nccl"
-    dev = torch.device("cuda", torch.cuda.current_device())
     S1 = np.asarray(S1)
     n1 = int(S1.shape[0])
     n2 = 0 if S2 is None else int(np.asarray(S2).shape[0])
     ntot, d = n1 + n2, int(ndim)
     C, Cw = -(-ntot // world), -(-n1 // world)
     bufs = None
-    try:
-        bufs = (torch.zeros((C, d), dtype=torch.float64, device=dev), torch.empty((world * C, d), dtype=torch.float64, device=dev),
-                torch.zeros((Cw, 2), dtype=torch.float64, device=dev), torch.empty((world * Cw, 2), dtype=torch.float64, device=dev))
-    except Exception:
-        bufs = None
+    if local_ok:
+        try:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            bufs = (torch.zeros((C, d), dtype=torch.float64, device=dev), torch.empty((world * C, d), dtype=torch.float64, device=dev),
+                    torch.zeros((Cw, 2), dtype=torch.float64, device=dev), torch.empty((world * Cw, 2), dtype=torch.float64, device=dev))
+        except Exception:
+            bufs = None
     if not agree_all(bufs is not None, group):
         return None
     mine, full, mine_w, full_w = bufs
@@ -345,12 +347,12 @@ def pruned_part_knn_dotp(Yd, wd, fd, kmax, group=None, ws=None):
     return out
 
 
-def pruned_part_feed(S1, ndim, kmax, weight, fs, group=None, verify=True):
+def pruned_part_feed(S1, ndim, kmax, weight, fs, group=None, verify=True, local_ok=True):
     """``MCEvidence.evidence()`` under a process group for an auto-evidence search that takes the pruned walk (C5's shape), with the
     k-d preparation DISTRIBUTED: the chain reaches every device (one upload per node when enabled), is whitened there
     (``mce_evidence_feed_whiten[_dev]_f64``), then ``pruned_part_knn_dotp``; the usual all-reduce of the sums ends the call.  Returns
-    (dotp, J), or None when the route does not apply (decided from the shape alone, the same on every rank; the caller falls back to
-    the part feed)."""
+    (dotp, J), or None when the route does not apply on EVERY rank (the shape, and ``local_ok``: this rank's device is the current
+    one -- agreed in one all-reduce(MIN); the caller falls back to the part feed).  Collective whatever ``local_ok`` is."""
     import torch
     import torch.distributed as dist
     from . import _capi
@@ -359,16 +361,15 @@ def pruned_part_feed(S1, ndim, kmax, weight, fs, group=None, verify=True):
     n = int(np.asarray(S1).shape[0])
     applies = False
     try:
-        applies = world >= 2 and _capi.prune_part_applies(n, ndim, kmax, world)
+        applies = bool(local_ok) and world >= 2 and _capi.prune_part_applies(n, ndim, kmax, world)
     except Exception:
         applies = False
     if not agree_all(applies, group):
         return None
     dev = torch.device("cuda", torch.cuda.current_device())
-    gathered, hostsum = None, None
-    if node_upload_enabled(group):
-        hostsum = _HostFingerprint(S1, None, ndim, weight, fs) if verify else None
-        gathered = gather_chain_on_device(S1, None, ndim, weight, fs, group)
+    want_node = node_upload_enabled(group)
+    hostsum = _HostFingerprint(S1, None, ndim, weight, fs) if (verify and want_node) else None
+    gathered = gather_chain_on_device(S1, None, ndim, weight, fs, group, local_ok=want_node)      # (collective whatever this rank wants)
     failed, part, jac, csum = None, None, float("nan"), None
     Xd = wd = fd = None
     try:
@@ -529,10 +530,9 @@ def pairs_once_feed(S1, ndim, kmax, weight, fs, group=None, verify=True):
     dev = torch.device("cuda", torch.cuda.current_device())
     failed, impl, jac, csum = None, None, float("nan"), None
     # one upload per node (gather_chain_on_device) when enabled: the ranks' inputs are then compared through host fingerprints
-    gathered, hostsum = None, None
-    if node_upload_enabled(group):
-        hostsum = _HostFingerprint(S1, None, ndim, weight, fs) if verify else None
-        gathered = gather_chain_on_device(S1, None, ndim, weight, fs, group)
+    want_node = node_upload_enabled(group)
+    hostsum = _HostFingerprint(S1, None, ndim, weight, fs) if (verify and want_node) else None
+    gathered = gather_chain_on_device(S1, None, ndim, weight, fs, group, local_ok=want_node)      # (collective whatever this rank wants)
     try:
         Xd = torch.empty((n, ndim), dtype=torch.float64, device=dev)
         wd = torch.empty(n, dtype=torch.float64, device=dev)

@@ -535,6 +535,43 @@ def test_pairs_once_route_is_agreed_by_all_ranks():
     assert got[0] == got[1] == (False, True, False)
 
 
+def _route2_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if rank == 1:
+        os.environ["MCE_NODE_UPLOAD"] = "1"         # set on ONE rank only
+    else:
+        os.environ.pop("MCE_NODE_UPLOAD", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mcevidence_amd import parallel, _capi
+    _capi.prune_part_applies = lambda n, d, kmax, nparts: True        # (no library call on the CPU box)
+    S = np.random.default_rng(0).standard_normal((64, 3))
+    w = np.ones(64)
+    a = parallel.pruned_part_feed(S, 3, 4, w, w, local_ok=(rank != 0))            # rank 0's device is not the current one
+    b = parallel.gather_chain_on_device(S, None, 3, w, w, local_ok=(rank != 0))   # ... so nobody takes the node upload either
+    c = parallel.gather_chain_on_device(S, None, 3, w, w, local_ok=parallel.node_upload_enabled(None))   # the variable on one rank
+    q.put((rank, (a, b, c)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_kd_route_and_node_upload_are_agreed_by_all_ranks():
+    """The distributed k-d preparation and the one-upload-per-node gather are collectives too: a rank that cannot take them (its
+    device is not the current one, the variable set elsewhere only, no GPU at all) enters them with its own 'no', and EVERY
+    rank falls back to the part feed together -- none is left waiting in a gather the others never join."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_route2_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == (None, None, None)
+
+
 def _perm_worker(rank, world, port, q, mode):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
