@@ -700,14 +700,20 @@ def main():
         progress("evidence() from host arrays under the process group")
         # the whole MCEvidence(...).evidence() call from host arrays under the process group: each rank uploads the chain once,
         # whitens on its device, searches its share (mce_evidence_feed_part_f64), ONE all-reduce -- the PCIe-inclusive figure
-        mce.evidence()
-        ctx.barrier()
-        t2 = time.perf_counter()
-        lnE_e2e = mce.evidence()
-        mine = torch.tensor([time.perf_counter() - t2, float(np.max(np.abs(lnE_e2e - lnE)))], dtype=torch.float64, device=dev)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        e2e_ranks = [dict(rank=i, seconds=round(float(t[0]), 4), max_abs_dlnE_vs_resident_path=float(t[1])) for i, t in enumerate(allr)]
+        # (guarded like the sections below: the class's routes carry failure flags through their collectives, so the ranks fail
+        # TOGETHER; a failure becomes {"error": ...} in the line, never a lost headline)
+        try:
+            mce.evidence()
+            ctx.barrier()
+            t2 = time.perf_counter()
+            lnE_e2e = mce.evidence()
+            mine = torch.tensor([time.perf_counter() - t2, float(np.max(np.abs(lnE_e2e - lnE)))], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            e2e_ranks = [dict(rank=i, seconds=round(float(t[0]), 4), max_abs_dlnE_vs_resident_path=float(t[1])) for i, t in enumerate(allr)]
+        except Exception as exc:
+            e2e_ranks = dict(error="%s: %s" % (type(exc).__name__, exc))
+            progress("evidence() under the process group failed: %s" % exc)
 
     # Two ranks or more: the same workload through the ALL-PAIRS-ONCE partition as well, by default (round 6; MCE_BENCH_PAIRS_ONCE=0
     # skips it) -- every rank's sweep, the exchange of the candidates and the all-reduces inside the timed region, data resident --
@@ -842,7 +848,9 @@ def main():
                                              note="pure fp64 arithmetic: v_mfma_f64_16x16x4_f64 over all pairs (2*4*KS flop/pair, unpadded rows) + fp64 refine")
                 fp64_mode["max_abs_dlnE_vs_default_mode"] = float(np.max(np.abs(np.array(fp64_mode["lnE"]) - lnE)))
                 extras = extra_configs(ctx, orc, pkg, a.extras_scale)
-        if e2e_ranks:
+        if isinstance(e2e_ranks, dict):
+            e2e = e2e_ranks
+        elif e2e_ranks:
             slow = max(r["seconds"] for r in e2e_ranks)
             e2e = dict(seconds=slow, queries_per_s=round(n / slow, 1), per_rank=e2e_ranks,
                        max_abs_dlnE_vs_resident_path=max(r["max_abs_dlnE_vs_resident_path"] for r in e2e_ranks),
