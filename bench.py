@@ -720,7 +720,7 @@ def main():
     # so that the first run on a multi-GPU node times both partitions.  `value` stays the default partition's.  The section is
     # guarded: whatever fails in it (on any rank: the partition's collectives carry failure flags, so the ranks fail TOGETHER
     # and nobody is left in a collective) becomes {"error": ...} in the line, never a lost headline.
-    pairs_once = None
+    pairs_once, po_stats, lnE1 = None, None, None
     if dist_on and world >= 2 and os.environ.get("MCE_BENCH_PAIRS_ONCE", "1") != "0" and a.mode == 0:
         from mcevidence_amd import parallel
         impl = None
@@ -737,20 +737,26 @@ def main():
                 for _ in range(max(a.warmup, 1)):
                     dp1 = parallel.pairs_once_knn_dotp(Xh, weight, fsh, kmax, stats=st, impl=impl)
                 ctx.barrier()
+                _capi.set_profiling(True)      # (the same event brackets as the default partition's steps: this rank's sweep kernel)
                 t3 = time.perf_counter()
                 for _ in range(a.steps):
                     dp1 = parallel.pairs_once_knn_dotp(Xh, weight, fsh, kmax, stats=st, impl=impl)
                 mine_s = time.perf_counter() - t3
                 ctx.barrier()
-                mine = torch.tensor([time.perf_counter() - t3, float(st["sent"]), float(st["received"]), mine_s, float(torch.cuda.current_device())],
-                                    dtype=torch.float64, device=dev)
+                t_all = time.perf_counter() - t3
+                po_stats = _capi.last_search_stats()
+                _capi.set_profiling(False)
+                mine = torch.tensor([t_all, float(st["sent"]), float(st["received"]), mine_s, float(torch.cuda.current_device()),
+                                     po_stats["kernel_ms"], po_stats["search_ms"]], dtype=torch.float64, device=dev)
                 allr = [torch.zeros_like(mine) for _ in range(world)]
                 dist.all_gather(allr, mine)
+                allr = [t.cpu().numpy() for t in allr]
                 ms1 = max(float(t[0]) for t in allr) / a.steps * 1e3
                 lnE1 = lnE_from_dotp(dp1, c3)
                 pairs_once = dict(ms_per_step=round(ms1, 3), queries_per_s=round(n / (ms1 * 1e-3), 1), kernel=_capi.last_kernel(),
                                   per_rank=[dict(rank=i, device=int(t[4]), ms_per_step=round(float(t[3]) / a.steps * 1e3, 3), candidates_sent=int(t[1]),
-                                                 candidates_received=int(t[2])) for i, t in enumerate(allr)],
+                                                 candidates_received=int(t[2]), kernel_ms=round(float(t[5]), 3), search_ms=round(float(t[6]), 3))
+                                            for i, t in enumerate(allr)],
                                   candidates_sent=[int(t[1]) for t in allr], candidates_received=[int(t[2]) for t in allr],
                                   max_abs_dlnE_vs_default_partition=float(np.max(np.abs(lnE1 - lnE))),
                                   vs_default_partition=round(ms_step / ms1, 3),
@@ -771,6 +777,30 @@ def main():
     if want_extras and dist_on:
         extras = extra_configs(ctx, orc, pkg, a.extras_scale)   # every rank takes part
 
+    # Two ranks or more: the line's `value` is the FASTER of the library's two partitions of this workload, both timed above over
+    # the same K steps between the same barriers (round 6: the all-pairs-once partition is predicted ahead at 2, 4 and 8 ranks --
+    # profiles/r06_final/pairs_once_emulated.json -- but had never met a second GPU; the run decides, and says so:
+    # `config.partition` names the one `value` is of, `partitions` carries both).  It must have reproduced the default partition's
+    # ln E to 1e-9 to be eligible.  MCE_BENCH_HEADLINE=default keeps the default partition whatever the times.
+    partition = "default"
+    partitions = None
+    head_per_rank = head.get("per_rank")
+    dlnE_ref = head.get("max_abs_dlnE_vs_reference")
+    if pairs_once is not None and "ms_per_step" in pairs_once:
+        partitions = dict(default=dict(ms_per_step=round(ms_step, 3), queries_per_s=round(n / (ms_step * 1e-3), 1), kernel=head["kernel"],
+                                       what="mce_knn_dotp_part_f64_dev: every rank takes its share of the symmetric sweep's units, one all-reduce"),
+                          pairs_once=dict(ms_per_step=pairs_once["ms_per_step"], queries_per_s=pairs_once["queries_per_s"], kernel=pairs_once["kernel"],
+                                          what="every pair of rows multiplied once per NODE: " + pairs_once["collectives"]))
+        if (pairs_once["ms_per_step"] < ms_step and pairs_once["max_abs_dlnE_vs_default_partition"] < 1e-9 and po_stats is not None
+                and po_stats["kernel_ms"] > 0 and os.environ.get("MCE_BENCH_HEADLINE", "") != "default"):
+            partition = "pairs_once"
+            ms_step, kern_ms, stats, lnE = pairs_once["ms_per_step"], po_stats["kernel_ms"], po_stats, lnE1
+            head = dict(head, kernel=pairs_once["kernel"])
+            head_per_rank = pairs_once["per_rank"]
+            g = golden_lnE("C3", c3)
+            dlnE_ref = float(np.max(np.abs(lnE1 - np.array(g["lnE"])))) if g is not None else None
+        partitions["value_is_of"] = partition
+
     out = None
     if rank == 0:
         kdesc = head["kernel"]
@@ -789,7 +819,8 @@ def main():
         all_pairs = float(n) * n * flop_pair / world                 # what a sweep without the symmetry would execute on this rank
         lib_hash = _capi.source_hash()
         prof = profile_counters(kdesc, lib_hash)
-        stale = bool(prof.get("stale", True))
+        # (the committed counters are one launch of the profiled shape on ONE GPU: a rank's share of it, or another size, is another launch)
+        stale = bool(prof.get("stale", True)) or world > 1 or (n, d, kmax) != (1_000_000, 27, 10)
         live = (lambda k: None if stale else prof.get(k))           # counters of other sources are not this kernel's
         roof = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
                     traffic=live("traffic"), kernel_ms=round(kern_ms, 3), kernel=kdesc,
@@ -855,15 +886,17 @@ def main():
             e2e = dict(seconds=slow, queries_per_s=round(n / slow, 1), per_rank=e2e_ranks,
                        max_abs_dlnE_vs_resident_path=max(r["max_abs_dlnE_vs_resident_path"] for r in e2e_ranks),
                        note="every rank: one upload of the chain, device covariance + whitening, its share of the search, one all-reduce")
-        dlnE = head.get("max_abs_dlnE_vs_reference") if (n, d, kmax) == (1_000_000, 27, 10) else None
+        dlnE = dlnE_ref if (n, d, kmax) == (1_000_000, 27, 10) else None
         out = dict(metric="knn_queries_per_sec", value=round(n / (ms_step * 1e-3), 1), unit="queries/s", n_gpus=world,
                    steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True,
                    scaling="strong", vs_baseline=None, dtype="f64" if a.mode == 1 else "f16 filter + f64 refine (exact f64 results)", data="synthetic",
                    config=dict(workload="C3: auto-evidence, seeded Gaussian chain N=%d D=%d kmax=%d (K=%d true neighbours/query), %s" %
-                               (n, d, kmax, K, "one GPU" if world == 1 else "the library's partition over %d GPUs (DESIGN.md 5), one all-reduce of kmax doubles" % world),
-                               N=n, D=d, kmax=kmax, ranks=world),
+                               (n, d, kmax, K, "one GPU" if world == 1 else
+                                ("the all-pairs-once partition over %d GPUs (DESIGN.md 5): bounds all-reduce, candidates all_to_all, one all-reduce of kmax doubles" % world
+                                 if partition == "pairs_once" else "the library's partition over %d GPUs (DESIGN.md 5), one all-reduce of kmax doubles" % world)),
+                               N=n, D=d, kmax=kmax, ranks=world, partition=(None if world == 1 else partition)),
                    ranks_seen=(dist.get_world_size() if dist_on else 1), backend=(dist.get_backend() if dist_on else None),
-                   per_rank=head.get("per_rank"),
+                   per_rank=head_per_rank, partitions=partitions,
                    max_abs_dlnE_vs_reference=dlnE, lnE=[round(float(x), 10) for x in lnE],
                    roofline=roof, cpu_baseline=cpu, evidence_call_from_host=e2e, certificate=head.get("certificate"), configs=extras, fp64_mode=fp64_mode)
         if pairs_once is not None:

@@ -170,6 +170,8 @@ def test_bench_gpus_2_from_a_plain_shell():
     assert [r["rank"] for r in two["per_rank"]] == [0, 1] and all(r["device"] == 0 for r in two["per_rank"])
     # both partitions in the line by default; at 150 k rows (293 blocks on 2 ranks) the all-pairs-once partition applies
     assert "error" not in two["pairs_once"] and two["pairs_once"]["max_abs_dlnE_vs_default_partition"] < LNE_TOL, two["pairs_once"]
+    assert two["partitions"]["value_is_of"] == two["config"]["partition"] and one["partitions"] is None and one["config"]["partition"] is None
+    assert two["ms_per_step"] == min(two["partitions"]["default"]["ms_per_step"], two["partitions"]["pairs_once"]["ms_per_step"])
     assert two["steps"] == 2 and two["warmup"] == 1 and two["scaling"] == "strong"
     e2e = two["evidence_call_from_host"]                  # the class under the process group: part feed + one all-reduce
     assert len(e2e["per_rank"]) == 2 and e2e["max_abs_dlnE_vs_resident_path"] < LNE_TOL
@@ -212,6 +214,15 @@ def test_bench_gpus_2_under_the_launcher():
     assert "error" not in po and "skipped" not in po, po
     assert "pairs-once" in po["kernel"] and po["max_abs_dlnE_vs_default_partition"] < LNE_TOL and po["ms_per_step"] > 0
     assert sum(po["candidates_sent"]) == sum(po["candidates_received"]) > 0
-    assert [r["rank"] for r in po["per_rank"]] == [0, 1] and all(r["ms_per_step"] > 0 for r in po["per_rank"])
+    assert [r["rank"] for r in po["per_rank"]] == [0, 1] and all(r["ms_per_step"] > 0 and r["kernel_ms"] > 0 for r in po["per_rank"])
+    # `value` is the faster of the two (both timed over the same steps), and the line says which: ms_per_step, the kernel the roofline
+    # is of and the per-rank figures all belong to that one
+    pt = line["partitions"]
+    fastest = "pairs_once" if pt["pairs_once"]["ms_per_step"] < pt["default"]["ms_per_step"] else "default"
+    assert pt["value_is_of"] == line["config"]["partition"] == fastest
+    assert line["ms_per_step"] == pt[fastest]["ms_per_step"] and line["roofline"]["kernel"] == pt[fastest]["kernel"]
+    assert abs(line["value"] - 1_000_000 / (line["ms_per_step"] * 1e-3)) < 1.0
+    assert ("pairs-once" in line["roofline"]["kernel"]) == (fastest == "pairs_once") and line["roofline"]["traffic"] is None
+    assert ("candidates_sent" in line["per_rank"][0]) == (fastest == "pairs_once")
     e2e = line["evidence_call_from_host"]
     assert len(e2e["per_rank"]) == 2 and e2e["max_abs_dlnE_vs_resident_path"] < LNE_TOL
