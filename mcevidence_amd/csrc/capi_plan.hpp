@@ -44,7 +44,9 @@ struct Plan {
     const mce::KnnF16Variant* vh = nullptr;   // non-null: fp16-filter path
     const mce::KnnDeepVariant* vd = nullptr;  // non-null: the DEEP fp16 filter (knn_deep.hpp: 64 <= d <= 127, K <= 16); vh and v are null then
     bool filter() const { return vh != nullptr || vd != nullptr; }      // exact lists behind an fp16 filter (no refine in the merge; certified by default)
-    bool generic = false;                     // plain exact kernel (d > 63 or K > 32)
+    const mce::KnnLongVariant* vl = nullptr;  // non-null: the long-row fp64 sweep (knn_long.hpp: 128 <= d <= 1024, K <= 32); KS = its padded k-steps
+    size_t off_xf = 0, off_xn = 0;            // ... its packed queries and their squared norms
+    bool generic = false;                     // plain exact kernel (K > 32, or d > 127 with the long-row sweep turned off)
     int KST = 0;
     size_t off_yh = 0, off_xh = 0, off_qinfo = 0, off_params = 0;
     int KS = 0, KCAP = 0, QT = 0, CT = 0;
@@ -129,6 +131,54 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     // 64 <= d <= 127 (round 5): the fp64 MFMA sweep at KS = 20..32, one query tile per wave -- the vector-FMA kernel below was
     // 66x the time of d = 63 at 100 k rows (knn_generic.hpp); it keeps d > 127 and K > 32
     const bool wide_f64 = d > MCE_MAX_DIM && d <= mce::kWideMaxDim && K <= MCE_MAX_K;
+    // 128 <= d <= 1024 (round 6): the fp64 MFMA sweep with the k dimension in blocks (knn_long.hpp) -- the vector-FMA kernel below ran
+    // these at 0.12 of the fp64 vector peak; it keeps K > 32.  (MCE_LONG=0: comparisons.)
+    static const bool long_on = [] { const char* e = getenv("MCE_LONG"); return !(e && e[0] == '0'); }();
+    if (long_on && d >= mce::kLongMinDim && d <= mce::kLongMaxDim && K <= MCE_MAX_K) {
+        p.ksel = std::min<int>(K + kRefineMargin, MCE_MAX_K);          // (GEMM-form keys: the merge picks the K on exact distances)
+        p.vl = &mce::g_knn_long[p.ksel <= 8 ? 0 : (p.ksel <= 16 ? 1 : 2)];
+        p.v = nullptr;
+        p.vh = nullptr;
+        p.KCAP = p.vl->kcap;
+        p.CT = p.vl->ct;
+        p.QT = mce::kLongQT;
+        p.KS = mce::long_ksp(d);
+        p.nqblk = (int)std::max<int64_t>(1, (nq + mce::kLongQPB - 1) / mce::kLongQPB);
+        p.nq_pad = (int64_t)p.nqblk * mce::kLongQPB;
+        const int64_t rows_per_chunk = (int64_t)p.CT * 16;
+        p.nchunk = (nr + rows_per_chunk - 1) / rows_per_chunk;
+        p.nrow_pad = p.nchunk * rows_per_chunk;
+        // reference splits: fill the chip (one 512-thread workgroup per CU) and trim the last partial round; every split re-pays a
+        // list warm-up of a few chunks' worth of insertions
+        int best_r = 1;
+        double best_c = 1e300;
+        const int rmax = (int)std::min<int64_t>(mce::kMaxLists, p.nchunk);
+        for (int r = 1; r <= rmax; ++r) {
+            const double c = std::ceil((double)p.nqblk * r / kAssumedCUs) * (std::ceil((double)p.nchunk / r) + 16.0);
+            if (c < best_c * 0.98) { best_c = c; best_r = r; }
+        }
+        p.rsplit = best_r;
+        p.L = p.rsplit;
+        p.cost = best_c;
+        p.pl_nr = nr;
+        size_t off = 0;
+        p.off_pd = off;
+        off = align_up(off + (size_t)p.L * p.KCAP * (size_t)p.nq_pad * sizeof(double), 256);
+        p.off_pi = off;
+        off = align_up(off + (size_t)p.L * p.KCAP * (size_t)p.nq_pad * sizeof(int), 256);
+        p.off_center = off;
+        off = align_up(off + (size_t)(d + 4) * sizeof(double), 256);
+        p.off_msum = off;
+        off = align_up(off + (size_t)mce::kLongMeanBlocks * (size_t)d * sizeof(double), 256);
+        p.off_yf = off;
+        off = align_up(off + (size_t)p.nrow_pad * (size_t)p.KS * 4 * sizeof(double), 256);
+        p.off_xf = off;
+        off = align_up(off + (size_t)p.nq_pad * (size_t)p.KS * 4 * sizeof(double), 256);
+        p.off_xn = off;
+        off = align_up(off + (size_t)p.nq_pad * sizeof(double), 256);
+        p.total = off + 256;
+        return MCE_OK;
+    }
     if ((d > MCE_MAX_DIM && !wide_f64) || K > MCE_MAX_K) {
         // outside the MFMA kernels' register budgets: plain exact kernel, lists [1][K][nq_pad]
         p.generic = true;

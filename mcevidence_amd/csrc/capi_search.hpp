@@ -44,7 +44,12 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
     double* msum = reinterpret_cast<double*>(ws + p.off_msum);
     double* box_y = center + mce::kMaxDimPad;
     double* box_x = center + 2 * mce::kMaxDimPad;
-    if (d > MCE_MAX_DIM) {      // (the fp64 sweep's wide form, 64 <= d <= 127: means only, 128 of the 192 doubles at `center`)
+    if (p.vl) {                 // (the long-row sweep: its own column means, any d)
+        hipLaunchKernelGGL(mce::long_col_mean_partial_kernel, dim3(mce::kLongMeanBlocks), dim3(256), 0, st, dY, nr, (int)d, mce::kLongMeanBlocks, msum);
+        MCE_HIP(hipGetLastError());
+        hipLaunchKernelGGL(mce::long_col_mean_final_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, msum, nr, (int)d, mce::kLongMeanBlocks, center);
+        MCE_HIP(hipGetLastError());
+    } else if (d > MCE_MAX_DIM) {      // (the fp64 sweep's wide form, 64 <= d <= 127: means only, 128 of the 192 doubles at `center`)
         static_assert(3 * mce::kMaxDimPad >= 128 && mce::kStatStride >= 128, "wide column means");
         hipLaunchKernelGGL(mce::col_mean_wide_partial_kernel, dim3(mce::kMeanBlocks), dim3(256), 0, st, dY, nr, (int)d, msum);
         MCE_HIP(hipGetLastError());
@@ -92,6 +97,36 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
         return MCE_OK;
     };
     const int threads = 256;
+    if (p.vl) {
+        // ---- the long-row fp64 sweep (128 <= d <= 1024; knn_long.hpp): both sets packed in MFMA fragment order, k blocks of 32 dimensions ----
+        double* yf = reinterpret_cast<double*>(ws + p.off_yf);
+        double* xf = reinterpret_cast<double*>(ws + p.off_xf);
+        double* xn = reinterpret_cast<double*>(ws + p.off_xn);
+        hipLaunchKernelGGL(mce::pack_refs_kernel, dim3((unsigned)((p.nrow_pad + threads - 1) / threads)), dim3(threads), 0, st, dY, nr, (int)d, p.KS, p.nrow_pad, center, yf);
+        MCE_HIP(hipGetLastError());
+        const int64_t qe = p.nq_pad * (int64_t)p.KS;
+        hipLaunchKernelGGL(mce::long_pack_queries_kernel, dim3((unsigned)((qe + 255) / 256)), dim3(256), 0, st, dX, nq, (int)d, p.KS, p.nq_pad, center, xf);
+        MCE_HIP(hipGetLastError());
+        hipLaunchKernelGGL(mce::long_query_norms_kernel, dim3((unsigned)((p.nq_pad + 255) / 256)), dim3(256), 0, st, dX, nq, (int)d, p.nq_pad, center, xn);
+        MCE_HIP(hipGetLastError());
+        mce::LongArgs a;
+        a.Yf = yf; a.Xf = xf; a.xn = xn;
+        a.nchunk_total = p.nchunk; a.rsplit = p.rsplit; a.KSP = p.KS; a.KSB = mce::long_ksb(d);
+        a.nq = nq; a.nq_pad = p.nq_pad; a.nqblk = p.nqblk;
+        a.self_exclude = (self_mode == MCE_SELF_EXCLUDE) ? 1 : 0;
+        a.self_offset = self_offset;
+        a.ksel = p.ksel > K ? p.ksel : K;
+        a.part_d = pd; a.part_i = pi;
+        int rc = prof_begin();
+        if (rc != MCE_OK) return rc;
+        MCE_HIP(p.vl->launch(a, st));
+        rc = prof_end();
+        if (rc != MCE_OK) return rc;
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d ksp=%d", p.vl->name, p.nqblk * p.rsplit, mce::kThreads,
+                 p.vl->lds_bytes, p.QT, p.CT, p.rsplit, p.KS);
+        g_last_flops_main = g_last_flops_all = (double)p.nq_pad * (double)p.nrow_pad * 2.0 * 4.0 * p.KS;
+        return MCE_OK;
+    }
     if (p.vd) {
         // ---- the deep fp16 filter (64 <= d <= 127; knn_deep.hpp) + exact fp64 refine -------------------------------------------
         _Float16* yh = reinterpret_cast<_Float16*>(ws + p.off_yh);

@@ -112,6 +112,17 @@ struct KnnDeepVariant {
     size_t lds_bytes;
     const char* name;
 };
+// ---- long-row fp64 variants (knn_long.hpp): 128 <= d <= 1024, K <= 32; lists of 8, 16 or 32 entries ----
+struct LongArgs;                   // knn_long.hpp
+typedef hipError_t (*knn_long_launch_fn)(const LongArgs&, hipStream_t);
+struct KnnLongVariant {
+    knn_long_launch_fn launch;
+    int kcap, ct;
+    size_t lds_bytes;
+    const char* name;
+};
+constexpr int kNumLongKcap = 3;    // index 0, 1, 2 <-> KCAP = 8, 16, 32
+extern const KnnLongVariant g_knn_long[kNumLongKcap];
 constexpr int kNumDeepKST = 3;     // index 0, 1, 2 <-> KST = 5, 6, 8
 extern const KnnDeepVariant g_knn_deep_kcap4[kNumDeepKST];
 extern const KnnDeepVariant g_knn_deep_kcap8[kNumDeepKST];

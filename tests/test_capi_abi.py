@@ -60,7 +60,8 @@ def test_argument_validation_without_gpu():
     assert _capi.knn_workspace_bytes(1000, 1000, 6, 4) > 0
     assert _capi.dotp_workspace_bytes(1000, 4) >= 4 * 4 * 8
     assert _capi.knn_workspace_bytes(10, 10, 100, 4) > 0         # 64 <= d <= 127: the fp64 sweep's wide form
-    assert _capi.knn_workspace_bytes(10, 10, 300, 4) > 0         # d > 127: generic exact kernel
+    assert _capi.knn_workspace_bytes(10, 10, 300, 4) > 0         # d > 127: the long-row fp64 sweep (K > 32: the generic exact kernel)
+    assert _capi.knn_workspace_bytes(10, 100, 300, 40) > 0
     with pytest.raises(ValueError):
         _capi.knn_workspace_bytes(10, 10, 2000, 4)
 

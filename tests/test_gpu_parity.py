@@ -320,12 +320,41 @@ def test_knn_adversarial_inputs_stay_exact(capi, kind, d):
     assert np.all(np.diff(dist, axis=1) >= 0)
 
 
+@pytest.mark.parametrize("n,nq,d,K,self_mode", [(3001, 3001, 128, 7, 2), (3001, 3001, 129, 1, 2), (5000, 777, 160, 14, 0), (4000, 4000, 200, 15, 1), (2500, 2500, 256, 30, 2),
+                                                (2100, 100, 511, 32, 0), (1500, 1500, 1024, 5, 2), (40000, 40000, 130, 9, 2), (33, 33, 128, 32, 2), (70000, 300, 300, 6, 0),
+                                                (300, 70000, 128, 3, 0)])
+def test_long_rows_on_the_blocked_fp64_sweep(capi, n, nq, d, K, self_mode):
+    """128 <= d <= 1024 (round 6): the fp64 MFMA sweep with the k dimension in blocks of 32 (knn_long.hpp) --
+    several query blocks, reference splits, ragged ends, every list length, the self row in and out.  GEMM-form keys select K + 2
+    candidates, the merge picks the K on exact direct-difference distances: the oracle's rows, all of them."""
+    rng = np.random.default_rng(n + d + K)
+    Y = rng.standard_normal((n, d))
+    X = Y if self_mode else rng.standard_normal((nq, d))
+    dist, idx = capi.knn(X, Y, K, self_mode=self_mode)
+    assert "knn_long_kernel<KCAP=%d>" % (8 if K <= 6 else 16 if K <= 14 else 32) in capi.last_kernel(), capi.last_kernel()
+    od, oi = orc.knn_brute(X, Y, K, self_mode=2 if self_mode == 2 else 0)
+    assert np.array_equal(idx, oi) and _rel(dist, od) < 1e-13          # (the merge's fma chain against the oracle's plain sum: last-ulp)
+    if self_mode == 1:
+        assert np.all(dist[:, 0] == 0.0) and np.array_equal(idx[:, 0], np.arange(n))
+    if self_mode == 2 and n <= 5000 and d <= 200:          # (beyond: r^d overflows the oracle's literal volume)
+        # the fused call and the partitioned entry point on the same path
+        w = rng.integers(1, 5, n).astype(np.float64)
+        fs = -rng.random(n)
+        dotp = capi.knn_dotp(Y, None, w, fs, K + 1, 1)
+        want = orc.dotp_literal(np.concatenate([np.zeros((n, 1)), od], axis=1), w, fs, d, 1, K + 1)
+        assert np.allclose(dotp[1:], want[1:], rtol=1e-12, atol=0.0)
+        parts = sum(capi.knn_dotp_part(Y, w, fs, K + 1, p, 3) for p in range(3))
+        assert np.allclose(parts[1:], dotp[1:], rtol=1e-13, atol=0.0)
+
+
 @pytest.mark.parametrize("d,K,kernel", [(64, 5, "knn_deep_kernel<KST=5"), (79, 3, "knn_deep_kernel<KST=5"), (80, 20, "knn_mfma_kernel<KS=24"), (100, 12, "knn_deep_kernel<KST=8"),
-                                        (90, 16, "knn_deep_kernel<KST=6"), (127, 32, "knn_mfma_kernel<KS=32"), (128, 6, "generic"), (10, 40, "generic"), (200, 33, "generic"), (100, 33, "generic")])
+                                        (90, 16, "knn_deep_kernel<KST=6"), (127, 32, "knn_mfma_kernel<KS=32"), (128, 6, "knn_long_kernel<KCAP=8"), (10, 40, "generic"), (200, 33, "generic"), (100, 33, "generic"),
+                                        (129, 14, "knn_long_kernel<KCAP=16"), (200, 32, "knn_long_kernel<KCAP=32"), (300, 15, "knn_long_kernel<KCAP=32"), (1024, 3, "knn_long_kernel<KCAP=8")])
 def test_beyond_the_filter_kernels_limits(capi, d, K, kernel):
     """64 <= d <= 127: the DEEP fp16 filter (round 6: 5, 6 or 8 k-steps, K <= 16) or -- longer lists, search mode 1 -- the fp64 MFMA
-    sweep at KS = 20..32, one query tile per wave (round 5: the vector-FMA kernel took 66x the time of d = 63).  d > 127 or K > 32:
-    the plain exact kernel -- no shape the reference accepts is refused."""
+    sweep at KS = 20..32, one query tile per wave (round 5: the vector-FMA kernel took 66x the time of d = 63).  128 <= d <= 1024
+    (round 6): the fp64 MFMA sweep with the k dimension in blocks (knn_long.hpp).  K > 32: the plain exact kernel -- no shape the
+    reference accepts is refused."""
     rng = np.random.default_rng(d * 7 + K)
     Y = rng.standard_normal((1500, d))
     X = rng.standard_normal((333, d))
@@ -541,7 +570,7 @@ def test_device_feeders_beyond_63_dimensions(d, split):
             _capi.evidence_feed(wide[:, 2:], None, 128, 0, 3, np.ones(3000), np.zeros(3000))
         calls.clear()
         lnE = pkg.MCEvidence([wide], kmax=3, verbose=0, backend=Spy()).evidence()
-        assert calls.get("feed", 0) == 0 and np.all(np.isfinite(lnE)) and "generic" in _capi.last_kernel()
+        assert calls.get("feed", 0) == 0 and np.all(np.isfinite(lnE)) and "knn_long_kernel" in _capi.last_kernel()
 
 
 def _feed_problems(rng, count):

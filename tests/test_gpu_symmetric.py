@@ -776,7 +776,8 @@ def test_concurrent_searches_on_many_streams_and_threads_are_bit_identical(spin_
     shapes = [(9000, 6, 2, 0), (26862, 6, 2, 0), (60000, 8, 3, 0), (40000, 27, 10, 0),          # kind 0: exhaustive (automatic splits, seeds)
               (150000, 27, 10, 2), (120000, 45, 6, 2), (200000, 20, 4, 2), (70000, 27, 10, 2),    # kind 2: symmetric sweep
               (300000, 3, 5, 1), (400000, 6, 4, 1), (250000, 2, 3, 1), (131072, 10, 5, 0),         # kind 1: pruned walk
-              (50000, 70, 5, 0), (60000, 100, 10, 0)]                                               # (round 6) kind 0 at d >= 64: the deep filter
+              (50000, 70, 5, 0), (60000, 100, 10, 0),                                               # (round 6) kind 0 at d >= 64: the deep filter
+              (20000, 200, 6, 0)]                                                                   # ... at d >= 128: the long-row fp64 sweep
     modes = {0: dict(prune_mode=capi.PRUNE_OFF, sym_mode=capi.SYM_OFF), 1: dict(prune_mode=capi.PRUNE_FORCE, sym_mode=capi.SYM_OFF),
              2: dict(prune_mode=capi.PRUNE_OFF, sym_mode=capi.SYM_FORCE)}
     jobs = []
@@ -804,7 +805,7 @@ def test_concurrent_searches_on_many_streams_and_threads_are_bit_identical(spin_
         assert ("pruned" in k) == (j["kind"] == 1) and ("symmetric" in k) == (j["kind"] == 2), k
         if j["kind"] == 2:
             assert "panel-kernel" in k
-        assert ("knn_deep_kernel" in k) == (j["d"] >= 64), k
+        assert ("knn_deep_kernel" in k) == (64 <= j["d"] <= 127) and ("knn_long_kernel" in k) == (j["d"] >= 128), k
 
     def check(tag):
         bad = []

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised shapes through the C ABI against the CPU oracle (development tool; run on a GPU box).
 
-    python tools/fuzz_shapes.py --seconds 600 --seed 1 [--max-rows 60000] [--out gpurun_out/fuzz.json]
+    python tools/fuzz_shapes.py --seconds 600 --seed 1 [--max-rows 60000] [--min-rows 1] [--out gpurun_out/fuzz.json]
 
 The parity tests pin chosen shapes; this draws them: sizes from one row to --max-rows, d from 1 to 140, K from 1 to 40, separate
 and shared sets, with and without the self row, every process-wide search / prune / symmetric mode, and data that is meant to hurt
@@ -62,17 +62,20 @@ def log_int(rng, lo, hi):
     return int(round(np.exp(rng.uniform(np.log(lo), np.log(hi + 1))))) if hi > lo else lo
 
 
-def draw(rng, max_rows):
+def draw(rng, max_rows, min_rows=1, d_range=None):
     dsel = rng.integers(0, 10)
     d = int(rng.integers(1, 9)) if dsel < 4 else int(rng.integers(9, 33)) if dsel < 6 else int(rng.integers(33, 64)) if dsel < 7 else \
         int(rng.integers(64, 128)) if dsel < 9 else int(rng.integers(128, 141))
+    if d_range:
+        d = int(rng.integers(d_range[0], d_range[1] + 1))
     K = int(rng.integers(1, 17)) if rng.random() < 0.7 else int(rng.integers(17, 33)) if rng.random() < 0.8 else int(rng.integers(33, 41))
     budget = max_rows if d < 64 else max(2000, max_rows // 3)
     same = rng.random() < 0.55
-    nr = max(log_int(rng, 1, budget), K + 1)
-    if rng.random() < 0.15:
+    lo = max(1, min(min_rows, budget))
+    nr = max(log_int(rng, lo, budget), K + 1)
+    if rng.random() < 0.15 and min_rows <= 1:
         nr = max(K + 1, min(nr, K + int(rng.integers(0, 3))))            # barely enough reference rows
-    nq = nr if same else log_int(rng, 1, budget)
+    nq = nr if same else log_int(rng, lo, budget)
     self_mode = (1 if rng.random() < 0.3 else 2) if same else 0
     if self_mode == 2 and nr <= K:
         nr = nq = K + 1
@@ -123,7 +126,7 @@ def run_case(c, with_sums):
         srt = np.sort(idx, axis=1)
         if np.any(srt[:, 1:] == srt[:, :-1]):
             problems.append("a reference row named twice for one query")
-    if with_sums and sm != 1 and c["kind"] not in ("tiny", "huge") and K >= 1:
+    if with_sums and sm != 1 and c["kind"] not in ("tiny", "huge") and c["d"] <= 150:          # (beyond: the oracle's literal r^d / Gamma overflows)
         k0 = 1 if sm == 2 else 0
         kmax = K + k0
         w = rng.integers(1, 6, c["nq"]).astype(np.float64)
@@ -160,6 +163,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--max-rows", type=int, default=60000)
+    ap.add_argument("--min-rows", type=int, default=1, help="large draws only: several query blocks, reference splits, the trailing partial round")
+    ap.add_argument("--dims", default=None, help="lo,hi: every draw's d from this range (e.g. 128,600: the long-row sweep)")
     ap.add_argument("--out", default=None)
     ap.add_argument("--replay", default=None, help="one case as JSON (printed by a failing run)")
     a = ap.parse_args()
@@ -172,7 +177,7 @@ def main():
     t0 = time.time()
     n, failures, families, refused = 0, [], {}, {}
     while time.time() - t0 < a.seconds:
-        c = draw(rng, a.max_rows)
+        c = draw(rng, a.max_rows, a.min_rows, [int(v) for v in a.dims.split(",")] if a.dims else None)
         problems, kern = run_case(c, n % 3 == 0)
         n += 1
         if kern is None:
@@ -194,7 +199,7 @@ def main():
         if problems:
             failures.append(dict(case=c, kernel=kern, problems=problems))
             print("MISMATCH " + json.dumps(dict(case=c, kernel=kern, problems=problems)), flush=True)
-    summary = dict(draws=n, seconds=round(time.time() - t0, 1), seed=a.seed, max_rows=a.max_rows, mismatches=len(failures), refused_out_of_range=refused,
+    summary = dict(draws=n, seconds=round(time.time() - t0, 1), seed=a.seed, max_rows=a.max_rows, min_rows=a.min_rows, dims=a.dims, mismatches=len(failures), refused_out_of_range=refused,
                    kernels_reached=dict(sorted(families.items(), key=lambda kv: -kv[1])), failures=failures[:50], library_source_hash=_capi.source_hash())
     print(json.dumps(summary), flush=True)
     if a.out:

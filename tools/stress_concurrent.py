@@ -14,7 +14,8 @@ shapes = [(9000, 6, 2, 0), (26862, 6, 2, 0), (60000, 8, 3, 0), (100000, 6, 4, 0)
           (150000, 27, 10, 2), (200000, 45, 6, 2), (300000, 20, 4, 2), (70000, 27, 10, 2),
           (400000, 3, 5, 1), (600000, 6, 4, 1), (250000, 2, 3, 1),
           (16384, 6, 4, 0), (33000, 45, 10, 0), (5000, 27, 5, 0), (131072, 10, 5, 0), (180000, 27, 8, 0),
-          (60000, 70, 5, 0), (90000, 100, 10, 0), (40000, 127, 13, 0)]          # (round 6: the deep filter, 5 / 8 / 8 k-steps)
+          (60000, 70, 5, 0), (90000, 100, 10, 0), (40000, 127, 13, 0),          # (round 6: the deep filter, 5 / 8 / 8 k-steps)
+          (30000, 160, 7, 0), (20000, 300, 20, 0)]                              # (round 6: the long-row fp64 sweep)
 for (n, d, kmax, kind) in shapes:          # kind: 0 automatic exhaustive, 1 pruned walk, 2 symmetric
     X = torch.from_numpy(rng.standard_normal((n, d)) @ (np.eye(d) + 0.3 * rng.standard_normal((d, d)))).cuda()
     K = kmax - 1
