@@ -601,7 +601,13 @@ def extra_configs(ctx, orc, pkg, scale=1.0):
             nsample, algs = min(nsample, 100), tuple((alg, min(nr, 500)) for alg, nr in algs)
         progress("preparing config %s" % name)
         cfg = prep_config(name, scale)
-        res, _, _ = time_config(ctx, cfg, steps, warmup, nsample=0 if ctx.dist_on else nsample, orc=orc)
+        try:
+            res, _, _ = time_config(ctx, cfg, steps, warmup, nsample=0 if ctx.dist_on else nsample, orc=orc)
+        except Exception as exc:      # (a section of the line, never the line: the headline above is already measured)
+            progress("config %s failed: %s: %s" % (name, type(exc).__name__, exc))
+            out[name] = dict(error="%s: %s" % (type(exc).__name__, exc))
+            del cfg
+            continue
         if ctx.rank == 0 and not ctx.dist_on:
             if name == "C4" and "max_abs_dlnE_vs_reference" in res:
                 # ... and ln E through the class (device feeders, from host arrays) for this pair

@@ -64,6 +64,14 @@ for c in C2 C4 C5; do
     summarise $out/pmc_summary_$c.csv S:/tmp/pc_${tag}_$c || exit 1
   fi
 done
+# the kernels beyond the BASELINE configs' shapes (round 6): the deep fp16 filter (64 <= d <= 127) and the long-row fp64 sweep (d >= 128),
+# 100 k x 100 k auto evidence each -- one process, one kernel row per variant
+SHAPES="100000,64,9 100000,100,9 100000,127,9 100000,128,9 100000,256,9"
+pass /tmp/kh_$tag $out/shapes_under_kernel_trace.log --kernel-trace --stats --output-format csv -d /tmp/kh_$tag -o kt -- python3 $R/tools/shape_times.py $SHAPES
+cp $(need /tmp/kh_$tag "*kernel_stats.csv" $out/shapes_under_kernel_trace.log) $out/kernel_stats_shapes.csv || exit 1
+grep "^100000," $out/shapes_under_kernel_trace.log > $out/shape_times.txt
+pass /tmp/ph_$tag $out/shapes_under_sq.log --pmc $SQ --kernel-trace --output-format csv -d /tmp/ph_$tag -o ps -- python3 $R/tools/shape_times.py $SHAPES
+summarise $out/pmc_summary_shapes.csv S:/tmp/ph_$tag || exit 1
 pass /tmp/kf_$tag $out/bench_fp64_under_kernel_trace.log --kernel-trace --stats --output-format csv -d /tmp/kf_$tag -o kt -- $B --mode 1 --steps 2 --warmup 1
 cp $(need /tmp/kf_$tag "*kernel_stats.csv" $out/bench_fp64_under_kernel_trace.log) $out/kernel_stats_fp64.csv || exit 1
 grep '^{"metric"' $out/bench_fp64_under_kernel_trace.log | tail -1 > $out/bench_fp64.json
@@ -80,6 +88,7 @@ json.dump(dict(tag=sys.argv[2], source_hash=bench.source_hash(), library_source_
                          "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_* --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-extras (separate passes)",
                          "rocprofv3 --kernel-trace --stats -- python3 tools/run_configs.py C2 | C4 | C5",
                          "rocprofv3 --pmc SQ_* --kernel-trace -- python3 tools/run_configs.py C2 | C4 | C5 (pmc_summary_<C>.csv: per dispatch = sum / dispatches)",
+                         "rocprofv3 --kernel-trace --stats | --pmc SQ_* --kernel-trace -- python3 tools/shape_times.py 100000,64,9 100000,100,9 100000,127,9 100000,128,9 100000,256,9 (kernel_stats_shapes.csv, pmc_summary_shapes.csv, shape_times.txt)",
                          "rocprofv3 --kernel-trace --stats -- python3 bench.py --mode 1 --steps 2 --warmup 1 --cpu-sample 0 --no-extras"]),
           open(os.path.join(sys.argv[1], "meta.json"), "w"), indent=1)
 PY
