@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Randomised `MCEvidence(...).evidence()` calls on the GPU against the same class on the CPU oracle (development tool; GPU box).
+
+    python tools/fuzz_class.py --seconds 300 --seed 1 [--max-rows 40000] [--out gpurun_out/fuzz_class.json]
+
+Every draw builds one chain (or two) -- rows, dimensions, integer or unit weights, nuisance columns behind `ndim`, a prior volume,
+correlated / strongly anisotropic / far-from-the-origin / clustered parameters -- and evaluates it twice with the same arguments
+(kmax, split + s1frac under one seed, covtype, pos_lnp): `backend=HipBackend()` (the product: device feeders up to d = 127, the
+fused search + reduction) and `backend=OracleBackend()` (tests/helpers.py: the class's host path over the CPU oracle's exact
+search).  ln E must agree to 1e-9 for every k (BASELINE.md's tolerance).  A mismatch is printed with its draw (`--replay`)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+from helpers import OracleBackend        # noqa: E402   (checker only)
+import mcevidence_amd as pkg             # noqa: E402
+from mcevidence_amd import _capi         # noqa: E402
+
+LNE_TOL = 1e-9
+CPU_ONLY = os.environ.get("MCE_FUZZ_CPU_ONLY") == "1"          # (dry run of this script without a GPU: the oracle on both sides)
+KINDS = ("corr", "corr", "aniso", "offset", "clusters", "unit")
+
+
+def make_theta(rng, kind, n, d):
+    z = rng.standard_normal((n, d))
+    if kind == "unit":
+        return z
+    if kind == "corr":
+        return z @ (np.eye(d) + 0.4 * rng.standard_normal((d, d)))
+    if kind == "aniso":
+        return z * np.exp(rng.uniform(-4, 4, d))
+    if kind == "offset":          # CosmoMC-like: the mean thousands of sigma from the origin
+        return z * np.exp(rng.uniform(-2, 2, d)) + 3.0e3 * rng.standard_normal(d)
+    if kind == "clusters":
+        c = rng.standard_normal((3, d)) * 4.0
+        return c[rng.integers(0, 3, n)] + z
+    raise ValueError(kind)
+
+
+def draw(rng, max_rows):
+    dsel = rng.integers(0, 10)
+    d = int(rng.integers(1, 9)) if dsel < 5 else int(rng.integers(9, 41)) if dsel < 8 else int(rng.integers(41, 128)) if dsel < 9 else int(rng.integers(128, 161))
+    n = int(round(np.exp(rng.uniform(np.log(max(300, 8 * d)), np.log(max_rows if d < 64 else max(2000, max_rows // 3))))))
+    kmax = int(rng.integers(2, 13))
+    return dict(n=n, d=d, kmax=kmax, kind=str(KINDS[rng.integers(0, len(KINDS))]), weights=str(rng.choice(["unit", "int"])), extra=int(rng.integers(0, 4)),
+                split=bool(rng.random() < 0.35), s1frac=float(rng.choice([0.5, 0.5, 0.3, 0.7])), covtype=str(rng.choice(["single", "all"])),
+                priorvolume=float(rng.choice([1.0, 1.0, 3.0])), pos_lnp=bool(rng.random() < 0.15), two_chains=bool(rng.random() < 0.2), seed=int(rng.integers(0, 2**31)))
+
+
+def chain_of(rng, c, n):
+    d = c["d"]
+    theta = make_theta(rng, c["kind"], n, d)
+    mu = theta.mean(axis=0)
+    cov = np.atleast_2d(np.cov(theta.T))
+    dev = theta - mu
+    lnL = -0.5 * np.einsum("ij,jk,ik->i", dev, np.linalg.inv(cov), dev)
+    w = np.ones(n) if c["weights"] == "unit" else rng.integers(1, 6, n).astype(np.float64)
+    cols = [w, lnL if c["pos_lnp"] else -lnL, theta]
+    if c["extra"]:
+        cols.append(rng.standard_normal((n, c["extra"])) * 7.0)          # nuisance columns behind ndim
+    return np.column_stack(cols)
+
+
+def run_case(c):
+    rng = np.random.default_rng(c["seed"])
+    chains = [chain_of(rng, c, c["n"])]
+    if c["two_chains"]:
+        chains.append(chain_of(np.random.default_rng(c["seed"] + 1), c, max(300, c["n"] // 2)))
+    out = {}
+    kernel = None
+    for name in ("hip", "oracle"):
+        np.random.seed(c["seed"] % (2**31))          # the reference's split draws from the global generator
+        kw = dict(kmax=c["kmax"], ndim=c["d"], split=c["split"], s1frac=c["s1frac"], priorvolume=c["priorvolume"], verbose=0)
+        if name == "oracle" or CPU_ONLY:
+            kw["backend"] = OracleBackend()
+        try:
+            m = pkg.MCEvidence([ch.copy() for ch in chains], **kw)
+            out[name] = np.asarray(m.evidence(covtype=c["covtype"], pos_lnp=c["pos_lnp"]), dtype=np.float64)
+        except Exception as exc:
+            out[name] = "%s: %s" % (type(exc).__name__, exc)
+        if name == "hip" and not CPU_ONLY:
+            kernel = _capi.last_kernel()
+    a, b = out["hip"], out["oracle"]
+    problems = []
+    if isinstance(a, str) or isinstance(b, str):
+        if not (isinstance(a, str) and isinstance(b, str) and a.split(":")[0] == b.split(":")[0]):          # (the same refusal on both sides is an answer)
+            problems.append("hip: %s | oracle: %s" % (a if isinstance(a, str) else "ok", b if isinstance(b, str) else "ok"))
+    else:
+        fin = np.isfinite(b)
+        # (where the oracle's literal r^d overflowed -- long rows -- there is nothing to compare with; the product sums in log space)
+        if a.shape != b.shape or not np.all(np.isfinite(a[fin])) or (fin.any() and np.max(np.abs(a[fin] - b[fin])) > LNE_TOL):
+            problems.append("ln E differs: max %r; hip %r oracle %r" % (float(np.max(np.abs(a[fin] - b[fin]))) if a.shape == b.shape and fin.any() else None,
+                                                                          a.tolist(), b.tolist()))
+    return problems, kernel
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300.0)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--max-rows", type=int, default=40000)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--replay", default=None)
+    a = ap.parse_args()
+    if a.replay:
+        c = json.loads(a.replay)
+        problems, kern = run_case(c)
+        print(json.dumps(dict(case=c, kernel=kern, problems=problems)))
+        return 1 if problems else 0
+    rng = np.random.default_rng(a.seed)
+    t0 = time.time()
+    n, failures, fam = 0, [], {}
+    while time.time() - t0 < a.seconds:
+        c = draw(rng, a.max_rows)
+        problems, kern = run_case(c)
+        n += 1
+        key = (kern or "?").split(" grid=")[0].split(">")[0] + (">" if kern and "<" in kern else "")
+        key += " split" if c["split"] else ""
+        fam[key] = fam.get(key, 0) + 1
+        if problems:
+            failures.append(dict(case=c, kernel=kern, problems=problems))
+            print("MISMATCH " + json.dumps(dict(case=c, kernel=kern, problems=problems)), flush=True)
+    summary = dict(draws=n, seconds=round(time.time() - t0, 1), seed=a.seed, max_rows=a.max_rows, mismatches=len(failures), tolerance=LNE_TOL,
+                   last_kernel_of_the_draws=dict(sorted(fam.items(), key=lambda kv: -kv[1])), failures=failures[:50], library_source_hash=(None if CPU_ONLY else _capi.source_hash()))
+    print(json.dumps(summary), flush=True)
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        json.dump(summary, open(a.out, "w"), indent=1)
+    return min(len(failures), 100)
+
+
+if __name__ == "__main__":
+    sys.exit(main())
