@@ -106,9 +106,23 @@ def run_case(c, with_sums):
     with np.errstate(divide="ignore", invalid="ignore"):
         rel = np.abs(dist - od) / np.where(od != 0, np.abs(od), 1.0)
     rel = np.where(od == 0, np.abs(dist), rel)
+    # The fp64 sweeps (search mode 1; lists longer than 16 at d >= 64; d >= 128) SELECT on GEMM-form keys |x|^2 + |y|^2 - 2 x.y, good to
+    # ~eps R^2 absolute (R: the set's extent about its mean), and report exact distances of what they selected: where neighbours lie
+    # closer together than that -- d = 1 with clusters 1e6 spacings apart -- the K-th may be swapped for an almost equally near row
+    # (docs/design/sweep_f64.md; the default filter path has no such limit).  Such draws are counted, not failed.
+    gemm = ("knn_mfma_kernel" in kern) or ("knn_long_kernel" in kern)
+    allow = 0.0
+    if gemm:
+        mu = Y.mean(axis=0)
+        allow = 512.0 * np.finfo(np.float64).eps * max(float(np.max(np.einsum("ij,ij->i", Y - mu, Y - mu))), float(np.max(np.einsum("ij,ij->i", X - mu, X - mu))))
+    key_res = False
     if not np.all(rel <= DIST_RTOL):
-        r, k = np.unravel_index(int(np.nanargmax(np.where(np.isnan(rel), np.inf, rel))), rel.shape)
-        problems.append("distance off: row %d col %d got %r want %r" % (r, k, dist[r, k], od[r, k]))
+        off = ~(rel <= DIST_RTOL)
+        if gemm and np.all(np.abs(dist[off] ** 2 - od[off] ** 2) <= allow):
+            key_res = True
+        else:
+            r, k = np.unravel_index(int(np.nanargmax(np.where(np.isnan(rel), np.inf, rel))), rel.shape)
+            problems.append("distance off: row %d col %d got %r want %r" % (r, k, dist[r, k], od[r, k]))
     bad = idx != oi
     if np.any(bad):
         # a different row is fine only at an exactly tied distance: the row named must lie at the oracle's distance for that column
@@ -116,6 +130,10 @@ def run_case(c, with_sums):
         diff = X[rows] - Y[idx[rows, cols]]
         dd = np.sqrt(np.einsum("ij,ij->i", diff, diff))
         ok = np.abs(dd - od[rows, cols]) <= 4e-16 * np.maximum(od[rows, cols], 1e-300) + 0.0
+        if gemm and not np.all(ok):
+            near = np.abs(dd ** 2 - od[rows, cols] ** 2) <= allow
+            key_res = key_res or bool(np.any(near & ~ok))
+            ok |= near
         if sm == 2:
             ok &= idx[rows, cols] != rows
         if not np.all(ok):
@@ -147,7 +165,7 @@ def run_case(c, with_sums):
                     kern += " | part: " + _capi.last_kernel()
             except Exception as exc:
                 problems.append("sums: %s: %s" % (type(exc).__name__, exc))
-    return problems, kern
+    return problems, kern + (" | key-resolution" if key_res else "")
 
 
 def kernel_family(k):
@@ -175,7 +193,7 @@ def main():
         return 1 if problems else 0
     rng = np.random.default_rng(a.seed)
     t0 = time.time()
-    n, failures, families, refused = 0, [], {}, {}
+    n, failures, families, refused, keyres = 0, [], {}, {}, []
     while time.time() - t0 < a.seconds:
         c = draw(rng, a.max_rows, a.min_rows, [int(v) for v in a.dims.split(",")] if a.dims else None)
         problems, kern = run_case(c, n % 3 == 0)
@@ -191,6 +209,9 @@ def main():
             else:
                 refused[msg.split(":")[0]] = refused.get(msg.split(":")[0], 0) + 1
             continue
+        if kern.endswith(" | key-resolution"):
+            kern = kern[:-len(" | key-resolution")]
+            keyres.append(dict(d=c["d"], K=c["K"], kind=c["kind"], kernel=kernel_family(kern.split(" | part: ")[0])))
         fam = kernel_family(kern.split(" | part: ")[0])
         families[fam] = families.get(fam, 0) + 1
         if " | part: " in kern:
@@ -200,6 +221,7 @@ def main():
             failures.append(dict(case=c, kernel=kern, problems=problems))
             print("MISMATCH " + json.dumps(dict(case=c, kernel=kern, problems=problems)), flush=True)
     summary = dict(draws=n, seconds=round(time.time() - t0, 1), seed=a.seed, max_rows=a.max_rows, min_rows=a.min_rows, dims=a.dims, mismatches=len(failures), refused_out_of_range=refused,
+                   gemm_form_draws_with_a_neighbour_swapped_within_the_keys_resolution=keyres,
                    kernels_reached=dict(sorted(families.items(), key=lambda kv: -kv[1])), failures=failures[:50], library_source_hash=_capi.source_hash())
     print(json.dumps(summary), flush=True)
     if a.out:
