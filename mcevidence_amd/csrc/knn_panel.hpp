@@ -600,7 +600,9 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_panel_kernel(PanelArgs args_
     // row of the tile; todo: the accumulators still to be looked at (a redo passes what is left).  Wave-wide compares, scalar
     // branches over the empty ones; the lanes under the gate append (query, row) to the wave's queue.  Returns the accumulators
     // NOT handled because the queue was full.  (Static s_setprio for either half of the workgroup -- MI355X_MICROARCH.md, two
-    // waves per SIMD, item 4 -- was measured in round 5: 36.9-37.1 ms either way against 36.7-37.3, nothing.)
+    // waves per SIMD, item 4 -- was measured in round 5: 36.9-37.1 ms either way against 36.7-37.3, nothing.  DYNAMIC priority, round 6 --
+    // raised while a wave sweeps and dropped inside its candidate tiles and drains, or the other way round: +1.0 % / +0.15 %,
+    // profiles/r06_mid/panel_dynamic_priority_ab.txt.)
     auto event = [&](const v16f& c, const float (&l1)[5], const int qt, const float gq, const bool rowflag, const int jb0, const unsigned todo, const int qlimit) __attribute__((always_inline)) -> unsigned {
         (void)l1;
         const unsigned wbase = (lanew[qt] + (unsigned)jb0) | (rowflag ? (1u << kHSymRowBits) : 0u);
