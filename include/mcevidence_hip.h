@@ -52,7 +52,7 @@ extern "C" {
 #define MCE_ERR_VERIFY (-7)    /* the re-check of sampled rows disagrees with the search (mce_options.verify) -> RuntimeError */
 
 #define MCE_MAX_K 32    /* neighbours per query handled by the MFMA kernels (fp16 filter: 17..32 in two sweeps) */
-#define MCE_MAX_DIM 63  /* dimensions handled by the one-to-four k-step fp16 filter (64..127: the deep fp16 filter for K <= 16, else the
+#define MCE_MAX_DIM 63  /* dimensions handled by the one-to-four k-step fp16 filter (64..127: the deep fp16 filter, K <= 32 -- search mode 1: the
                            fp64 sweep; 128..1024: the fp64 sweep with the k dimension in blocks; feeders: d <= 127) */
 #define MCE_GENERIC_MAX_K 1024   /* beyond MCE_MAX_K a plain exact kernel takes over, up to this many neighbours; rows up to */
 #define MCE_GENERIC_MAX_DIM 1024 /* this long; larger -> MCE_ERR_K_RANGE / MCE_ERR_DIM_RANGE                                 */

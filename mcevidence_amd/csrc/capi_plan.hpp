@@ -42,7 +42,7 @@ constexpr int kRefineMargin = 2;
 struct Plan {
     const mce::KnnVariant* v = nullptr;
     const mce::KnnF16Variant* vh = nullptr;   // non-null: fp16-filter path
-    const mce::KnnDeepVariant* vd = nullptr;  // non-null: the DEEP fp16 filter (knn_deep.hpp: 64 <= d <= 127, K <= 16); vh and v are null then
+    const mce::KnnDeepVariant* vd = nullptr;  // non-null: the DEEP fp16 filter (knn_deep.hpp: 64 <= d <= 127, K <= 32); vh and v are null then
     bool filter() const { return vh != nullptr || vd != nullptr; }      // exact lists behind an fp16 filter (no refine in the merge; certified by default)
     const mce::KnnLongVariant* vl = nullptr;  // non-null: the long-row fp64 sweep (knn_long.hpp: 128 <= d <= 1024, K <= 32); KS = its padded k-steps
     size_t off_xf = 0, off_xn = 0;            // ... its packed queries and their squared norms
@@ -205,14 +205,19 @@ int make_plan(int64_t nq, int64_t nr, int32_t d, int32_t K, int32_t self_mode, P
     while (ki < mce::kNumKcap - 1 && mce::kKcapList[ki] < K) ++ki;
     p.KCAP = mce::kKcapList[ki];
     const bool f16 = !wide_f64 && (eff_search_mode() != 1) && mce::f16_supported(d, K);
-    // 64 <= d <= 127 (round 6): the fp16 filter with 5, 6 or 8 k-steps (knn_deep.hpp) for K <= 16; search mode 1, or longer lists,
-    // keep the fp64 sweep's wide form.  (MCE_DEEP=0: comparisons.)
+    // 64 <= d <= 127 (round 6): the fp16 filter with 5, 6 or 8 k-steps (knn_deep.hpp), K <= 32 (beyond 16 in two passes); search mode 1
+    // keeps the fp64 sweep's wide form.  (MCE_DEEP=0: comparisons.)
     static const bool deep_on = [] { const char* e = getenv("MCE_DEEP"); return !(e && e[0] == '0'); }();
     const bool deep = wide_f64 && (eff_search_mode() != 1) && mce::deep_supported(d, K) && deep_on;
     const bool filt = f16 || deep;          // fp16 operands in the workspace, 32-row tiles, 512-query blocks
     p.vd = nullptr;
     int qpb, rows_per_tile;
     if (deep) {
+        if (K > 16) {                          // 16 nearest per reference split first, then the next K - 16 beyond them (knn_deep.hpp, LOWER)
+            p.twopass = true;
+            ki = 3;
+            p.KCAP = 16;
+        }
         p.KST = mce::deep_ksteps(d);
         const mce::KnnDeepVariant* tab = ki == 0 ? mce::g_knn_deep_kcap4 : ki == 1 ? mce::g_knn_deep_kcap8 : ki == 2 ? mce::g_knn_deep_kcap12 : mce::g_knn_deep_kcap16;
         p.vd = &tab[p.KST == 5 ? 0 : (p.KST == 6 ? 1 : 2)];

@@ -169,13 +169,42 @@ int run_search(Plan& p, const double* dX, int64_t nq, const double* dY, int64_t 
         }
         int rc = prof_begin();
         if (rc != MCE_OK) return rc;
-        MCE_HIP(p.vd->launch(a, st));
+        double seed_rows = (double)a.seed_tg * (K + a.self_exclude) * 32.0 * p.rsplit;
+        if (p.twopass) {
+            // lists [2 * rsplit][16][nq_pad]: pass 1 fills splits 0 .. rsplit - 1 with each split's 16 nearest (its seed phase bounds the
+            // 16th), pass 2 the next K - 16 beyond them into rsplit .. 2 rsplit - 1 (its seed phase bounds the K-th OVERALL: K (+ 1) groups);
+            // the merge takes the K best of all
+            const int64_t tiles_split = (p.nchunk / p.rsplit) * p.CT;
+            const Tuning tun = read_tuning();
+            const int64_t want = (tun.f16_seed_rows >= 0 ? tun.f16_seed_rows : MCE_H_SEED_ROWS) / 32;
+            auto tg_for = [&](int G) {
+                int64_t tg = std::min<int64_t>(want, tiles_split / 4) / G;
+                if (tg < 1) tg = std::min<int64_t>(want, tiles_split / 2) / G;
+                return (int)std::max<int64_t>(tg, 0);
+            };
+            const int tg2 = a.seed_tg;                  // (computed above for K (+ 1) groups)
+            a.ksel = 16;
+            a.seed_groups = 16 + a.self_exclude;
+            a.seed_tg = tg_for(a.seed_groups);
+            const int tg1 = a.seed_tg;
+            MCE_HIP(p.vd->launch(a, st));
+            a.lo_d = pd;
+            a.lo_i = pi;
+            a.part_d = pd + (size_t)p.rsplit * p.KCAP * (size_t)p.nq_pad;
+            a.part_i = pi + (size_t)p.rsplit * p.KCAP * (size_t)p.nq_pad;
+            a.ksel = K - 16;
+            a.seed_groups = K + a.self_exclude;
+            a.seed_tg = tg2;
+            MCE_HIP(p.vd->launch_lower(a, st));
+            seed_rows = ((double)tg1 * (16 + a.self_exclude) + (double)tg2 * (K + a.self_exclude)) * 32.0 * p.rsplit;
+        } else {
+            MCE_HIP(p.vd->launch(a, st));
+        }
         rc = prof_end();
         if (rc != MCE_OK) return rc;
-        const double seed_rows = (double)a.seed_tg * (K + a.self_exclude) * 32.0 * p.rsplit;
-        g_last_flops_main = g_last_flops_all = (double)p.nq_pad * ((double)p.nrow_pad + seed_rows) * 2.0 * 16.0 * p.KST;
-        snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d seed=%dx%d", p.vd->name, p.nqblk * p.rsplit, mce::kHThreads,
-                 p.vd->lds_bytes, p.QT, p.CT, p.rsplit, K + a.self_exclude, a.seed_tg);
+        g_last_flops_main = g_last_flops_all = (double)p.nq_pad * ((p.twopass ? 2.0 : 1.0) * (double)p.nrow_pad + seed_rows) * 2.0 * 16.0 * p.KST;
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "%s grid=%d block=%d lds=%zu qt=%d ct=%d rsplit=%d%s seed=%dx%d", p.vd->name, p.nqblk * p.rsplit, mce::kHThreads,
+                 p.vd->lds_bytes, p.QT, p.CT, p.rsplit, p.twopass ? " two passes" : "", K + a.self_exclude, a.seed_tg);
         return MCE_OK;
     }
     if (p.vh) {

@@ -40,6 +40,10 @@ struct DeepArgs {
     int D, ksel, self_exclude, nqblk, rsplit;
     int seed_tg;                 // tiles per seed group (0: no seed phase -- a split too small for K + 1 groups)
     int debug;                   // test hooks: 8 every candidate through the redo list
+    int seed_groups = 0;         // groups of the seed phase (0: ksel + self_exclude); the SECOND pass of a search for 16 < K <= 32 neighbours
+                                 // bounds the K-th distance overall, not the (K - 16)-th: K + self_exclude groups
+    const double* lo_d = nullptr;   // LOWER instantiation (second pass): the first pass's lists [rsplit][KCAP][nq_pad] -- only what lies beyond a
+    const int* lo_i = nullptr;      // split's 16th neighbour (lexicographically in (distance, row)) enters this pass's lists
 };
 
 __host__ __device__ constexpr int deep_chunk_tiles(int KST) { return KST == 5 ? 8 : (KST == 6 ? 8 : 6); }     // 40 / 48 / 48 KB per buffer
@@ -52,12 +56,15 @@ __host__ __device__ constexpr size_t deep_lds_bytes(int KST)
            + (size_t)kHWaves * kHQT * 32 * 4                           // K-th bound per query as of the last drain (float, rounded up)
            + (size_t)kHWaves * deep_chunk_tiles(KST) * kHQT * 4;       // redo list
 }
-__host__ __device__ constexpr bool deep_supported(int D, int K) { return D >= 64 && D <= 127 && K >= 1 && K <= 16; }
+// (K <= 16: one pass; 17..32: two sweeps of 16-entry lists -- each split's 16 nearest, then the next K - 16 beyond them -- as the
+//  exhaustive sweep does it, knn_f16.hpp LOWER)
+__host__ __device__ constexpr bool deep_supported(int D, int K) { return D >= 64 && D <= 127 && K >= 1 && K <= 32; }
 __host__ __device__ constexpr int deep_ksteps(int D) { return (D + 1 + 15) / 16 == 7 ? 8 : (D + 1 + 15) / 16; }     // 5, 6, 8 (seven would not tile the staging buffer)
 
-template <int KST, int KCAP>
+template <int KST, int KCAP, bool LOWER = false>
 __global__ __launch_bounds__(kHThreads, 2) void knn_deep_kernel(DeepArgs a)
 {
+    static_assert(!LOWER || KCAP == 16, "second pass: 16-entry lists");
     static_assert(kHQT == 2 && (KST == 5 || KST == 6 || KST == 8), "8 waves x 2 query tiles; 5, 6 or 8 k-steps");
     constexpr int QT = 2;
     constexpr int QPW = 64;
@@ -104,6 +111,14 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_deep_kernel(DeepArgs a)
     int own_i[KCAP];
 #pragma unroll
     for (int k = 0; k < KCAP; ++k) { own_d[k] = INF; own_i[k] = -1; }
+    // second pass: the owned query's 16th neighbour of the first pass in this split (list not full: +inf, nothing is left)
+    double lo_own_d = -1.0;
+    int lo_own_i = -1;
+    if constexpr (LOWER) {
+        const int64_t o = ((int64_t)split * KCAP + (KCAP - 1)) * a.nq_pad + qwave0 + lane;
+        lo_own_d = gptr(a.lo_d)[o];
+        lo_own_i = gptr(a.lo_i)[o];
+    }
 
     // ---- B fragments (fp16 query rows) + per-query gate constants -----------------------------------------------------
     v8h b[QT][KST];
@@ -216,9 +231,12 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_deep_kernel(DeepArgs a)
             while (__any(cur >= 0)) {
                 const bool on = cur >= 0;
                 const int ce = on ? cur : 0;
-                const double d2 = on ? wqd[ce] : INF;
+                double d2 = on ? wqd[ce] : INF;
                 const int j = wq[ce];
                 cur = on ? wnx[ce] : -1;
+                if constexpr (LOWER) {      // only what lies beyond the first pass's 16th neighbour of this split
+                    if (!(d2 > lo_own_d || (d2 == lo_own_d && j > lo_own_i))) d2 = INF;
+                }
                 // ascending list, ties by row; d2 = +inf (idle lane) changes nothing
                 bool c_hi = (d2 < own_d[KCAP - 1]) || (d2 == own_d[KCAP - 1] && j < own_i[KCAP - 1] && d2 < INF);
 #pragma unroll
@@ -324,7 +342,7 @@ __global__ __launch_bounds__(kHThreads, 2) void knn_deep_kernel(DeepArgs a)
 
     // ---- seed phase: G groups of seed_tg tiles from the start of the split, group minima only (see the header) -----------
     // (tiles [0, G * seed_tg) of the split; the chunks are staged as in the sweep proper, which then starts again at chunk 0)
-    const int seed_G = a.ksel + (a.self_exclude ? 1 : 0);
+    const int seed_G = a.seed_groups > 0 ? a.seed_groups : a.ksel + (a.self_exclude ? 1 : 0);
     const int seed_tiles = a.seed_tg > 0 ? seed_G * a.seed_tg : 0;
     if (seed_tiles > 0) {
         float gmax[QT] = {-__builtin_huge_valf(), -__builtin_huge_valf()};      // max over the finished groups of the lane's group minimum

@@ -111,6 +111,7 @@ struct KnnDeepVariant {
     int kst, kcap, ct;
     size_t lds_bytes;
     const char* name;
+    knn_deep_launch_fn launch_lower;   // LOWER = true instantiation (KCAP = 16 only), else null
 };
 // ---- long-row fp64 variants (knn_long.hpp): 128 <= d <= 1024, K <= 32; lists of 8, 16 or 32 entries ----
 struct LongArgs;                   // knn_long.hpp

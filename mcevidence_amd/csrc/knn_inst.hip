@@ -124,13 +124,13 @@ extern template hipError_t launch_panel_variant<4, MCE_KCAP, true>(const PanelAr
 #endif
 
 #if MCE_INST_DEEP
-template <int KST, int KCAP>
+template <int KST, int KCAP, bool LOWER = false>
 hipError_t launch_deep_variant(const DeepArgs& a, hipStream_t st)
 {
     constexpr size_t LDS = deep_lds_bytes(KST);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set[kMaxDevices] = {};
-    auto kern = knn_deep_kernel<KST, KCAP>;
+    auto kern = knn_deep_kernel<KST, KCAP, LOWER>;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= kMaxDevices || !attr_set[dev]) {
@@ -193,7 +193,12 @@ extern const KnnF16Variant MCE_CAT(g_knn_f16_kcap, MCE_KCAP)[kMaxKST] = {
 };
 #endif
 #if MCE_INST_DEEP
-#define MCE_DEEP_VARIANT(KST) {&launch_deep_variant<KST, MCE_KCAP>, KST, MCE_KCAP, deep_chunk_tiles(KST), deep_lds_bytes(KST), "knn_deep_kernel<KST=" #KST ",KCAP=" MCE_STR(MCE_KCAP) ">"}
+#if MCE_KCAP == 16
+#define MCE_DEEP_LOWER(KST) (&launch_deep_variant<KST, MCE_KCAP, true>)          // second pass of a search for 16 < K <= 32 neighbours
+#else
+#define MCE_DEEP_LOWER(KST) nullptr
+#endif
+#define MCE_DEEP_VARIANT(KST) {&launch_deep_variant<KST, MCE_KCAP>, KST, MCE_KCAP, deep_chunk_tiles(KST), deep_lds_bytes(KST), "knn_deep_kernel<KST=" #KST ",KCAP=" MCE_STR(MCE_KCAP) ">", MCE_DEEP_LOWER(KST)}
 extern const KnnDeepVariant MCE_CAT(g_knn_deep_kcap, MCE_KCAP)[kNumDeepKST] = {MCE_DEEP_VARIANT(5), MCE_DEEP_VARIANT(6), MCE_DEEP_VARIANT(8)};
 #endif
 #else
@@ -202,6 +207,11 @@ extern const KnnDeepVariant MCE_CAT(g_knn_deep_kcap, MCE_KCAP)[kNumDeepKST] = {M
 template __global__ void knn_deep_kernel<5, MCE_KCAP>(DeepArgs);
 template __global__ void knn_deep_kernel<6, MCE_KCAP>(DeepArgs);
 template __global__ void knn_deep_kernel<8, MCE_KCAP>(DeepArgs);
+#if MCE_KCAP == 16
+template __global__ void knn_deep_kernel<5, MCE_KCAP, true>(DeepArgs);
+template __global__ void knn_deep_kernel<6, MCE_KCAP, true>(DeepArgs);
+template __global__ void knn_deep_kernel<8, MCE_KCAP, true>(DeepArgs);
+#endif
 #endif
 #if MCE_INST_F16
 #define MCE_F16_INST(KST, PR, LW, SY) template __global__ void knn_f16_kernel<KST, MCE_KCAP, PR, LW, SY>(const _Float16*, int64_t, int, const _Float16*, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int64_t, int, int, int64_t, int, double*, int*, const int*, const float*, int, const int*, const int*, const float*, const float*, const float*, int, int, const int*, const double*, const int*, int, SymParams, float*);
