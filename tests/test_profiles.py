@@ -191,3 +191,26 @@ def test_round4_walk_numbers_quoted_in_the_design_notes():
 def test_mfma_error_model_histogram_is_committed():
     h = json.load(open(os.path.join(PROF4, "mfma_error_model.json")))
     assert h["tiles_total"] >= 10000 and h["max_over_everything"] < 0.5
+
+
+def test_deep_and_long_kernels_have_their_own_trace_and_counter_rows():
+    """round 6: the kernels beyond the BASELINE configs' shapes -- the deep fp16 filter (64 <= d <= 127) and the long-row fp64 sweep
+    (d >= 128) -- are in the final profile too: 100 k x 100 k auto evidence at d = 64 / 100 / 127 / 128 / 256 under the kernel trace and
+    an SQ counter pass (kernel_stats_shapes.csv, pmc_summary_shapes.csv, shape_times.txt).  The flops DESIGN.md 3 quotes follow
+    from SQ_INSTS_MFMA: 32 768 per fp16 MFMA (32x32x16), 2 048 per fp64 MFMA (16x16x4)."""
+    n = 100000.0
+    # the long-row sweep at d = 128 and 256 share one kernel row (KCAP = 16): two dispatches per shape x (1 + 3 reps)
+    ms_long, calls = _avg_ms("kernel_stats_shapes.csv", "knn_long_kernel<16>")
+    assert calls >= 8 and 70.0 < ms_long < 100.0            # mean of the d = 128 (~58 ms) and d = 256 (~116 ms) launches
+    mf = _per_dispatch("pmc_summary_shapes.csv", "knn_long_kernel<16>", "SQ_INSTS_MFMA")
+    # KSP = 35 (d = 128) and 72 (d = 256) k-steps, padded rows of 1173 x 256 queries by the padded references: mean over the two shapes
+    nq_pad, nr_pad = 391 * 256.0, 782 * 128.0
+    want = nq_pad * nr_pad * (35 + 72) / 2.0 / 256.0          # one fp64 MFMA = 16 x 16 pairs x 4 dimensions
+    assert abs(mf / want - 1.0) < 0.02, (mf, want)
+    tf = mf * 2048.0 / (ms_long * 1e-3) / 1e12
+    assert 40.0 < tf < 60.0                                    # 0.5 - 0.75 of the 78.6 TFLOP/s fp64 MFMA peak
+    for kst, lo, hi in ((5, 2.5, 5.0), (8, 3.0, 6.5)):
+        ms_deep, _ = _avg_ms("kernel_stats_shapes.csv", "knn_deep_kernel<%d, 12" % kst)
+        assert lo < ms_deep < hi, (kst, ms_deep)
+    times = open(os.path.join(PROF, "shape_times.txt")).read()
+    assert "knn_long_kernel<KCAP=16>" in times and "knn_deep_kernel<KST=5,KCAP=12>" in times
