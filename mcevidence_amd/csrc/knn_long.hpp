@@ -12,7 +12,8 @@
 //  * the k dimension goes in BLOCKS of at most kLongKSB = 8 k-steps (32 dimensions), all of one length.  A workgroup (8 waves x 2 query tiles = 256 queries)
 //    holds the accumulators of a whole CHUNK of CT reference tiles in registers (2 x CT x 8 VGPRs: 128 at CT = 8) and walks the
 //    chunk's k blocks: per block, CT x 8 A fragments come through LDS (one DMA stage of CT x 4 KB, double buffered, one barrier
-//    per block) and each wave loads ITS 2 x 8 query fragments of the block from global memory (packed in B-fragment order by
+//    per block) and each wave loads ITS 2 x 8 query fragments of the NEXT block from global memory -- each into the register its
+//    predecessor just left, right behind the MFMAs that read it -- (packed in B-fragment order by
 //    long_pack_queries_kernel: 512 contiguous bytes per fragment; L2 resident -- the workgroup's 256 queries are
 //    256 x 8 x (d + 1) bytes) -- 16 x CT MFMAs per wave between barriers, every A fragment feeding two of them;
 //  * after the last block the chunk's 2 x CT accumulator tiles ARE squared distances and go through knn_mfma.hpp's gate
@@ -190,6 +191,17 @@ __global__ __launch_bounds__(kThreads, 1) void knn_long_kernel(LongArgs A)
 
     if (c_begin < c_end) stage_async(c_begin, 0, 0);
     int buf = 0;
+    // this wave's query fragments of the CURRENT block.  They do not depend on the chunk; the fragments of the next block are
+    // loaded into the same registers k-step by k-step, each right behind the MFMAs that read it (below): their latency rides under
+    // the rest of the block instead of in front of the next one
+    // (PREFETCH: measured, same box -- 100 k x 100 k at d = 128 / 160 / 256 with lists of 8 or 16: -2.4 / -2.2 / -6 %; d = 512 +-0, 1024
+    // +1 %; with lists of 32 -- four tiles per chunk, half the MFMAs between two loads -- +2 to +8 %: those load at the top of the block)
+    constexpr bool PREFETCH = (CT == 8);
+    double b[QT][KSBMAX];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < KSBMAX; ++ks) b[qt][ks] = (PREFETCH && ks < KSB) ? Xf[((qtile0 + qt) * (int64_t)KSP + ks) * 64 + lane] : 0.0;
 #pragma unroll 1
     for (int64_t c = c_begin; c < c_end; ++c) {
         v4d acc[QT][CT];
@@ -199,13 +211,14 @@ __global__ __launch_bounds__(kThreads, 1) void knn_long_kernel(LongArgs A)
             for (int t = 0; t < CT; ++t) acc[qt][t] = xn4[qt];
 #pragma unroll 1
         for (int kb = 0; kb < NKB; ++kb) {
-            // this wave's query fragments of the block (issued before the wait: they ride under the DMA's landing)
-            double b[QT][KSBMAX];
+            const int kb_next = kb + 1 < NKB ? kb + 1 : 0;
+            if constexpr (!PREFETCH) {
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
+                for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-                for (int ks = 0; ks < KSBMAX; ++ks)
-                    b[qt][ks] = ks < KSB ? Xf[((qtile0 + qt) * (int64_t)KSP + (int64_t)kb * KSB + ks) * 64 + lane] : 0.0;
+                    for (int ks = 0; ks < KSBMAX; ++ks)
+                        b[qt][ks] = ks < KSB ? Xf[((qtile0 + qt) * (int64_t)KSP + (int64_t)kb * KSB + ks) * 64 + lane] : 0.0;
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of the stage has landed (and its fragments) ...
             __syncthreads();                                    // ... everybody's has; the other buffer is free
             if (kb + 1 < NKB) stage_async(c, kb + 1, buf ^ 1);
@@ -221,6 +234,10 @@ __global__ __launch_bounds__(kThreads, 1) void knn_long_kernel(LongArgs A)
                     for (int t = 0; t < CT; ++t)
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) acc[qt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[qt][ks], acc[qt][t], 0, 0, 0);
+                    if constexpr (PREFETCH) {
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) b[qt][ks] = Xf[((qtile0 + qt) * (int64_t)KSP + (int64_t)kb_next * KSB + ks) * 64 + lane];
+                    }
                 }
                 // (keeps the A fragments of LATER k-steps out of registers: with all 8 x CT reads hoisted the kernel spills)
                 __builtin_amdgcn_sched_barrier(0);
