@@ -347,6 +347,42 @@ def test_long_rows_on_the_blocked_fp64_sweep(capi, n, nq, d, K, self_mode):
         assert np.allclose(parts[1:], dotp[1:], rtol=1e-13, atol=0.0)
 
 
+def test_ab_switches_bring_the_older_kernels_back(tmp_path):
+    """MCE_LONG=0 / MCE_DEEP=0 (read once per process: a child process each) put 128 <= d and 64 <= d <= 127 back on the kernels that
+    served them before round 6 -- the vector-FMA kernel and the fp64 sweep's wide form: the same rows, distances equal to the last
+    ulp (exact distances summed in another order)."""
+    import os
+    import subprocess
+    import sys
+    from helpers import REPO
+    code = (
+        "import sys, json, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from mcevidence_amd import _capi\n"
+        "out = {}\n"
+        "for d, K in ((130, 5), (100, 20), (70, 3)):\n"
+        "    Y = np.random.default_rng(d + K).standard_normal((2500, d))\n"
+        "    dist, idx = _capi.knn(Y, Y, K, self_mode=_capi.SELF_EXCLUDE)\n"
+        "    np.save(sys.argv[1] + '_%%d_d.npy' %% d, dist); np.save(sys.argv[1] + '_%%d_i.npy' %% d, idx)\n"
+        "    out[str(d)] = _capi.last_kernel()\n"
+        "print(json.dumps(out))\n") % REPO
+    kernels = {}
+    for tag, env_extra in (("new", {}), ("old", {"MCE_LONG": "0", "MCE_DEEP": "0"})):
+        env = {k: v for k, v in os.environ.items() if k not in ("MCE_LONG", "MCE_DEEP")}
+        env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", code, str(tmp_path / tag)], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        import json
+        kernels[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "knn_long_kernel" in kernels["new"]["130"] and "knn_generic_kernel" in kernels["old"]["130"]
+    assert "knn_deep_kernel" in kernels["new"]["100"] and "two passes" in kernels["new"]["100"] and "knn_mfma_kernel<KS=28" in kernels["old"]["100"]
+    assert "knn_deep_kernel<KST=5" in kernels["new"]["70"] and "knn_mfma_kernel<KS=20" in kernels["old"]["70"]
+    for d in (130, 100, 70):
+        dn, do = np.load(str(tmp_path / "new") + "_%d_d.npy" % d), np.load(str(tmp_path / "old") + "_%d_d.npy" % d)
+        assert np.array_equal(np.load(str(tmp_path / "new") + "_%d_i.npy" % d), np.load(str(tmp_path / "old") + "_%d_i.npy" % d))
+        assert _rel(dn, do) < 1e-14
+
+
 @pytest.mark.parametrize("d,K,kernel", [(64, 5, "knn_deep_kernel<KST=5"), (79, 3, "knn_deep_kernel<KST=5"), (80, 20, "knn_deep_kernel<KST=6,KCAP=16"), (100, 12, "knn_deep_kernel<KST=8"),
                                         (90, 16, "knn_deep_kernel<KST=6"), (127, 32, "knn_deep_kernel<KST=8,KCAP=16"), (128, 6, "knn_long_kernel<KCAP=8"), (10, 40, "generic"), (200, 33, "generic"), (100, 33, "generic"),
                                         (129, 14, "knn_long_kernel<KCAP=16"), (200, 32, "knn_long_kernel<KCAP=32"), (300, 15, "knn_long_kernel<KCAP=32"), (1024, 3, "knn_long_kernel<KCAP=8")])
