@@ -589,6 +589,47 @@ def sklearn_baseline(cfg, algs, orc, seed=0, nrows_all=20000):
                 cores=len(os.sched_getaffinity(0)), algorithms=out)
 
 
+def beyond_baseline_shapes(ctx):
+    """The kernels that serve rows longer than the BASELINE configs' (round 6): 100 k x 100 k auto evidence at d = 64 / 100 / 127 (the deep
+    fp16 filter; kmax 25: its two passes), 128 / 256 (the long-row fp64 sweep) -- resident data, fused search + reduction, best of 3,
+    with the library's own event bracket around the dominant kernel.  Not a BASELINE metric: a section of the line."""
+    torch, _capi, dev = ctx.torch, ctx.capi, ctx.dev
+    out = []
+    for n, d, kmax in ((100000, 64, 10), (100000, 100, 10), (100000, 127, 10), (100000, 100, 25), (100000, 128, 10), (100000, 256, 10)):
+        try:
+            g = torch.Generator(device="cpu").manual_seed(n + d)
+            X = torch.randn((n, d), dtype=torch.float64, generator=g).to(dev)
+            w = torch.ones(n, dtype=torch.float64, device=dev)
+            fs = torch.zeros(n, dtype=torch.float64, device=dev)
+            wsb = _capi.knn_workspace_bytes(n, n, d, kmax - 1) + _capi.dotp_workspace_bytes(n, kmax)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            res = torch.zeros(kmax, dtype=torch.float64, device=dev)
+            st = torch.cuda.current_stream().cuda_stream
+            best, kms = 1e30, None
+            for it in range(4):
+                _capi.set_profiling(it > 0)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _capi.knn_dotp_dev(X.data_ptr(), n, X.data_ptr(), n, d, kmax, 1, 0, w.data_ptr(), fs.data_ptr(), res.data_ptr(), 0, ws.data_ptr(), wsb, st)
+                torch.cuda.synchronize()
+                t = (time.perf_counter() - t0) * 1e3
+                if it > 0 and t < best:
+                    best, stats = t, _capi.last_search_stats()
+                _capi.set_profiling(False)
+            kdesc = _capi.last_kernel()
+            fp64 = "knn_long_kernel" in kdesc or "knn_mfma_kernel" in kdesc
+            peak = FP64_PEAK_TFLOPS if fp64 else F16_PEAK_TFLOPS
+            tf = stats["flops_main"] / (stats["kernel_ms"] * 1e-3) / 1e12 if stats["kernel_ms"] > 0 else None
+            out.append(dict(n=n, d=d, kmax=kmax, ms=round(best, 3), kernel_ms=round(stats["kernel_ms"], 3), queries_per_s=round(n / (best * 1e-3), 1), kernel=kdesc,
+                            roofline=dict(bound="mfma", achieved=None if tf is None else round(tf, 2), peak=peak, unit="TFLOP/s", frac=None if tf is None else round(tf / peak, 4),
+                                          executed_flops_per_launch=stats["flops_main"])))
+            del X, ws, w, fs
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            out.append(dict(n=n, d=d, kmax=kmax, error="%s: %s" % (type(exc).__name__, exc)))
+    return out
+
+
 def extra_configs(ctx, orc, pkg, scale=1.0):
     """C2, C4, C5 of BASELINE.json (C1 is the CPU plumbing config): resident data, the same timing as the headline."""
     torch, _capi, world = ctx.torch, ctx.capi, ctx.world
@@ -848,6 +889,7 @@ def main():
         cpu = None
         fp64_mode = None
         e2e = None
+        shapes = None
         if not dist_on:
             if a.cpu_sample > 0:
                 rng = np.random.default_rng(0)
@@ -885,6 +927,8 @@ def main():
                                              note="pure fp64 arithmetic: v_mfma_f64_16x16x4_f64 over all pairs (2*4*KS flop/pair, unpadded rows) + fp64 refine")
                 fp64_mode["max_abs_dlnE_vs_default_mode"] = float(np.max(np.abs(np.array(fp64_mode["lnE"]) - lnE)))
                 extras = extra_configs(ctx, orc, pkg, a.extras_scale)
+                if a.extras_scale == 1.0:
+                    shapes = beyond_baseline_shapes(ctx)
         if isinstance(e2e_ranks, dict):
             e2e = e2e_ranks
         elif e2e_ranks:
@@ -904,7 +948,8 @@ def main():
                    ranks_seen=(dist.get_world_size() if dist_on else 1), backend=(dist.get_backend() if dist_on else None),
                    per_rank=head_per_rank, partitions=partitions,
                    max_abs_dlnE_vs_reference=dlnE, lnE=[round(float(x), 10) for x in lnE],
-                   roofline=roof, cpu_baseline=cpu, evidence_call_from_host=e2e, certificate=head.get("certificate"), configs=extras, fp64_mode=fp64_mode)
+                   roofline=roof, cpu_baseline=cpu, evidence_call_from_host=e2e, certificate=head.get("certificate"), configs=extras, fp64_mode=fp64_mode,
+                   beyond_baseline_shapes=shapes)
         if pairs_once is not None:
             out["pairs_once"] = pairs_once
         print(json.dumps(out), flush=True)

@@ -226,3 +226,23 @@ def test_bench_gpus_2_under_the_launcher():
     assert ("candidates_sent" in line["per_rank"][0]) == (fastest == "pairs_once")
     e2e = line["evidence_call_from_host"]
     assert len(e2e["per_rank"]) == 2 and e2e["max_abs_dlnE_vs_resident_path"] < LNE_TOL
+
+
+@pytest.mark.gpu
+def test_beyond_baseline_shapes_section():
+    """the default one-GPU line also times the kernels that serve rows longer than the BASELINE configs' (round 6): the deep fp16 filter
+    at d = 64 / 100 / 127 (and its two passes at kmax = 25), the long-row fp64 sweep at d = 128 / 256 -- each with a roofline object"""
+    import torch
+    import torch.distributed as dist
+    import bench
+    from mcevidence_amd import _capi
+    ctx = bench.Ctx(torch, dist, _capi, 1, 0, torch.device("cuda", 0))
+    out = bench.beyond_baseline_shapes(ctx)
+    assert [(o["d"], o["kmax"]) for o in out] == [(64, 10), (100, 10), (127, 10), (100, 25), (128, 10), (256, 10)]
+    assert all("error" not in o for o in out), out
+    for o in out:
+        want = "knn_long_kernel" if o["d"] >= 128 else "knn_deep_kernel"
+        assert want in o["kernel"] and ("two passes" in o["kernel"]) == (o["kmax"] == 25), o["kernel"]
+        r = o["roofline"]
+        assert r["peak"] == (78.6 if o["d"] >= 128 else 2500.0) and 0.05 < r["frac"] < 1.0 and 0 < o["kernel_ms"] <= o["ms"]
+    assert out[0]["ms"] < 8.0 and out[4]["ms"] < 120.0          # (100 k x 100 k x 64 asked for <= 6 ms; d = 128 took 278 on the vector-FMA kernel)
